@@ -1,0 +1,133 @@
+/*
+ * lfx_oracle.h -- CPU oracle for the per-scan feature-extraction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a CPU restatement of the reference algorithm
+ * (tier4/lidar_feature_extraction, extraction/ package).  It exists to CHECK the HIP
+ * product path and to be timed as the `cpu_baseline` leg of bench.py.  Nothing in the
+ * product (lidar_feature_extraction_amd/, include/) may include, link, import or call
+ * anything in this directory; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do.
+ *
+ * Parity pinning: every function below is checked against the known-answer vectors of
+ * the reference's own unit tests (the .cpp files of extraction/test/, restated as data in
+ * tests/golden/reference_unit_vectors.json) and, where the reference source compiles
+ * from its own files with what this image holds (math.cpp, convolution.cpp,
+ * index_range.cpp), against that compiled reference code (oracle/_ref, see Makefile).
+ * The full per-scan path (label.hpp, fill.hpp, occlusion.hpp, ring.hpp ...) needs PCL,
+ * range-v3, boost and rclcpp, which this image lacks: it is unbuildable here, so the
+ * whole-scan behaviour is pinned by the unit vectors of each stage, not by a run of the
+ * reference node.
+ *
+ * All citations are file:line relative to /root/reference/.
+ */
+#ifndef LFX_ORACLE_H_
+#define LFX_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* extraction/include/lidar_feature_extraction/hyper_parameter.hpp:32-65 */
+typedef struct orc_params {
+  int32_t padding;                       /* convolution_padding            */
+  double neighbor_degree_threshold;      /* degrees                        */
+  double distance_diff_threshold;
+  double parallel_beam_min_range_ratio;
+  double edge_threshold;
+  double surface_threshold;
+  double min_range;
+  double max_range;
+  int32_t n_blocks;
+} orc_params;
+
+/* extraction/include/lidar_feature_extraction/point_label.hpp:32-42 */
+enum {
+  ORC_LABEL_DEFAULT = 0, ORC_LABEL_EDGE = 1, ORC_LABEL_EDGE_NEIGHBOR = 2,
+  ORC_LABEL_SURFACE = 3, ORC_LABEL_SURFACE_NEIGHBOR = 4, ORC_LABEL_OUT_OF_RANGE = 5,
+  ORC_LABEL_OCCLUDED = 6, ORC_LABEL_PARALLEL_BEAM = 7
+};
+
+/* per-ring outcome; every non-zero value = "ring contributes nothing"
+ * (extraction/app/feature_extraction.cpp:116,126,154-156) */
+enum {
+  ORC_RING_OK = 0,
+  ORC_RING_SPARSE = 1,            /* N < padding+1   ring.cpp:46-59 (RemoveSparseRings)       */
+  ORC_RING_TOO_FEW_CONV = 2,      /* N < 2P+1        convolution.cpp:39-43                    */
+  ORC_RING_TOO_FEW_BLOCKS = 3,    /* N-2P < n_blocks index_range.cpp:35-40                    */
+  ORC_RING_BLOCK_TOO_SMALL = 4,   /* a block slice has < 2 points  neighbor.hpp:71-75         */
+  ORC_RING_ZERO_NORM_PAIR = 5,    /* adjacent pair both (0,0) in xy  math.cpp:40-42           */
+  ORC_RING_OTHER = 6
+};
+
+/* ---- stage level (each mirrors one reference function; used for the unit vectors) ---- */
+double orc_xy_norm(double x, double y);                                   /* math.hpp:36-39 */
+int orc_calc_radian(double x1, double y1, double x2, double y2, double *out); /* math.cpp:34-46; returns 1 when the reference throws */
+double orc_inner_product(const double *a, const double *b, int n);        /* math.hpp:43-53 */
+int orc_convolution1d(const double *input, int n, const double *weight, int m, double *out); /* convolution.cpp:35-66; 1 = throws */
+void orc_make_weight(int padding, double *out /* 2P+1 */);                /* curvature.cpp:36-42 */
+int orc_calc_curvature(const double *range, int n, int padding, double *out); /* curvature.cpp:44-50; 1 = throws */
+void orc_argsort(const double *values, int n, int *out);                  /* algorithm.hpp:65-71 */
+int orc_index_range(int start, int end, int n_blocks, int *bounds /* n_blocks+1 */); /* index_range.cpp:32-66; 1 = throws */
+int orc_padded_index_range(int size, int n_blocks, int padding, int *bounds); /* index_range.hpp:59-66 */
+int orc_polar_less_f64(double ax, double ay, double bx, double by);      /* ring.hpp:54-99 with double fields (test_ring.cpp) */
+int orc_polar_less_f32(float ax, float ay, float bx, float by);          /* ring.hpp:54-99 with float fields (PointXYZIR) */
+void orc_sort_by_atan2_f64(const double *x, const double *y, int n, int *indices /* in/out, n */); /* ring.hpp:101-112 */
+int orc_is_neighbor_xy(float x1, float y1, float x2, float y2, double radian_threshold, int *out); /* neighbor.hpp:44-48 */
+int orc_is_in_inclusive_range(double v, double min, double max);         /* range.hpp:40-43 */
+
+/* Neighbour checker handed to the fill / label stages: either the debug checker
+ * (groups != NULL; neighbor.hpp:116-136) or the XY checker over float points
+ * (neighbor.hpp:64-114).  Return value of every stage: 0 ok, 1 the reference throws
+ * std::invalid_argument, 2 the reference throws std::out_of_range. */
+int orc_fill_from_left(uint8_t *labels, int n, const int *groups, const float *x, const float *y,
+                       double radian_threshold, int begin, int end, uint8_t label);   /* fill.hpp:40-68 */
+int orc_fill_from_right(uint8_t *labels, int n, const int *groups, const float *x, const float *y,
+                        double radian_threshold, int begin, int end, uint8_t label);  /* fill.hpp:70-99 */
+int orc_fill_neighbors(uint8_t *labels, int n, const int *groups, const float *x, const float *y,
+                       double radian_threshold, int index, int padding, uint8_t label); /* fill.hpp:101-117 */
+int orc_edge_label_assign(uint8_t *labels, const double *curvature, int n, const int *groups,
+                          const float *x, const float *y, double radian_threshold,
+                          int padding, double threshold);                             /* label.hpp:61-100 */
+int orc_surface_label_assign(uint8_t *labels, const double *curvature, int n, const int *groups,
+                             const float *x, const float *y, double radian_threshold,
+                             int padding, double threshold);                          /* label.hpp:102-139 */
+int orc_assign_label(uint8_t *labels, const double *curvature, int n, const float *x, const float *y,
+                     double radian_threshold, int n_blocks, int padding,
+                     double edge_threshold, double surface_threshold);                /* label.hpp:141-164 */
+int orc_label_occluded(uint8_t *labels, int n, const float *x, const float *y, double radian_threshold,
+                       int padding, double distance_diff_threshold);                  /* occlusion.hpp:37-91 */
+void orc_label_out_of_range(uint8_t *labels, int n, const float *x, const float *y,
+                            double min_range, double max_range);                      /* out_of_range.hpp:36-48 */
+void orc_label_parallel_beam(uint8_t *labels, int n, const float *x, const float *y,
+                             double range_ratio_threshold);                           /* parallel_beam.hpp:36-51 */
+void orc_label_to_color(uint8_t label, uint8_t rgb[3]);                               /* color_points.cpp:39-68 */
+
+/* ---- whole scan: the body of FeatureExtraction::Callback, feature_extraction.cpp:114-157 ----
+ * Input: n points, `stride` bytes apart; x,y,z f32 and ring u16 at the given byte offsets
+ * (PointXYZIR: stride 32, x0 y4 z8 ring20; lib/.../point_type.hpp:62-86).
+ * Outputs (caller allocated, any may be NULL):
+ *   labels[n], curvature[n]      addressed by ORIGINAL point index (Default / 0.0 for skipped rings)
+ *   sorted_index[n]              rings ascending, each ring angle-sorted (ring.hpp:141-147)
+ *   ring_id/ring_count/ring_status[max_rings]  ascending ring id; *n_rings entries
+ *   edge_index/surface_index[n]  original indices, canonical order (ring asc, angle asc)
+ *   edge_points/surface_points   4 floats per point: x, y, z, (float)curvature (label.hpp:166-179)
+ *   ties[2]                      [0] adjacent pairs the angle predicate calls equal, [1] adjacent
+ *                                equal curvatures met inside a block argsort (unspecified order
+ *                                in the reference: std::sort is unstable)
+ * canonical_ties != 0: break both kinds of tie by the lower index first (what the HIP path
+ * defines); 0: leave them to std::sort exactly as the reference does.
+ * Returns 0, or -1 on bad arguments. */
+int orc_extract(const void *points, size_t n, size_t stride, size_t off_x, size_t off_y, size_t off_z,
+                size_t off_ring, const orc_params *params, int canonical_ties,
+                uint8_t *labels, double *curvature, int32_t *sorted_index,
+                int32_t *ring_id, int32_t *ring_count, int32_t *ring_status, int32_t max_rings,
+                int32_t *n_rings, int32_t *edge_index, int32_t *n_edge, int32_t *surface_index,
+                int32_t *n_surface, float *edge_points, float *surface_points, int64_t *ties);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* LFX_ORACLE_H_ */
