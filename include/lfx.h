@@ -1,0 +1,197 @@
+/*
+ * lfx.h -- C ABI of the MI355X-native lidar feature extraction hot path.
+ *
+ * The reference (tier4/lidar_feature_extraction) has no plugin/FFI boundary: its per-scan
+ * extraction is the C++ body of FeatureExtraction::Callback,
+ *   /root/reference/extraction/app/feature_extraction.cpp:114-157
+ * between GetPointCloud<PointXYZIR> (:94) and ToPointXYZ/ToRosMsg (:161-166).  This header is
+ * the drop-in boundary for exactly those lines: PointXYZIR points in (32-byte AoS,
+ * lib/include/lidar_feature_library/point_type.hpp:62-86), edge + surface clouds, per-point
+ * labels and curvature out.  Plain pointers and sizes only; no C++ or torch types.
+ * INTEGRATION.md shows the replacement of lines 114-157 that binds these entry points.
+ *
+ * Threading: a context is NOT thread-safe; use one context per GPU / per calling thread
+ * (the reference's caller is a single-threaded executor, feature_extraction.cpp:185).
+ * Every function returns LFX_OK (0) or a negative lfx_error; lfx_last_error() gives text.
+ * No exception crosses this boundary: the reference's per-ring std::invalid_argument
+ * (feature_extraction.cpp:154-156: warn, ring contributes nothing) becomes ring_status[].
+ */
+#ifndef LFX_H_
+#define LFX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFX_VERSION 1
+#define LFX_MAX_PADDING 15          /* convolution_padding supported by the window kernels        */
+#define LFX_MAX_RING_ID 255         /* ring ids must be < 256 (every spinning lidar fielded today) */
+#define LFX_MAX_RING_POINTS 4096    /* points of one ring must fit one workgroup's LDS             */
+
+/* The nine node parameters: extraction/include/lidar_feature_extraction/hyper_parameter.hpp:32-65
+ * (same names, same units; the neighbour threshold is in DEGREES, converted as
+ * lib/include/lidar_feature_library/degree_to_radian.hpp:34-37 does). */
+typedef struct lfx_params {
+  int32_t padding;                        /* convolution_padding            default 5    */
+  double neighbor_degree_threshold;       /*                                default 2.0  */
+  double distance_diff_threshold;         /*                                default 0.3  */
+  double parallel_beam_min_range_ratio;   /*                                default 0.02 */
+  double edge_threshold;                  /*                                default 0.05 */
+  double surface_threshold;               /*                                default 0.05 */
+  double min_range;                       /*                                default 0.1  */
+  double max_range;                       /*                                default 100  */
+  int32_t n_blocks;                       /*                                default 6    */
+} lfx_params;
+
+/* Where x, y, z (f32) and ring (u16) sit inside one point record.  PointXYZIR is
+ * {32, 0, 4, 8, 20} (point_type.hpp:62-86; convert.py:134-145 of point_type_converter). */
+typedef struct lfx_layout {
+  uint32_t point_step, off_x, off_y, off_z, off_ring;
+} lfx_layout;
+
+typedef struct lfx_config {
+  uint32_t max_points_per_scan;   /* capacity of one scan                                   */
+  uint32_t max_batch;             /* scans per lfx_extract_batch* call                      */
+  uint32_t max_points_per_ring;   /* 0 = LFX_MAX_RING_POINTS; rounded up to a power of two  */
+  uint32_t max_rings;             /* rings a scan may hold (workgroups launched per scan); 0 = 256 */
+  lfx_layout layout;              /* all-zero = PointXYZIR                                  */
+} lfx_config;
+
+/* PointLabel values: extraction/include/lidar_feature_extraction/point_label.hpp:32-42 */
+enum lfx_label {
+  LFX_LABEL_DEFAULT = 0, LFX_LABEL_EDGE = 1, LFX_LABEL_EDGE_NEIGHBOR = 2, LFX_LABEL_SURFACE = 3,
+  LFX_LABEL_SURFACE_NEIGHBOR = 4, LFX_LABEL_OUT_OF_RANGE = 5, LFX_LABEL_OCCLUDED = 6,
+  LFX_LABEL_PARALLEL_BEAM = 7
+};
+
+/* Per-ring outcome.  Non-zero = the ring contributes no label, curvature or feature point,
+ * exactly as a ring the reference removes (RemoveSparseRings, ring.cpp:46-59) or abandons on
+ * std::invalid_argument (feature_extraction.cpp:154-156). */
+enum lfx_ring_status {
+  LFX_RING_OK = 0,
+  LFX_RING_SPARSE = 1,            /* N < padding+1                 ring.cpp:46-59             */
+  LFX_RING_TOO_FEW_CONV = 2,      /* N < 2*padding+1               convolution.cpp:39-43      */
+  LFX_RING_TOO_FEW_BLOCKS = 3,    /* N - 2*padding < n_blocks      index_range.cpp:35-40      */
+  LFX_RING_BLOCK_TOO_SMALL = 4,   /* a block holds < 2 points      neighbor.hpp:71-75         */
+  LFX_RING_ZERO_NORM_PAIR = 5,    /* adjacent points both (0,0)    math.cpp:40-42             */
+  LFX_RING_TOO_LARGE = 7          /* N > max_points_per_ring (no reference counterpart)       */
+};
+
+enum lfx_error {
+  LFX_OK = 0,
+  LFX_ERR_INVALID_ARGUMENT = -1,
+  LFX_ERR_NO_DEVICE = -2,         /* no HIP device / kernel image: the product has NO CPU fallback */
+  LFX_ERR_HIP = -3,
+  LFX_ERR_CAPACITY = -4,          /* more points / scans than the context was created for     */
+  LFX_ERR_RING_ID = -5,           /* a point carries ring > LFX_MAX_RING_ID                    */
+  LFX_ERR_OUT_OF_MEMORY = -6
+};
+
+typedef struct lfx_ctx lfx_ctx;
+
+/* One scan's results in host memory (owned by the context, valid until its next call). */
+typedef struct lfx_scan_result {
+  uint32_t n_points;
+  const uint8_t *labels;          /* [n_points] lfx_label, addressed by ORIGINAL point index   */
+  const double *curvature;        /* [n_points] f64, original index (curvature.cpp:44-50)      */
+  const uint32_t *sorted_index;   /* [n_points] rings ascending, angle ascending inside a ring (ring.hpp:141-147) */
+  uint32_t n_rings;
+  const uint16_t *ring_id;        /* [n_rings] ascending                                        */
+  const uint32_t *ring_count;     /* [n_rings] points of the ring                               */
+  const uint32_t *ring_offset;    /* [n_rings] start of the ring inside sorted_index            */
+  const uint8_t *ring_status;     /* [n_rings] lfx_ring_status                                  */
+  uint32_t n_edge;
+  const float *edge_points;       /* [n_edge][4] x, y, z, (float)curvature  (label.hpp:166-179) */
+  const uint32_t *edge_index;     /* [n_edge] original point index; ring asc, angle asc         */
+  uint32_t n_surface;
+  const float *surface_points;    /* [n_surface][4]                                             */
+  const uint32_t *surface_index;
+} lfx_scan_result;
+
+/* Device-resident results of the last lfx_extract_batch_device call (device pointers owned by
+ * the context).  Scan s owns positions [scan_begin[s], scan_begin[s+1]) of every per-point
+ * array; its features occupy the first n_edge[s] / n_surface[s] records from scan_begin[s]. */
+typedef struct lfx_device_view {
+  uint32_t batch;
+  const uint32_t *scan_begin;     /* device [batch+1]                                           */
+  const uint8_t *labels_sorted;   /* device: label of sorted position k (see sorted_index)      */
+  const double *curvature_sorted; /* device                                                     */
+  const uint32_t *sorted_index;   /* device: original index (within its scan) of sorted position k */
+  const uint32_t *scan_info;      /* device [batch][4]: n_rings, error bits, n_edge, n_surface  */
+  const uint16_t *ring_id;        /* device [batch][256] by slot                                */
+  const uint32_t *ring_count;     /* device [batch][256] by slot                                */
+  const uint32_t *ring_offset;    /* device [batch][256] by slot                                */
+  const uint8_t *ring_status;     /* device [batch][256] by slot                                */
+  const float *edge_points;       /* device [total][4]                                          */
+  const uint32_t *edge_index;
+  const float *surface_points;
+  const uint32_t *surface_index;
+} lfx_device_view;
+
+/* --- parameters ------------------------------------------------------------------------ */
+void lfx_default_params(lfx_params *p);   /* code defaults, hyper_parameter.hpp:35-43 */
+void lfx_launch_params(lfx_params *p);    /* lidar_feature_launch/config/lidar_feature_extraction.param.yaml:3-10 */
+
+/* --- context --------------------------------------------------------------------------- */
+/* Replaces the node's construction of HyperParameters / EdgeLabel / SurfaceLabel
+ * (feature_extraction.cpp:68-72).  Fails with LFX_ERR_NO_DEVICE when no MI355X is present. */
+int lfx_create(lfx_ctx **ctx, int device_id, const lfx_params *params, const lfx_config *config);
+void lfx_destroy(lfx_ctx *ctx);
+const char *lfx_last_error(const lfx_ctx *ctx);   /* ctx may be NULL: error of the last failed lfx_create */
+const char *lfx_status_string(int ring_status);
+
+/* --- the operator: feature_extraction.cpp:114-157 ---------------------------------------- */
+/* Host points in, host results out (synchronous; H2D + kernels + D2H). */
+int lfx_extract(lfx_ctx *ctx, const void *points, size_t n_points, lfx_scan_result *out);
+int lfx_extract_batch(lfx_ctx *ctx, const void *const *points, const size_t *n_points, uint32_t batch,
+                      lfx_scan_result *out /* [batch] */);
+
+/* Device points in, results stay on the device (asynchronous on `stream`, a hipStream_t or NULL).
+ * d_points: the scans' point records back to back; n_points: host array [batch]. */
+int lfx_extract_batch_device(lfx_ctx *ctx, const void *d_points, const uint32_t *n_points, uint32_t batch,
+                             void *stream);
+int lfx_device_results(const lfx_ctx *ctx, lfx_device_view *view);
+/* Copy scan `scan` of the last device batch to host memory (synchronises the stream). */
+int lfx_download_scan(lfx_ctx *ctx, uint32_t scan, void *stream, lfx_scan_result *out);
+
+/* --- per-stage entry points (device-backed mirrors of the reference's free functions) ----- */
+/* One ring given as angle-sorted x[n], y[n] host arrays; every stage runs the same device
+ * routines the fused ring kernel runs.  Optional inputs may be NULL.
+ *   groups     replaces the XY neighbour test by NeighborCheckDebug (neighbor.hpp:116-136)
+ *   curvature_in  use these values instead of computing them (EdgeLabel/SurfaceLabel tests)
+ * flags select what runs; outputs may be NULL. */
+#define LFX_STAGE_LABEL 1u          /* AssignLabel              label.hpp:141-164          */
+#define LFX_STAGE_OCCLUSION 2u      /* LabelOccludedPoints      occlusion.hpp:81-91        */
+#define LFX_STAGE_OUT_OF_RANGE 4u   /* LabelOutOfRange          out_of_range.hpp:36-48     */
+#define LFX_STAGE_PARALLEL_BEAM 8u  /* LabelParallelBeamPoints  parallel_beam.hpp:36-51    */
+#define LFX_STAGE_SINGLE_BLOCK 16u  /* label the whole array as one block without borders (EdgeLabel::Assign, label.hpp:72-95) */
+#define LFX_STAGE_CURVATURE 32u     /* CalcCurvature must succeed (N >= 2P+1)  curvature.cpp:44-50 */
+#define LFX_STAGE_ALL 47u           /* what the fused ring kernel runs */
+int lfx_stage_ring(lfx_ctx *ctx, const lfx_params *params, uint32_t flags, uint32_t n, const float *x,
+                   const float *y, const int32_t *groups, const double *curvature_in,
+                   const double *range_in /* use these ranges instead of sqrt(x^2+y^2) (CalcCurvature tests) */,
+                   double *range_out /* [n]  Range, range.hpp:45-74 */,
+                   double *curvature_out /* [n]  CalcCurvature, curvature.cpp:44-50 */,
+                   uint8_t *link_out /* [n-1] IsNeighborXY(i,i+1), neighbor.hpp:44-48 */,
+                   uint8_t *labels_out /* [n] */, int32_t *ring_status_out);
+/* Convolution1D (convolution.cpp:35-66) for any odd weight; returns LFX_ERR_INVALID_ARGUMENT where the reference throws. */
+int lfx_stage_convolution1d(lfx_ctx *ctx, const double *input, uint32_t n, const double *weight, uint32_t m,
+                            double *out);
+/* ExtractAngleSortedRings (ring.hpp:141-147) alone: per-ring angle-sorted original indices. */
+int lfx_stage_ring_projection(lfx_ctx *ctx, const void *points, size_t n_points, uint32_t *sorted_index,
+                              uint32_t *n_rings, uint16_t *ring_id /* [256] */, uint32_t *ring_count /* [256] */);
+
+/* --- measurement ------------------------------------------------------------------------- */
+#define LFX_N_KERNELS 5   /* 0 ring_histogram 1 ring_scan 2 ring_scatter 3 ring_extract 4 feature_compact */
+int lfx_set_profiling(lfx_ctx *ctx, int enabled);
+/* Sum of HIP-event durations per kernel since profiling was enabled, and launches counted. */
+int lfx_kernel_times(lfx_ctx *ctx, double ms[LFX_N_KERNELS], uint64_t launches[LFX_N_KERNELS]);
+const char *lfx_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* LFX_H_ */

@@ -1,0 +1,110 @@
+"""ctypes binding of the C ABI in include/lfx.h (liblfx.so: HIP kernels + host side).
+
+There is no fallback: if the library has not been built, or no MI355X is present when a
+context is created, this raises.  Build with `python __graft_entry__.py` (or
+`make -C lidar_feature_extraction_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "liblfx.so")
+
+LFX_N_KERNELS = 5
+MAX_RINGS = 256
+
+STAGE_LABEL, STAGE_OCCLUSION, STAGE_OUT_OF_RANGE, STAGE_PARALLEL_BEAM = 1, 2, 4, 8
+STAGE_SINGLE_BLOCK, STAGE_CURVATURE, STAGE_ALL = 16, 32, 47
+
+
+class LfxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lfx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    """lfx_params == HyperParameters, extraction/include/lidar_feature_extraction/hyper_parameter.hpp:32-65"""
+    _fields_ = [("padding", C.c_int32), ("neighbor_degree_threshold", C.c_double),
+                ("distance_diff_threshold", C.c_double), ("parallel_beam_min_range_ratio", C.c_double),
+                ("edge_threshold", C.c_double), ("surface_threshold", C.c_double),
+                ("min_range", C.c_double), ("max_range", C.c_double), ("n_blocks", C.c_int32)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32),
+                ("off_z", C.c_uint32), ("off_ring", C.c_uint32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("max_points_per_scan", C.c_uint32), ("max_batch", C.c_uint32),
+                ("max_points_per_ring", C.c_uint32), ("max_rings", C.c_uint32), ("layout", Layout)]
+
+
+class ScanResult(C.Structure):
+    _fields_ = [("n_points", C.c_uint32), ("labels", C.POINTER(C.c_uint8)), ("curvature", C.POINTER(C.c_double)),
+                ("sorted_index", C.POINTER(C.c_uint32)), ("n_rings", C.c_uint32),
+                ("ring_id", C.POINTER(C.c_uint16)), ("ring_count", C.POINTER(C.c_uint32)),
+                ("ring_offset", C.POINTER(C.c_uint32)), ("ring_status", C.POINTER(C.c_uint8)),
+                ("n_edge", C.c_uint32), ("edge_points", C.POINTER(C.c_float)), ("edge_index", C.POINTER(C.c_uint32)),
+                ("n_surface", C.c_uint32), ("surface_points", C.POINTER(C.c_float)),
+                ("surface_index", C.POINTER(C.c_uint32))]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("batch", C.c_uint32)] + [(n, C.c_void_p) for n in (
+        "scan_begin", "labels_sorted", "curvature_sorted", "sorted_index", "scan_info", "ring_id",
+        "ring_count", "ring_offset", "ring_status", "edge_points", "edge_index", "surface_points",
+        "surface_index")]
+
+
+EXPORTS = [
+    "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
+    "lfx_status_string", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
+    "lfx_device_results", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
+    "lfx_stage_ring_projection", "lfx_set_profiling", "lfx_kernel_times", "lfx_kernel_name",
+]
+"""Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "liblfx.so is not built (%s): run `python __graft_entry__.py` -- there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    L.lfx_default_params.argtypes = [C.POINTER(Params)]
+    L.lfx_default_params.restype = None
+    L.lfx_launch_params.argtypes = [C.POINTER(Params)]
+    L.lfx_launch_params.restype = None
+    L.lfx_create.argtypes = [C.POINTER(vp), i32, C.POINTER(Params), C.POINTER(Config)]
+    L.lfx_destroy.argtypes = [vp]
+    L.lfx_destroy.restype = None
+    L.lfx_last_error.argtypes = [vp]
+    L.lfx_last_error.restype = C.c_char_p
+    L.lfx_status_string.argtypes = [i32]
+    L.lfx_status_string.restype = C.c_char_p
+    L.lfx_extract.argtypes = [vp, vp, C.c_size_t, C.POINTER(ScanResult)]
+    L.lfx_extract_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), u32, C.POINTER(ScanResult)]
+    L.lfx_extract_batch_device.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
+    L.lfx_device_results.argtypes = [vp, C.POINTER(DeviceView)]
+    L.lfx_download_scan.argtypes = [vp, u32, vp, C.POINTER(ScanResult)]
+    L.lfx_stage_ring.argtypes = [vp, C.POINTER(Params), u32, u32] + [vp] * 10
+    L.lfx_stage_convolution1d.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.lfx_stage_ring_projection.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(u32), vp, vp]
+    L.lfx_set_profiling.argtypes = [vp, i32]
+    L.lfx_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.lfx_kernel_name.argtypes = [i32]
+    L.lfx_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(ctx, rc):
+    if rc != 0:
+        raise LfxError(rc, (load().lfx_last_error(ctx) or b"").decode())

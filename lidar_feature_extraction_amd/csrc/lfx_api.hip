@@ -1,0 +1,714 @@
+// lfx_api.hip -- host side of the C ABI declared in include/lfx.h.
+//
+// Owns device scratch, turns the nine node parameters into kernel constants, launches the five
+// kernels of lfx_kernels.hpp on the caller's stream and moves results.  There is no CPU
+// implementation of the path here: without a gfx950 device every entry point fails.
+#include "../../include/lfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "lfx_kernels.hpp"
+
+namespace
+{
+
+std::string g_create_error;
+
+const char * kKernelNames[LFX_N_KERNELS] = {
+  "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_extract_kernel",
+  "feature_compact_kernel"};
+
+uint32_t next_pow2(uint32_t v)
+{
+  uint32_t p = 1;
+  while (p < v) {p <<= 1;}
+  return p;
+}
+
+// IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
+// acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
+// acos(c) < threshold, found by bisection over the ordered doubles with the HOST's acos -- the
+// same libm call the reference node makes on this machine.  (+inf: never a neighbour.)
+int64_t ordered_key(double d)
+{
+  int64_t k;
+  std::memcpy(&k, &d, 8);
+  return k < 0 ? std::numeric_limits<int64_t>::min() - k : k;
+}
+
+double from_ordered_key(int64_t k)
+{
+  const int64_t b = k < 0 ? std::numeric_limits<int64_t>::min() - k : k;
+  double d;
+  std::memcpy(&d, &b, 8);
+  return d;
+}
+
+double cos_bound(double radian_threshold)
+{
+  if (!(std::acos(1.0) < radian_threshold)) {return std::numeric_limits<double>::infinity();}
+  if (std::acos(-1.0) < radian_threshold) {return -1.0;}
+  int64_t lo = ordered_key(-1.0), hi = ordered_key(1.0);   // predicate false at lo, true at hi
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (std::acos(from_ordered_key(mid)) < radian_threshold) {hi = mid;} else {lo = mid;}
+  }
+  return from_ordered_key(hi);
+}
+
+template<typename T>
+struct DevBuf
+{
+  T * p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count)
+  {
+    n = count;
+    return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T) + 16);
+  }
+  void release()
+  {
+    if (p) {(void)hipFree(p);}
+    p = nullptr;
+  }
+};
+
+struct HostScan
+{
+  std::vector<uint8_t> labels, labels_sorted, ring_status;
+  std::vector<double> curvature, curvature_sorted;
+  std::vector<uint32_t> sorted_index, ring_count, ring_offset, edge_index, surface_index;
+  std::vector<uint16_t> ring_id;
+  std::vector<float> edge_points, surface_points;
+};
+
+}  // namespace
+
+struct lfx_ctx
+{
+  int device = 0;
+  lfx_params params{};
+  lfx::Params dev{};
+  lfx::Layout layout{};
+  uint32_t max_points = 0, max_batch = 0, cap = 0, max_chunks = 0, max_rings = 0, ring_threads = 0;
+  size_t total_cap = 0, ring_lds = 0;
+  std::string err;
+
+  // device scratch
+  DevBuf<uint32_t> scan_begin, scan_info, chunk_base, ring_off_by_id, ring_count, ring_offset, ring_nedge,
+    ring_nsurf, sidx, seg, edge_idx, surf_idx;
+  DevBuf<uint16_t> chunk_hist, ring_id;
+  DevBuf<uint8_t> ring_status, label_s, staging;
+  DevBuf<float> sx, sy;
+  DevBuf<double> curv_s;
+  DevBuf<float4> edge_pts, surf_pts;
+
+  hipStream_t stream = nullptr;          // used by the synchronous host entry points
+  std::vector<uint32_t> h_scan_begin;    // of the last batch
+  std::vector<uint32_t> uploaded_begin;  // what scan_begin on the device currently holds
+  uint32_t last_batch = 0;
+  const void * last_points = nullptr;
+  std::vector<HostScan> host;
+
+  bool profiling = false;
+  struct Span { hipEvent_t a, b; int k; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> free_events;
+  double ms[LFX_N_KERNELS] = {0, 0, 0, 0, 0};
+  uint64_t launches[LFX_N_KERNELS] = {0, 0, 0, 0, 0};
+};
+
+namespace
+{
+
+#define LFX_HIP(ctx, call) \
+  do { \
+    const hipError_t e_ = (call); \
+    if (e_ != hipSuccess) { \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      return LFX_ERR_HIP; \
+    } \
+  } while (0)
+
+int fail(lfx_ctx * ctx, int code, const std::string & msg)
+{
+  if (ctx) {ctx->err = msg;}
+  return code;
+}
+
+hipEvent_t take_event(lfx_ctx * c)
+{
+  if (!c->free_events.empty()) {
+    hipEvent_t e = c->free_events.back();
+    c->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct Timed
+{
+  Timed(lfx_ctx * c, int k, hipStream_t s)
+  : c_(c), k_(k), s_(s)
+  {
+    if (c_->profiling) {
+      a_ = take_event(c_);
+      b_ = take_event(c_);
+      (void)hipEventRecord(a_, s_);
+    }
+  }
+  ~Timed()
+  {
+    if (c_->profiling) {
+      (void)hipEventRecord(b_, s_);
+      c_->spans.push_back({a_, b_, k_});
+    }
+  }
+  lfx_ctx * c_;
+  int k_;
+  hipStream_t s_;
+  hipEvent_t a_ = nullptr, b_ = nullptr;
+};
+
+int drain_spans(lfx_ctx * c)
+{
+  for (auto & sp : c->spans) {
+    LFX_HIP(c, hipEventSynchronize(sp.b));
+    float t = 0.f;
+    LFX_HIP(c, hipEventElapsedTime(&t, sp.a, sp.b));
+    c->ms[sp.k] += t;
+    c->launches[sp.k] += 1;
+    c->free_events.push_back(sp.a);
+    c->free_events.push_back(sp.b);
+  }
+  c->spans.clear();
+  return LFX_OK;
+}
+
+int validate_params(const lfx_params * p, std::string & why)
+{
+  // hyper_parameter.hpp:45-53 asserts every parameter > 0
+  if (!p) {why = "params is NULL"; return LFX_ERR_INVALID_ARGUMENT;}
+  if (p->padding <= 0 || p->padding > LFX_MAX_PADDING) {
+    why = "convolution_padding must be in [1, " + std::to_string(LFX_MAX_PADDING) + "]";
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  if (p->n_blocks <= 0) {why = "n_blocks must be > 0"; return LFX_ERR_INVALID_ARGUMENT;}
+  if (!(p->neighbor_degree_threshold > 0) || !(p->distance_diff_threshold > 0) ||
+    !(p->parallel_beam_min_range_ratio > 0) || !(p->edge_threshold > 0) || !(p->surface_threshold > 0) ||
+    !(p->min_range > 0) || !(p->max_range > 0))
+  {
+    why = "every threshold / range parameter must be > 0 (hyper_parameter.hpp:45-53)";
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  return LFX_OK;
+}
+
+lfx::Params device_params(const lfx_params & p)
+{
+  lfx::Params d;
+  d.P = p.padding;
+  d.B = p.n_blocks;
+  d.cos_bound = cos_bound(p.neighbor_degree_threshold * M_PI / 180.0);   // degree_to_radian.hpp:34-37
+  d.dist_diff = p.distance_diff_threshold;
+  d.pb_ratio = p.parallel_beam_min_range_ratio;
+  d.edge_thr = p.edge_threshold;
+  d.surf_thr = p.surface_threshold;
+  d.min_range = p.min_range;
+  d.max_range = p.max_range;
+  return d;
+}
+
+uint32_t ring_threads_for(uint32_t cap)
+{
+  return cap >= 4096 ? 1024u : cap >= 2048 ? 512u : 256u;
+}
+
+// Launch the five kernels for `batch` scans whose records lie back to back at d_points.
+int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uint32_t batch, hipStream_t st)
+{
+  if (!d_points || !n_points || batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "empty batch");}
+  if (batch > c->max_batch) {return fail(c, LFX_ERR_CAPACITY, "batch exceeds max_batch");}
+  c->h_scan_begin.resize(batch + 1);
+  uint32_t longest = 0;
+  size_t total = 0;
+  for (uint32_t s = 0; s < batch; s++) {
+    if (n_points[s] > c->max_points) {return fail(c, LFX_ERR_CAPACITY, "scan exceeds max_points_per_scan");}
+    c->h_scan_begin[s] = (uint32_t)total;
+    total += n_points[s];
+    longest = n_points[s] > longest ? n_points[s] : longest;
+  }
+  c->h_scan_begin[batch] = (uint32_t)total;
+  if (total > c->total_cap) {return fail(c, LFX_ERR_CAPACITY, "batch exceeds the context's point capacity");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  if (c->uploaded_begin != c->h_scan_begin) {
+    // pageable source: the runtime stages it before returning, so the vector may change afterwards
+    LFX_HIP(c, hipMemcpyAsync(c->scan_begin.p, c->h_scan_begin.data(), (batch + 1) * 4, hipMemcpyHostToDevice, st));
+    c->uploaded_begin = c->h_scan_begin;
+  }
+  c->last_batch = batch;
+  c->last_points = d_points;
+  LFX_HIP(c, hipMemsetAsync(c->scan_info.p, 0, (size_t)batch * 16, st));
+  const uint8_t * pts = static_cast<const uint8_t *>(d_points);
+  const uint32_t chunks = (longest + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
+  if (chunks == 0) {return LFX_OK;}
+  {
+    Timed t(c, 0, st);
+    hipLaunchKernelGGL(lfx::ring_histogram_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
+      pts, c->layout, c->scan_begin.p, c->chunk_hist.p, c->scan_info.p, c->max_chunks);
+  }
+  {
+    Timed t(c, 1, st);
+    hipLaunchKernelGGL(lfx::ring_scan_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
+      c->scan_begin.p, c->chunk_hist.p, c->chunk_base.p, c->ring_off_by_id.p, c->ring_id.p, c->ring_count.p,
+      c->ring_offset.p, c->scan_info.p, c->max_chunks);
+  }
+  {
+    Timed t(c, 2, st);
+    hipLaunchKernelGGL(lfx::ring_scatter_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
+      pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->ring_off_by_id.p, c->sx.p, c->sy.p, c->sidx.p,
+      c->max_chunks);
+  }
+  {
+    Timed t(c, 3, st);
+    hipLaunchKernelGGL(lfx::ring_extract_kernel, dim3(c->max_rings, batch), dim3(c->ring_threads), c->ring_lds, st,
+      c->dev, c->cap, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->sx.p, c->sy.p,
+      c->sidx.p, c->label_s.p, c->curv_s.p, c->seg.p, c->ring_status.p, c->ring_nedge.p, c->ring_nsurf.p);
+  }
+  {
+    Timed t(c, 4, st);
+    hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3(c->max_rings, batch), dim3(256), 0, st,
+      pts, c->layout, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p,
+      c->ring_nsurf.p, c->sx.p, c->sy.p, c->sidx.p, c->curv_s.p, c->seg.p, c->edge_pts.p, c->edge_idx.p,
+      c->surf_pts.p, c->surf_idx.p);
+  }
+  LFX_HIP(c, hipGetLastError());
+  return LFX_OK;
+}
+
+int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
+{
+  if (s >= c->last_batch) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "scan index outside the last batch");}
+  if (c->host.size() < c->last_batch) {c->host.resize(c->last_batch);}
+  HostScan & h = c->host[s];
+  const uint32_t b = c->h_scan_begin[s], n = c->h_scan_begin[s + 1] - b;
+  uint32_t info[4] = {0, 0, 0, 0};
+  uint16_t rid[lfx::kRings];
+  uint32_t rcount[lfx::kRings], roff[lfx::kRings];
+  uint8_t rstat[lfx::kRings];
+  LFX_HIP(c, hipMemcpyAsync(info, c->scan_info.p + (size_t)s * 4, 16, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipMemcpyAsync(rid, c->ring_id.p + (size_t)s * lfx::kRings, sizeof(rid), hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipMemcpyAsync(rcount, c->ring_count.p + (size_t)s * lfx::kRings, sizeof(rcount), hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipMemcpyAsync(roff, c->ring_offset.p + (size_t)s * lfx::kRings, sizeof(roff), hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipMemcpyAsync(rstat, c->ring_status.p + (size_t)s * lfx::kRings, sizeof(rstat), hipMemcpyDeviceToHost, st));
+  h.labels_sorted.resize(n);
+  h.curvature_sorted.resize(n);
+  h.sorted_index.resize(n);
+  if (n) {
+    LFX_HIP(c, hipMemcpyAsync(h.labels_sorted.data(), c->label_s.p + b, n, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.curvature_sorted.data(), c->curv_s.p + b, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.sorted_index.data(), c->sidx.p + b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  }
+  LFX_HIP(c, hipStreamSynchronize(st));
+  if (info[lfx::kInfoError] & 1u) {
+    return fail(c, LFX_ERR_RING_ID, "a point carries a ring id above LFX_MAX_RING_ID");
+  }
+  const uint32_t nr = info[lfx::kInfoRings];
+  if (nr > c->max_rings) {
+    return fail(c, LFX_ERR_CAPACITY, "scan holds more rings than the context's max_rings");
+  }
+  const uint32_t ne = info[lfx::kInfoEdge], ns = info[lfx::kInfoSurface];
+  h.edge_points.resize((size_t)ne * 4);
+  h.edge_index.resize(ne);
+  h.surface_points.resize((size_t)ns * 4);
+  h.surface_index.resize(ns);
+  if (ne) {
+    LFX_HIP(c, hipMemcpyAsync(h.edge_points.data(), c->edge_pts.p + b, (size_t)ne * 16, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.edge_index.data(), c->edge_idx.p + b, (size_t)ne * 4, hipMemcpyDeviceToHost, st));
+  }
+  if (ns) {
+    LFX_HIP(c, hipMemcpyAsync(h.surface_points.data(), c->surf_pts.p + b, (size_t)ns * 16, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.surface_index.data(), c->surf_idx.p + b, (size_t)ns * 4, hipMemcpyDeviceToHost, st));
+  }
+  LFX_HIP(c, hipStreamSynchronize(st));
+  h.ring_id.assign(rid, rid + nr);
+  h.ring_count.assign(rcount, rcount + nr);
+  h.ring_offset.assign(roff, roff + nr);
+  h.ring_status.assign(rstat, rstat + nr);
+  // back to the caller's point order (labels[k] / curvature[k] belong to input point k)
+  h.labels.assign(n, LFX_LABEL_DEFAULT);
+  h.curvature.assign(n, 0.0);
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t o = h.sorted_index[k];
+    if (o < n) {
+      h.labels[o] = h.labels_sorted[k];
+      h.curvature[o] = h.curvature_sorted[k];
+    }
+  }
+  if (out) {
+    out->n_points = n;
+    out->labels = h.labels.data();
+    out->curvature = h.curvature.data();
+    out->sorted_index = h.sorted_index.data();
+    out->n_rings = nr;
+    out->ring_id = h.ring_id.data();
+    out->ring_count = h.ring_count.data();
+    out->ring_offset = h.ring_offset.data();
+    out->ring_status = h.ring_status.data();
+    out->n_edge = ne;
+    out->edge_points = h.edge_points.data();
+    out->edge_index = h.edge_index.data();
+    out->n_surface = ns;
+    out->surface_points = h.surface_points.data();
+    out->surface_index = h.surface_index.data();
+  }
+  return LFX_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+void lfx_default_params(lfx_params * p)   // hyper_parameter.hpp:35-43
+{
+  if (!p) {return;}
+  *p = lfx_params{5, 2.0, 0.3, 0.02, 0.05, 0.05, 0.1, 100.0, 6};
+}
+
+void lfx_launch_params(lfx_params * p)   // lidar_feature_launch/config/lidar_feature_extraction.param.yaml:3-10
+{
+  if (!p) {return;}
+  *p = lfx_params{2, 3.0, 0.3, 0.02, 50.0, 0.05, 0.1, 1000.0, 6};
+}
+
+const char * lfx_status_string(int s)
+{
+  switch (s) {
+    case LFX_RING_OK: return "ok";
+    case LFX_RING_SPARSE: return "ring has fewer than padding+1 points (removed)";
+    case LFX_RING_TOO_FEW_CONV: return "ring has fewer than 2*padding+1 points (convolution)";
+    case LFX_RING_TOO_FEW_BLOCKS: return "ring has fewer than n_blocks points between its borders";
+    case LFX_RING_BLOCK_TOO_SMALL: return "a block of the ring holds fewer than 2 points";
+    case LFX_RING_ZERO_NORM_PAIR: return "two adjacent points are both (0,0) in xy";
+    case LFX_RING_TOO_LARGE: return "ring holds more points than max_points_per_ring";
+    default: return "unknown";
+  }
+}
+
+const char * lfx_kernel_name(int k) {return (k >= 0 && k < LFX_N_KERNELS) ? kKernelNames[k] : "";}
+
+const char * lfx_last_error(const lfx_ctx * ctx) {return ctx ? ctx->err.c_str() : g_create_error.c_str();}
+
+int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const lfx_config * config)
+{
+  if (!out) {return LFX_ERR_INVALID_ARGUMENT;}
+  *out = nullptr;
+  std::string why;
+  if (validate_params(params, why) != LFX_OK) {g_create_error = why; return LFX_ERR_INVALID_ARGUMENT;}
+  if (!config || config->max_points_per_scan == 0 || config->max_batch == 0) {
+    g_create_error = "config must give max_points_per_scan and max_batch";
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) {
+    g_create_error = "no HIP device: this library has no CPU path";
+    return LFX_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is not gfx950 (MI355X): ") + prop.gcnArchName;
+    return LFX_ERR_NO_DEVICE;
+  }
+  lfx_ctx * c = new lfx_ctx();
+  c->device = device_id;
+  c->params = *params;
+  c->dev = device_params(*params);
+  const lfx_layout & L = config->layout;
+  if (L.point_step == 0) {
+    c->layout = lfx::Layout{32, 0, 4, 8, 20};     // PointXYZIR, point_type.hpp:62-86
+  } else {
+    if (L.point_step % 4 || L.off_x % 4 || L.off_y % 4 || L.off_z % 4 || L.off_ring % 2 ||
+      L.off_x + 4 > L.point_step || L.off_y + 4 > L.point_step || L.off_z + 4 > L.point_step ||
+      L.off_ring + 2 > L.point_step)
+    {
+      delete c;
+      g_create_error = "layout: fields must be aligned and lie inside point_step";
+      return LFX_ERR_INVALID_ARGUMENT;
+    }
+    c->layout = lfx::Layout{L.point_step, L.off_x, L.off_y, L.off_z, L.off_ring};
+  }
+  c->max_points = config->max_points_per_scan;
+  c->max_batch = config->max_batch;
+  uint32_t ring_cap = config->max_points_per_ring ? config->max_points_per_ring : LFX_MAX_RING_POINTS;
+  ring_cap = ring_cap > c->max_points ? c->max_points : ring_cap;
+  c->cap = next_pow2(ring_cap < 64 ? 64 : ring_cap);
+  if (c->cap > LFX_MAX_RING_POINTS) {
+    delete c;
+    g_create_error = "max_points_per_ring exceeds LFX_MAX_RING_POINTS";
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  c->max_rings = config->max_rings ? (config->max_rings > lfx::kRings ? lfx::kRings : config->max_rings) : lfx::kRings;
+  c->ring_threads = ring_threads_for(c->cap);
+  c->ring_lds = lfx::ring_lds_bytes(c->cap);
+  c->max_chunks = (c->max_points + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
+  c->total_cap = (size_t)c->max_points * c->max_batch;
+  if (c->total_cap >= (1ull << 32)) {
+    delete c;
+    g_create_error = "max_points_per_scan * max_batch must stay below 2^32";
+    return LFX_ERR_CAPACITY;
+  }
+
+  hipError_t e = hipSetDevice(device_id);
+  const size_t nb = c->max_batch, tc = c->total_cap, tables = nb * lfx::kRings, chunk_tab = nb * c->max_chunks * lfx::kRings;
+  auto ok = [&](hipError_t r) {if (e == hipSuccess) {e = r;}};
+  ok(c->scan_begin.alloc(nb + 1)); ok(c->scan_info.alloc(nb * 4));
+  ok(c->chunk_hist.alloc(chunk_tab)); ok(c->chunk_base.alloc(chunk_tab));
+  ok(c->ring_off_by_id.alloc(tables)); ok(c->ring_id.alloc(tables)); ok(c->ring_count.alloc(tables));
+  ok(c->ring_offset.alloc(tables)); ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
+  ok(c->ring_nsurf.alloc(tables));
+  ok(c->sx.alloc(tc)); ok(c->sy.alloc(tc)); ok(c->sidx.alloc(tc)); ok(c->seg.alloc(tc));
+  ok(c->label_s.alloc(tc)); ok(c->curv_s.alloc(tc));
+  ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
+  if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
+  if (e == hipSuccess) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_extract_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ring_lds);
+  }
+  if (e == hipSuccess) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_stage_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx::ring_lds_bytes(LFX_MAX_RING_POINTS));
+  }
+  if (e != hipSuccess) {
+    g_create_error = std::string("device setup failed: ") + hipGetErrorString(e);
+    lfx_destroy(c);
+    return e == hipErrorOutOfMemory ? LFX_ERR_OUT_OF_MEMORY : LFX_ERR_HIP;
+  }
+  *out = c;
+  return LFX_OK;
+}
+
+void lfx_destroy(lfx_ctx * c)
+{
+  if (!c) {return;}
+  (void)hipSetDevice(c->device);
+  if (c->stream) {(void)hipStreamSynchronize(c->stream);}
+  for (auto & sp : c->spans) {(void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);}
+  for (auto & ev : c->free_events) {(void)hipEventDestroy(ev);}
+  c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
+  c->ring_off_by_id.release(); c->ring_id.release(); c->ring_count.release(); c->ring_offset.release();
+  c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release();
+  c->sx.release(); c->sy.release(); c->sidx.release(); c->seg.release(); c->label_s.release();
+  c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
+  c->staging.release();
+  if (c->stream) {(void)hipStreamDestroy(c->stream);}
+  delete c;
+}
+
+int lfx_extract_batch_device(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uint32_t batch, void * stream)
+{
+  if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  return run_batch(c, d_points, n_points, batch, static_cast<hipStream_t>(stream));
+}
+
+int lfx_device_results(const lfx_ctx * c, lfx_device_view * v)
+{
+  if (!c || !v) {return LFX_ERR_INVALID_ARGUMENT;}
+  v->batch = c->last_batch;
+  v->scan_begin = c->scan_begin.p;
+  v->labels_sorted = c->label_s.p;
+  v->curvature_sorted = c->curv_s.p;
+  v->sorted_index = c->sidx.p;
+  v->scan_info = c->scan_info.p;
+  v->ring_id = c->ring_id.p;
+  v->ring_count = c->ring_count.p;
+  v->ring_offset = c->ring_offset.p;
+  v->ring_status = c->ring_status.p;
+  v->edge_points = reinterpret_cast<const float *>(c->edge_pts.p);
+  v->edge_index = c->edge_idx.p;
+  v->surface_points = reinterpret_cast<const float *>(c->surf_pts.p);
+  v->surface_index = c->surf_idx.p;
+  return LFX_OK;
+}
+
+int lfx_download_scan(lfx_ctx * c, uint32_t scan, void * stream, lfx_scan_result * out)
+{
+  if (!c || !out) {return LFX_ERR_INVALID_ARGUMENT;}
+  LFX_HIP(c, hipSetDevice(c->device));
+  return download(c, scan, static_cast<hipStream_t>(stream), out);
+}
+
+int lfx_extract_batch(
+  lfx_ctx * c, const void * const * points, const size_t * n_points, uint32_t batch, lfx_scan_result * out)
+{
+  if (!c || !points || !n_points || !out || batch == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (batch > c->max_batch) {return fail(c, LFX_ERR_CAPACITY, "batch exceeds max_batch");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  std::vector<uint32_t> n32(batch);
+  size_t total = 0;
+  for (uint32_t s = 0; s < batch; s++) {
+    if (n_points[s] > c->max_points) {return fail(c, LFX_ERR_CAPACITY, "scan exceeds max_points_per_scan");}
+    if (n_points[s] && !points[s]) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "points[s] is NULL");}
+    n32[s] = (uint32_t)n_points[s];
+    total += n_points[s];
+  }
+  if (total == 0) {
+    for (uint32_t s = 0; s < batch; s++) {std::memset(&out[s], 0, sizeof(out[s]));}
+    return LFX_OK;
+  }
+  if (!c->staging.p) {
+    if (c->staging.alloc(c->total_cap * c->layout.step) != hipSuccess) {
+      return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the input staging buffer");
+    }
+  }
+  size_t at = 0;
+  for (uint32_t s = 0; s < batch; s++) {
+    const size_t bytes = n_points[s] * c->layout.step;
+    if (bytes) {
+      LFX_HIP(c, hipMemcpyAsync(c->staging.p + at, points[s], bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    at += bytes;
+  }
+  const int rc = run_batch(c, c->staging.p, n32.data(), batch, c->stream);
+  if (rc != LFX_OK) {return rc;}
+  for (uint32_t s = 0; s < batch; s++) {
+    const int r = download(c, s, c->stream, &out[s]);
+    if (r != LFX_OK) {return r;}
+  }
+  return LFX_OK;
+}
+
+int lfx_extract(lfx_ctx * c, const void * points, size_t n_points, lfx_scan_result * out)
+{
+  const void * p[1] = {points};
+  const size_t n[1] = {n_points};
+  return lfx_extract_batch(c, p, n, 1, out);
+}
+
+// ---------------------------------------------------------------------------- stage entry points
+int lfx_stage_ring(
+  lfx_ctx * c, const lfx_params * params, uint32_t flags, uint32_t n, const float * x, const float * y,
+  const int32_t * groups, const double * curvature_in, const double * range_in, double * range_out,
+  double * curvature_out, uint8_t * link_out, uint8_t * labels_out, int32_t * ring_status_out)
+{
+  if (!c || !x || !y || n == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  const lfx_params * pp = params ? params : &c->params;
+  std::string why;
+  if (validate_params(pp, why) != LFX_OK) {return fail(c, LFX_ERR_INVALID_ARGUMENT, why);}
+  if (n > LFX_MAX_RING_POINTS) {return fail(c, LFX_ERR_CAPACITY, "ring longer than LFX_MAX_RING_POINTS");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  const lfx::Params dp = device_params(*pp);
+  const uint32_t cap = next_pow2(n < 64 ? 64 : n);
+  float * dx = nullptr, * dy = nullptr;
+  int32_t * dg = nullptr, * dstat = nullptr;
+  double * dci = nullptr, * dri = nullptr, * dr = nullptr, * dc = nullptr;
+  uint8_t * dl = nullptr, * dlab = nullptr;
+  auto cleanup = [&] {
+      (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dg); (void)hipFree(dstat); (void)hipFree(dci); (void)hipFree(dri);
+      (void)hipFree(dr); (void)hipFree(dc); (void)hipFree(dl); (void)hipFree(dlab);
+    };
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) {if (e == hipSuccess) {e = r;}};
+  ok(hipMalloc(&dx, n * 4)); ok(hipMalloc(&dy, n * 4)); ok(hipMalloc(&dstat, 4));
+  ok(hipMalloc(&dr, n * 8)); ok(hipMalloc(&dc, n * 8)); ok(hipMalloc(&dl, n)); ok(hipMalloc(&dlab, n));
+  if (groups) {ok(hipMalloc(&dg, n * 4));}
+  if (curvature_in) {ok(hipMalloc(&dci, n * 8));}
+  if (range_in) {ok(hipMalloc(&dri, n * 8));}
+  if (e == hipSuccess) {
+    ok(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    ok(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+    if (groups) {ok(hipMemcpy(dg, groups, n * 4, hipMemcpyHostToDevice));}
+    if (curvature_in) {ok(hipMemcpy(dci, curvature_in, n * 8, hipMemcpyHostToDevice));}
+    if (range_in) {ok(hipMemcpy(dri, range_in, n * 8, hipMemcpyHostToDevice));}
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lfx::ring_stage_kernel, dim3(1), dim3(256), lfx::ring_lds_bytes(cap), c->stream,
+      dp, cap, flags, (int)n, dx, dy, dg, dci, dri, dr, dc, dl, dlab, dstat);
+    ok(hipGetLastError());
+    ok(hipStreamSynchronize(c->stream));
+  }
+  if (e == hipSuccess) {
+    if (range_out) {ok(hipMemcpy(range_out, dr, n * 8, hipMemcpyDeviceToHost));}
+    if (curvature_out) {ok(hipMemcpy(curvature_out, dc, n * 8, hipMemcpyDeviceToHost));}
+    if (link_out && n > 1) {ok(hipMemcpy(link_out, dl, n - 1, hipMemcpyDeviceToHost));}
+    if (labels_out) {ok(hipMemcpy(labels_out, dlab, n, hipMemcpyDeviceToHost));}
+    if (ring_status_out) {ok(hipMemcpy(ring_status_out, dstat, 4, hipMemcpyDeviceToHost));}
+  }
+  cleanup();
+  if (e != hipSuccess) {return fail(c, LFX_ERR_HIP, std::string("lfx_stage_ring: ") + hipGetErrorString(e));}
+  return LFX_OK;
+}
+
+int lfx_stage_convolution1d(lfx_ctx * c, const double * input, uint32_t n, const double * weight, uint32_t m, double * out)
+{
+  if (!c || !input || !weight || !out || m == 0 || (m % 2) == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (n < m) {   // convolution.cpp:39-43 throws std::invalid_argument
+    return fail(c, LFX_ERR_INVALID_ARGUMENT, "Input array size cannot be smaller than weight size");
+  }
+  LFX_HIP(c, hipSetDevice(c->device));
+  double * di = nullptr, * dw = nullptr, * dout = nullptr;
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) {if (e == hipSuccess) {e = r;}};
+  ok(hipMalloc(&di, n * 8)); ok(hipMalloc(&dw, m * 8)); ok(hipMalloc(&dout, n * 8));
+  if (e == hipSuccess) {
+    ok(hipMemcpy(di, input, n * 8, hipMemcpyHostToDevice));
+    ok(hipMemcpy(dw, weight, m * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(lfx::convolution1d_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+      di, (int)n, dw, (int)m, dout);
+    ok(hipGetLastError());
+    ok(hipStreamSynchronize(c->stream));
+    ok(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(di); (void)hipFree(dw); (void)hipFree(dout);
+  if (e != hipSuccess) {return fail(c, LFX_ERR_HIP, std::string("lfx_stage_convolution1d: ") + hipGetErrorString(e));}
+  return LFX_OK;
+}
+
+int lfx_stage_ring_projection(
+  lfx_ctx * c, const void * points, size_t n_points, uint32_t * sorted_index, uint32_t * n_rings,
+  uint16_t * ring_id, uint32_t * ring_count)
+{
+  if (!c || !sorted_index) {return LFX_ERR_INVALID_ARGUMENT;}
+  lfx_scan_result r;
+  const int rc = lfx_extract(c, points, n_points, &r);
+  if (rc != LFX_OK) {return rc;}
+  std::memcpy(sorted_index, r.sorted_index, (size_t)r.n_points * 4);
+  if (n_rings) {*n_rings = r.n_rings;}
+  for (uint32_t k = 0; k < r.n_rings; k++) {
+    if (ring_id) {ring_id[k] = r.ring_id[k];}
+    if (ring_count) {ring_count[k] = r.ring_count[k];}
+  }
+  return LFX_OK;
+}
+
+// ---------------------------------------------------------------------------- measurement
+int lfx_set_profiling(lfx_ctx * c, int enabled)
+{
+  if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  const int rc = drain_spans(c);
+  c->profiling = enabled != 0;
+  for (int k = 0; k < LFX_N_KERNELS; k++) {c->ms[k] = 0; c->launches[k] = 0;}
+  return rc;
+}
+
+int lfx_kernel_times(lfx_ctx * c, double ms[LFX_N_KERNELS], uint64_t launches[LFX_N_KERNELS])
+{
+  if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  const int rc = drain_spans(c);
+  for (int k = 0; k < LFX_N_KERNELS; k++) {
+    if (ms) {ms[k] = c->ms[k];}
+    if (launches) {launches[k] = c->launches[k];}
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,211 @@
+"""Host-side mirror of the reference's extraction node for tests, the bench and Python users.
+
+The reference operator is the body of FeatureExtraction::Callback
+(/root/reference/extraction/app/feature_extraction.cpp:114-157); its construction reads the
+nine HyperParameters (hyper_parameter.hpp:32-65).  `FeatureExtraction` here keeps those names:
+construct with HyperParameters, call ExtractFeatures(cloud) per scan.  Everything runs in the
+HIP library through the C ABI (binding.py); nothing is computed in Python.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import binding as B
+from .synth import POINT_DTYPE
+
+LABEL_NAMES = ["Default", "Edge", "EdgeNeighbor", "Surface", "SurfaceNeighbor", "OutOfRange",
+               "Occluded", "ParallelBeam"]          # point_label.hpp:32-42
+RING_STATUS_NAMES = {0: "ok", 1: "sparse", 2: "too_few_for_convolution", 3: "too_few_for_blocks",
+                     4: "block_too_small", 5: "zero_norm_pair", 7: "too_large"}
+
+
+@dataclass
+class HyperParameters:
+    """hyper_parameter.hpp:35-43 (code defaults)."""
+    padding: int = 5
+    neighbor_degree_threshold: float = 2.0
+    distance_diff_threshold: float = 0.3
+    parallel_beam_min_range_ratio: float = 0.02
+    edge_threshold: float = 0.05
+    surface_threshold: float = 0.05
+    min_range: float = 0.1
+    max_range: float = 100.0
+    n_blocks: int = 6
+
+    @staticmethod
+    def launch_yaml():
+        """lidar_feature_launch/config/lidar_feature_extraction.param.yaml:3-10"""
+        return HyperParameters(padding=2, neighbor_degree_threshold=3.0, edge_threshold=50.0, max_range=1000.0)
+
+    def to_c(self):
+        return B.Params(self.padding, self.neighbor_degree_threshold, self.distance_diff_threshold,
+                        self.parallel_beam_min_range_ratio, self.edge_threshold, self.surface_threshold,
+                        self.min_range, self.max_range, self.n_blocks)
+
+
+@dataclass
+class ScanFeatures:
+    labels: np.ndarray          # u8 [n], original point order
+    curvature: np.ndarray       # f64 [n], original point order
+    sorted_index: np.ndarray    # u32 [n], rings ascending / angle ascending
+    ring_id: np.ndarray
+    ring_count: np.ndarray
+    ring_offset: np.ndarray
+    ring_status: np.ndarray
+    edge_points: np.ndarray     # f32 [n_edge,4]: x y z (float)curvature
+    edge_index: np.ndarray      # u32 [n_edge] original indices
+    surface_points: np.ndarray
+    surface_index: np.ndarray
+
+    @property
+    def edge_xyz(self):
+        """what the node publishes on scan_edge (ToPointXYZ, feature_extraction.cpp:163)"""
+        return self.edge_points[:, :3]
+
+    @property
+    def surface_xyz(self):
+        return self.surface_points[:, :3]
+
+
+def _np(ptr, n, dtype, shape=None):
+    if n == 0:
+        return np.zeros((0,) + tuple(shape[1:]) if shape else 0, dtype)
+    a = np.ctypeslib.as_array(ptr, shape=(n,) if shape is None else shape).astype(dtype, copy=True)
+    return a
+
+
+def _result(r):
+    ne, ns, n, nr = r.n_edge, r.n_surface, r.n_points, r.n_rings
+    return ScanFeatures(
+        labels=_np(r.labels, n, np.uint8), curvature=_np(r.curvature, n, np.float64),
+        sorted_index=_np(r.sorted_index, n, np.uint32),
+        ring_id=_np(r.ring_id, nr, np.uint16), ring_count=_np(r.ring_count, nr, np.uint32),
+        ring_offset=_np(r.ring_offset, nr, np.uint32), ring_status=_np(r.ring_status, nr, np.uint8),
+        edge_points=_np(r.edge_points, ne, np.float32, (ne, 4)) if ne else np.zeros((0, 4), np.float32),
+        edge_index=_np(r.edge_index, ne, np.uint32),
+        surface_points=_np(r.surface_points, ns, np.float32, (ns, 4)) if ns else np.zeros((0, 4), np.float32),
+        surface_index=_np(r.surface_index, ns, np.uint32))
+
+
+class FeatureExtraction:
+    """One context = one GPU = one calling thread (feature_extraction.cpp:65-87,185)."""
+
+    def __init__(self, params=None, device=0, max_points_per_scan=262144, max_batch=1,
+                 max_points_per_ring=0, max_rings=0):
+        self._L = B.load()
+        self.params = params or HyperParameters()
+        self._ctx = C.c_void_p()
+        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, B.Layout(0, 0, 0, 0, 0))
+        cp = self.params.to_c()
+        rc = self._L.lfx_create(C.byref(self._ctx), device, C.byref(cp), C.byref(cfg))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise B.LfxError(rc, (self._L.lfx_last_error(None) or b"").decode())
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.lfx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- the operator ------------------------------------------------------------------
+    def ExtractFeatures(self, cloud):
+        """cloud: POINT_DTYPE array (PointXYZIR records).  Returns ScanFeatures."""
+        return self.extract_batch([cloud])[0]
+
+    def extract_batch(self, clouds):
+        clouds = [np.ascontiguousarray(c) for c in clouds]
+        for c in clouds:
+            if c.dtype != POINT_DTYPE:
+                raise TypeError("clouds must be POINT_DTYPE (32-byte PointXYZIR) arrays")
+        nb = len(clouds)
+        ptrs = (C.c_void_p * nb)(*[c.ctypes.data for c in clouds])
+        ns = (C.c_size_t * nb)(*[len(c) for c in clouds])
+        res = (B.ScanResult * nb)()
+        B.check(self._ctx, self._L.lfx_extract_batch(self._ctx, ptrs, ns, nb, res))
+        return [_result(res[i]) for i in range(nb)]
+
+    def extract_batch_device(self, d_points, n_points, stream=0):
+        """d_points: device address of the scans' records back to back; asynchronous on `stream`."""
+        n = np.ascontiguousarray(n_points, dtype=np.uint32)
+        B.check(self._ctx, self._L.lfx_extract_batch_device(
+            self._ctx, C.c_void_p(int(d_points)), n.ctypes.data_as(C.POINTER(C.c_uint32)), len(n),
+            C.c_void_p(int(stream))))
+
+    def device_view(self):
+        v = B.DeviceView()
+        B.check(self._ctx, self._L.lfx_device_results(self._ctx, C.byref(v)))
+        return v
+
+    def download(self, scan, stream=0):
+        r = B.ScanResult()
+        B.check(self._ctx, self._L.lfx_download_scan(self._ctx, scan, C.c_void_p(int(stream)), C.byref(r)))
+        return _result(r)
+
+    # --- per-stage entry points ------------------------------------------------------------
+    def stage_ring(self, x, y, flags, params=None, groups=None, curvature_in=None, range_in=None):
+        """Run selected stages of the ring kernel on one angle-sorted ring.
+        Returns dict(range, curvature, link, labels, status)."""
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        n = len(x)
+        g = None if groups is None else np.ascontiguousarray(groups, np.int32)
+        ci = None if curvature_in is None else np.ascontiguousarray(curvature_in, np.float64)
+        ri = None if range_in is None else np.ascontiguousarray(range_in, np.float64)
+        out_r, out_c = np.zeros(n), np.zeros(n)
+        out_l, out_lab = np.zeros(max(n - 1, 0), np.uint8), np.zeros(n, np.uint8)
+        st = C.c_int32(0)
+        cp = (params or self.params).to_c()
+
+        def p(a):
+            return None if a is None else C.c_void_p(a.ctypes.data)
+
+        B.check(self._ctx, self._L.lfx_stage_ring(
+            self._ctx, C.byref(cp), flags, n, p(x), p(y), p(g), p(ci), p(ri), p(out_r), p(out_c),
+            p(out_l) if n > 1 else None, p(out_lab), C.cast(C.byref(st), C.c_void_p)))
+        return {"range": out_r, "curvature": out_c, "link": out_l.astype(bool), "labels": out_lab,
+                "status": st.value}
+
+    def convolution1d(self, values, weight):
+        """Convolution1D, convolution.cpp:35-66 (raises LfxError where the reference throws)."""
+        v = np.ascontiguousarray(values, np.float64)
+        w = np.ascontiguousarray(weight, np.float64)
+        out = np.zeros(len(v))
+        B.check(self._ctx, self._L.lfx_stage_convolution1d(
+            self._ctx, C.c_void_p(v.ctypes.data), len(v), C.c_void_p(w.ctypes.data), len(w),
+            C.c_void_p(out.ctypes.data)))
+        return out
+
+    def ring_projection(self, cloud):
+        """ExtractAngleSortedRings, ring.hpp:141-147 -> {ring id: sorted original indices}."""
+        cloud = np.ascontiguousarray(cloud)
+        n = len(cloud)
+        idx = np.zeros(n, np.uint32)
+        nr = C.c_uint32(0)
+        rid = np.zeros(B.MAX_RINGS, np.uint16)
+        cnt = np.zeros(B.MAX_RINGS, np.uint32)
+        B.check(self._ctx, self._L.lfx_stage_ring_projection(
+            self._ctx, C.c_void_p(cloud.ctypes.data), n, C.c_void_p(idx.ctypes.data), C.byref(nr),
+            C.c_void_p(rid.ctypes.data), C.c_void_p(cnt.ctypes.data)))
+        out, off = {}, 0
+        for k in range(nr.value):
+            out[int(rid[k])] = idx[off:off + cnt[k]].copy()
+            off += int(cnt[k])
+        return out
+
+    # --- measurement ---------------------------------------------------------------------
+    def set_profiling(self, on):
+        B.check(self._ctx, self._L.lfx_set_profiling(self._ctx, int(bool(on))))
+
+    def kernel_times(self):
+        ms = (C.c_double * B.LFX_N_KERNELS)()
+        cnt = (C.c_uint64 * B.LFX_N_KERNELS)()
+        B.check(self._ctx, self._L.lfx_kernel_times(self._ctx, ms, cnt))
+        return {self._L.lfx_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(B.LFX_N_KERNELS)}

@@ -1,0 +1,85 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/lfx.h
+declares, and refuses to run without a device (no CPU fallback).  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from lidar_feature_extraction_amd import binding as LB
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LB.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return LB.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "lfx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lfx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "liblfx.so does not export " + n
+    assert sorted(LB.EXPORTS) == names
+
+
+def test_parameter_sets(lib):
+    p = LB.Params()
+    lib.lfx_default_params(C.byref(p))      # hyper_parameter.hpp:35-43
+    assert (p.padding, p.neighbor_degree_threshold, p.distance_diff_threshold, p.parallel_beam_min_range_ratio,
+            p.edge_threshold, p.surface_threshold, p.min_range, p.max_range, p.n_blocks) == \
+        (5, 2.0, 0.3, 0.02, 0.05, 0.05, 0.1, 100.0, 6)
+    lib.lfx_launch_params(C.byref(p))       # lidar_feature_extraction.param.yaml:3-10
+    assert (p.padding, p.neighbor_degree_threshold, p.edge_threshold, p.surface_threshold, p.max_range, p.n_blocks) == \
+        (2, 3.0, 50.0, 0.05, 1000.0, 6)
+
+
+def test_invalid_arguments_are_rejected_before_any_device_work(lib):
+    ctx = C.c_void_p()
+    p = LB.Params()
+    lib.lfx_default_params(C.byref(p))
+    cfg = LB.Config(1000, 1, 0, 0, LB.Layout(0, 0, 0, 0, 0))
+    p.padding = 0                            # hyper_parameter.hpp:45 asserts padding > 0
+    assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg)) == -1
+    p.padding = 99
+    assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg)) == -1
+    lib.lfx_default_params(C.byref(p))
+    cfg0 = LB.Config(0, 1, 0, 0, LB.Layout(0, 0, 0, 0, 0))
+    assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg0)) == -1
+    assert lib.lfx_status_string(5).decode().startswith("two adjacent points")
+    assert lib.lfx_kernel_name(3) == b"ring_extract_kernel"
+
+
+def test_no_cpu_fallback_without_a_device(lib):
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    p = LB.Params()
+    lib.lfx_default_params(C.byref(p))
+    cfg = LB.Config(1000, 1, 0, 0, LB.Layout(0, 0, 0, 0, 0))
+    assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg)) == -2          # LFX_ERR_NO_DEVICE
+    assert b"no CPU path" in lib.lfx_last_error(None)
+    from lidar_feature_extraction_amd import FeatureExtraction
+    with pytest.raises(LB.LfxError):
+        FeatureExtraction(max_points_per_scan=1000)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may reference it."""
+    for base in ("lidar_feature_extraction_amd", "include"):
+        for dirpath, _d, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle" not in text.lower().replace("no cpu", ""), os.path.join(dirpath, f)

@@ -1,0 +1,481 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle on
+the same seeded inputs, plus the reference's own unit-test vectors run through the device stages.
+All marked gpu; run on the MI355X box with `pytest -m gpu`."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, POINT_DTYPE  # noqa: E402
+from lidar_feature_extraction_amd import binding as LB  # noqa: E402
+from oracle import binding as OB  # noqa: E402
+from tests.parity import assert_scan_equal, status_codes_equal_where_single_cause  # noqa: E402
+
+LAB = OB.LABEL
+
+
+def oracle_params(hp):
+    return OB.Params(hp.padding, hp.neighbor_degree_threshold, hp.distance_diff_threshold,
+                     hp.parallel_beam_min_range_ratio, hp.edge_threshold, hp.surface_threshold,
+                     hp.min_range, hp.max_range, hp.n_blocks)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    f = FeatureExtraction(device=0, max_points_per_scan=262144, max_batch=8)
+    yield f
+    f.close()
+
+
+def names(labels):
+    return [OB.LABEL_NAMES[v] for v in labels]
+
+
+def xy(points):
+    p = np.asarray(points, dtype=np.float32).reshape(-1, 2)
+    return np.ascontiguousarray(p[:, 0]), np.ascontiguousarray(p[:, 1])
+
+
+# ------------------------------------------------------------------ whole scans vs the oracle
+PARAM_SETS = {"defaults": HyperParameters(), "launch_yaml": HyperParameters.launch_yaml()}
+
+
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+@pytest.mark.parametrize("shape", [(16, 900, 15.0), (16, 1800, 15.0), (64, 1800, 15.0), (128, 2048, 22.5)])
+def test_scan_parity(shape, pname):
+    rings, cols, vfov = shape
+    hp = PARAM_SETS[pname]
+    f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=2,
+                          max_points_per_ring=cols, max_rings=rings)
+    clouds = [make_scan(rings, cols, seed=1234 + i, vfov_deg=vfov) for i in range(2)]
+    got = f.extract_batch(clouds)
+    for i, c in enumerate(clouds):
+        want = OB.extract(c, oracle_params(hp), canonical_ties=False)   # std::sort exactly as the reference
+        assert want["angle_ties"] == 0 and want["curvature_ties"] == 0
+        assert_scan_equal(got[i], want, "%dx%d/%s/scan%d" % (rings, cols, pname, i))
+        assert len(got[i].edge_index) > 0 and len(got[i].surface_index) > 0
+    f.close()
+
+
+@pytest.mark.parametrize("variant", ["ragged", "shuffled", "rotated", "reversed", "ragged_shuffled"])
+def test_scan_parity_input_orders(fx, variant):
+    kw = {"ragged": dict(drop_fraction=0.13), "shuffled": dict(shuffle=True), "rotated": dict(start_col=517),
+          "reversed": dict(reverse=True), "ragged_shuffled": dict(drop_fraction=0.3, shuffle=True)}[variant]
+    c = make_scan(32, 1024, seed=77, **kw)
+    got = fx.ExtractFeatures(c)
+    want = OB.extract(c, canonical_ties=False)
+    assert_scan_equal(got, want, variant)
+
+
+def _cloud(ring, x, y, z=None):
+    c = np.zeros(len(ring), POINT_DTYPE)
+    c["ring"], c["x"], c["y"] = ring, x, y
+    c["z"] = 0.5 if z is None else z
+    c["pad"] = 1.0
+    return c
+
+
+def test_ring_skip_conditions(fx):
+    """Rings the reference removes or abandons contribute nothing (feature_extraction.cpp:116,154-156)."""
+    rng = np.random.default_rng(5)
+    parts = []
+
+    def ring_pts(rid, n, r0=8.0):
+        az = np.sort(rng.uniform(-3.0, 3.0, n))
+        r = r0 + 0.01 * rng.standard_normal(n)
+        return rid, r * np.cos(az), r * np.sin(az)
+
+    sizes = {0: 400, 1: 3, 2: 9, 3: 14, 4: 16, 5: 21, 7: 300, 9: 5}   # P=5,B=6: <6 sparse, <11 conv, <16 blocks, 16..21 block<2
+    ring, x, y = [], [], []
+    for rid, n in sizes.items():
+        r_, x_, y_ = ring_pts(rid, n)
+        ring += [r_] * n
+        x += list(x_)
+        y += list(y_)
+    # ring 7: two adjacent points exactly (0,0) in xy -> CalcRadian throws (math.cpp:40-42)
+    c = _cloud(np.array(ring, np.uint16), np.array(x, np.float32), np.array(y, np.float32))
+    sel7 = np.nonzero(c["ring"] == 7)[0]
+    c["x"][sel7[100]] = 0.0
+    c["y"][sel7[100]] = 0.0
+    c["x"][sel7[101]] = 0.0
+    c["y"][sel7[101]] = 0.0
+    c["z"][sel7[101]] = 0.7
+    perm = rng.permutation(len(c))
+    c = c[perm]
+    got = fx.ExtractFeatures(c)
+    want = OB.extract(c, canonical_ties=True)
+    assert want["ring_status"].tolist().count(0) == 1
+    # two identical (0,0) points tie under the angle predicate: canonical (index) order on both sides
+    assert_scan_equal(got, want, "skip[ties]")
+    status_codes_equal_where_single_cause(got, want)
+    st = dict(zip(got.ring_id.tolist(), got.ring_status.tolist()))
+    assert st[1] == 1 and st[9] == 1 and st[2] == 2 and st[3] == 3 and st[7] == 5 and st[0] == 0
+    assert st[4] != 0 and st[5] != 0
+
+
+def test_one_zero_norm_point_breaks_links_only(fx):
+    """A single (0,0) point: cos = 0/0 = NaN, acos(NaN) < thr is false -> link broken, ring kept."""
+    c = make_scan(4, 600, seed=9)
+    k = np.nonzero(c["ring"] == 2)[0][300]
+    c["x"][k] = 0.0
+    c["y"][k] = 0.0
+    got = fx.ExtractFeatures(c)
+    want = OB.extract(c, canonical_ties=False)
+    assert want["ring_status"].tolist() == [0, 0, 0, 0]
+    assert_scan_equal(got, want, "one-zero")
+
+
+def test_batch_of_ragged_scans_and_empty_scan(fx):
+    clouds = [make_scan(16, 500, seed=3), make_scan(8, 1200, seed=4, drop_fraction=0.2),
+              np.zeros(0, POINT_DTYPE), make_scan(24, 300, seed=5, shuffle=True), make_scan(2, 64, seed=6)]
+    got = fx.extract_batch(clouds)
+    for i, c in enumerate(clouds):
+        if len(c) == 0:
+            assert len(got[i].labels) == 0 and len(got[i].edge_index) == 0 and len(got[i].ring_id) == 0
+            continue
+        assert_scan_equal(got[i], OB.extract(c, canonical_ties=False), "batch%d" % i)
+
+
+def test_duplicate_points_canonical_ties(fx):
+    """Exact duplicates tie under the angle predicate; the HIP path orders ties by arrival index."""
+    c = make_scan(8, 400, seed=21)
+    c = np.concatenate([c, c[100:140]])
+    got = fx.ExtractFeatures(c)
+    want = OB.extract(c, canonical_ties=True)
+    assert want["angle_ties"] > 0
+    assert_scan_equal(got, want, "dups[ties]")
+
+
+def test_curvature_ties_canonical(fx):
+    """Noise-free symmetric data gives exactly equal curvatures inside a block; lower index first."""
+    n = 600
+    az = -math.pi + 2 * math.pi * (np.arange(n) + 0.5) / n
+    r = 5.0 + 1.0 * (np.arange(n) % 7 == 0)        # exact repeating pattern -> exact ties
+    c = _cloud(np.zeros(n, np.uint16), (r * np.cos(az)).astype(np.float32), (r * np.sin(az)).astype(np.float32))
+    got = fx.ExtractFeatures(c)
+    want = OB.extract(c, canonical_ties=True)
+    assert_scan_equal(got, want, "curvties[ties]")
+
+
+def test_error_on_ring_id_out_of_range(fx):
+    c = make_scan(4, 200, seed=1)
+    c["ring"][17] = 300
+    with pytest.raises(LB.LfxError) as e:
+        fx.ExtractFeatures(c)
+    assert e.value.code == -5
+
+
+def test_capacity_errors():
+    f = FeatureExtraction(device=0, max_points_per_scan=1000, max_batch=1)
+    with pytest.raises(LB.LfxError) as e:
+        f.ExtractFeatures(make_scan(4, 300, seed=1))
+    assert e.value.code == -4
+    with pytest.raises(LB.LfxError):
+        f.extract_batch([make_scan(2, 100), make_scan(2, 100)])
+    f.close()
+
+
+def test_ring_longer_than_capacity_is_reported():
+    c = make_scan(2, 3000, seed=8)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_points_per_ring=2048)
+    got = f.ExtractFeatures(c)
+    assert got.ring_status.tolist() == [7, 7] and not got.labels.any() and len(got.edge_index) == 0
+    f.close()
+
+
+def test_device_resident_path_with_torch(fx):
+    import torch
+    clouds = [make_scan(16, 900, seed=40 + i) for i in range(3)]
+    host = np.concatenate(clouds).view(np.uint8)
+    dev = torch.from_numpy(host.copy()).to("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    fx.extract_batch_device(dev.data_ptr(), [len(c) for c in clouds], stream)
+    torch.cuda.synchronize()
+    for i, c in enumerate(clouds):
+        assert_scan_equal(fx.download(i, stream), OB.extract(c, canonical_ties=False), "device%d" % i)
+
+
+def test_large_random_parameters(fx):
+    """Other paddings / block counts / thresholds, incl. the largest supported padding."""
+    rng = np.random.default_rng(11)
+    c = make_scan(6, 1500, seed=31, drop_fraction=0.05)
+    for pad, nb in [(1, 1), (2, 3), (3, 10), (8, 6), (15, 4), (7, 97)]:
+        hp = HyperParameters(padding=pad, n_blocks=nb, neighbor_degree_threshold=float(rng.uniform(0.3, 4.0)),
+                             distance_diff_threshold=float(rng.uniform(0.05, 1.0)),
+                             parallel_beam_min_range_ratio=float(rng.uniform(0.001, 0.1)),
+                             edge_threshold=float(rng.uniform(0.001, 1.0)), surface_threshold=float(rng.uniform(0.001, 1.0)),
+                             min_range=0.5, max_range=9.0)
+        f = FeatureExtraction(hp, device=0, max_points_per_scan=len(c), max_batch=1)
+        assert_scan_equal(f.ExtractFeatures(c), OB.extract(c, oracle_params(hp), canonical_ties=False), "P%d/B%d" % (pad, nb))
+        f.close()
+
+
+def test_f64_sqrt_and_divide_are_correctly_rounded(fx):
+    """Range (math.hpp:36-39) and the link cosine feed orderings: they must equal IEEE results."""
+    rng = np.random.default_rng(2)
+    n = 4096
+    x = (rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+    y = (rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+    out = fx.stage_ring(x, y, 0)
+    want = np.sqrt(x.astype(np.float64) ** 2 + y.astype(np.float64) ** 2)
+    assert out["range"].tobytes() == want.tobytes()
+
+
+# ------------------------------------------------------------------ properties at full size
+def test_full_size_properties():
+    """64x1800 (BASELINE config) x 8 scans: size-independent properties of the outputs."""
+    hp = HyperParameters()
+    clouds = [make_scan(64, 1800, seed=500 + i) for i in range(8)]
+    f = FeatureExtraction(hp, device=0, max_points_per_scan=64 * 1800, max_batch=8, max_points_per_ring=2048, max_rings=64)
+    got = f.extract_batch(clouds)
+    again = f.extract_batch(clouds)
+    for c, g, g2 in zip(clouds, got, again):
+        n = len(c)
+        assert g.labels.tobytes() == g2.labels.tobytes() and g.curvature.tobytes() == g2.curvature.tobytes()   # deterministic
+        assert np.array_equal(np.sort(g.sorted_index), np.arange(n))                                           # a permutation
+        assert np.array_equal(np.nonzero(g.labels == 1)[0], np.sort(g.edge_index))
+        assert np.array_equal(np.nonzero(g.labels == 3)[0], np.sort(g.surface_index))
+        # ring-major, angle-ascending emission order
+        pos = np.empty(n, np.int64)
+        pos[g.sorted_index] = np.arange(n)
+        assert np.all(np.diff(pos[g.edge_index]) > 0) and np.all(np.diff(pos[g.surface_index]) > 0)
+        ang = np.arctan2(c["y"][g.sorted_index].astype(np.float64), c["x"][g.sorted_index].astype(np.float64))
+        for off, cnt in zip(g.ring_offset, g.ring_count):
+            assert np.all(np.diff(ang[off:off + cnt]) > 0)
+        # feature clouds carry the input coordinates and the narrowed curvature
+        assert np.array_equal(g.edge_points[:, 0], c["x"][g.edge_index]) and np.array_equal(g.edge_points[:, 2], c["z"][g.edge_index])
+        assert np.array_equal(g.edge_points[:, 3], g.curvature[g.edge_index].astype(np.float32))
+        assert np.all(g.curvature[g.edge_index] >= hp.edge_threshold) and np.all(g.curvature[g.surface_index] <= hp.surface_threshold)
+        # no two picks of one kind within reach: adjacent picks in a ring are > padding apart unless a link is broken
+        # (checked exactly by the oracle comparison below on one scan)
+    assert_scan_equal(got[3], OB.extract(clouds[3], canonical_ties=False), "full-size")
+    f.close()
+
+
+# ------------------------------------------------------------------ reference unit vectors on the device
+def test_refvec_curvature_convolution(fx, refvec):
+    for c in refvec["calc_curvature"]["cases"]:
+        r = np.asarray(c["range"], np.float64)
+        hp = HyperParameters(padding=c["padding"])
+        out = fx.stage_ring(r.astype(np.float32), np.zeros(len(r), np.float32), LB.STAGE_CURVATURE, hp, range_in=r)
+        assert out["status"] == 0 and out["curvature"].tolist() == c["expect"]
+    for c in refvec["make_weight"]["cases"]:
+        # MakeWeight is the stencil the device applies: an impulse response reveals it
+        p = c["padding"]
+        imp = np.zeros(4 * p + 1)
+        imp[2 * p] = 1.0
+        w = fx.convolution1d(imp, np.asarray(c["expect"], np.float64))
+        assert w[p:3 * p + 1].tolist() == c["expect"][::-1]
+    for c in refvec["convolution1d"]["cases"]:
+        if c.get("throws"):
+            with pytest.raises(LB.LfxError):
+                fx.convolution1d(c["input"], c["weight"])
+        else:
+            assert fx.convolution1d(c["input"], c["weight"]).tolist() == c["expect"]
+
+
+def test_refvec_range_and_neighbor(fx, refvec):
+    for c in refvec["xy_norm"]["cases"]:
+        out = fx.stage_ring([c["x"], 1.0], [c["y"], 1.0], 0)
+        assert out["range"][0] == c["expect"]
+    pts = refvec["range"]["points_xy"]
+    x, y = xy(pts)
+    out = fx.stage_ring(x, y, 0)
+    for (px, py), r in zip(pts, out["range"]):
+        assert abs(r - math.sqrt(px * px + py * py)) < refvec["range"]["tolerance"]
+    for c in refvec["is_neighbor_xy"]["cases"]:
+        thr = c["threshold"] if "threshold" in c else math.pi / 2 + c["threshold_pi_half_plus"]
+        hp = HyperParameters(neighbor_degree_threshold=math.degrees(thr))
+        x, y = xy([c["p0"], c["p1"]])
+        assert bool(fx.stage_ring(x, y, 0, hp)["link"][0]) == c["expect"]
+    n = refvec["neighbor_check_xy"]
+    for c in n["cases"]:
+        thr = c["threshold"] if "threshold" in c else math.pi / 4 + c["threshold_pi_quarter_plus"]
+        sl = n["points_xy"][c["slice"][0]:c["slice"][1]] if "slice" in c else n["points_xy"]
+        i, j = c["pair"]
+        assert j == i + 1
+        x, y = xy(sl)
+        hp = HyperParameters(neighbor_degree_threshold=math.degrees(thr))
+        assert bool(fx.stage_ring(x, y, 0, hp)["link"][i]) == c["expect"]
+    # CalcRadian vectors (test_math.cpp:42-65) through the link test: acos(...) < expected +- tol
+    tol = refvec["calc_radian"]["tolerance"]
+    for c in refvec["calc_radian"]["cases"]:
+        a = c["args"]
+        x, y = xy([[a[0], a[1]], [a[2], a[3]]])
+        if c.get("throws"):
+            out = fx.stage_ring(x, y, LB.STAGE_OCCLUSION, HyperParameters(padding=1))
+            assert out["status"] == 5
+            continue
+        want = c["expect_pi_times"] * math.pi
+        above = fx.stage_ring(x, y, 0, HyperParameters(neighbor_degree_threshold=math.degrees(want + tol)))["link"][0]
+        assert bool(above)
+        if want - tol > 0:
+            below = fx.stage_ring(x, y, 0, HyperParameters(neighbor_degree_threshold=math.degrees(want - tol)))["link"][0]
+            assert not bool(below)
+
+
+def test_refvec_masks(fx, refvec):
+    for c in refvec["out_of_range"]["cases"]:
+        x, y = xy(c["points_xy"])
+        hp = HyperParameters(min_range=c["min_range"], max_range=c["max_range"])
+        assert names(fx.stage_ring(x, y, LB.STAGE_OUT_OF_RANGE, hp)["labels"]) == c["expect"]
+    for c in refvec["parallel_beam"]["cases"]:
+        x, y = xy(c["points_xy"])
+        hp = HyperParameters(parallel_beam_min_range_ratio=c["threshold"])
+        assert names(fx.stage_ring(x, y, LB.STAGE_PARALLEL_BEAM, hp)["labels"]) == c["expect"]
+    o = refvec["occlusion"]
+    for c in o["cases"]:
+        x, y = xy(c["points_xy"])
+        hp = HyperParameters(padding=c["padding"], neighbor_degree_threshold=math.degrees(o["neighbor_radian_threshold"]),
+                             distance_diff_threshold=o["distance_threshold"])
+        out = fx.stage_ring(x, y, LB.STAGE_OCCLUSION, hp)
+        assert out["status"] == 0 and names(out["labels"]) == c["expect"]
+    # a checker over a single point throws (test_neighbor.cpp:144-162): status, not labels
+    x, y = xy(refvec["neighbor_check_xy"]["too_few_points_throws"]["points_xy"])
+    assert fx.stage_ring(x, y, LB.STAGE_OCCLUSION, HyperParameters(padding=1))["status"] != 0
+
+
+def test_refvec_labelling(fx, refvec):
+    flags = LB.STAGE_LABEL | LB.STAGE_SINGLE_BLOCK
+    for c in refvec["edge_label"]["cases"]:
+        n = len(c["groups"])
+        hp = HyperParameters(padding=c["padding"], edge_threshold=c["threshold"], surface_threshold=1e-300)
+        cv = np.asarray(c["curvature"], np.float64) + 1.0        # keep every value above the surface threshold
+        hp.edge_threshold = c["threshold"] + 1.0
+        out = fx.stage_ring(np.ones(n), np.zeros(n), flags, hp, groups=c["groups"], curvature_in=cv)
+        assert out["status"] == 0 and names(out["labels"]) == c["expect"]
+    # FillNeighbors (fill.hpp:101-117) = what one pick does: make `index` the only candidate
+    for c in refvec["fill_neighbors"]["cases"]:
+        n = len(c["groups"])
+        cv = np.full(n, 1.0)
+        cv[c["index"]] = 5.0
+        hp = HyperParameters(padding=c["padding"], edge_threshold=3.0, surface_threshold=1e-300)
+        out = fx.stage_ring(np.ones(n), np.zeros(n), flags, hp, groups=c["groups"], curvature_in=cv)
+        lab = names(out["labels"])
+        assert lab[c["index"]] == "Edge"
+        lab[c["index"]] = "EdgeNeighbor"
+        assert lab == c["expect"]
+    # FillFromLeft / FillFromRight (fill.hpp:40-99) are the two halves of that fill; their vectors
+    # are replayed as picks at the fill's origin with the other half cut off by a group change
+    for which in ("fill_from_left", "fill_from_right"):
+        for c in refvec[which]["cases"]:
+            if c.get("throws") or c["label"] == "Default":
+                continue
+            g = list(c["groups"])
+            n = len(g)
+            if which == "fill_from_left":
+                origin, length = c["begin"], c["end"] - c["begin"]
+                g2 = [(-1 - k) for k in range(origin)] + g[origin:]          # nothing to the left is linked
+            else:
+                origin, length = c["end"], c["end"] - c["begin"]
+                g2 = g[:origin + 1] + [(-1 - k) for k in range(n - origin - 1)]
+            cv = np.full(n, 1.0)
+            cv[origin] = 5.0
+            hp = HyperParameters(padding=max(length - 1, 1), edge_threshold=3.0, surface_threshold=1e-300)
+            if length - 1 < 1:
+                continue
+            out = fx.stage_ring(np.ones(n), np.zeros(n), flags, hp, groups=g2, curvature_in=cv)
+            lab = ["Edge" if v in ("Edge", "EdgeNeighbor") else v for v in names(out["labels"])]
+            assert lab == c["expect"], (which, c)
+
+
+def test_refvec_argsort_order_through_labelling(fx, refvec):
+    """Argsort vectors (test_algorithm.cpp:36-49): the device never sorts, but visiting order is
+    observable: with padding covering the whole array and all links intact, the single pick of an
+    edge pass is the argmax (last of argsort), of a surface pass the argmin (first of argsort)."""
+    flags = LB.STAGE_LABEL | LB.STAGE_SINGLE_BLOCK
+    for c in refvec["argsort"]["cases"]:
+        v = np.asarray(c["values"], np.float64) + 1.0
+        n = len(v)
+        g = np.zeros(n, np.int32)
+        hp = HyperParameters(padding=n, edge_threshold=0.5, surface_threshold=1e-300)
+        lab = fx.stage_ring(np.ones(n), np.zeros(n), flags, hp, groups=g, curvature_in=v)["labels"]
+        if len(set(c["values"])) == n:
+            assert int(np.nonzero(lab == LAB["Edge"])[0][0]) == c["expect"][-1]
+        hp = HyperParameters(padding=n, edge_threshold=1e300, surface_threshold=1e300)
+        lab = fx.stage_ring(np.ones(n), np.zeros(n), flags, hp, groups=g, curvature_in=v)["labels"]
+        assert int(np.nonzero(lab == LAB["Surface"])[0][0]) == c["expect"][0]
+
+
+def test_refvec_index_range_through_labelling(fx, refvec):
+    """PaddedIndexRange vectors (test_index_range.cpp:147-176): block boundaries are observable as
+    the places where a fill stops although every link is intact."""
+    for c in refvec["padded_index_range"]["cases"]:
+        n, nb, pad, bounds = c["size"], c["n_blocks"], c["padding"], c["bounds"]
+        az = np.linspace(-1.0, 1.0, n)
+        x, y = (5 * np.cos(az)).astype(np.float32), (5 * np.sin(az)).astype(np.float32)
+        hp = HyperParameters(padding=pad, n_blocks=nb, neighbor_degree_threshold=90.0, edge_threshold=1e300,
+                             surface_threshold=1e300)
+        out = fx.stage_ring(x, y, LB.STAGE_LABEL | LB.STAGE_CURVATURE, hp)
+        lab = out["labels"]
+        assert out["status"] == 0
+        assert not lab[:bounds[0]].any() and not lab[bounds[-1]:].any()      # borders stay Default
+        assert lab[bounds[0]:bounds[-1]].all()                               # every block point is labelled
+        oc = OB.lib()
+        want = np.zeros(n, np.uint8)
+        cv = np.ascontiguousarray(out["curvature"])
+        import ctypes as C
+        assert oc.orc_assign_label(want.ctypes.data_as(C.POINTER(C.c_uint8)), cv.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                   x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                                   math.radians(90.0), nb, pad, 1e300, 1e300) == 0
+        assert lab.tolist() == want.tolist()
+
+
+def test_refvec_ring_projection(fx, refvec):
+    e = refvec["extract_angle_sorted_rings"]
+    pts = np.zeros(len(e["points_ring_xy"]), POINT_DTYPE)
+    for k, (r, px, py) in enumerate(e["points_ring_xy"]):
+        pts[k]["ring"], pts[k]["x"], pts[k]["y"] = r, px, py
+    got = fx.ring_projection(pts)
+    assert {str(k): v.tolist() for k, v in got.items()} == e["expect"]
+    s = refvec["sort_by_atan2"]
+    pts = np.zeros(len(s["points_xy"]), POINT_DTYPE)
+    for k, (px, py) in enumerate(s["points_xy"]):
+        pts[k]["x"], pts[k]["y"] = px, py
+    assert fx.ring_projection(pts)[0].tolist() == s["expect"]
+    # the predicate against atan2 on the special pairs (test_ring.cpp:47-101): sort each pair
+    for a, b in refvec["polar_less_specific"]["pairs"]:
+        pts = np.zeros(2, POINT_DTYPE)
+        pts[0]["x"], pts[0]["y"], pts[1]["x"], pts[1]["y"] = a[0], a[1], b[0], b[1]
+        order = fx.ring_projection(pts)[0].tolist()
+        ta, tb = math.atan2(a[1], a[0]), math.atan2(b[1], b[0])
+        if ta < tb:
+            assert order == [0, 1], (a, b)
+        elif tb < ta:
+            assert order == [1, 0], (a, b)
+    # 10000 random points (test_ring.cpp:103-127), in float: equal to sorting by atan2
+    n = refvec["polar_less_random"]["n"]
+    rng = np.random.default_rng(0)
+    for chunk in range(3):
+        m = 4000 if chunk < 2 else n - 8000
+        pts = np.zeros(m, POINT_DTYPE)
+        pts["x"] = rng.uniform(-1, 1, m).astype(np.float32)
+        pts["y"] = rng.uniform(-1, 1, m).astype(np.float32)
+        order = fx.ring_projection(pts)[0]
+        want = np.argsort(np.arctan2(pts["y"].astype(np.float64), pts["x"].astype(np.float64)), kind="stable")
+        assert np.array_equal(order, want)
+    rs = refvec["remove_sparse_rings"]
+    ring, x, y = [], [], []
+    for rid, size in rs["ring_sizes"].items():
+        for k in range(size):
+            ring.append(int(rid)); x.append(math.cos(0.1 * k + 0.05)); y.append(math.sin(0.1 * k + 0.05))
+    cloud = _cloud(np.array(ring, np.uint16), np.array(x, np.float32), np.array(y, np.float32))
+    for c in rs["cases"]:
+        f = FeatureExtraction(HyperParameters(padding=c["n_min_points"] - 1), device=0, max_points_per_scan=64, max_batch=1)
+        g = f.ExtractFeatures(cloud)
+        assert [int(r) for r, s in zip(g.ring_id, g.ring_status) if s != 1] == c["kept"]
+        f.close()
+
+
+def test_refvec_append_xyzir(fx, refvec):
+    """AppendXYZIR (test_label.cpp:55-74): the feature clouds carry x,y,z and (float)curvature."""
+    c = make_scan(4, 400, seed=12)
+    g = fx.ExtractFeatures(c)
+    assert len(g.edge_index) > 0
+    assert np.array_equal(g.edge_points[:, 3], g.curvature[g.edge_index].astype(np.float32))
+    assert np.array_equal(g.edge_points[:, 1], c["y"][g.edge_index])
+    a = refvec["append_xyzir"]
+    for (x, y, z, _i, _r), cv, want in zip(a["points_xyzir"], a["curvature"], a["expect_xyzir"]):
+        assert [np.float32(x), np.float32(y), np.float32(z), np.float32(cv)] == want[:4]
