@@ -154,6 +154,13 @@ int lfx_extract_batch(lfx_ctx *ctx, const void *const *points, const size_t *n_p
 int lfx_extract_batch_device(lfx_ctx *ctx, const void *d_points, const uint32_t *n_points, uint32_t batch,
                              void *stream);
 int lfx_device_results(const lfx_ctx *ctx, lfx_device_view *view);
+/* Pack the last device batch's edge and surface clouds back to back, in scan order, into
+ * caller-provided DEVICE buffers (what one rank hands to the multi-GPU gather):
+ * d_edge_out / d_surface_out [capacity_points][4] floats (16-byte aligned); d_offsets_out u32
+ * [2][batch+1]: exclusive prefix of the per-scan edge counts, then of the surface counts
+ * (entry [batch] = total).  Asynchronous on `stream`. */
+int lfx_pack_features(lfx_ctx *ctx, float *d_edge_out, float *d_surface_out, uint32_t *d_offsets_out,
+                      size_t capacity_points, void *stream);
 /* Copy scan `scan` of the last device batch to host memory (synchronises the stream). */
 int lfx_download_scan(lfx_ctx *ctx, uint32_t scan, void *stream, lfx_scan_result *out);
 

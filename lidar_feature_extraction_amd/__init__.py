@@ -5,4 +5,4 @@ mirror of the reference node's operator.  Importing this package does not need a
 `FeatureExtraction` does, and raises if the library or the device is missing (no CPU fallback).
 """
 from .extraction import FeatureExtraction, HyperParameters, ScanFeatures, LABEL_NAMES, RING_STATUS_NAMES  # noqa: F401
-from .synth import POINT_DTYPE, SENSORS, make_scan, make_batch  # noqa: F401
+from .synth import POINT_DTYPE, SENSORS, make_scan, make_batch, concat  # noqa: F401

@@ -61,7 +61,7 @@ class DeviceView(C.Structure):
 EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
     "lfx_status_string", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
-    "lfx_device_results", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
+    "lfx_device_results", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_set_profiling", "lfx_kernel_times", "lfx_kernel_name",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
@@ -76,6 +76,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "liblfx.so is not built (%s): run `python __graft_entry__.py` -- there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (SONAME libamdhip64.so.7,
+    # the name liblfx.so needs).  Loading torch first makes liblfx.so bind to that copy; the other
+    # order would put a second runtime into the process, and the later one sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     L.lfx_default_params.argtypes = [C.POINTER(Params)]
@@ -93,6 +100,7 @@ def load():
     L.lfx_extract_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), u32, C.POINTER(ScanResult)]
     L.lfx_extract_batch_device.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     L.lfx_device_results.argtypes = [vp, C.POINTER(DeviceView)]
+    L.lfx_pack_features.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.lfx_download_scan.argtypes = [vp, u32, vp, C.POINTER(ScanResult)]
     L.lfx_stage_ring.argtypes = [vp, C.POINTER(Params), u32, u32] + [vp] * 10
     L.lfx_stage_convolution1d.argtypes = [vp, vp, u32, vp, u32, vp]

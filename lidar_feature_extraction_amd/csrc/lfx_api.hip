@@ -540,6 +540,24 @@ int lfx_device_results(const lfx_ctx * c, lfx_device_view * v)
   return LFX_OK;
 }
 
+int lfx_pack_features(
+  lfx_ctx * c, float * d_edge_out, float * d_surface_out, uint32_t * d_offsets_out, size_t capacity_points,
+  void * stream)
+{
+  if (!c || !d_edge_out || !d_surface_out || !d_offsets_out) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint32_t batch = c->last_batch;
+  const uint32_t capacity = capacity_points > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity_points;
+  hipLaunchKernelGGL(lfx::feature_offsets_kernel, dim3(1), dim3(256), 0, st, c->scan_info.p, batch, d_offsets_out);
+  hipLaunchKernelGGL(lfx::feature_pack_kernel, dim3(8, batch), dim3(256), 0, st,
+    c->scan_begin.p, c->scan_info.p, d_offsets_out, batch, c->edge_pts.p, c->surf_pts.p,
+    reinterpret_cast<float4 *>(d_edge_out), reinterpret_cast<float4 *>(d_surface_out), capacity);
+  LFX_HIP(c, hipGetLastError());
+  return LFX_OK;
+}
+
 int lfx_download_scan(lfx_ctx * c, uint32_t scan, void * stream, lfx_scan_result * out)
 {
   if (!c || !out) {return LFX_ERR_INVALID_ARGUMENT;}

@@ -748,6 +748,61 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Batch-level packing for the multi-GPU gather: exclusive prefix of the per-scan feature counts
+// (one workgroup walks the batch), then a copy of every scan's clouds to its packed offset.
+__global__ __launch_bounds__(256) void feature_offsets_kernel(
+  const uint32_t * __restrict__ scan_info, uint32_t batch, uint32_t * __restrict__ offsets /* [2][batch+1] */)
+{
+  __shared__ uint32_t part[2][256];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (batch + 255) / 256;
+  const uint32_t lo = tid * per, hi = (lo + per < batch) ? lo + per : batch;
+  uint32_t e = 0, s = 0;
+  for (uint32_t k = lo; k < hi; k++) {e += scan_info[k * 4 + kInfoEdge]; s += scan_info[k * 4 + kInfoSurface];}
+  part[0][tid] = e;
+  part[1][tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const uint32_t a = tid >= d ? part[0][tid - d] : 0u, b = tid >= d ? part[1][tid - d] : 0u;
+    __syncthreads();
+    part[0][tid] += a;
+    part[1][tid] += b;
+    __syncthreads();
+  }
+  uint32_t ce = part[0][tid] - e, cs = part[1][tid] - s;
+  for (uint32_t k = lo; k < hi; k++) {
+    offsets[k] = ce;
+    offsets[batch + 1 + k] = cs;
+    ce += scan_info[k * 4 + kInfoEdge];
+    cs += scan_info[k * 4 + kInfoSurface];
+  }
+  if (tid == 255) {
+    offsets[batch] = part[0][255];
+    offsets[2 * batch + 1] = part[1][255];
+  }
+}
+
+__global__ __launch_bounds__(256) void feature_pack_kernel(
+  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
+  const uint32_t * __restrict__ offsets, uint32_t batch, const float4 * __restrict__ edge_pts,
+  const float4 * __restrict__ surf_pts, float4 * __restrict__ edge_out, float4 * __restrict__ surf_out,
+  uint32_t capacity)
+{
+  const uint32_t s = blockIdx.y;
+  const uint32_t ne = scan_info[s * 4 + kInfoEdge], ns = scan_info[s * 4 + kInfoSurface];
+  const size_t b = scan_begin[s];
+  const uint32_t oe = offsets[s], os = offsets[batch + 1 + s];
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < ne + ns; k += gridDim.x * blockDim.x) {
+    if (k < ne) {
+      if (oe + k < capacity) {edge_out[oe + k] = edge_pts[b + k];}
+    } else {
+      const uint32_t q = k - ne;
+      if (os + q < capacity) {surf_out[os + q] = surf_pts[b + q];}
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-stage kernel: one ring handed over as sorted x, y (lfx_stage_ring).
 __global__ __launch_bounds__(1024) void ring_stage_kernel(
   Params prm, uint32_t cap, uint32_t flags, int N, const float * __restrict__ x, const float * __restrict__ y,

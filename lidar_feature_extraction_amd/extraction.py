@@ -144,6 +144,12 @@ class FeatureExtraction:
         B.check(self._ctx, self._L.lfx_device_results(self._ctx, C.byref(v)))
         return v
 
+    def pack_features(self, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream=0):
+        """Pack the last device batch's clouds into caller-owned device buffers (see lfx.h)."""
+        B.check(self._ctx, self._L.lfx_pack_features(
+            self._ctx, C.c_void_p(int(d_edge_out)), C.c_void_p(int(d_surface_out)), C.c_void_p(int(d_offsets_out)),
+            int(capacity_points), C.c_void_p(int(stream))))
+
     def download(self, scan, stream=0):
         r = B.ScanResult()
         B.check(self._ctx, self._L.lfx_download_scan(self._ctx, scan, C.c_void_p(int(stream)), C.byref(r)))

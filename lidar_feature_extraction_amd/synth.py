@@ -108,3 +108,14 @@ def make_scan(rings=64, cols=1800, seed=1234, vfov_deg=15.0, sigma=0.01, n_pilla
 def make_batch(n_scans, rings=64, cols=1800, seed=1234, **kw):
     """n_scans scans with seeds seed, seed+1, ... (seeds 1234+scan_id)."""
     return [make_scan(rings, cols, seed + i, **kw) for i in range(n_scans)]
+
+
+def concat(clouds):
+    """Back-to-back copy of several scans, keeping the 32-byte record layout (np.concatenate would
+    repack the fields)."""
+    out = np.zeros(sum(len(c) for c in clouds), POINT_DTYPE)
+    at = 0
+    for c in clouds:
+        out[at:at + len(c)] = c
+        at += len(c)
+    return out

@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, POINT_DTYPE  # noqa: E402
-from lidar_feature_extraction_amd import binding as LB  # noqa: E402
+from lidar_feature_extraction_amd import binding as LB, synth  # noqa: E402
 from oracle import binding as OB  # noqa: E402
 from tests.parity import assert_scan_equal, status_codes_equal_where_single_cause  # noqa: E402
 
@@ -140,8 +140,10 @@ def test_batch_of_ragged_scans_and_empty_scan(fx):
 
 def test_duplicate_points_canonical_ties(fx):
     """Exact duplicates tie under the angle predicate; the HIP path orders ties by arrival index."""
-    c = make_scan(8, 400, seed=21)
-    c = np.concatenate([c, c[100:140]])
+    base = make_scan(8, 400, seed=21)
+    c = np.zeros(len(base) + 40, POINT_DTYPE)
+    c[:len(base)] = base
+    c[len(base):] = base[100:140]
     got = fx.ExtractFeatures(c)
     want = OB.extract(c, canonical_ties=True)
     assert want["angle_ties"] > 0
@@ -188,7 +190,7 @@ def test_ring_longer_than_capacity_is_reported():
 def test_device_resident_path_with_torch(fx):
     import torch
     clouds = [make_scan(16, 900, seed=40 + i) for i in range(3)]
-    host = np.concatenate(clouds).view(np.uint8)
+    host = synth.concat(clouds).view(np.uint8)
     dev = torch.from_numpy(host.copy()).to("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     fx.extract_batch_device(dev.data_ptr(), [len(c) for c in clouds], stream)
