@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/s of the per-scan extraction hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (ring projection, range, curvature, labelling, masks,
+compaction: lfx_extract_batch_device) over one batch of synthetic scans whose point records are
+already resident in HBM.  Workload at every N: HDL-64E-shaped 64-ring x 1800-column scans
+(BASELINE.json configs[2], the shape the metric is quoted on), `--batch` scans per step per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; scan i of the stream goes to rank i mod N (weak scaling: `--batch`
+scans per step on every rank) and every step ends with the RCCL gather of the labelled clouds to
+rank 0 (lidar_feature_extraction_amd/gather.py), inside the timed region.
+
+Rank 0 prints ONE JSON line; "roofline" prices the dominant kernel against the HBM roof with the
+path's ALGORITHMIC bytes (25*N_pts + 16*(N_edge+N_surface) per scan), its duration
+measured live with HIP events on the launch stream; "cpu_baseline" is the CPU oracle (a port of
+the reference algorithm, oracle/) timed on this host on a bounded sample of the same scans.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU")
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--cols", type=int, default=1800)
+    ap.add_argument("--unique", type=int, default=16, help="distinct synthetic scans per GPU (tiled to --batch)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (a.gpus, world), file=sys.stderr)
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if not os.path.exists(os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, concat
+    from lidar_feature_extraction_amd.gather import gather_clouds
+
+    # ---- synthetic stream: scan i -> rank i mod world; seeds 1234 + scan id
+    n_unique = max(1, min(a.unique, a.batch))
+    clouds = [make_scan(a.rings, a.cols, seed=1234 + (j * world + rank)) for j in range(n_unique)]
+    n_pts = len(clouds[0])
+    tiled = [clouds[j % n_unique] for j in range(a.batch)]
+    host = concat(tiled).view(np.uint8)
+    d_points = torch.from_numpy(host).to(dev)
+    n_list = np.array([len(c) for c in tiled], np.uint32)
+    cap = 1 << int(np.ceil(np.log2(max(a.cols, 64))))
+    fx = FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
+                           max_points_per_ring=cap, max_rings=a.rings)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    use_gather = world > 1 and not a.no_gather
+    if use_gather:
+        feat_cap = int(a.batch * n_pts * 0.35) + 1024
+        edge_buf = torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev)
+        surf_buf = torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev)
+        offs = torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)
+
+    def step():
+        fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
+        if use_gather:
+            fx.pack_features(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
+            gather_clouds(edge_buf, surf_buf, offs, a.batch, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    scans_total = a.batch * a.steps * world
+    value = scans_total / dt
+
+    # ---- per-kernel durations: HIP events on the launch stream, same steps again
+    fx.set_profiling(True)
+    for _ in range(a.steps):
+        fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
+    torch.cuda.synchronize()
+    kt = fx.kernel_times()
+    fx.set_profiling(False)
+    per_launch_us = {k: (1e3 * ms / max(cnt, 1)) for k, (ms, cnt) in kt.items()}
+    dominant = max(per_launch_us, key=per_launch_us.get)
+    sum_us = sum(per_launch_us.values())
+
+    # ---- algorithmic bytes of one launch (= one batch): 25 B/point + 16 B/feature point
+    feats = []
+    parity = None
+    for j in range(n_unique):
+        g = fx.download(j, stream)
+        feats.append(len(g.edge_index) + len(g.surface_index))
+        if j == 0 and rank == 0:
+            from oracle import binding as oracle          # checker only (never timed as the product)
+            w = oracle.extract(clouds[0], canonical_ties=False)
+            parity = bool(np.array_equal(g.labels, w["labels"]) and g.curvature.tobytes() == w["curvature"].tobytes()
+                          and np.array_equal(g.edge_index, w["edge_index"].astype(np.uint32))
+                          and np.array_equal(g.surface_index, w["surface_index"].astype(np.uint32)))
+    feat_batch = sum(feats[j % n_unique] for j in range(a.batch))
+    algo_bytes = 25 * n_pts * a.batch + 16 * feat_batch
+    achieved = algo_bytes / (per_launch_us[dominant] * 1e-6) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("batch") == a.batch and tj.get("rings") == a.rings and tj.get("cols") == a.cols:
+                traffic = tj.get("hbm_bytes_per_launch", {}).get(dominant)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items()},
+                "whole_path_frac": round(algo_bytes / (sum_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import binding as oracle
+        oracle.extract(clouds[0], canonical_ties=False)   # warm
+        done, t1 = 0, time.perf_counter()
+        while True:
+            oracle.extract(clouds[done % n_unique], canonical_ties=False)
+            done += 1
+            el = time.perf_counter() - t1
+            if el >= a.cpu_seconds or done >= 2000:
+                break
+        cpu = {"value": round(done / el, 3), "unit": "scans/s", "cores": 1, "kind": "port",
+               "ms_per_scan": round(1e3 * el / done, 3),
+               "sample": "%d scans of %dx%d (the bench's own inputs, %d distinct), oracle/lfx_oracle.cpp, 1 thread, %.1f s"
+                         % (done, a.rings, a.cols, n_unique, el)}
+
+    if rank == 0:
+        out = {
+            "metric": "scans/sec (64-ring x 1800 synthetic scans, extraction hot path, inputs resident in HBM)",
+            "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 4), "ms_per_scan": round(1e3 * dt / (a.batch * a.steps), 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "hdl64-64x1800 (BASELINE.json configs[2])", "rings": a.rings, "cols": a.cols,
+                       "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": "code defaults",
+                       "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "")},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_spot_check": parity,
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    fx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

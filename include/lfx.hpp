@@ -1,0 +1,126 @@
+// lfx.hpp -- C++ host side over the C ABI (lfx.h): what a maintainer of the reference node calls.
+//
+// The reference operator is the body of FeatureExtraction::Callback,
+// /root/reference/extraction/app/feature_extraction.cpp:114-157; this header gives it a name,
+// lfx::FeatureExtraction::ExtractFeatures(cloud), with the reference's types: PointXYZIR in
+// (lib/include/lidar_feature_library/point_type.hpp:62-86), edge and surface PointXYZIR clouds out
+// (intensity = (float)curvature, label.hpp:166-179), plus the per-point labels and curvature.
+// Header only; link with liblfx.so.  Errors of the C ABI become lfx::Error; per-ring conditions
+// the reference reports with RCLCPP_WARN (feature_extraction.cpp:154-156) are in ring_status.
+#ifndef LFX_HPP_
+#define LFX_HPP_
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lfx.h"
+
+namespace lfx
+{
+
+struct alignas(16) PointXYZIR   // same 32-byte layout as the reference's PCL point type
+{
+  float x, y, z, pad;
+  float intensity;
+  std::uint16_t ring;
+  std::uint8_t reserved[10];
+};
+static_assert(sizeof(PointXYZIR) == 32, "PointXYZIR must be 32 bytes");
+
+struct Error : std::runtime_error
+{
+  Error(int c, const std::string & what)
+  : std::runtime_error(what), code(c) {}
+  int code;
+};
+
+struct HyperParameters : lfx_params   // hyper_parameter.hpp:32-65
+{
+  HyperParameters() {lfx_default_params(this);}
+  static HyperParameters LaunchYaml() {HyperParameters p; lfx_launch_params(&p); return p;}
+};
+
+struct RingInfo
+{
+  std::uint16_t id;
+  std::uint32_t count, offset;
+  lfx_ring_status status;
+};
+
+struct Features
+{
+  std::vector<PointXYZIR> edge, surface;        // rings ascending, angle ascending inside a ring
+  std::vector<std::uint32_t> edge_index, surface_index;   // original point indices
+  std::vector<std::uint8_t> labels;             // PointLabel per input point (point_label.hpp:32-42)
+  std::vector<double> curvature;                // per input point
+  std::vector<std::uint32_t> sorted_index;      // ExtractAngleSortedRings, ring.hpp:141-147
+  std::vector<RingInfo> rings;
+};
+
+class FeatureExtraction
+{
+public:
+  explicit FeatureExtraction(
+    const HyperParameters & params = HyperParameters(), int device = 0,
+    std::uint32_t max_points_per_scan = 262144, std::uint32_t max_points_per_ring = 0,
+    std::uint32_t max_rings = 0)
+  {
+    lfx_config cfg{};
+    cfg.max_points_per_scan = max_points_per_scan;
+    cfg.max_batch = 1;
+    cfg.max_points_per_ring = max_points_per_ring;
+    cfg.max_rings = max_rings;
+    const int rc = lfx_create(&ctx_, device, &params, &cfg);
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(nullptr));}
+  }
+  ~FeatureExtraction() {lfx_destroy(ctx_);}
+  FeatureExtraction(const FeatureExtraction &) = delete;
+  FeatureExtraction & operator=(const FeatureExtraction &) = delete;
+
+  // feature_extraction.cpp:114-157 for one cloud.
+  Features ExtractFeatures(const PointXYZIR * points, std::size_t n) const
+  {
+    lfx_scan_result r{};
+    const int rc = lfx_extract(ctx_, points, n, &r);
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+    Features f;
+    f.labels.assign(r.labels, r.labels + r.n_points);
+    f.curvature.assign(r.curvature, r.curvature + r.n_points);
+    f.sorted_index.assign(r.sorted_index, r.sorted_index + r.n_points);
+    f.edge_index.assign(r.edge_index, r.edge_index + r.n_edge);
+    f.surface_index.assign(r.surface_index, r.surface_index + r.n_surface);
+    fill(f.edge, r.edge_points, r.edge_index, r.n_edge, points);
+    fill(f.surface, r.surface_points, r.surface_index, r.n_surface, points);
+    for (std::uint32_t k = 0; k < r.n_rings; k++) {
+      f.rings.push_back(
+        RingInfo{r.ring_id[k], r.ring_count[k], r.ring_offset[k], static_cast<lfx_ring_status>(r.ring_status[k])});
+    }
+    return f;
+  }
+  Features ExtractFeatures(const std::vector<PointXYZIR> & cloud) const
+  {
+    return ExtractFeatures(cloud.data(), cloud.size());
+  }
+  lfx_ctx * handle() const {return ctx_;}
+
+private:
+  static void fill(
+    std::vector<PointXYZIR> & out, const float * pts, const std::uint32_t * idx, std::uint32_t n,
+    const PointXYZIR * in)
+  {
+    out.resize(n);
+    for (std::uint32_t k = 0; k < n; k++) {
+      PointXYZIR q{};
+      q.x = pts[4 * k]; q.y = pts[4 * k + 1]; q.z = pts[4 * k + 2]; q.pad = 1.0f;
+      q.intensity = pts[4 * k + 3];            // (float)curvature, label.hpp:176
+      q.ring = in[idx[k]].ring;
+      out[k] = q;
+    }
+  }
+  lfx_ctx * ctx_ = nullptr;
+};
+
+}  // namespace lfx
+#endif  // LFX_HPP_
