@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -24,13 +25,6 @@ std::string g_create_error;
 const char * kKernelNames[LFX_N_KERNELS] = {
   "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_extract_kernel",
   "feature_compact_kernel"};
-
-uint32_t next_pow2(uint32_t v)
-{
-  uint32_t p = 1;
-  while (p < v) {p <<= 1;}
-  return p;
-}
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -99,16 +93,18 @@ struct lfx_ctx
   lfx::Layout layout{};
   uint32_t max_points = 0, max_batch = 0, cap = 0, max_chunks = 0, max_rings = 0, ring_threads = 0;
   size_t total_cap = 0, ring_lds = 0;
+  uint32_t ring_flags = LFX_STAGE_ALL;   // LFX_DEBUG_RING_FLAGS overrides it for kernel ablations (wrong results)
   std::string err;
 
   // device scratch
   DevBuf<uint32_t> scan_begin, scan_info, chunk_base, ring_off_by_id, ring_count, ring_offset, ring_nedge,
-    ring_nsurf, sidx, seg, edge_idx, surf_idx;
+    ring_nsurf, sidx, rec_idx, edge_idx, surf_idx;
   DevBuf<uint16_t> chunk_hist, ring_id;
   DevBuf<uint8_t> ring_status, label_s, staging;
-  DevBuf<float> sx, sy;
+  DevBuf<float2> sxy;
+  DevBuf<float> sz;
   DevBuf<double> curv_s;
-  DevBuf<float4> edge_pts, surf_pts;
+  DevBuf<float4> edge_pts, surf_pts, rec_pts;
 
   hipStream_t stream = nullptr;          // used by the synchronous host entry points
   std::vector<uint32_t> h_scan_begin;    // of the last batch
@@ -230,7 +226,7 @@ lfx::Params device_params(const lfx_params & p)
 
 uint32_t ring_threads_for(uint32_t cap)
 {
-  return cap >= 4096 ? 1024u : cap >= 2048 ? 512u : 256u;
+  return cap > 1024 ? 512u : 256u;
 }
 
 // Launch the five kernels for `batch` scans whose records lie back to back at d_points.
@@ -275,21 +271,21 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   {
     Timed t(c, 2, st);
     hipLaunchKernelGGL(lfx::ring_scatter_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
-      pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->ring_off_by_id.p, c->sx.p, c->sy.p, c->sidx.p,
-      c->max_chunks);
+      pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->ring_off_by_id.p, c->sxy.p, c->sz.p,
+      c->sidx.p, c->max_chunks);
   }
   {
     Timed t(c, 3, st);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, dim3(c->max_rings, batch), dim3(c->ring_threads), c->ring_lds, st,
-      c->dev, c->cap, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->sx.p, c->sy.p,
-      c->sidx.p, c->label_s.p, c->curv_s.p, c->seg.p, c->ring_status.p, c->ring_nedge.p, c->ring_nsurf.p);
+      c->dev, c->cap, c->ring_flags, pts, c->layout, c->scan_begin.p, c->scan_info.p, c->ring_count.p,
+      c->ring_offset.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
+      c->rec_idx.p, c->ring_status.p, c->ring_nedge.p, c->ring_nsurf.p);
   }
   {
     Timed t(c, 4, st);
     hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3(c->max_rings, batch), dim3(256), 0, st,
-      pts, c->layout, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p,
-      c->ring_nsurf.p, c->sx.p, c->sy.p, c->sidx.p, c->curv_s.p, c->seg.p, c->edge_pts.p, c->edge_idx.p,
-      c->surf_pts.p, c->surf_idx.p);
+      c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p, c->ring_nsurf.p,
+      c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p, c->surf_idx.p);
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -451,7 +447,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->max_batch = config->max_batch;
   uint32_t ring_cap = config->max_points_per_ring ? config->max_points_per_ring : LFX_MAX_RING_POINTS;
   ring_cap = ring_cap > c->max_points ? c->max_points : ring_cap;
-  c->cap = next_pow2(ring_cap < 64 ? 64 : ring_cap);
+  c->cap = ((ring_cap < 64 ? 64 : ring_cap) + 63u) & ~63u;
   if (c->cap > LFX_MAX_RING_POINTS) {
     delete c;
     g_create_error = "max_points_per_ring exceeds LFX_MAX_RING_POINTS";
@@ -459,6 +455,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   }
   c->max_rings = config->max_rings ? (config->max_rings > lfx::kRings ? lfx::kRings : config->max_rings) : lfx::kRings;
   c->ring_threads = ring_threads_for(c->cap);
+  if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->ring_flags = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = std::getenv("LFX_DEBUG_RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
   c->ring_lds = lfx::ring_lds_bytes(c->cap);
   c->max_chunks = (c->max_points + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
   c->total_cap = (size_t)c->max_points * c->max_batch;
@@ -476,7 +474,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->ring_off_by_id.alloc(tables)); ok(c->ring_id.alloc(tables)); ok(c->ring_count.alloc(tables));
   ok(c->ring_offset.alloc(tables)); ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
   ok(c->ring_nsurf.alloc(tables));
-  ok(c->sx.alloc(tc)); ok(c->sy.alloc(tc)); ok(c->sidx.alloc(tc)); ok(c->seg.alloc(tc));
+  ok(c->sxy.alloc(tc)); ok(c->sz.alloc(tc)); ok(c->sidx.alloc(tc)); ok(c->rec_pts.alloc(tc)); ok(c->rec_idx.alloc(tc));
   ok(c->label_s.alloc(tc)); ok(c->curv_s.alloc(tc));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
@@ -507,7 +505,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
   c->ring_off_by_id.release(); c->ring_id.release(); c->ring_count.release(); c->ring_offset.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release();
-  c->sx.release(); c->sy.release(); c->sidx.release(); c->seg.release(); c->label_s.release();
+  c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
   if (c->stream) {(void)hipStreamDestroy(c->stream);}
@@ -625,7 +623,7 @@ int lfx_stage_ring(
   if (n > LFX_MAX_RING_POINTS) {return fail(c, LFX_ERR_CAPACITY, "ring longer than LFX_MAX_RING_POINTS");}
   LFX_HIP(c, hipSetDevice(c->device));
   const lfx::Params dp = device_params(*pp);
-  const uint32_t cap = next_pow2(n < 64 ? 64 : n);
+  const uint32_t cap = ((n < 64 ? 64 : n) + 63u) & ~63u;
   float * dx = nullptr, * dy = nullptr;
   int32_t * dg = nullptr, * dstat = nullptr;
   double * dci = nullptr, * dri = nullptr, * dr = nullptr, * dc = nullptr;

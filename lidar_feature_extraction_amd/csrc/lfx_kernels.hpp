@@ -34,7 +34,7 @@
 namespace lfx
 {
 
-constexpr int kChunkPoints = 1024;     // points per workgroup in the ring bucketing kernels
+constexpr int kChunkPoints = 2048;     // points per workgroup in the ring bucketing kernels
 constexpr int kChunkThreads = 256;
 constexpr int kChunkSlots = kChunkPoints / kChunkThreads;
 constexpr int kRings = 256;            // ring ids 0..255
@@ -137,37 +137,51 @@ __global__ __launch_bounds__(kRings) void ring_scan_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: stable scatter of (x, y, original index) into ring-major SoA.  The rank of a point among
-// the points of its ring inside the chunk comes from wave ballots (one per key bit), so the order
-// of arrival is kept: position = ring offset + points of the ring in earlier chunks + rank.
+// K2: stable scatter of (x, y | z | original index) into ring-major arrays.  The rank of a point
+// among the points of its ring inside the chunk comes from wave ballots (one per key bit), so the
+// order of arrival is kept.  The chunk is first laid out ring-major in LDS; the stores to HBM then
+// walk that layout, so a wave writes runs of consecutive positions (one run per ring) instead of
+// 64 scattered dwords.
 __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   const uint32_t * __restrict__ chunk_base, const uint32_t * __restrict__ ring_off_by_id,
-  float * __restrict__ sx, float * __restrict__ sy, uint32_t * __restrict__ sidx, uint32_t max_chunks)
+  float2 * __restrict__ sxy, float * __restrict__ sz, uint32_t * __restrict__ sidx, uint32_t max_chunks)
 {
   const uint32_t s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
   if (chunk * kChunkPoints >= n) {return;}
   const uint32_t lane = tid & 63, wave = tid >> 6;
+  const uint32_t n_here = (n - chunk * kChunkPoints) < (uint32_t)kChunkPoints ? (n - chunk * kChunkPoints) : (uint32_t)kChunkPoints;
   constexpr int kGroups = kChunkSlots * (kChunkThreads / 64);      // (slot, wave) pairs in arrival order
   __shared__ uint16_t wcnt[kGroups][kRings];
+  __shared__ uint32_t cstart[kRings];                              // start of each ring inside the staged chunk
+  __shared__ uint32_t gbase[kRings];                               // where that run starts in the scan's arrays
+  __shared__ uint32_t staged;                                      // points with a valid ring id in this chunk
+  __shared__ float2 st_xy[kChunkPoints];
+  __shared__ float st_z[kChunkPoints];
+  __shared__ uint16_t st_src[kChunkPoints];
+  __shared__ uint8_t st_ring[kChunkPoints];
   for (int i = tid; i < kGroups * kRings; i += kChunkThreads) {(&wcnt[0][0])[i] = 0;}
   __syncthreads();
 
-  float x[kChunkSlots], y[kChunkSlots];
+  float x[kChunkSlots], y[kChunkSlots], z[kChunkSlots];
   uint32_t key[kChunkSlots], rank[kChunkSlots];
 #pragma unroll
   for (int i = 0; i < kChunkSlots; i++) {
     const uint32_t e = chunk * kChunkPoints + i * kChunkThreads + tid;
     key[i] = kRings;                       // lanes past the end form their own group
-    x[i] = y[i] = 0.f;
+    x[i] = y[i] = z[i] = 0.f;
     if (e < n) {
       const uint8_t * p = pts + (size_t)(b + e) * L.step;
       x[i] = *reinterpret_cast<const float *>(p + L.ox);
       y[i] = *reinterpret_cast<const float *>(p + L.oy);
+      z[i] = *reinterpret_cast<const float *>(p + L.oz);
       const uint32_t ring = *reinterpret_cast<const uint16_t *>(p + L.oring);
       key[i] = ring < kRings ? ring : kRings;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < kChunkSlots; i++) {
     uint64_t peers = ~0ull;
 #pragma unroll
     for (int bit = 0; bit < 9; bit++) {
@@ -179,6 +193,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     if (rank[i] == 0 && key[i] < kRings) {wcnt[i * (kChunkThreads / 64) + wave][key[i]] = (uint16_t)__popcll(peers);}
   }
   __syncthreads();
+  uint32_t mine = 0;
   {
     uint32_t acc = 0;                      // thread = ring id: exclusive prefix over the arrival groups
     for (int g = 0; g < kGroups; g++) {
@@ -186,49 +201,75 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
       wcnt[g][tid] = (uint16_t)acc;
       acc += v;
     }
+    mine = acc;                            // points of ring `tid` in this chunk
+    cstart[tid] = acc;
   }
   __syncthreads();
-  const uint32_t * cb = chunk_base + ((size_t)s * max_chunks + chunk) * kRings;
+  for (uint32_t d = 1; d < kRings; d <<= 1) {       // inclusive scan of the ring counts
+    const uint32_t a = tid >= d ? cstart[tid - d] : 0u;
+    __syncthreads();
+    cstart[tid] += a;
+    __syncthreads();
+  }
+  {
+    const uint32_t start = cstart[tid] - mine;
+    if (tid == kRings - 1) {staged = cstart[tid];}
+    __syncthreads();
+    cstart[tid] = start;
+    gbase[tid] = b + ring_off_by_id[s * kRings + tid] + chunk_base[((size_t)s * max_chunks + chunk) * kRings + tid];
+  }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < kChunkSlots; i++) {
     if (key[i] < kRings) {
-      const uint32_t pos = b + ring_off_by_id[s * kRings + key[i]] + cb[key[i]] +
-        wcnt[i * (kChunkThreads / 64) + wave][key[i]] + rank[i];
-      sx[pos] = x[i];
-      sy[pos] = y[i];
-      sidx[pos] = chunk * kChunkPoints + i * kChunkThreads + tid;
+      const uint32_t lp = cstart[key[i]] + wcnt[i * (kChunkThreads / 64) + wave][key[i]] + rank[i];
+      st_xy[lp] = make_float2(x[i], y[i]);
+      st_z[lp] = z[i];
+      st_src[lp] = (uint16_t)(i * kChunkThreads + tid);
+      st_ring[lp] = (uint8_t)key[i];
     }
+  }
+  __syncthreads();
+  // (a point with a ring id above 255 is not staged; the host rejects such a scan, LFX_ERR_RING_ID)
+  const uint32_t n_staged = staged < n_here ? staged : n_here;
+  for (uint32_t o = tid; o < n_staged; o += kChunkThreads) {
+    const uint32_t r = st_ring[o];
+    const uint32_t pos = gbase[r] + (o - cstart[r]);
+    sxy[pos] = st_xy[o];
+    sz[pos] = st_z[o];
+    sidx[pos] = chunk * kChunkPoints + st_src[o];
   }
 }
 
 // ==========================================================================================
-// Ring workspace in LDS.
+// Ring workspace in LDS (one workgroup = one ring of N <= cap points, cap a multiple of 64).
 //
 // Bit arrays hold one bit per sorted position, 64 per word, with one zero word in front and
 // behind so that 32-bit windows around any position can be read without bounds tests.
 struct RingWork
 {
-  float * x;            // [cap]            aliased by hmask after the stencil phase
-  float * y;            // [cap]            aliased by rmask
-  uint32_t * idx;       // [cap]            original index (within the scan)
   double * r;           // [cap]  Range     range.hpp:52-56
   double * c;           // [cap]  curvature curvature.cpp:44-50
-  uint8_t * lab;        // [cap]
+  float * x;            // [cap]  (the slow labelling path reuses x, y as its mask arrays)
+  float * y;            // [cap]
+  uint8_t * lab;        // [cap]  label after the block labelling, then the final label
   uint64_t * link;      // IsNeighborXY(i, i+1) on the whole ring
   uint64_t * llink;     // the same, cut at block boundaries and ring borders (label.hpp:157-159)
   uint64_t * cand, * alive, * sel, * selE, * covE, * selS, * covS, * jumpL, * jumpR, * featE, * featS;
   uint32_t * wbase;     // [2][cap/64] in-ring offsets of the per-word feature counts
   int * flags;          // [8]
+  uint8_t * base;       // start of the workspace: scratch of the fallback angle sort
   __device__ uint32_t * hmask() {return reinterpret_cast<uint32_t *>(x);}
   __device__ uint32_t * rmask() {return reinterpret_cast<uint32_t *>(y);}
 };
 
 constexpr int kBitArrays = 13;
+enum { kFlagUnsorted = 0, kFlagZeroPair = 1, kFlagBlockSmall = 2, kFlagBlockBig = 3, kFlagXYClobbered = 4 };
 
 __host__ __device__ inline size_t ring_lds_bytes(uint32_t cap)
 {
   const size_t words = cap / 64 + 2;
-  return (size_t)cap * (4 + 4 + 4 + 8 + 8 + 1) + kBitArrays * words * 8 + 2 * (cap / 64) * 4 + 8 * 4 + 64;
+  return (size_t)cap * (8 + 8 + 4 + 4 + 1) + kBitArrays * words * 8 + 2 * (cap / 64) * 4 + 8 * 4 + 64;
 }
 
 __device__ inline RingWork carve(uint8_t * base, uint32_t cap)
@@ -236,17 +277,17 @@ __device__ inline RingWork carve(uint8_t * base, uint32_t cap)
   RingWork w;
   const size_t words = cap / 64 + 2;
   uint8_t * p = base;
+  w.base = base;
   w.r = reinterpret_cast<double *>(p); p += (size_t)cap * 8;
   w.c = reinterpret_cast<double *>(p); p += (size_t)cap * 8;
+  w.x = reinterpret_cast<float *>(p); p += (size_t)cap * 4;
+  w.y = reinterpret_cast<float *>(p); p += (size_t)cap * 4;
   uint64_t * bits = reinterpret_cast<uint64_t *>(p); p += kBitArrays * words * 8;
   w.link = bits + 0 * words; w.llink = bits + 1 * words; w.cand = bits + 2 * words;
   w.alive = bits + 3 * words; w.sel = bits + 4 * words; w.selE = bits + 5 * words;
   w.covE = bits + 6 * words; w.selS = bits + 7 * words; w.covS = bits + 8 * words;
   w.jumpL = bits + 9 * words; w.jumpR = bits + 10 * words; w.featE = bits + 11 * words;
   w.featS = bits + 12 * words;
-  w.x = reinterpret_cast<float *>(p); p += (size_t)cap * 4;
-  w.y = reinterpret_cast<float *>(p); p += (size_t)cap * 4;
-  w.idx = reinterpret_cast<uint32_t *>(p); p += (size_t)cap * 4;
   w.wbase = reinterpret_cast<uint32_t *>(p); p += 2 * (size_t)(cap / 64) * 4;
   w.flags = reinterpret_cast<int *>(p); p += 8 * 4;
   w.lab = p;
@@ -266,6 +307,16 @@ __device__ inline uint32_t window32(const uint64_t * bits, int i)
 __device__ inline bool bit_at(const uint64_t * bits, int i)
 {
   return (bits[(i >> 6) + 1] >> (i & 63)) & 1ull;
+}
+
+// 64 bits of a bit array starting at position g (any alignment, g >= -64).
+__device__ inline uint64_t word_at(const uint64_t * bits, int g)
+{
+  const int o = g + 64;
+  const int w = o >> 6, sh = o & 63;
+  uint64_t v = bits[w] >> sh;
+  if (sh) {v |= bits[w + 1] << (64 - sh);}
+  return v;
 }
 
 // One wave covers 64 consecutive positions starting at a multiple of 64: its ballot IS the word.
@@ -323,10 +374,13 @@ __device__ inline int block_boundary(int N, int P, int B, int j)
 }
 
 // ------------------------------------------------------------------------------------------
-// Angle order: verify that the ring as bucketed is strictly increasing under the predicate
-// (then it IS the sorted order, whatever sort the reference runs); otherwise bitonic-sort it.
-// Returns true when a sort was needed.  x, y, idx are LDS arrays of length >= M (pow2 >= N).
-__device__ inline bool angle_sort(RingWork & w, int N, uint32_t cap)
+// Angle order.  w.x / w.y hold the ring as bucketed.  If it is strictly increasing under the
+// predicate it IS the sorted order (whatever sort the reference runs) and nothing is done.
+// Otherwise the ring is bitonic-sorted (total order: predicate, then arrival index) in scratch
+// laid over the whole workspace, written back to gx/gy/gidx, and w.x / w.y are refilled.
+// Returns true when a sort was needed.
+__device__ inline bool angle_sort(
+  RingWork & w, int N, float2 * gxy, uint32_t * gidx /* the ring's slices in global memory */)
 {
   const int T = blockDim.x, tid = threadIdx.x;
   int bad = 0;
@@ -336,7 +390,17 @@ __device__ inline bool angle_sort(RingWork & w, int N, uint32_t cap)
   if (!__syncthreads_or(bad)) {return false;}
   uint32_t M = 1;
   while (M < (uint32_t)N) {M <<= 1;}
-  for (uint32_t i = N + tid; i < M; i += T) {w.idx[i] = kSentinel; w.x[i] = 0.f; w.y[i] = 0.f;}
+  // 12*M <= 24*N <= 25*cap bytes: the scratch fits the workspace
+  float * sx = reinterpret_cast<float *>(w.base);
+  float * sy = sx + M;
+  uint32_t * si = reinterpret_cast<uint32_t *>(sy + M);
+  for (uint32_t i = tid; i < M; i += T) {
+    const bool in = i < (uint32_t)N;
+    const float2 v = in ? gxy[i] : make_float2(0.f, 0.f);
+    sx[i] = v.x;
+    sy[i] = v.y;
+    si[i] = in ? gidx[i] : kSentinel;
+  }
   __syncthreads();
   for (uint32_t k = 2; k <= M; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -344,24 +408,35 @@ __device__ inline bool angle_sort(RingWork & w, int N, uint32_t cap)
         const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // bit j clear
         const uint32_t p = i | j;
         const bool asc = (i & k) == 0;
-        const float ax = w.x[i], ay = w.y[i], bx = w.x[p], by = w.y[p];
-        const uint32_t ai = w.idx[i], bi = w.idx[p];
+        const float ax = sx[i], ay = sy[i], bx = sx[p], by = sy[p];
+        const uint32_t ai = si[i], bi = si[p];
         const bool swap = asc ? sort_less(bx, by, bi, ax, ay, ai) : sort_less(ax, ay, ai, bx, by, bi);
         if (swap) {
-          w.x[i] = bx; w.y[i] = by; w.idx[i] = bi;
-          w.x[p] = ax; w.y[p] = ay; w.idx[p] = ai;
+          sx[i] = bx; sy[i] = by; si[i] = bi;
+          sx[p] = ax; sy[p] = ay; si[p] = ai;
         }
       }
       __syncthreads();
     }
   }
-  (void)cap;
+  for (int i = tid; i < N; i += T) {
+    gxy[i] = make_float2(sx[i], sy[i]);
+    gidx[i] = si[i];
+  }
+  __syncthreads();          // all waves are done with the scratch; the workgroup's own global stores
+                            // are visible to it after the barrier (workgroup-scope fence)
+  for (int i = tid; i < N; i += T) {
+    const float2 v = gxy[i];
+    w.x[i] = v.x;
+    w.y[i] = v.y;
+  }
+  __syncthreads();
   return true;
 }
 
 // ------------------------------------------------------------------------------------------
-// Range, curvature, links.  `groups` (debug neighbour test) and `curv_in` (given curvature) are
-// only used by the per-stage entry points.  Sets flags[1] when an adjacent pair is both (0,0).
+// Range, curvature, links.  `groups` (debug neighbour test), `curv_in` (given curvature) and
+// `range_in` are only used by the per-stage entry points.
 __device__ inline void stencil_phase(
   RingWork & w, const Params & prm, int N, int Npad, const int32_t * groups, const double * curv_in,
   const double * range_in)
@@ -370,6 +445,7 @@ __device__ inline void stencil_phase(
   for (int i = tid; i < N; i += T) {
     const double x = (double)w.x[i], y = (double)w.y[i];
     w.r[i] = range_in ? range_in[i] : sqrt(x * x + y * y);           // math.hpp:36-39
+    w.lab[i] = kDefault;
   }
   __syncthreads();
   int zero_pair = 0;
@@ -403,12 +479,219 @@ __device__ inline void stencil_phase(
       w.c[i] = cv;
     }
   }
-  if (zero_pair) {w.flags[1] = 1;}
+  if (zero_pair) {w.flags[kFlagZeroPair] = 1;}
 }
 
-// ------------------------------------------------------------------------------------------
-// Block structure: mark block starts, cut the links at block ends, detect blocks of < 2 points.
-// single_block: one block [0, N) (EdgeLabel::Assign on a bare array).
+// ==========================================================================================
+// Block labelling, fast path: one wave per block, everything in registers.
+//
+// Lane l of the wave owns the block's local positions q = 64k + l (k < K <= kWaveChunks).  A set
+// of points is a K-word bitmask held wave-uniformly (the ballot of a per-lane predicate is
+// exactly the word of its 64 positions), so a round of the pick/suppress iteration is ballots
+// and funnel shifts -- no LDS, no barrier.
+constexpr int kWaveChunks = 6;            // blocks of up to 384 points take the fast path
+
+// window of a uniform word array around local position 64k + lane; W[0] is a zero pad word.
+// In 32-bit halves U[2j], U[2j+1] of W[j]: the window starts at half 2(k+1)-1, 2(k+1) or 2(k+1)+1
+// for lanes < 16, 16..47, >= 48, at bit (lane+16)&31 -- two selects between wave-uniform halves
+// and one v_alignbit.
+__device__ inline uint32_t uwindow(const uint64_t (&W)[kWaveChunks + 2], int k, bool hi, int sh)
+{
+  const int lane = threadIdx.x & 63;
+  const uint32_t u0 = (uint32_t)(W[k] >> 32), u1 = (uint32_t)W[k + 1], u2 = (uint32_t)(W[k + 1] >> 32),
+    u3 = (uint32_t)W[k + 2];
+  const uint32_t lo = lane < 16 ? u0 : (lane >= 48 ? u2 : u1);
+  const uint32_t up = lane < 16 ? u1 : (lane >= 48 ? u3 : u2);
+  return __builtin_amdgcn_alignbit(up, lo, (uint32_t)(lane + 16) & 31u);
+}
+
+// One pass over one block.  `taken` (bit k = local position 64k+lane is no longer Default) is the
+// per-lane state handed from the edge pass to the surface pass; the pass returns which of the
+// lane's positions it picked (`sel`) and which it reached (`cov`, picks included).
+template<bool EDGE, int PT>
+__device__ inline void wave_pass(
+  const RingWork & w, const Params & prm, int b0, int nb, int K, int lane, bool hi, int sh,
+  const double (&cq)[kWaveChunks], const uint32_t (&reach)[kWaveChunks], uint32_t taken,
+  uint32_t & sel, uint32_t & cov)
+{
+  const int P = PT > 0 ? PT : prm.P;
+  uint64_t A[kWaveChunks + 2], S[kWaveChunks + 2];
+  uint32_t H[kWaveChunks];
+  sel = 0;
+  cov = 0;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks + 2; k++) {A[k] = 0; S[k] = 0;}
+  uint64_t any = 0;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    if (k < K) {
+      const int q = 64 * k + lane;
+      bool cd = q < nb;
+      if (EDGE) {
+        cd = cd && cq[k] >= prm.edge_thr;                                 // label.hpp:80-82
+      } else {
+        cd = cd && cq[k] <= prm.surf_thr && !((taken >> k) & 1u);         // label.hpp:119-121, still Default
+      }
+      A[k + 1] = __ballot(cd);
+      any |= A[k + 1];
+    }
+  }
+  if (any == 0) {return;}
+  // priority masks: which candidates in reach come first (curvature, then index)
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    H[k] = 0;
+    if (k < K && A[k + 1] != 0) {
+      const int q = 64 * k + lane;
+      const uint32_t m = uwindow(A, k, hi, sh) & reach[k] & ~(1u << 16);
+      const double ci = cq[k];
+      uint32_t higher = 0;
+      if (PT > 0) {
+#pragma unroll
+        for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {
+          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nb - 1 ? nb - 1 : q + d;
+          const double cl = w.c[b0 + jl], cr = w.c[b0 + jr];
+          const bool fl = EDGE ? (cl > ci) : (cl < ci || cl == ci);      // left neighbour: lower index
+          const bool fr = EDGE ? (cr > ci || cr == ci) : (cr < ci);      // right neighbour: higher index
+          higher |= (fl ? 1u : 0u) << (16 - d);
+          higher |= (fr ? 1u : 0u) << (16 + d);
+        }
+      } else {
+        for (int d = 1; d <= P; d++) {
+          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nb - 1 ? nb - 1 : q + d;
+          const double cl = w.c[b0 + jl], cr = w.c[b0 + jr];
+          const bool fl = EDGE ? (cl > ci) : (cl < ci || cl == ci);
+          const bool fr = EDGE ? (cr > ci || cr == ci) : (cr < ci);
+          higher |= (fl ? 1u : 0u) << (16 - d);
+          higher |= (fr ? 1u : 0u) << (16 + d);
+        }
+      }
+      H[k] = higher & m;
+    }
+  }
+  // rounds: a live candidate with no live candidate of higher priority in reach is picked;
+  // everything a pick reaches (the pick included) leaves the live set
+  for (;; ) {
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {
+        uint64_t s = 0;
+        if (A[k + 1] != 0) {
+          const bool live = (A[k + 1] >> lane) & 1ull;
+          const bool pick = live && (uwindow(A, k, hi, sh) & H[k]) == 0;
+          s = __ballot(pick);
+          sel |= (pick ? 1u : 0u) << k;
+        }
+        S[k + 1] = s;
+      }
+    }
+    uint64_t left = 0;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {
+        if ((S[k] | S[k + 1] | S[k + 2]) != 0) {
+          const bool hit = (uwindow(S, k, hi, sh) & reach[k]) != 0;
+          cov |= (hit ? 1u : 0u) << k;
+          A[k + 1] &= ~__ballot(hit);
+        }
+        left |= A[k + 1];
+      }
+    }
+    if (left == 0) {break;}
+  }
+}
+
+template<int PT>
+__device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N, bool single_block)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const bool hi = lane >= 16;
+  const int sh = (lane + 48) & 63;
+  const int P = PT > 0 ? PT : prm.P;
+  const int nblocks = single_block ? 1 : prm.B;
+  for (int j = wave; j < nblocks; j += nwaves) {
+    const int b0 = single_block ? 0 : block_boundary(N, prm.P, prm.B, j);
+    const int b1 = single_block ? N : block_boundary(N, prm.P, prm.B, j + 1);
+    const int nb = b1 - b0;
+    const int K = (nb + 63) >> 6;
+    double cq[kWaveChunks];
+    uint32_t reach[kWaveChunks];
+    {
+      uint64_t LL[kWaveChunks + 2];
+#pragma unroll
+      for (int k = 0; k < kWaveChunks + 2; k++) {LL[k] = 0;}
+#pragma unroll
+      for (int k = 0; k < kWaveChunks; k++) {
+        cq[k] = 0.;
+        if (k < K) {
+          // links inside the block (label.hpp:157-159: the checker is sliced to the block)
+          const int rem = nb - 1 - 64 * k;
+          const uint64_t keep = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+          LL[k + 1] = word_at(w.link, b0 + 64 * k) & keep;
+          const int q = 64 * k + lane;
+          if (q < nb) {cq[k] = w.c[b0 + q];}
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kWaveChunks; k++) {
+        reach[k] = 0;
+        if (k < K) {
+          const uint32_t ll = uwindow(LL, k, hi, sh);                    // bit 16+d: link between q+d and q+d+1
+          int L = __clz((int)~(ll << 16));
+          int R = __ffs((int)~(ll >> 16)) - 1;
+          L = L < P ? L : P;
+          R = R < P ? R : P;
+          reach[k] = (64 * k + lane < nb) ? (((1u << (L + R + 1)) - 1u) << (16 - L)) : 0u;   // fill.hpp:101-117
+        }
+      }
+    }
+    uint32_t selE, covE, selS, covS;
+    wave_pass<true, PT>(w, prm, b0, nb, K, lane, hi, sh, cq, reach, 0u, selE, covE);
+    wave_pass<false, PT>(w, prm, b0, nb, K, lane, hi, sh, cq, reach, covE, selS, covS);
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {
+        const int q = 64 * k + lane;
+        if (q < nb) {
+          uint8_t lab = kDefault;
+          if ((selE >> k) & 1u) {
+            lab = kEdge;
+          } else if ((selS >> k) & 1u) {
+            lab = kSurface;
+          } else if ((covS >> k) & 1u) {
+            lab = kSurfaceNeighbor;
+          } else if ((covE >> k) & 1u) {
+            lab = kEdgeNeighbor;
+          }
+          w.lab[b0 + q] = lab;
+        }
+      }
+    }
+  }
+}
+
+// Block sizes: a block of < 2 points makes the reference throw (neighbor.hpp:71-75 on the slice);
+// a block of more than 64*kWaveChunks points takes the slow labelling path.
+__device__ inline void block_check(RingWork & w, const Params & prm, int N, bool single_block)
+{
+  const int T = blockDim.x, tid = threadIdx.x;
+  if (single_block) {
+    if (tid == 0) {
+      if (N < 2) {w.flags[kFlagBlockSmall] = 1;}
+      if (N > 64 * kWaveChunks) {w.flags[kFlagBlockBig] = 1;}
+    }
+    return;
+  }
+  for (int j = tid; j < prm.B; j += T) {
+    const int nb = block_boundary(N, prm.P, prm.B, j + 1) - block_boundary(N, prm.P, prm.B, j);
+    if (nb < 2) {w.flags[kFlagBlockSmall] = 1;}
+    if (nb > 64 * kWaveChunks) {w.flags[kFlagBlockBig] = 1;}
+  }
+}
+
+// ==========================================================================================
+// Block labelling, slow path (blocks longer than 512 points): the same iteration over the whole
+// ring at once with the point sets as LDS bit arrays and a barrier between the half rounds.
 __device__ inline void block_phase(RingWork & w, const Params & prm, int N, int Npad, bool single_block)
 {
   const int T = blockDim.x, tid = threadIdx.x, P = prm.P, B = prm.B;
@@ -418,12 +701,9 @@ __device__ inline void block_phase(RingWork & w, const Params & prm, int N, int 
   const int first = single_block ? 0 : P, last = single_block ? N : N - P;
   if (!single_block) {
     for (int j = tid; j < B; j += T) {
-      const int b0 = block_boundary(N, P, B, j), b1 = block_boundary(N, P, B, j + 1);
-      if (b1 - b0 < 2) {w.flags[2] = 1;}                             // neighbor.hpp:71-75 on the slice
+      const int b1 = block_boundary(N, P, B, j + 1);
       if (b1 - 1 >= 0) {atomicOr(reinterpret_cast<unsigned long long *>(&w.cand[((b1 - 1) >> 6) + 1]), 1ull << ((b1 - 1) & 63));}
     }
-  } else if (tid == 0 && N < 2) {
-    w.flags[2] = 1;
   }
   __syncthreads();
   for (int i0 = 0; i0 < Npad; i0 += T) {
@@ -435,10 +715,6 @@ __device__ inline void block_phase(RingWork & w, const Params & prm, int N, int 
   __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------
-// One labelling pass over all blocks of the ring at once (EDGE: label.hpp:72-95 descending with
-// c >= threshold; surface: label.hpp:113-134 ascending with c <= threshold on points the edge
-// pass left Default).  Writes sel (picked) and cov (reached by a pick, the pick included).
 template<bool EDGE>
 __device__ inline void label_pass(
   RingWork & w, const Params & prm, int N, int Npad, bool single_block, uint64_t * selAll, uint64_t * covAll)
@@ -511,39 +787,53 @@ __device__ inline void label_pass(
   }
 }
 
+__device__ inline void label_blocks_lds(RingWork & w, const Params & prm, int N, int Npad, bool single_block)
+{
+  const int T = blockDim.x, tid = threadIdx.x;
+  block_phase(w, prm, N, Npad, single_block);
+  if (tid == 0) {w.flags[kFlagXYClobbered] = 1;}
+  label_pass<true>(w, prm, N, Npad, single_block, w.selE, w.covE);
+  label_pass<false>(w, prm, N, Npad, single_block, w.selS, w.covS);
+  for (int i = tid; i < N; i += T) {
+    uint8_t lab = kDefault;
+    if (bit_at(w.selE, i)) {
+      lab = kEdge;
+    } else if (bit_at(w.selS, i)) {
+      lab = kSurface;
+    } else if (bit_at(w.covS, i)) {
+      lab = kSurfaceNeighbor;
+    } else if (bit_at(w.covE, i)) {
+      lab = kEdgeNeighbor;
+    }
+    w.lab[i] = lab;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Masks (feature_extraction.cpp:135-138, in this order, each overwriting) and the final label.
 __device__ inline void mask_phase(RingWork & w, const Params & prm, int N, int Npad, uint32_t flags)
 {
   const int T = blockDim.x, tid = threadIdx.x, P = prm.P;
   const bool do_occ = flags & 2u, do_oor = flags & 4u, do_pb = flags & 8u;
-  for (int i0 = 0; i0 < Npad; i0 += T) {
-    const int i = i0 + tid;
-    bool jl = false, jr = false;
-    if (do_occ) {
+  if (do_occ) {
+    for (int i0 = 0; i0 < Npad; i0 += T) {
+      const int i = i0 + tid;
+      bool jl = false, jr = false;
       // occlusion.hpp:44-57: i in [0, N-P-1), linked pair, far side to the right
       if (i + 1 < N && i < N - P - 1 && bit_at(w.link, i)) {jl = w.r[i + 1] > w.r[i] + prm.dist_diff;}
       // occlusion.hpp:67-79: i in [P+1, N-1], linked pair (i, i-1), far side to the left
       if (i < N && i >= P + 1 && bit_at(w.link, i - 1)) {jr = w.r[i - 1] > w.r[i] + prm.dist_diff;}
+      const int w0 = i0 + (tid & ~63);
+      store_word(w.jumpL, w0, Npad, jl);
+      store_word(w.jumpR, w0, Npad, jr);
     }
-    const int w0 = i0 + (tid & ~63);
-    store_word(w.jumpL, w0, Npad, jl);
-    store_word(w.jumpR, w0, Npad, jr);
+    __syncthreads();
   }
-  __syncthreads();
   for (int i0 = 0; i0 < Npad; i0 += T) {
     const int i = i0 + tid;
     uint8_t lab = kDefault;
     if (i < N) {
-      if (bit_at(w.selE, i)) {
-        lab = kEdge;
-      } else if (bit_at(w.selS, i)) {
-        lab = kSurface;
-      } else if (bit_at(w.covS, i)) {
-        lab = kSurfaceNeighbor;
-      } else if (bit_at(w.covE, i)) {
-        lab = kEdgeNeighbor;
-      }
+      lab = w.lab[i];
       if (do_occ) {
         const uint32_t lk = window32(w.link, i);
         // FillFromLeft from a jump at i-k (k = 1..P+1) reaches i when links i-k+1 .. i-1 hold
@@ -572,7 +862,7 @@ __device__ inline void mask_phase(RingWork & w, const Params & prm, int N, int N
   __syncthreads();
 }
 
-// Runs label + mask phases on a ring whose x, y (and idx) are in LDS.  Returns the ring status.
+// Runs the stencil, labelling and mask phases on a ring whose x, y are in LDS.  Returns the status.
 __device__ inline uint8_t process_ring(
   RingWork & w, const Params & prm, int N, uint32_t flags, const int32_t * groups, const double * curv_in,
   const double * range_in)
@@ -588,61 +878,66 @@ __device__ inline uint8_t process_ring(
   if (do_label && !single_block && N - 2 * P < prm.B) {return kTooFewBlocks;}
   const int words = (Npad >> 6) + 2;
   for (int k = tid; k < words; k += T) {
-    w.link[k] = 0; w.llink[k] = 0; w.cand[k] = 0; w.alive[k] = 0; w.sel[k] = 0; w.selE[k] = 0; w.covE[k] = 0;
-    w.selS[k] = 0; w.covS[k] = 0; w.jumpL[k] = 0; w.jumpR[k] = 0; w.featE[k] = 0; w.featS[k] = 0;
+    w.link[k] = 0; w.jumpL[k] = 0; w.jumpR[k] = 0; w.featE[k] = 0; w.featS[k] = 0;
+    w.llink[k] = 0; w.cand[k] = 0; w.alive[k] = 0; w.sel[k] = 0; w.selE[k] = 0; w.covE[k] = 0;
+    w.selS[k] = 0; w.covS[k] = 0;
   }
-  if (tid < 8) {w.flags[tid] = 0;}
+  if (tid < 8 && tid != kFlagUnsorted) {w.flags[tid] = 0;}
   __syncthreads();
   stencil_phase(w, prm, N, Npad, groups, curv_in, range_in);
+  if (do_label) {block_check(w, prm, N, single_block);}
   __syncthreads();
+  if (w.flags[kFlagZeroPair]) {return kZeroNormPair;}
+  if (w.flags[kFlagBlockSmall]) {return kBlockTooSmall;}
   if (do_label) {
-    block_phase(w, prm, N, Npad, single_block);
-  }
-  if (w.flags[1]) {return kZeroNormPair;}
-  if (w.flags[2]) {return kBlockTooSmall;}
-  if (do_label) {
-    label_pass<true>(w, prm, N, Npad, single_block, w.selE, w.covE);
-    label_pass<false>(w, prm, N, Npad, single_block, w.selS, w.covS);
+    if (w.flags[kFlagBlockBig]) {
+      label_blocks_lds(w, prm, N, Npad, single_block);
+    } else if (P == 5) {
+      label_blocks_wave<5>(w, prm, N, single_block);
+    } else if (P == 2) {
+      label_blocks_wave<2>(w, prm, N, single_block);
+    } else {
+      label_blocks_wave<0>(w, prm, N, single_block);
+    }
+    __syncthreads();
   }
   mask_phase(w, prm, N, Npad, flags);
   return kOk;
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: one workgroup per (ring slot, scan).
-__global__ __launch_bounds__(1024) void ring_extract_kernel(
-  Params prm, uint32_t cap, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
+// K3: one workgroup per (ring slot, scan).  Writes the per-point outputs in ring-major order and
+// the ring's feature records (edge from the front of the ring's segment, surface from its back).
+__global__ __launch_bounds__(512) void ring_extract_kernel(
+  Params prm, uint32_t cap, uint32_t stage_flags, const uint8_t * __restrict__ pts, Layout L,
+  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
   const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_offset,
-  float * __restrict__ sx, float * __restrict__ sy, uint32_t * __restrict__ sidx,
-  uint8_t * __restrict__ label_s, double * __restrict__ curv_s, uint32_t * __restrict__ seg,
-  uint8_t * __restrict__ ring_status, uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf)
+  float2 * __restrict__ sxy, const float * __restrict__ sz, uint32_t * __restrict__ sidx,
+  uint8_t * __restrict__ label_s, double * __restrict__ curv_s, float4 * __restrict__ rec_pts,
+  uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status, uint32_t * __restrict__ ring_nedge,
+  uint32_t * __restrict__ ring_nsurf)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const uint32_t slot = blockIdx.x, s = blockIdx.y;
   if (slot >= scan_info[s * 4 + kInfoRings]) {return;}
   const int T = blockDim.x, tid = threadIdx.x;
   const int N = (int)ring_count[s * kRings + slot];
-  const size_t off = (size_t)scan_begin[s] + ring_offset[s * kRings + slot];
+  const size_t sb = scan_begin[s];
+  const size_t off = sb + ring_offset[s * kRings + slot];
   uint8_t status = kOk;
+  bool resorted = false;
   RingWork w = carve(lds_raw, cap);
   if ((uint32_t)N > cap) {
     status = kTooLarge;
   } else {
     for (int i = tid; i < N; i += T) {
-      w.x[i] = sx[off + i];
-      w.y[i] = sy[off + i];
-      w.idx[i] = sidx[off + i];
+      const float2 v = sxy[off + i];
+      w.x[i] = v.x;
+      w.y[i] = v.y;
     }
     __syncthreads();
-    if (angle_sort(w, N, cap)) {
-      for (int i = tid; i < N; i += T) {
-        sx[off + i] = w.x[i];
-        sy[off + i] = w.y[i];
-        sidx[off + i] = w.idx[i];
-      }
-    }
-    __syncthreads();
-    status = process_ring(w, prm, N, 47u, nullptr, nullptr, nullptr);
+    resorted = angle_sort(w, N, sxy + off, sidx + off);
+    status = process_ring(w, prm, N, stage_flags, nullptr, nullptr, nullptr);
   }
   if (status != kOk) {
     // the ring contributes nothing (feature_extraction.cpp:116,154-156)
@@ -657,8 +952,6 @@ __global__ __launch_bounds__(1024) void ring_extract_kernel(
     }
     return;
   }
-  // in-ring compaction: edge positions ascending from the front of the ring's segment, surface
-  // positions ascending from its back (edge + surface <= N, so they never meet)
   const int nwords = (N + 63) >> 6;
   if (tid < 64) {
     uint32_t ce = 0, cs = 0;
@@ -685,28 +978,38 @@ __global__ __launch_bounds__(1024) void ring_extract_kernel(
     }
   }
   __syncthreads();
+  const bool reload_xy = w.flags[kFlagXYClobbered] != 0;
   for (int i = tid; i < N; i += T) {
     const uint8_t lab = w.lab[i];
+    const double c = w.c[i];
     label_s[off + i] = lab;
-    curv_s[off + i] = w.c[i];
-    const uint64_t below = (1ull << (i & 63)) - 1ull;
-    if (lab == kEdge) {
-      seg[off + w.wbase[i >> 6] + __popcll(w.featE[(i >> 6) + 1] & below)] = (uint32_t)i;
-    } else if (lab == kSurface) {
-      seg[off + N - 1 - (w.wbase[cap / 64 + (i >> 6)] + __popcll(w.featS[(i >> 6) + 1] & below))] = (uint32_t)i;
+    curv_s[off + i] = c;
+    if (lab == kEdge || lab == kSurface) {
+      const uint64_t below = (1ull << (i & 63)) - 1ull;
+      const uint32_t orig = sidx[off + i];
+      // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
+      const float z = resorted ? *reinterpret_cast<const float *>(pts + (sb + orig) * L.step + L.oz) : sz[off + i];
+      float x = w.x[i], y = w.y[i];
+      if (reload_xy) {const float2 v = sxy[off + i]; x = v.x; y = v.y;}
+      size_t at;
+      if (lab == kEdge) {
+        at = off + w.wbase[i >> 6] + __popcll(w.featE[(i >> 6) + 1] & below);
+      } else {
+        at = off + N - 1 - (w.wbase[cap / 64 + (i >> 6)] + __popcll(w.featS[(i >> 6) + 1] & below));
+      }
+      rec_pts[at] = make_float4(x, y, z, (float)c);
+      rec_idx[at] = orig;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: pack the per-ring lists into the scan's edge / surface clouds, rings ascending
-// (AppendXYZIR, label.hpp:166-179: intensity <- (float)curvature).
+// K4: copy the per-ring feature records into the scan's edge / surface clouds, rings ascending.
 __global__ __launch_bounds__(256) void feature_compact_kernel(
-  const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
-  uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
-  const uint32_t * __restrict__ ring_offset, const uint32_t * __restrict__ ring_nedge,
-  const uint32_t * __restrict__ ring_nsurf, const float * __restrict__ sx, const float * __restrict__ sy,
-  const uint32_t * __restrict__ sidx, const double * __restrict__ curv_s, const uint32_t * __restrict__ seg,
+  const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ scan_info,
+  const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_offset,
+  const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf,
+  const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx,
   float4 * __restrict__ edge_pts, uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts,
   uint32_t * __restrict__ surf_idx)
 {
@@ -731,18 +1034,13 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     scan_info[s * 4 + kInfoSurface] = sbase + ns;
   }
   for (uint32_t k = tid; k < ne + ns; k += blockDim.x) {
-    const bool edge = k < ne;
-    const uint32_t q = edge ? k : k - ne;
-    const uint32_t i = edge ? seg[off + q] : seg[off + N - 1 - q];
-    const uint32_t orig = sidx[off + i];
-    const float z = *reinterpret_cast<const float *>(pts + (b + orig) * L.step + L.oz);
-    const float4 v = make_float4(sx[off + i], sy[off + i], z, (float)curv_s[off + i]);
-    if (edge) {
-      edge_pts[b + ebase + q] = v;
-      edge_idx[b + ebase + q] = orig;
+    if (k < ne) {
+      edge_pts[b + ebase + k] = rec_pts[off + k];
+      edge_idx[b + ebase + k] = rec_idx[off + k];
     } else {
-      surf_pts[b + sbase + q] = v;
-      surf_idx[b + sbase + q] = orig;
+      const uint32_t q = k - ne;
+      surf_pts[b + sbase + q] = rec_pts[off + N - 1 - q];
+      surf_idx[b + sbase + q] = rec_idx[off + N - 1 - q];
     }
   }
 }
@@ -804,7 +1102,7 @@ __global__ __launch_bounds__(256) void feature_pack_kernel(
 
 // ------------------------------------------------------------------------------------------
 // Per-stage kernel: one ring handed over as sorted x, y (lfx_stage_ring).
-__global__ __launch_bounds__(1024) void ring_stage_kernel(
+__global__ __launch_bounds__(512) void ring_stage_kernel(
   Params prm, uint32_t cap, uint32_t flags, int N, const float * __restrict__ x, const float * __restrict__ y,
   const int32_t * __restrict__ groups, const double * __restrict__ curv_in,
   const double * __restrict__ range_in, double * __restrict__ range_out,
@@ -817,7 +1115,6 @@ __global__ __launch_bounds__(1024) void ring_stage_kernel(
   for (int i = tid; i < N; i += T) {
     w.x[i] = x[i];
     w.y[i] = y[i];
-    w.idx[i] = i;
     w.lab[i] = kDefault;
     w.r[i] = 0.;
     w.c[i] = 0.;

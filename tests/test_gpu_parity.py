@@ -214,6 +214,22 @@ def test_large_random_parameters(fx):
         f.close()
 
 
+def test_long_blocks_take_the_lds_labelling_path(fx):
+    """Blocks longer than 512 points are labelled by the LDS/barrier variant of the same iteration."""
+    c = make_scan(3, 3600, seed=17, drop_fraction=0.02)
+    for nb in (1, 2, 5, 6, 7):
+        hp = HyperParameters(n_blocks=nb)
+        f = FeatureExtraction(hp, device=0, max_points_per_scan=len(c), max_batch=1)
+        assert_scan_equal(f.ExtractFeatures(c), OB.extract(c, oracle_params(hp), canonical_ties=False), "B%d" % nb)
+        f.close()
+    # and an unsorted ring that needs the fallback angle sort at the same time
+    c2 = make_scan(2, 3000, seed=18, shuffle=True)
+    hp = HyperParameters(n_blocks=3)
+    f = FeatureExtraction(hp, device=0, max_points_per_scan=len(c2), max_batch=1)
+    assert_scan_equal(f.ExtractFeatures(c2), OB.extract(c2, oracle_params(hp), canonical_ties=False), "B3-shuffled")
+    f.close()
+
+
 def test_f64_sqrt_and_divide_are_correctly_rounded(fx):
     """Range (math.hpp:36-39) and the link cosine feed orderings: they must equal IEEE results."""
     rng = np.random.default_rng(2)
