@@ -192,7 +192,7 @@ int lfx_stage_ring_projection(lfx_ctx *ctx, const void *points, size_t n_points,
                               uint32_t *n_rings, uint16_t *ring_id /* [256] */, uint32_t *ring_count /* [256] */);
 
 /* --- measurement ------------------------------------------------------------------------- */
-#define LFX_N_KERNELS 5   /* 0 ring_histogram 1 ring_scan 2 ring_scatter 3 ring_extract 4 feature_compact */
+#define LFX_N_KERNELS 7   /* ring_histogram, ring_scan, ring_scatter, ring_unit, ring_extract, ring_totals, feature_compact */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);
 /* Sum of HIP-event durations per kernel since profiling was enabled, and launches counted. */
 int lfx_kernel_times(lfx_ctx *ctx, double ms[LFX_N_KERNELS], uint64_t launches[LFX_N_KERNELS]);

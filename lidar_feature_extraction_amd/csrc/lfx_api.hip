@@ -23,8 +23,8 @@ namespace
 std::string g_create_error;
 
 const char * kKernelNames[LFX_N_KERNELS] = {
-  "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_extract_kernel",
-  "feature_compact_kernel"};
+  "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_unit_kernel",
+  "ring_extract_kernel", "ring_totals_kernel", "feature_compact_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -91,14 +91,16 @@ struct lfx_ctx
   lfx_params params{};
   lfx::Params dev{};
   lfx::Layout layout{};
-  uint32_t max_points = 0, max_batch = 0, cap = 0, max_chunks = 0, max_rings = 0, ring_threads = 0;
+  uint32_t max_points = 0, max_batch = 0, cap = 0, max_chunks = 0, max_rings = 0, ring_threads = 0, slow_grid = 0;
   size_t total_cap = 0, ring_lds = 0;
-  uint32_t ring_flags = LFX_STAGE_ALL;   // LFX_DEBUG_RING_FLAGS overrides it for kernel ablations (wrong results)
+  uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
+  bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
 
   // device scratch
   DevBuf<uint32_t> scan_begin, scan_info, chunk_base, ring_off_by_id, ring_count, ring_offset, ring_nedge,
-    ring_nsurf, sidx, rec_idx, edge_idx, surf_idx;
+    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, slow_list, sidx, rec_idx, edge_idx,
+    surf_idx;
   DevBuf<uint16_t> chunk_hist, ring_id;
   DevBuf<uint8_t> ring_status, label_s, staging;
   DevBuf<float2> sxy;
@@ -117,8 +119,8 @@ struct lfx_ctx
   struct Span { hipEvent_t a, b; int k; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> free_events;
-  double ms[LFX_N_KERNELS] = {0, 0, 0, 0, 0};
-  uint64_t launches[LFX_N_KERNELS] = {0, 0, 0, 0, 0};
+  double ms[LFX_N_KERNELS] = {};
+  uint64_t launches[LFX_N_KERNELS] = {};
 };
 
 namespace
@@ -274,18 +276,40 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->ring_off_by_id.p, c->sxy.p, c->sz.p,
       c->sidx.p, c->max_chunks);
   }
-  {
+  // ring_flags[max_batch][256], then the slow-list counter
+  uint32_t * slow_count = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;
+  LFX_HIP(c, hipMemsetAsync(c->ring_flags.p, 0, (size_t)batch * lfx::kRings * 4, st));
+  LFX_HIP(c, hipMemsetAsync(slow_count, 0, 4, st));
+  if (c->fast_path) {
     Timed t(c, 3, st);
-    hipLaunchKernelGGL(lfx::ring_extract_kernel, dim3(c->max_rings, batch), dim3(c->ring_threads), c->ring_lds, st,
-      c->dev, c->cap, c->ring_flags, pts, c->layout, c->scan_begin.p, c->scan_info.p, c->ring_count.p,
-      c->ring_offset.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
-      c->rec_idx.p, c->ring_status.p, c->ring_nedge.p, c->ring_nsurf.p);
+    const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
+    hipLaunchKernelGGL(lfx::ring_unit_kernel, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
+      dim3(64 * lfx::kUnitWaves), 0, st,
+      c->dev, c->cap, c->max_rings, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->sxy.p,
+      c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
+      c->unit_ns.p, c->ring_flags.p, slow_count, c->slow_list.p);
   }
   {
     Timed t(c, 4, st);
+    const dim3 grid = c->fast_path ? dim3(c->slow_grid) : dim3(c->max_rings, batch);
+    hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
+      c->dev, c->cap, c->stage_flags, c->fast_path ? 1u : 0u, pts, c->layout, c->scan_begin.p, c->scan_info.p,
+      c->ring_count.p, c->ring_offset.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
+      c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->ring_flags.p, slow_count, c->slow_list.p,
+      c->max_rings);
+  }
+  {
+    Timed t(c, 5, st);
+    hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
+      c->scan_info.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p, c->ring_ebase.p,
+      c->ring_sbase.p, c->fast_path ? (uint32_t)c->dev.B : 1u, c->max_rings);
+  }
+  {
+    Timed t(c, 6, st);
     hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3(c->max_rings, batch), dim3(256), 0, st,
-      c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p, c->ring_nsurf.p,
-      c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p, c->surf_idx.p);
+      c->dev, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p,
+      c->ring_nsurf.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p, c->unit_ns.p, c->ring_flags.p,
+      c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p, c->surf_idx.p, c->max_rings);
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -455,7 +479,9 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   }
   c->max_rings = config->max_rings ? (config->max_rings > lfx::kRings ? lfx::kRings : config->max_rings) : lfx::kRings;
   c->ring_threads = ring_threads_for(c->cap);
-  if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->ring_flags = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
+  c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
+  c->slow_grid = 1024;
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
   c->ring_lds = lfx::ring_lds_bytes(c->cap);
   c->max_chunks = (c->max_points + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
@@ -473,7 +499,9 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->chunk_hist.alloc(chunk_tab)); ok(c->chunk_base.alloc(chunk_tab));
   ok(c->ring_off_by_id.alloc(tables)); ok(c->ring_id.alloc(tables)); ok(c->ring_count.alloc(tables));
   ok(c->ring_offset.alloc(tables)); ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
-  ok(c->ring_nsurf.alloc(tables));
+  ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
+  ok(c->ring_flags.alloc(tables + 1)); ok(c->slow_list.alloc(tables));
+  ok(c->unit_ne.alloc(tables * lfx::kUnitMaxBlocks)); ok(c->unit_ns.alloc(tables * lfx::kUnitMaxBlocks));
   ok(c->sxy.alloc(tc)); ok(c->sz.alloc(tc)); ok(c->sidx.alloc(tc)); ok(c->rec_pts.alloc(tc)); ok(c->rec_idx.alloc(tc));
   ok(c->label_s.alloc(tc)); ok(c->curv_s.alloc(tc));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
@@ -504,7 +532,8 @@ void lfx_destroy(lfx_ctx * c)
   for (auto & ev : c->free_events) {(void)hipEventDestroy(ev);}
   c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
   c->ring_off_by_id.release(); c->ring_id.release(); c->ring_count.release(); c->ring_offset.release();
-  c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release();
+  c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->unit_ne.release(); c->unit_ns.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();

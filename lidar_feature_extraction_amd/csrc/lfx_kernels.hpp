@@ -508,9 +508,11 @@ __device__ inline uint32_t uwindow(const uint64_t (&W)[kWaveChunks + 2], int k, 
 // One pass over one block.  `taken` (bit k = local position 64k+lane is no longer Default) is the
 // per-lane state handed from the edge pass to the surface pass; the pass returns which of the
 // lane's positions it picked (`sel`) and which it reached (`cov`, picks included).
+// cl[q] is the curvature at local position q (q in [0, nloc)); `inblk` bit k says whether the
+// lane's position 64k+lane belongs to the block being labelled.
 template<bool EDGE, int PT>
 __device__ inline void wave_pass(
-  const RingWork & w, const Params & prm, int b0, int nb, int K, int lane, bool hi, int sh,
+  const double * cl_, const Params & prm, int nloc, uint32_t inblk, int K, int lane, bool hi, int sh,
   const double (&cq)[kWaveChunks], const uint32_t (&reach)[kWaveChunks], uint32_t taken,
   uint32_t & sel, uint32_t & cov)
 {
@@ -525,8 +527,7 @@ __device__ inline void wave_pass(
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
     if (k < K) {
-      const int q = 64 * k + lane;
-      bool cd = q < nb;
+      bool cd = (inblk >> k) & 1u;
       if (EDGE) {
         cd = cd && cq[k] >= prm.edge_thr;                                 // label.hpp:80-82
       } else {
@@ -549,8 +550,8 @@ __device__ inline void wave_pass(
       if (PT > 0) {
 #pragma unroll
         for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {
-          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nb - 1 ? nb - 1 : q + d;
-          const double cl = w.c[b0 + jl], cr = w.c[b0 + jr];
+          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nloc - 1 ? nloc - 1 : q + d;
+          const double cl = cl_[jl], cr = cl_[jr];
           const bool fl = EDGE ? (cl > ci) : (cl < ci || cl == ci);      // left neighbour: lower index
           const bool fr = EDGE ? (cr > ci || cr == ci) : (cr < ci);      // right neighbour: higher index
           higher |= (fl ? 1u : 0u) << (16 - d);
@@ -558,8 +559,8 @@ __device__ inline void wave_pass(
         }
       } else {
         for (int d = 1; d <= P; d++) {
-          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nb - 1 ? nb - 1 : q + d;
-          const double cl = w.c[b0 + jl], cr = w.c[b0 + jr];
+          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nloc - 1 ? nloc - 1 : q + d;
+          const double cl = cl_[jl], cr = cl_[jr];
           const bool fl = EDGE ? (cl > ci) : (cl < ci || cl == ci);
           const bool fr = EDGE ? (cr > ci || cr == ci) : (cr < ci);
           higher |= (fl ? 1u : 0u) << (16 - d);
@@ -645,9 +646,12 @@ __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N
         }
       }
     }
+    uint32_t inblk = 0;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {inblk |= (64 * k + lane < nb ? 1u : 0u) << k;}
     uint32_t selE, covE, selS, covS;
-    wave_pass<true, PT>(w, prm, b0, nb, K, lane, hi, sh, cq, reach, 0u, selE, covE);
-    wave_pass<false, PT>(w, prm, b0, nb, K, lane, hi, sh, cq, reach, covE, selS, covS);
+    wave_pass<true, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, cq, reach, 0u, selE, covE);
+    wave_pass<false, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, cq, reach, covE, selS, covS);
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
@@ -905,143 +909,508 @@ __device__ inline uint8_t process_ring(
   return kOk;
 }
 
-// ------------------------------------------------------------------------------------------
-// K3: one workgroup per (ring slot, scan).  Writes the per-point outputs in ring-major order and
-// the ring's feature records (edge from the front of the ring's segment, surface from its back).
-__global__ __launch_bounds__(512) void ring_extract_kernel(
-  Params prm, uint32_t cap, uint32_t stage_flags, const uint8_t * __restrict__ pts, Layout L,
-  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
-  const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_offset,
-  float2 * __restrict__ sxy, const float * __restrict__ sz, uint32_t * __restrict__ sidx,
-  uint8_t * __restrict__ label_s, double * __restrict__ curv_s, float4 * __restrict__ rec_pts,
-  uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status, uint32_t * __restrict__ ring_nedge,
-  uint32_t * __restrict__ ring_nsurf)
+// ==========================================================================================
+// K3 (fast path): one WAVE per (ring, block) unit; no workgroup barrier anywhere.
+//
+// Unit j of a ring owns the output positions of block j (the first / last unit also own the ring's
+// P-wide borders) and loads them with a halo of P+1 positions on either side: enough for the
+// curvature window (P), the occlusion fills that can reach an owned point (P+1) and the
+// parallel-beam test (1).  Lane l holds local positions q = 64k + l in registers; range and
+// curvature also go to a wave-private LDS slab so that neighbours can be read by position.
+// Rings the fast path cannot take (not angle-sorted as bucketed, skip conditions, blocks that do
+// not fit a wave) are appended to `slow_list` and redone whole by ring_extract_kernel.
+constexpr int kUnitWaves = 4;
+constexpr int kUnitSpan = 64 * kWaveChunks;
+constexpr int kUnitMaxBlocks = 64;        // per-unit count tables are sized for n_blocks <= 64
+
+struct UnitLds
 {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  const uint32_t slot = blockIdx.x, s = blockIdx.y;
-  if (slot >= scan_info[s * 4 + kInfoRings]) {return;}
-  const int T = blockDim.x, tid = threadIdx.x;
+  double r[kUnitSpan];
+  double c[kUnitSpan];
+  float x[kUnitSpan + 2];
+  float y[kUnitSpan + 2];
+};
+
+// LDS traffic of one wave is executed in order; this only stops the compiler from moving a
+// lane's LDS read above another lane's LDS write of the same wave.
+#define LFX_WAVE_SYNC() \
+  do { \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier(); \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// bits of word k (positions 64k .. 64k+63) that lie in [lo, hi)
+__device__ inline uint64_t range_word(int k, int lo, int hi)
+{
+  int a = lo - 64 * k, b = hi - 64 * k;
+  a = a < 0 ? 0 : a;
+  b = b > 64 ? 64 : b;
+  if (b <= a) {return 0ull;}
+  const uint64_t upto_b = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+  const uint64_t upto_a = (1ull << a) - 1ull;          // a <= 63 here
+  return upto_b & ~upto_a;
+}
+
+template<int PT>
+__device__ inline void unit_body(
+  const Params & prm, UnitLds & U, uint32_t ring_cap, uint32_t s, uint32_t slot, int j,
+  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ ring_count,
+  const uint32_t * __restrict__ ring_offset, const float2 * __restrict__ sxy, const float * __restrict__ sz,
+  const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
+  float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
+  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags,
+  uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
+{
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane >= 16;
+  const int sh = (lane + 48) & 63;
+  const int P = PT > 0 ? PT : prm.P, B = prm.B;
   const int N = (int)ring_count[s * kRings + slot];
-  const size_t sb = scan_begin[s];
-  const size_t off = sb + ring_offset[s * kRings + slot];
-  uint8_t status = kOk;
-  bool resorted = false;
-  RingWork w = carve(lds_raw, cap);
-  if ((uint32_t)N > cap) {
-    status = kTooLarge;
-  } else {
-    for (int i = tid; i < N; i += T) {
-      const float2 v = sxy[off + i];
-      w.x[i] = v.x;
-      w.y[i] = v.y;
-    }
-    __syncthreads();
-    resorted = angle_sort(w, N, sxy + off, sidx + off);
-    status = process_ring(w, prm, N, stage_flags, nullptr, nullptr, nullptr);
-  }
-  if (status != kOk) {
-    // the ring contributes nothing (feature_extraction.cpp:116,154-156)
-    for (int i = tid; i < N; i += T) {
-      label_s[off + i] = kDefault;
-      curv_s[off + i] = 0.;
-    }
-    if (tid == 0) {
-      ring_status[s * kRings + slot] = status;
-      ring_nedge[s * kRings + slot] = 0;
-      ring_nsurf[s * kRings + slot] = 0;
-    }
+  const size_t off = (size_t)scan_begin[s] + ring_offset[s * kRings + slot];
+  uint32_t * flag = ring_flags + s * kRings + slot;
+#define LFX_DEFER() \
+  do { \
+    if (lane == 0 && atomicOr(flag, 1u) == 0u) {slow_list[atomicAdd(slow_count, 1u)] = s * kRings + slot;} \
+    return; \
+  } while (0)
+  // skip conditions and over-long rings are the slow path's business (it also reports them)
+  if (N < 2 * P + 1 || N - 2 * P < B || (uint32_t)N > ring_cap) {
+    if (j == 0) {LFX_DEFER();}
     return;
   }
-  const int nwords = (N + 63) >> 6;
-  if (tid < 64) {
-    uint32_t ce = 0, cs = 0;
-    for (int base = 0; base < nwords; base += 64) {
-      const int k = base + tid;
-      const uint32_t ne = k < nwords ? __popcll(w.featE[k + 1]) : 0u;
-      const uint32_t ns = k < nwords ? __popcll(w.featS[k + 1]) : 0u;
-      uint32_t ie = ne, is = ns;
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t te = __shfl_up(ie, d), ts = __shfl_up(is, d);
-        if (tid >= d) {ie += te; is += ts;}
+  const int b0 = block_boundary(N, P, B, j), b1 = block_boundary(N, P, B, j + 1);
+  const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? N : b1;
+  const int H = P + 1, g0 = o0 - H, span = o1 + H - g0;
+  if (b1 - b0 < 2 || span > kUnitSpan) {LFX_DEFER();}
+  const int K = (span + 63) >> 6;
+
+  float x[kWaveChunks], y[kWaveChunks];
+  double r[kWaveChunks], cq[kWaveChunks];
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    x[k] = 0.f; y[k] = 0.f; r[k] = 0.; cq[k] = 0.;
+    if (k < K) {
+      const int q = 64 * k + lane, i = g0 + q;
+      if (i >= 0 && i < N && q < span) {
+        const float2 v = sxy[off + i];
+        x[k] = v.x;
+        y[k] = v.y;
       }
-      if (k < nwords) {
-        w.wbase[k] = ce + ie - ne;
-        w.wbase[cap / 64 + k] = cs + is - ns;
-      }
-      ce += __shfl(ie, 63);
-      cs += __shfl(is, 63);
-    }
-    if (tid == 0) {
-      ring_status[s * kRings + slot] = kOk;
-      ring_nedge[s * kRings + slot] = ce;
-      ring_nsurf[s * kRings + slot] = cs;
+      U.x[q] = x[k];
+      U.y[q] = y[k];
     }
   }
-  __syncthreads();
-  const bool reload_xy = w.flags[kFlagXYClobbered] != 0;
-  for (int i = tid; i < N; i += T) {
-    const uint8_t lab = w.lab[i];
-    const double c = w.c[i];
-    label_s[off + i] = lab;
-    curv_s[off + i] = c;
-    if (lab == kEdge || lab == kSurface) {
-      const uint64_t below = (1ull << (i & 63)) - 1ull;
-      const uint32_t orig = sidx[off + i];
-      // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-      const float z = resorted ? *reinterpret_cast<const float *>(pts + (sb + orig) * L.step + L.oz) : sz[off + i];
-      float x = w.x[i], y = w.y[i];
-      if (reload_xy) {const float2 v = sxy[off + i]; x = v.x; y = v.y;}
-      size_t at;
-      if (lab == kEdge) {
-        at = off + w.wbase[i >> 6] + __popcll(w.featE[(i >> 6) + 1] & below);
-      } else {
-        at = off + N - 1 - (w.wbase[cap / 64 + (i >> 6)] + __popcll(w.featS[(i >> 6) + 1] & below));
-      }
-      rec_pts[at] = make_float4(x, y, z, (float)c);
-      rec_idx[at] = orig;
+  LFX_WAVE_SYNC();
+  // angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, or slow path
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    if (k < K) {
+      const int q = 64 * k + lane, i = g0 + q;
+      if (i >= o0 && i < o1 && i + 1 < N) {bad = bad || !polar_less(x[k], y[k], U.x[q + 1], U.y[q + 1]);}
+      const double xd = (double)x[k], yd = (double)y[k];
+      r[k] = sqrt(xd * xd + yd * yd);                                    // math.hpp:36-39
+      U.r[q] = r[k];
     }
+  }
+  if (__ballot(bad) != 0ull) {LFX_DEFER();}
+  LFX_WAVE_SYNC();
+  // links (neighbor.hpp:44-48) as wave-uniform words; bit q <-> pair (q, q+1)
+  uint64_t LK[kWaveChunks + 2];
+#pragma unroll
+  for (int k = 0; k < kWaveChunks + 2; k++) {LK[k] = 0;}
+  bool zero_pair = false;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    if (k < K) {
+      const int q = 64 * k + lane, i = g0 + q;
+      bool lk = false;
+      if (i >= 0 && i + 1 < N && q + 1 < span) {
+        const double rn = U.r[q + 1];
+        if (i >= o0 && i < o1 && r[k] == 0. && rn == 0.) {zero_pair = true;}     // math.cpp:40-42 throws
+        const double dot = (double)x[k] * (double)U.x[q + 1] + (double)y[k] * (double)U.y[q + 1];
+        const double cosang = dot / (r[k] * rn);
+        lk = cosang >= prm.cos_bound && cosang <= 1.0;
+      }
+      LK[k + 1] = __ballot(lk);
+    }
+  }
+  if (__ballot(zero_pair) != 0ull) {LFX_DEFER();}
+  // curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
+  uint32_t inblk = 0, owned = 0;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    if (k < K) {
+      const int q = 64 * k + lane, i = g0 + q;
+      if (i >= b0 && i < b1) {
+        inblk |= 1u << k;
+        double sum = 0.;
+        if (PT > 0) {
+#pragma unroll
+          for (int d = -(PT > 0 ? PT : 0); d <= (PT > 0 ? PT : 0); d++) {
+            sum += U.r[q + d] * (d == 0 ? -2. * PT : 1.);
+          }
+        } else {
+          for (int d = -P; d <= P; d++) {sum += U.r[q + d] * (d == 0 ? -2. * P : 1.);}
+        }
+        cq[k] = sum * sum;
+      }
+      if (i >= o0 && i < o1) {owned |= 1u << k;}
+      U.c[q] = cq[k];
+    }
+  }
+  LFX_WAVE_SYNC();
+  // block labelling in span coordinates: the block is [qb0, qb1), links are cut at its ends
+  const int qb0 = b0 - g0, qb1 = b1 - g0;
+  uint32_t reach[kWaveChunks];
+  {
+    uint64_t LL[kWaveChunks + 2];
+#pragma unroll
+    for (int k = 0; k < kWaveChunks + 2; k++) {LL[k] = 0;}
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {LL[k + 1] = LK[k + 1] & range_word(k, qb0, qb1 - 1);}
+    }
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      reach[k] = 0;
+      if (k < K) {
+        const uint32_t ll = uwindow(LL, k, hi, sh);
+        int Lr = __clz((int)~(ll << 16));
+        int Rr = __ffs((int)~(ll >> 16)) - 1;
+        Lr = Lr < P ? Lr : P;
+        Rr = Rr < P ? Rr : P;
+        reach[k] = ((inblk >> k) & 1u) ? (((1u << (Lr + Rr + 1)) - 1u) << (16 - Lr)) : 0u;   // fill.hpp:101-117
+      }
+    }
+  }
+  uint32_t selE, covE, selS, covS;
+  wave_pass<true, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, 0u, selE, covE);
+  wave_pass<false, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, covE, selS, covS);
+  // occlusion jumps (occlusion.hpp:37-79) as uniform words; JRs is JR moved down one position
+  uint64_t JL[kWaveChunks + 2], JRs[kWaveChunks + 2];
+  {
+    uint64_t JR[kWaveChunks + 2];
+#pragma unroll
+    for (int k = 0; k < kWaveChunks + 2; k++) {JL[k] = 0; JR[k] = 0; JRs[k] = 0;}
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {
+        const int q = 64 * k + lane, i = g0 + q;
+        const uint32_t lw = uwindow(LK, k, hi, sh);
+        bool jl = false, jr = false;
+        if (i >= 0 && i + 1 < N && i < N - P - 1 && q + 1 < span && ((lw >> 16) & 1u)) {
+          jl = U.r[q + 1] > r[k] + prm.dist_diff;
+        }
+        if (i >= P + 1 && i < N && q >= 1 && q < span && ((lw >> 15) & 1u)) {
+          jr = U.r[q - 1] > r[k] + prm.dist_diff;
+        }
+        JL[k + 1] = __ballot(jl);
+        JR[k + 1] = __ballot(jr);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kWaveChunks + 1; k++) {JRs[k] = (JR[k] >> 1) | (JR[k + 1] << 63);}
+    JRs[kWaveChunks + 1] = JR[kWaveChunks + 1] >> 1;
+  }
+  // final labels of the owned points, per-point outputs, feature records
+  uint8_t lab[kWaveChunks];
+  uint64_t FE[kWaveChunks], FS[kWaveChunks];
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    lab[k] = kDefault;
+    FE[k] = 0;
+    FS[k] = 0;
+    if (k < K) {
+      const int q = 64 * k + lane, i = g0 + q;
+      const bool own = (owned >> k) & 1u;
+      uint8_t l = kDefault;
+      if (own) {
+        if ((selE >> k) & 1u) {
+          l = kEdge;
+        } else if ((selS >> k) & 1u) {
+          l = kSurface;
+        } else if ((covS >> k) & 1u) {
+          l = kSurfaceNeighbor;
+        } else if ((covE >> k) & 1u) {
+          l = kEdgeNeighbor;
+        }
+        const uint32_t lw = uwindow(LK, k, hi, sh);
+        int Lr = __clz((int)~(lw << 16));
+        Lr = Lr < P ? Lr : P;
+        const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);
+        int Rr = __ffs((int)~(lw >> 16)) - 1;
+        Rr = Rr < P ? Rr : P;
+        const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;
+        if ((uwindow(JL, k, hi, sh) & left) || (uwindow(JRs, k, hi, sh) & right)) {l = kOccluded;}
+        const double ri = r[k];
+        if (!(prm.min_range <= ri && ri <= prm.max_range)) {l = kOutOfRange;}             // range.hpp:40-43
+        if (i >= 1 && i + 1 < N) {                                                         // parallel_beam.hpp:43-49
+          const float ratio1 = (float)(fabs(U.r[q - 1] - ri) / ri);
+          const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
+          if ((double)ratio1 > prm.pb_ratio && (double)ratio2 > prm.pb_ratio) {l = kParallelBeam;}
+        }
+        label_s[off + i] = l;
+        curv_s[off + i] = cq[k];
+      }
+      lab[k] = l;
+      FE[k] = __ballot(own && l == kEdge);
+      FS[k] = __ballot(own && l == kSurface);
+    }
+  }
+  uint32_t pe = 0, ps = 0;
+  const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    if (k < K) {
+      if (lab[k] == kEdge || lab[k] == kSurface) {
+        const int q = 64 * k + lane, i = g0 + q;
+        // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
+        const float4 rec = make_float4(x[k], y[k], sz[off + i], (float)cq[k]);
+        const size_t at = lab[k] == kEdge ? off + o0 + pe + __popcll(FE[k] & below)
+                                          : off + o1 - 1 - (ps + __popcll(FS[k] & below));
+        rec_pts[at] = rec;
+        rec_idx[at] = sidx[off + i];
+      }
+      pe += __popcll(FE[k]);
+      ps += __popcll(FS[k]);
+    }
+  }
+  if (lane == 0) {
+    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
+    unit_ne[ui] = pe;
+    unit_ns[ui] = ps;
+    if (j == 0) {ring_status[s * kRings + slot] = kOk;}
+  }
+#undef LFX_DEFER
+}
+
+__global__ __launch_bounds__(64 * kUnitWaves) void ring_unit_kernel(
+  Params prm, uint32_t ring_cap, uint32_t max_rings, const uint32_t * __restrict__ scan_begin,
+  const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
+  const uint32_t * __restrict__ ring_offset, const float2 * __restrict__ sxy, const float * __restrict__ sz,
+  const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
+  float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
+  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags,
+  uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
+{
+  __shared__ UnitLds lds[kUnitWaves];
+  const uint32_t s = blockIdx.y;
+  const uint32_t u = blockIdx.x * kUnitWaves + (threadIdx.x >> 6);
+  const uint32_t slot = u / (uint32_t)prm.B;
+  const int j = (int)(u % (uint32_t)prm.B);
+  uint32_t nr = scan_info[s * 4 + kInfoRings];
+  nr = nr < max_rings ? nr : max_rings;
+  if (slot >= nr) {return;}
+  UnitLds & U = lds[threadIdx.x >> 6];
+  if (prm.P == 5) {
+    unit_body<5>(prm, U, ring_cap, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
+  } else if (prm.P == 2) {
+    unit_body<2>(prm, U, ring_cap, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
+  } else {
+    unit_body<0>(prm, U, ring_cap, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: copy the per-ring feature records into the scan's edge / surface clouds, rings ascending.
-__global__ __launch_bounds__(256) void feature_compact_kernel(
-  const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ scan_info,
+// K3 (slow path): one workgroup per ring, ring resident in LDS.  Takes the rings the fast path
+// deferred (use_list) or every ring of the batch (n_blocks > 64, debugging).  Writes the ring's
+// feature records as ONE segment (edge from the front of the ring, surface from its back) and
+// marks the ring so that feature_compact_kernel reads it that way.
+__global__ __launch_bounds__(512) void ring_extract_kernel(
+  Params prm, uint32_t cap, uint32_t stage_flags, uint32_t use_list, const uint8_t * __restrict__ pts, Layout L,
+  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
   const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_offset,
-  const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf,
-  const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx,
-  float4 * __restrict__ edge_pts, uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts,
-  uint32_t * __restrict__ surf_idx)
+  float2 * __restrict__ sxy, const float * __restrict__ sz, uint32_t * __restrict__ sidx,
+  uint8_t * __restrict__ label_s, double * __restrict__ curv_s, float4 * __restrict__ rec_pts,
+  uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status, uint32_t * __restrict__ unit_ne,
+  uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags, const uint32_t * __restrict__ slow_count,
+  const uint32_t * __restrict__ slow_list, uint32_t max_rings)
 {
-  const uint32_t slot = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-  const uint32_t nr = scan_info[s * 4 + kInfoRings];
-  if (slot >= nr) {return;}
-  __shared__ uint32_t red[2][256];
-  red[0][tid] = (tid < slot) ? ring_nedge[s * kRings + tid] : 0u;
-  red[1][tid] = (tid < slot) ? ring_nsurf[s * kRings + tid] : 0u;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
-    if ((int)tid < d) {red[0][tid] += red[0][tid + d]; red[1][tid] += red[1][tid + d];}
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  const int T = blockDim.x, tid = threadIdx.x;
+  const uint32_t n_items = use_list ? *slow_count : 1u;
+  for (uint32_t item = use_list ? blockIdx.x : 0u; item < n_items; item += use_list ? gridDim.x : 1u) {
+    uint32_t slot, s;
+    if (use_list) {
+      const uint32_t e = slow_list[item];
+      s = e / kRings;
+      slot = e % kRings;
+    } else {
+      slot = blockIdx.x;
+      s = blockIdx.y;
+      uint32_t nr = scan_info[s * 4 + kInfoRings];
+      nr = nr < max_rings ? nr : max_rings;
+      if (slot >= nr) {return;}
+    }
+    const int N = (int)ring_count[s * kRings + slot];
+    const size_t sb = scan_begin[s];
+    const size_t off = sb + ring_offset[s * kRings + slot];
+    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+    uint8_t status = kOk;
+    bool resorted = false;
+    RingWork w = carve(lds_raw, cap);
+    if ((uint32_t)N > cap) {
+      status = kTooLarge;
+    } else {
+      for (int i = tid; i < N; i += T) {
+        const float2 v = sxy[off + i];
+        w.x[i] = v.x;
+        w.y[i] = v.y;
+      }
+      __syncthreads();
+      resorted = angle_sort(w, N, sxy + off, sidx + off);
+      status = process_ring(w, prm, N, stage_flags, nullptr, nullptr, nullptr);
+    }
+    if (tid < kUnitMaxBlocks) {unit_ne[ui + tid] = 0; unit_ns[ui + tid] = 0;}
+    if (tid == 0) {ring_flags[s * kRings + slot] = 1u;}      // "one segment" layout of the records
+    if (status != kOk) {
+      // the ring contributes nothing (feature_extraction.cpp:116,154-156)
+      for (int i = tid; i < N; i += T) {
+        label_s[off + i] = kDefault;
+        curv_s[off + i] = 0.;
+      }
+      if (tid == 0) {ring_status[s * kRings + slot] = status;}
+      __syncthreads();
+      continue;
+    }
+    __syncthreads();
+    const int nwords = (N + 63) >> 6;
+    if (tid < 64) {
+      uint32_t ce = 0, cs = 0;
+      for (int base = 0; base < nwords; base += 64) {
+        const int k = base + tid;
+        const uint32_t ne = k < nwords ? __popcll(w.featE[k + 1]) : 0u;
+        const uint32_t ns = k < nwords ? __popcll(w.featS[k + 1]) : 0u;
+        uint32_t ie = ne, is = ns;
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t te = __shfl_up(ie, d), ts = __shfl_up(is, d);
+          if (tid >= d) {ie += te; is += ts;}
+        }
+        if (k < nwords) {
+          w.wbase[k] = ce + ie - ne;
+          w.wbase[cap / 64 + k] = cs + is - ns;
+        }
+        ce += __shfl(ie, 63);
+        cs += __shfl(is, 63);
+      }
+      if (tid == 0) {
+        ring_status[s * kRings + slot] = kOk;
+        unit_ne[ui] = ce;
+        unit_ns[ui] = cs;
+      }
+    }
+    __syncthreads();
+    const bool reload_xy = w.flags[kFlagXYClobbered] != 0;
+    for (int i = tid; i < N; i += T) {
+      const uint8_t lab = w.lab[i];
+      const double c = w.c[i];
+      label_s[off + i] = lab;
+      curv_s[off + i] = c;
+      if (lab == kEdge || lab == kSurface) {
+        const uint64_t below = (1ull << (i & 63)) - 1ull;
+        const uint32_t orig = sidx[off + i];
+        // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
+        const float z = resorted ? *reinterpret_cast<const float *>(pts + (sb + orig) * L.step + L.oz) : sz[off + i];
+        float x = w.x[i], y = w.y[i];
+        if (reload_xy) {const float2 v = sxy[off + i]; x = v.x; y = v.y;}
+        size_t at;
+        if (lab == kEdge) {
+          at = off + w.wbase[i >> 6] + __popcll(w.featE[(i >> 6) + 1] & below);
+        } else {
+          at = off + N - 1 - (w.wbase[cap / 64 + (i >> 6)] + __popcll(w.featS[(i >> 6) + 1] & below));
+        }
+        rec_pts[at] = make_float4(x, y, z, (float)c);
+        rec_idx[at] = orig;
+      }
+    }
     __syncthreads();
   }
-  const uint32_t ebase = red[0][0], sbase = red[1][0];
-  const uint32_t ne = ring_nedge[s * kRings + slot], ns = ring_nsurf[s * kRings + slot];
-  const uint32_t N = ring_count[s * kRings + slot];
+}
+
+// ------------------------------------------------------------------------------------------
+// K4a: per scan, ring totals and their exclusive prefix (rings ascending).
+__global__ __launch_bounds__(kRings) void ring_totals_kernel(
+  uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
+  uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf, uint32_t * __restrict__ ring_ebase,
+  uint32_t * __restrict__ ring_sbase, uint32_t n_units, uint32_t max_rings)
+{
+  const uint32_t s = blockIdx.x, slot = threadIdx.x;
+  uint32_t nr = scan_info[s * 4 + kInfoRings];
+  nr = nr < max_rings ? nr : max_rings;
+  uint32_t e = 0, f = 0;
+  if (slot < nr) {
+    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+    for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ui + j]; f += unit_ns[ui + j];}
+  }
+  __shared__ uint32_t pe[kRings], pf[kRings];
+  pe[slot] = e;
+  pf[slot] = f;
+  __syncthreads();
+  for (uint32_t d = 1; d < kRings; d <<= 1) {
+    const uint32_t a = slot >= d ? pe[slot - d] : 0u, b = slot >= d ? pf[slot - d] : 0u;
+    __syncthreads();
+    pe[slot] += a;
+    pf[slot] += b;
+    __syncthreads();
+  }
+  ring_nedge[s * kRings + slot] = e;
+  ring_nsurf[s * kRings + slot] = f;
+  ring_ebase[s * kRings + slot] = pe[slot] - e;
+  ring_sbase[s * kRings + slot] = pf[slot] - f;
+  if (slot == kRings - 1) {
+    scan_info[s * 4 + kInfoEdge] = pe[slot];
+    scan_info[s * 4 + kInfoSurface] = pf[slot];
+  }
+}
+
+// K4b: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
+// ring angle ascending (units ascending; a slow-path ring is one segment).
+__global__ __launch_bounds__(256) void feature_compact_kernel(
+  Params prm, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
+  const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_offset,
+  const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf,
+  const uint32_t * __restrict__ ring_ebase, const uint32_t * __restrict__ ring_sbase,
+  const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
+  const uint32_t * __restrict__ ring_flags, const float4 * __restrict__ rec_pts,
+  const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts, uint32_t * __restrict__ edge_idx,
+  float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx, uint32_t max_rings)
+{
+  const uint32_t slot = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  uint32_t nr = scan_info[s * 4 + kInfoRings];
+  nr = nr < max_rings ? nr : max_rings;
+  if (slot >= nr) {return;}
+  const int N = (int)ring_count[s * kRings + slot];
   const size_t b = scan_begin[s];
   const size_t off = b + ring_offset[s * kRings + slot];
-  if (slot == nr - 1 && tid == 0) {
-    scan_info[s * 4 + kInfoEdge] = ebase + ne;
-    scan_info[s * 4 + kInfoSurface] = sbase + ns;
-  }
-  for (uint32_t k = tid; k < ne + ns; k += blockDim.x) {
-    if (k < ne) {
-      edge_pts[b + ebase + k] = rec_pts[off + k];
-      edge_idx[b + ebase + k] = rec_idx[off + k];
-    } else {
-      const uint32_t q = k - ne;
-      surf_pts[b + sbase + q] = rec_pts[off + N - 1 - q];
-      surf_idx[b + sbase + q] = rec_idx[off + N - 1 - q];
+  uint32_t eb = ring_ebase[s * kRings + slot], fb = ring_sbase[s * kRings + slot];
+  const bool one_segment = ring_flags[s * kRings + slot] != 0u;
+  const int n_units = one_segment ? 1 : prm.B;
+  const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+  for (int j = 0; j < n_units; j++) {
+    int o0 = 0, o1 = N;
+    if (!one_segment) {
+      o0 = j == 0 ? 0 : block_boundary(N, prm.P, prm.B, j);
+      o1 = j == prm.B - 1 ? N : block_boundary(N, prm.P, prm.B, j + 1);
     }
+    const uint32_t ne = one_segment ? ring_nedge[s * kRings + slot] : unit_ne[ui + j];
+    const uint32_t ns = one_segment ? ring_nsurf[s * kRings + slot] : unit_ns[ui + j];
+    for (uint32_t k = tid; k < ne + ns; k += blockDim.x) {
+      if (k < ne) {
+        edge_pts[b + eb + k] = rec_pts[off + o0 + k];
+        edge_idx[b + eb + k] = rec_idx[off + o0 + k];
+      } else {
+        const uint32_t q = k - ne;
+        surf_pts[b + fb + q] = rec_pts[off + o1 - 1 - q];
+        surf_idx[b + fb + q] = rec_idx[off + o1 - 1 - q];
+      }
+    }
+    eb += ne;
+    fb += ns;
   }
 }
 

@@ -57,7 +57,7 @@ def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     cfg0 = LB.Config(0, 1, 0, 0, LB.Layout(0, 0, 0, 0, 0))
     assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg0)) == -1
     assert lib.lfx_status_string(5).decode().startswith("two adjacent points")
-    assert lib.lfx_kernel_name(3) == b"ring_extract_kernel"
+    assert lib.lfx_kernel_name(3) == b"ring_unit_kernel"
 
 
 def test_no_cpu_fallback_without_a_device(lib):
