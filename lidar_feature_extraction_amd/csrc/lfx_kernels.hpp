@@ -142,6 +142,7 @@ __global__ __launch_bounds__(kRings) void ring_scan_kernel(
 // order of arrival is kept.  The chunk is first laid out ring-major in LDS; the stores to HBM then
 // walk that layout, so a wave writes runs of consecutive positions (one run per ring) instead of
 // 64 scattered dwords.
+template<bool CANON>
 __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   const uint32_t * __restrict__ chunk_base, const uint32_t * __restrict__ ring_off_by_id,
@@ -157,10 +158,13 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   __shared__ uint32_t cstart[kRings];                              // start of each ring inside the staged chunk
   __shared__ uint32_t gbase[kRings];                               // where that run starts in the scan's arrays
   __shared__ uint32_t staged;                                      // points with a valid ring id in this chunk
-  __shared__ float2 st_xy[kChunkPoints];
-  __shared__ float st_z[kChunkPoints];
-  __shared__ uint16_t st_src[kChunkPoints];
-  __shared__ uint8_t st_ring[kChunkPoints];
+  // staging, skewed by one element per 32 (kSkew): with column-major input a wave's 64 points go to 64
+  // different rings, i.e. to staged positions one run length apart -- a power-of-two stride
+  constexpr int kStage = kChunkPoints + kChunkPoints / 32 + 1;
+  __shared__ float2 st_xy[kStage];
+  __shared__ float st_z[kStage];
+  __shared__ uint16_t st_src[kStage];
+  __shared__ uint8_t st_ring[kStage];
   for (int i = tid; i < kGroups * kRings; i += kChunkThreads) {(&wcnt[0][0])[i] = 0;}
   __syncthreads();
 
@@ -173,10 +177,18 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     x[i] = y[i] = z[i] = 0.f;
     if (e < n) {
       const uint8_t * p = pts + (size_t)(b + e) * L.step;
-      x[i] = *reinterpret_cast<const float *>(p + L.ox);
-      y[i] = *reinterpret_cast<const float *>(p + L.oy);
-      z[i] = *reinterpret_cast<const float *>(p + L.oz);
-      const uint32_t ring = *reinterpret_cast<const uint16_t *>(p + L.oring);
+      uint32_t ring;
+      if (CANON) {
+        // PointXYZIR (point_type.hpp:62-86): x y z pad | intensity ring: one 16-byte and one 4-byte load
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        x[i] = v.x; y[i] = v.y; z[i] = v.z;
+        ring = *reinterpret_cast<const uint32_t *>(p + 20) & 0xFFFFu;
+      } else {
+        x[i] = *reinterpret_cast<const float *>(p + L.ox);
+        y[i] = *reinterpret_cast<const float *>(p + L.oy);
+        z[i] = *reinterpret_cast<const float *>(p + L.oz);
+        ring = *reinterpret_cast<const uint16_t *>(p + L.oring);
+      }
       key[i] = ring < kRings ? ring : kRings;
     }
   }
@@ -222,7 +234,8 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
 #pragma unroll
   for (int i = 0; i < kChunkSlots; i++) {
     if (key[i] < kRings) {
-      const uint32_t lp = cstart[key[i]] + wcnt[i * (kChunkThreads / 64) + wave][key[i]] + rank[i];
+      uint32_t lp = cstart[key[i]] + wcnt[i * (kChunkThreads / 64) + wave][key[i]] + rank[i];
+      lp += lp >> 5;
       st_xy[lp] = make_float2(x[i], y[i]);
       st_z[lp] = z[i];
       st_src[lp] = (uint16_t)(i * kChunkThreads + tid);
@@ -233,11 +246,12 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   // (a point with a ring id above 255 is not staged; the host rejects such a scan, LFX_ERR_RING_ID)
   const uint32_t n_staged = staged < n_here ? staged : n_here;
   for (uint32_t o = tid; o < n_staged; o += kChunkThreads) {
-    const uint32_t r = st_ring[o];
+    const uint32_t os = o + (o >> 5);
+    const uint32_t r = st_ring[os];
     const uint32_t pos = gbase[r] + (o - cstart[r]);
-    sxy[pos] = st_xy[o];
-    sz[pos] = st_z[o];
-    sidx[pos] = chunk * kChunkPoints + st_src[o];
+    sxy[pos] = st_xy[os];
+    sz[pos] = st_z[os];
+    sidx[pos] = chunk * kChunkPoints + st_src[os];
   }
 }
 
@@ -952,9 +966,44 @@ __device__ inline uint64_t range_word(int k, int lo, int hi)
   return upto_b & ~upto_a;
 }
 
+// Branch-free form of polar_less for the common case; `special` is set when one of the
+// predicate's special cases applies (equal points, a zero point, a point on the x axis) and the
+// full predicate has to be evaluated instead.
+__device__ inline bool polar_less_fast(float ax, float ay, float bx, float by, bool & special)
+{
+  const float lena = ax * ax + ay * ay;
+  const float lenb = bx * bx + by * by;
+  special = (ax == bx && ay == by) || lena == 0.f || lenb == 0.f || ay == 0.f || by == 0.f;
+  const float det = ax * by - ay * bx;
+  return (ay * by > 0.f) ? (det > 0.f) : (ay < 0.f);
+}
+
+// Reciprocal of a positive finite double to ~2^-28 relative (v_rcp_f64 + one Newton step); used
+// only to decide threshold tests that are far from their threshold (see quotient_test).
+__device__ inline double rcp_approx(double d)
+{
+  const double y0 = __builtin_amdgcn_rcp(d);
+  return y0 * (2.0 - d * y0);
+}
+
+// Classifies (double)(a / b) against a threshold WITHOUT the IEEE division: returns 1 when the
+// quotient is certainly above thr, 0 when certainly below, 2 when it is within `band` (relative)
+// of thr or not finite -- the caller then performs the exact division.  band is far above the
+// error of a * rcp_approx(b), so a 0/1 answer equals the answer of the exact quotient.
+__device__ inline int quotient_test(double a, double yb /* rcp_approx(b) */, double thr, double band)
+{
+  const double q = a * yb;
+  const double lo = thr - fabs(thr) * band, hi = thr + fabs(thr) * band;
+  int res = 2;
+  if (q > hi) {res = 1;}
+  if (q < lo) {res = 0;}
+  if (!(fabs(q) < 1e300)) {res = 2;}       // inf / NaN: let the exact path decide
+  return res;
+}
+
 template<int PT>
 __device__ inline void unit_body(
-  const Params & prm, UnitLds & U, uint32_t ring_cap, uint32_t s, uint32_t slot, int j,
+  const Params & prm, UnitLds & U, uint32_t ring_cap, uint32_t dbg_flags, uint32_t s, uint32_t slot, int j,
   const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ ring_count,
   const uint32_t * __restrict__ ring_offset, const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
@@ -984,137 +1033,228 @@ __device__ inline void unit_body(
   const int H = P + 1, g0 = o0 - H, span = o1 + H - g0;
   if (b1 - b0 < 2 || span > kUnitSpan) {LFX_DEFER();}
   const int K = (span + 63) >> 6;
+  const int qb0 = b0 - g0, qb1 = b1 - g0;          // the block in span coordinates
+  const int qo0 = o0 - g0, qo1 = o1 - g0;          // the owned positions
+  const int qlo = g0 < 0 ? -g0 : 0;                // first / one-past-last position that is a ring point
+  const int qhi = (N - g0) < span ? (N - g0) : span;
 
+  // ---- A. load; x, y also to the wave's LDS slab (neighbours are read by position)
   float x[kWaveChunks], y[kWaveChunks];
-  double r[kWaveChunks], cq[kWaveChunks];
+  double r[kWaveChunks];
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
-    x[k] = 0.f; y[k] = 0.f; r[k] = 0.; cq[k] = 0.;
+    x[k] = 0.f; y[k] = 0.f; r[k] = 0.;
     if (k < K) {
-      const int q = 64 * k + lane, i = g0 + q;
-      if (i >= 0 && i < N && q < span) {
-        const float2 v = sxy[off + i];
-        x[k] = v.x;
-        y[k] = v.y;
-      }
+      const int q = 64 * k + lane;
+      int i = g0 + q;
+      const bool in = q >= qlo && q < qhi;
+      i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+      const float2 v = sxy[off + i];
+      x[k] = in ? v.x : 0.f;
+      y[k] = in ? v.y : 0.f;
       U.x[q] = x[k];
       U.y[q] = y[k];
     }
   }
   LFX_WAVE_SYNC();
-  // angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, or slow path
+  // ---- B. angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, else
+  //         slow path; range (math.hpp:36-39)
   bool bad = false;
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
     if (k < K) {
-      const int q = 64 * k + lane, i = g0 + q;
-      if (i >= o0 && i < o1 && i + 1 < N) {bad = bad || !polar_less(x[k], y[k], U.x[q + 1], U.y[q + 1]);}
+      const int q = 64 * k + lane;
+      const float xn = U.x[q + 1], yn = U.y[q + 1];
+      bool special;
+      const bool less = polar_less_fast(x[k], y[k], xn, yn, special);
+      const bool pair = q >= qo0 && q < qo1 && q + 1 < qhi;
+      bad = bad || (pair && (special || !less));
       const double xd = (double)x[k], yd = (double)y[k];
-      r[k] = sqrt(xd * xd + yd * yd);                                    // math.hpp:36-39
+      r[k] = sqrt(xd * xd + yd * yd);
       U.r[q] = r[k];
     }
   }
-  if (__ballot(bad) != 0ull) {LFX_DEFER();}
+  if (__ballot(bad) != 0ull) {
+    // re-evaluate with the full predicate: a special case is not necessarily out of order
+    bool really = false;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {
+        const int q = 64 * k + lane;
+        const bool pair = q >= qo0 && q < qo1 && q + 1 < qhi;
+        if (pair && !polar_less(x[k], y[k], U.x[q + 1], U.y[q + 1])) {really = true;}
+      }
+    }
+    if (__ballot(really) != 0ull) {LFX_DEFER();}
+  }
   LFX_WAVE_SYNC();
-  // links (neighbor.hpp:44-48) as wave-uniform words; bit q <-> pair (q, q+1)
+  // ---- C. links (neighbor.hpp:44-48) as wave-uniform words; bit q <-> pair (q, q+1)
   uint64_t LK[kWaveChunks + 2];
 #pragma unroll
   for (int k = 0; k < kWaveChunks + 2; k++) {LK[k] = 0;}
-  bool zero_pair = false;
+  {
+    bool zero_pair = false;
+    int lkres[kWaveChunks];
+    bool unsure = false;
 #pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
-    if (k < K) {
-      const int q = 64 * k + lane, i = g0 + q;
-      bool lk = false;
-      if (i >= 0 && i + 1 < N && q + 1 < span) {
+    for (int k = 0; k < kWaveChunks; k++) {
+      lkres[k] = 0;
+      if (k < K) {
+        const int q = 64 * k + lane;
+        const bool pair = q >= qlo && q + 1 < qhi;
         const double rn = U.r[q + 1];
-        if (i >= o0 && i < o1 && r[k] == 0. && rn == 0.) {zero_pair = true;}     // math.cpp:40-42 throws
+        zero_pair = zero_pair || (pair && q >= qo0 && q < qo1 && r[k] == 0. && rn == 0.);   // math.cpp:40-42 throws
         const double dot = (double)x[k] * (double)U.x[q + 1] + (double)y[k] * (double)U.y[q + 1];
-        const double cosang = dot / (r[k] * rn);
-        lk = cosang >= prm.cos_bound && cosang <= 1.0;
+        const double den = r[k] * rn;
+        const double yb = rcp_approx(den);
+        // cos_bound <= cos <= 1: both ends classified without the division when clear of them
+        const int above = quotient_test(dot, yb, prm.cos_bound, 0x1p-20);
+        const int over1 = quotient_test(dot, yb, 1.0, 0x1p-20);
+        int res = (above == 1 && over1 == 0) ? 1 : 0;
+        if (above == 2 || over1 == 2) {res = 2;}
+        if (above == 0 || over1 == 1) {res = 0;}
+        if (!pair) {res = 0;}
+        lkres[k] = res;
+        unsure = unsure || res == 2;
       }
-      LK[k + 1] = __ballot(lk);
     }
-  }
-  if (__ballot(zero_pair) != 0ull) {LFX_DEFER();}
-  // curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
-  uint32_t inblk = 0, owned = 0;
+    if (__ballot(unsure) != 0ull) {
 #pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
-    if (k < K) {
-      const int q = 64 * k + lane, i = g0 + q;
-      if (i >= b0 && i < b1) {
-        inblk |= 1u << k;
-        double sum = 0.;
-        if (PT > 0) {
-#pragma unroll
-          for (int d = -(PT > 0 ? PT : 0); d <= (PT > 0 ? PT : 0); d++) {
-            sum += U.r[q + d] * (d == 0 ? -2. * PT : 1.);
-          }
-        } else {
-          for (int d = -P; d <= P; d++) {sum += U.r[q + d] * (d == 0 ? -2. * P : 1.);}
+      for (int k = 0; k < kWaveChunks; k++) {
+        if (k < K && lkres[k] == 2) {
+          const int q = 64 * k + lane;
+          const double rn = U.r[q + 1];
+          const double dot = (double)x[k] * (double)U.x[q + 1] + (double)y[k] * (double)U.y[q + 1];
+          const double cosang = dot / (r[k] * rn);                       // math.cpp:44-45
+          lkres[k] = (cosang >= prm.cos_bound && cosang <= 1.0) ? 1 : 0; // acos(cos) < threshold; NaN -> false
         }
-        cq[k] = sum * sum;
       }
-      if (i >= o0 && i < o1) {owned |= 1u << k;}
-      U.c[q] = cq[k];
     }
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {LK[k + 1] = __ballot(lkres[k] == 1);}
+    }
+    if (__ballot(zero_pair) != 0ull) {LFX_DEFER();}
   }
-  LFX_WAVE_SYNC();
-  // block labelling in span coordinates: the block is [qb0, qb1), links are cut at its ends
-  const int qb0 = b0 - g0, qb1 = b1 - g0;
+  // ---- D. everything that needs the link words: occlusion (occlusion.hpp:37-91) and the reach of a
+  //         pick inside the block (fill.hpp:101-117)
+  uint32_t occ = 0, inblk = 0, owned = 0;
   uint32_t reach[kWaveChunks];
   {
-    uint64_t LL[kWaveChunks + 2];
+    uint64_t JL[kWaveChunks + 2], JR[kWaveChunks + 2], JRs[kWaveChunks + 2], LL[kWaveChunks + 2];
 #pragma unroll
-    for (int k = 0; k < kWaveChunks + 2; k++) {LL[k] = 0;}
-#pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
-      if (k < K) {LL[k + 1] = LK[k + 1] & range_word(k, qb0, qb1 - 1);}
-    }
-#pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
-      reach[k] = 0;
-      if (k < K) {
-        const uint32_t ll = uwindow(LL, k, hi, sh);
-        int Lr = __clz((int)~(ll << 16));
-        int Rr = __ffs((int)~(ll >> 16)) - 1;
-        Lr = Lr < P ? Lr : P;
-        Rr = Rr < P ? Rr : P;
-        reach[k] = ((inblk >> k) & 1u) ? (((1u << (Lr + Rr + 1)) - 1u) << (16 - Lr)) : 0u;   // fill.hpp:101-117
-      }
-    }
-  }
-  uint32_t selE, covE, selS, covS;
-  wave_pass<true, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, 0u, selE, covE);
-  wave_pass<false, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, covE, selS, covS);
-  // occlusion jumps (occlusion.hpp:37-79) as uniform words; JRs is JR moved down one position
-  uint64_t JL[kWaveChunks + 2], JRs[kWaveChunks + 2];
-  {
-    uint64_t JR[kWaveChunks + 2];
-#pragma unroll
-    for (int k = 0; k < kWaveChunks + 2; k++) {JL[k] = 0; JR[k] = 0; JRs[k] = 0;}
+    for (int k = 0; k < kWaveChunks + 2; k++) {JL[k] = 0; JR[k] = 0; JRs[k] = 0; LL[k] = 0;}
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
         const int q = 64 * k + lane, i = g0 + q;
+        const bool lk_here = (LK[k + 1] >> lane) & 1ull;                 // pair (q, q+1)
         const uint32_t lw = uwindow(LK, k, hi, sh);
-        bool jl = false, jr = false;
-        if (i >= 0 && i + 1 < N && i < N - P - 1 && q + 1 < span && ((lw >> 16) & 1u)) {
-          jl = U.r[q + 1] > r[k] + prm.dist_diff;
-        }
-        if (i >= P + 1 && i < N && q >= 1 && q < span && ((lw >> 15) & 1u)) {
-          jr = U.r[q - 1] > r[k] + prm.dist_diff;
-        }
+        const bool lk_prev = (lw >> 15) & 1u;                            // pair (q-1, q)
+        const int qm = q > 0 ? q - 1 : 0;
+        const bool jl = lk_here && i < N - P - 1 && U.r[q + 1] > r[k] + prm.dist_diff;       // occlusion.hpp:44-57
+        const bool jr = lk_prev && i >= P + 1 && q < qhi && U.r[qm] > r[k] + prm.dist_diff;  // occlusion.hpp:67-79
         JL[k + 1] = __ballot(jl);
         JR[k + 1] = __ballot(jr);
+        LL[k + 1] = LK[k + 1] & range_word(k, qb0, qb1 - 1);
       }
     }
 #pragma unroll
     for (int k = 0; k < kWaveChunks + 1; k++) {JRs[k] = (JR[k] >> 1) | (JR[k + 1] << 63);}
     JRs[kWaveChunks + 1] = JR[kWaveChunks + 1] >> 1;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      reach[k] = 0;
+      if (k < K) {
+        const int q = 64 * k + lane;
+        const uint32_t lw = uwindow(LK, k, hi, sh);
+        int Lr = __clz((int)~(lw << 16));
+        int Rr = __ffs((int)~(lw >> 16)) - 1;
+        Lr = Lr < P ? Lr : P;
+        Rr = Rr < P ? Rr : P;
+        const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
+        const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
+        const bool o = (uwindow(JL, k, hi, sh) & left) || (uwindow(JRs, k, hi, sh) & right);
+        occ |= (o ? 1u : 0u) << k;
+        const bool ib = q >= qb0 && q < qb1;
+        inblk |= (ib ? 1u : 0u) << k;
+        owned |= ((q >= qo0 && q < qo1) ? 1u : 0u) << k;
+        const uint32_t ll = uwindow(LL, k, hi, sh);
+        int Lb = __clz((int)~(ll << 16));
+        int Rb = __ffs((int)~(ll >> 16)) - 1;
+        Lb = Lb < P ? Lb : P;
+        Rb = Rb < P ? Rb : P;
+        reach[k] = ib ? (((1u << (Lb + Rb + 1)) - 1u) << (16 - Lb)) : 0u;
+      }
+    }
   }
-  // final labels of the owned points, per-point outputs, feature records
+  // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
+  double cq[kWaveChunks];
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    cq[k] = 0.;
+    if (k < K) {
+      const int q = 64 * k + lane;
+      int qq = q < P ? P : q;                                            // keep the window inside the slab
+      qq = qq > 64 * kWaveChunks - 1 - P ? 64 * kWaveChunks - 1 - P : qq;
+      double sum = 0.;                                                   // math.hpp:46-52: left to right from 0
+      if (PT > 0) {
+#pragma unroll
+        for (int d = -(PT > 0 ? PT : 0); d <= (PT > 0 ? PT : 0); d++) {
+          const double v = U.r[qq + d];
+          sum += (d == 0) ? v * (-2. * PT) : v;                          // r * 1.0 == r exactly
+        }
+      } else {
+        for (int d = -P; d <= P; d++) {
+          const double v = U.r[qq + d];
+          sum += (d == 0) ? v * (-2. * P) : v;
+        }
+      }
+      cq[k] = ((inblk >> k) & 1u) ? sum * sum : 0.;
+      U.c[q] = cq[k];
+    }
+  }
+  LFX_WAVE_SYNC();
+  // ---- F. block labelling
+  uint32_t selE = 0, covE = 0, selS = 0, covS = 0;
+  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, 0u, selE, covE);}
+  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, covE, selS, covS);}
+  // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
+  int pbres[kWaveChunks];
+  {
+    bool unsure = false;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      pbres[k] = 0;
+      if (k < K) {
+        const int q = 64 * k + lane, i = g0 + q;
+        const int qm = q > 0 ? q - 1 : 0;
+        const double ri = r[k];
+        const double a1 = fabs(U.r[qm] - ri), a2 = fabs(U.r[q + 1] - ri);
+        const double yb = rcp_approx(ri);
+        // parallel_beam.hpp:43-49: (float)(a / ri) > ratio; 2^-18 covers the float rounding too
+        const int t1 = quotient_test(a1, yb, prm.pb_ratio, 0x1p-18), t2 = quotient_test(a2, yb, prm.pb_ratio, 0x1p-18);
+        int res = (t1 == 1 && t2 == 1) ? 1 : 0;
+        if ((t1 == 2 && t2 != 0) || (t2 == 2 && t1 != 0)) {res = 2;}
+        if (!(i >= 1 && i + 1 < N) || !((owned >> k) & 1u)) {res = 0;}
+        pbres[k] = res;
+        unsure = unsure || res == 2;
+      }
+    }
+    if (__ballot(unsure) != 0ull) {
+#pragma unroll
+      for (int k = 0; k < kWaveChunks; k++) {
+        if (k < K && pbres[k] == 2) {
+          const int q = 64 * k + lane;
+          const int qm = q > 0 ? q - 1 : 0;
+          const double ri = r[k];
+          const float ratio1 = (float)(fabs(U.r[qm] - ri) / ri);
+          const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
+          pbres[k] = ((double)ratio1 > prm.pb_ratio && (double)ratio2 > prm.pb_ratio) ? 1 : 0;
+        }
+      }
+    }
+  }
   uint8_t lab[kWaveChunks];
   uint64_t FE[kWaveChunks], FS[kWaveChunks];
 #pragma unroll
@@ -1126,37 +1266,22 @@ __device__ inline void unit_body(
       const int q = 64 * k + lane, i = g0 + q;
       const bool own = (owned >> k) & 1u;
       uint8_t l = kDefault;
+      l = ((covE >> k) & 1u) ? (uint8_t)kEdgeNeighbor : l;
+      l = ((covS >> k) & 1u) ? (uint8_t)kSurfaceNeighbor : l;
+      l = ((selS >> k) & 1u) ? (uint8_t)kSurface : l;
+      l = ((selE >> k) & 1u) ? (uint8_t)kEdge : l;
+      l = ((occ >> k) & 1u) ? (uint8_t)kOccluded : l;
+      const double ri = r[k];
+      l = !(prm.min_range <= ri && ri <= prm.max_range) ? (uint8_t)kOutOfRange : l;        // range.hpp:40-43
+      l = pbres[k] == 1 ? (uint8_t)kParallelBeam : l;
+      l = own ? l : (uint8_t)kDefault;
       if (own) {
-        if ((selE >> k) & 1u) {
-          l = kEdge;
-        } else if ((selS >> k) & 1u) {
-          l = kSurface;
-        } else if ((covS >> k) & 1u) {
-          l = kSurfaceNeighbor;
-        } else if ((covE >> k) & 1u) {
-          l = kEdgeNeighbor;
-        }
-        const uint32_t lw = uwindow(LK, k, hi, sh);
-        int Lr = __clz((int)~(lw << 16));
-        Lr = Lr < P ? Lr : P;
-        const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);
-        int Rr = __ffs((int)~(lw >> 16)) - 1;
-        Rr = Rr < P ? Rr : P;
-        const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;
-        if ((uwindow(JL, k, hi, sh) & left) || (uwindow(JRs, k, hi, sh) & right)) {l = kOccluded;}
-        const double ri = r[k];
-        if (!(prm.min_range <= ri && ri <= prm.max_range)) {l = kOutOfRange;}             // range.hpp:40-43
-        if (i >= 1 && i + 1 < N) {                                                         // parallel_beam.hpp:43-49
-          const float ratio1 = (float)(fabs(U.r[q - 1] - ri) / ri);
-          const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
-          if ((double)ratio1 > prm.pb_ratio && (double)ratio2 > prm.pb_ratio) {l = kParallelBeam;}
-        }
         label_s[off + i] = l;
         curv_s[off + i] = cq[k];
       }
       lab[k] = l;
-      FE[k] = __ballot(own && l == kEdge);
-      FS[k] = __ballot(own && l == kSurface);
+      FE[k] = __ballot(l == kEdge);
+      FS[k] = __ballot(l == kSurface);
     }
   }
   uint32_t pe = 0, ps = 0;
@@ -1187,7 +1312,7 @@ __device__ inline void unit_body(
 }
 
 __global__ __launch_bounds__(64 * kUnitWaves) void ring_unit_kernel(
-  Params prm, uint32_t ring_cap, uint32_t max_rings, const uint32_t * __restrict__ scan_begin,
+  Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ scan_begin,
   const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
   const uint32_t * __restrict__ ring_offset, const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
@@ -1205,13 +1330,13 @@ __global__ __launch_bounds__(64 * kUnitWaves) void ring_unit_kernel(
   if (slot >= nr) {return;}
   UnitLds & U = lds[threadIdx.x >> 6];
   if (prm.P == 5) {
-    unit_body<5>(prm, U, ring_cap, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+    unit_body<5>(prm, U, ring_cap, dbg_flags, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
   } else if (prm.P == 2) {
-    unit_body<2>(prm, U, ring_cap, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+    unit_body<2>(prm, U, ring_cap, dbg_flags, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
   } else {
-    unit_body<0>(prm, U, ring_cap, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+    unit_body<0>(prm, U, ring_cap, dbg_flags, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
   }
 }
