@@ -94,6 +94,7 @@ struct lfx_ctx
   uint32_t max_points = 0, max_batch = 0, cap = 0, max_chunks = 0, max_rings = 0, ring_threads = 0, slow_grid = 0;
   size_t total_cap = 0, ring_lds = 0;
   uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
+  uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
@@ -288,7 +289,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     Timed t(c, 3, st);
     const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
     hipLaunchKernelGGL(lfx::ring_unit_kernel, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
-      dim3(64 * lfx::kUnitWaves), 0, st,
+      dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
       c->dev, c->cap, c->unit_flags, c->max_rings, c->scan_begin.p, c->scan_info.p, c->ring_count.p,
       c->ring_offset.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->ring_flags.p, slow_count, c->slow_list.p);
@@ -310,8 +311,9 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   {
     Timed t(c, 6, st);
-    hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3(c->max_rings, batch), dim3(256), 0, st,
-      c->dev, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p,
+    const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
+    hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings * n_units + 3) / 4, batch), dim3(256), 0, st,
+      c->dev, n_units, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p,
       c->ring_nsurf.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p, c->unit_ns.p, c->ring_flags.p,
       c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p, c->surf_idx.p, c->max_rings);
   }
@@ -487,6 +489,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
   c->slow_grid = 1024;
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_FLAGS")) {c->unit_flags = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
   c->ring_lds = lfx::ring_lds_bytes(c->cap);
   c->max_chunks = (c->max_points + lfx::kChunkPoints - 1) / lfx::kChunkPoints;

@@ -519,6 +519,20 @@ __device__ inline uint32_t uwindow(const uint64_t (&W)[kWaveChunks + 2], int k, 
   return __builtin_amdgcn_alignbit(up, lo, (uint32_t)(lane + 16) & 31u);
 }
 
+// bit `lane` of a wave-uniform word, and the number of set bits below it, without 64-bit shifts
+__device__ inline bool ubit(uint64_t w, int lane)
+{
+  const uint32_t half = lane < 32 ? (uint32_t)w : (uint32_t)(w >> 32);
+  return (half >> (lane & 31)) & 1u;
+}
+
+__device__ inline uint32_t ubelow(uint64_t w, int lane)
+{
+  const uint32_t lo = (uint32_t)w, up = (uint32_t)(w >> 32);
+  const uint32_t m = (1u << (lane & 31)) - 1u;
+  return lane < 32 ? __popc(lo & m) : __popc(lo) + __popc(up & m);
+}
+
 // One pass over one block.  `taken` (bit k = local position 64k+lane is no longer Default) is the
 // per-lane state handed from the edge pass to the surface pass; the pass returns which of the
 // lane's positions it picked (`sel`) and which it reached (`cov`, picks included).
@@ -527,8 +541,7 @@ __device__ inline uint32_t uwindow(const uint64_t (&W)[kWaveChunks + 2], int k, 
 template<bool EDGE, int PT>
 __device__ inline void wave_pass(
   const double * cl_, const Params & prm, int nloc, uint32_t inblk, int K, int lane, bool hi, int sh,
-  const double (&cq)[kWaveChunks], const uint32_t (&reach)[kWaveChunks], uint32_t taken,
-  uint32_t & sel, uint32_t & cov)
+  const uint32_t (&reach)[kWaveChunks], uint32_t taken, uint32_t & sel, uint32_t & cov)
 {
   const int P = PT > 0 ? PT : prm.P;
   uint64_t A[kWaveChunks + 2], S[kWaveChunks + 2];
@@ -538,47 +551,51 @@ __device__ inline void wave_pass(
 #pragma unroll
   for (int k = 0; k < kWaveChunks + 2; k++) {A[k] = 0; S[k] = 0;}
   uint64_t any = 0;
+  uint32_t alive = 0;                      // the lane's own bits of A
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
     if (k < K) {
       bool cd = (inblk >> k) & 1u;
+      const int q0 = 64 * k + lane;
+      const double c0 = cl_[q0 < nloc ? q0 : nloc - 1];
       if (EDGE) {
-        cd = cd && cq[k] >= prm.edge_thr;                                 // label.hpp:80-82
+        cd = cd && c0 >= prm.edge_thr;                                    // label.hpp:80-82
       } else {
-        cd = cd && cq[k] <= prm.surf_thr && !((taken >> k) & 1u);         // label.hpp:119-121, still Default
+        cd = cd && c0 <= prm.surf_thr && !((taken >> k) & 1u);            // label.hpp:119-121, still Default
       }
       A[k + 1] = __ballot(cd);
+      alive |= (cd ? 1u : 0u) << k;
       any |= A[k + 1];
     }
   }
   if (any == 0) {return;}
-  // priority masks: which candidates in reach come first (curvature, then index)
+  // priority masks: which candidates in reach come first (curvature, then index).  The slab may be
+  // read up to P positions outside [0, nloc): callers keep that addressable; the values are masked.
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
     H[k] = 0;
     if (k < K && A[k + 1] != 0) {
       const int q = 64 * k + lane;
+      const int qc = q < nloc ? q : nloc - 1;
       const uint32_t m = uwindow(A, k, hi, sh) & reach[k] & ~(1u << 16);
-      const double ci = cq[k];
+      const double ci = cl_[qc];
       uint32_t higher = 0;
       if (PT > 0) {
 #pragma unroll
         for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {
-          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nloc - 1 ? nloc - 1 : q + d;
-          const double cl = cl_[jl], cr = cl_[jr];
-          const bool fl = EDGE ? (cl > ci) : (cl < ci || cl == ci);      // left neighbour: lower index
-          const bool fr = EDGE ? (cr > ci || cr == ci) : (cr < ci);      // right neighbour: higher index
-          higher |= (fl ? 1u : 0u) << (16 - d);
-          higher |= (fr ? 1u : 0u) << (16 + d);
+          const double cl = cl_[qc - d], cr = cl_[qc + d];
+          const bool fl = EDGE ? (cl > ci) : (cl <= ci);                  // left neighbour: lower index
+          const bool fr = EDGE ? (cr >= ci) : (cr < ci);                  // right neighbour: higher index
+          higher |= fl ? (1u << (16 - d)) : 0u;
+          higher |= fr ? (1u << (16 + d)) : 0u;
         }
       } else {
         for (int d = 1; d <= P; d++) {
-          const int jl = q - d < 0 ? 0 : q - d, jr = q + d > nloc - 1 ? nloc - 1 : q + d;
-          const double cl = cl_[jl], cr = cl_[jr];
-          const bool fl = EDGE ? (cl > ci) : (cl < ci || cl == ci);
-          const bool fr = EDGE ? (cr > ci || cr == ci) : (cr < ci);
-          higher |= (fl ? 1u : 0u) << (16 - d);
-          higher |= (fr ? 1u : 0u) << (16 + d);
+          const double cl = cl_[qc - d], cr = cl_[qc + d];
+          const bool fl = EDGE ? (cl > ci) : (cl <= ci);
+          const bool fr = EDGE ? (cr >= ci) : (cr < ci);
+          higher |= fl ? (1u << (16 - d)) : 0u;
+          higher |= fr ? (1u << (16 + d)) : 0u;
         }
       }
       H[k] = higher & m;
@@ -592,8 +609,7 @@ __device__ inline void wave_pass(
       if (k < K) {
         uint64_t s = 0;
         if (A[k + 1] != 0) {
-          const bool live = (A[k + 1] >> lane) & 1ull;
-          const bool pick = live && (uwindow(A, k, hi, sh) & H[k]) == 0;
+          const bool pick = ((alive >> k) & 1u) && (uwindow(A, k, hi, sh) & H[k]) == 0;
           s = __ballot(pick);
           sel |= (pick ? 1u : 0u) << k;
         }
@@ -606,7 +622,9 @@ __device__ inline void wave_pass(
       if (k < K) {
         if ((S[k] | S[k + 1] | S[k + 2]) != 0) {
           const bool hit = (uwindow(S, k, hi, sh) & reach[k]) != 0;
-          cov |= (hit ? 1u : 0u) << k;
+          const uint32_t hb = (hit ? 1u : 0u) << k;
+          cov |= hb;
+          alive &= ~hb;
           A[k + 1] &= ~__ballot(hit);
         }
         left |= A[k + 1];
@@ -629,7 +647,6 @@ __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N
     const int b1 = single_block ? N : block_boundary(N, prm.P, prm.B, j + 1);
     const int nb = b1 - b0;
     const int K = (nb + 63) >> 6;
-    double cq[kWaveChunks];
     uint32_t reach[kWaveChunks];
     {
       uint64_t LL[kWaveChunks + 2];
@@ -637,14 +654,11 @@ __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N
       for (int k = 0; k < kWaveChunks + 2; k++) {LL[k] = 0;}
 #pragma unroll
       for (int k = 0; k < kWaveChunks; k++) {
-        cq[k] = 0.;
         if (k < K) {
           // links inside the block (label.hpp:157-159: the checker is sliced to the block)
           const int rem = nb - 1 - 64 * k;
           const uint64_t keep = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
           LL[k + 1] = word_at(w.link, b0 + 64 * k) & keep;
-          const int q = 64 * k + lane;
-          if (q < nb) {cq[k] = w.c[b0 + q];}
         }
       }
 #pragma unroll
@@ -664,8 +678,8 @@ __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {inblk |= (64 * k + lane < nb ? 1u : 0u) << k;}
     uint32_t selE, covE, selS, covS;
-    wave_pass<true, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, cq, reach, 0u, selE, covE);
-    wave_pass<false, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, cq, reach, covE, selS, covS);
+    wave_pass<true, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, 0u, selE, covE);
+    wave_pass<false, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, covE, selS, covS);
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
@@ -937,12 +951,14 @@ constexpr int kUnitWaves = 4;
 constexpr int kUnitSpan = 64 * kWaveChunks;
 constexpr int kUnitMaxBlocks = 64;        // per-unit count tables are sized for n_blocks <= 64
 
+constexpr int kSlabPad = 16;               // positions readable on either side of the curvature slab
 struct UnitLds
 {
   double r[kUnitSpan];
-  double c[kUnitSpan];
-  float x[kUnitSpan + 2];
-  float y[kUnitSpan + 2];
+  union {
+    double c[kUnitSpan + 2 * kSlabPad];      // from stage E on
+    struct {float x[kUnitSpan + 2]; float y[kUnitSpan + 2];} p;   // stages A-C
+  };
 };
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
@@ -1052,8 +1068,8 @@ __device__ inline void unit_body(
       const float2 v = sxy[off + i];
       x[k] = in ? v.x : 0.f;
       y[k] = in ? v.y : 0.f;
-      U.x[q] = x[k];
-      U.y[q] = y[k];
+      U.p.x[q] = x[k];
+      U.p.y[q] = y[k];
     }
   }
   LFX_WAVE_SYNC();
@@ -1064,7 +1080,7 @@ __device__ inline void unit_body(
   for (int k = 0; k < kWaveChunks; k++) {
     if (k < K) {
       const int q = 64 * k + lane;
-      const float xn = U.x[q + 1], yn = U.y[q + 1];
+      const float xn = U.p.x[q + 1], yn = U.p.y[q + 1];
       bool special;
       const bool less = polar_less_fast(x[k], y[k], xn, yn, special);
       const bool pair = q >= qo0 && q < qo1 && q + 1 < qhi;
@@ -1082,7 +1098,7 @@ __device__ inline void unit_body(
       if (k < K) {
         const int q = 64 * k + lane;
         const bool pair = q >= qo0 && q < qo1 && q + 1 < qhi;
-        if (pair && !polar_less(x[k], y[k], U.x[q + 1], U.y[q + 1])) {really = true;}
+        if (pair && !polar_less(x[k], y[k], U.p.x[q + 1], U.p.y[q + 1])) {really = true;}
       }
     }
     if (__ballot(really) != 0ull) {LFX_DEFER();}
@@ -1094,17 +1110,15 @@ __device__ inline void unit_body(
   for (int k = 0; k < kWaveChunks + 2; k++) {LK[k] = 0;}
   {
     bool zero_pair = false;
-    int lkres[kWaveChunks];
-    bool unsure = false;
+    uint32_t lk_yes = 0, lk_unsure = 0;      // bit k: the pair at 64k+lane is a link / needs the exact division
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
-      lkres[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
         const bool pair = q >= qlo && q + 1 < qhi;
         const double rn = U.r[q + 1];
         zero_pair = zero_pair || (pair && q >= qo0 && q < qo1 && r[k] == 0. && rn == 0.);   // math.cpp:40-42 throws
-        const double dot = (double)x[k] * (double)U.x[q + 1] + (double)y[k] * (double)U.y[q + 1];
+        const double dot = (double)x[k] * (double)U.p.x[q + 1] + (double)y[k] * (double)U.p.y[q + 1];
         const double den = r[k] * rn;
         const double yb = rcp_approx(den);
         // cos_bound <= cos <= 1: both ends classified without the division when clear of them
@@ -1114,25 +1128,25 @@ __device__ inline void unit_body(
         if (above == 2 || over1 == 2) {res = 2;}
         if (above == 0 || over1 == 1) {res = 0;}
         if (!pair) {res = 0;}
-        lkres[k] = res;
-        unsure = unsure || res == 2;
+        lk_yes |= (res == 1 ? 1u : 0u) << k;
+        lk_unsure |= (res == 2 ? 1u : 0u) << k;
       }
     }
-    if (__ballot(unsure) != 0ull) {
+    if (__ballot(lk_unsure != 0u) != 0ull) {
 #pragma unroll
       for (int k = 0; k < kWaveChunks; k++) {
-        if (k < K && lkres[k] == 2) {
+        if (k < K && ((lk_unsure >> k) & 1u)) {
           const int q = 64 * k + lane;
           const double rn = U.r[q + 1];
-          const double dot = (double)x[k] * (double)U.x[q + 1] + (double)y[k] * (double)U.y[q + 1];
+          const double dot = (double)x[k] * (double)U.p.x[q + 1] + (double)y[k] * (double)U.p.y[q + 1];
           const double cosang = dot / (r[k] * rn);                       // math.cpp:44-45
-          lkres[k] = (cosang >= prm.cos_bound && cosang <= 1.0) ? 1 : 0; // acos(cos) < threshold; NaN -> false
+          lk_yes |= ((cosang >= prm.cos_bound && cosang <= 1.0) ? 1u : 0u) << k;   // acos(cos) < threshold; NaN -> false
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
-      if (k < K) {LK[k + 1] = __ballot(lkres[k] == 1);}
+      if (k < K) {LK[k + 1] = __ballot((lk_yes >> k) & 1u);}
     }
     if (__ballot(zero_pair) != 0ull) {LFX_DEFER();}
   }
@@ -1142,18 +1156,23 @@ __device__ inline void unit_body(
   uint32_t reach[kWaveChunks];
   {
     uint64_t JL[kWaveChunks + 2], JR[kWaveChunks + 2], JRs[kWaveChunks + 2], LL[kWaveChunks + 2];
+    uint32_t lkw[kWaveChunks];
 #pragma unroll
     for (int k = 0; k < kWaveChunks + 2; k++) {JL[k] = 0; JR[k] = 0; JRs[k] = 0; LL[k] = 0;}
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {lkw[k] = 0;}
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
         const int q = 64 * k + lane, i = g0 + q;
-        const bool lk_here = (LK[k + 1] >> lane) & 1ull;                 // pair (q, q+1)
         const uint32_t lw = uwindow(LK, k, hi, sh);
+        lkw[k] = lw;
+        const bool lk_here = (lw >> 16) & 1u;                            // pair (q, q+1)
         const bool lk_prev = (lw >> 15) & 1u;                            // pair (q-1, q)
         const int qm = q > 0 ? q - 1 : 0;
-        const bool jl = lk_here && i < N - P - 1 && U.r[q + 1] > r[k] + prm.dist_diff;       // occlusion.hpp:44-57
-        const bool jr = lk_prev && i >= P + 1 && q < qhi && U.r[qm] > r[k] + prm.dist_diff;  // occlusion.hpp:67-79
+        const double rq = U.r[q];
+        const bool jl = lk_here && i < N - P - 1 && U.r[q + 1] > rq + prm.dist_diff;         // occlusion.hpp:44-57
+        const bool jr = lk_prev && i >= P + 1 && q < qhi && U.r[qm] > rq + prm.dist_diff;    // occlusion.hpp:67-79
         JL[k + 1] = __ballot(jl);
         JR[k + 1] = __ballot(jr);
         LL[k + 1] = LK[k + 1] & range_word(k, qb0, qb1 - 1);
@@ -1167,7 +1186,7 @@ __device__ inline void unit_body(
       reach[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
-        const uint32_t lw = uwindow(LK, k, hi, sh);
+        const uint32_t lw = lkw[k];
         int Lr = __clz((int)~(lw << 16));
         int Rr = __ffs((int)~(lw >> 16)) - 1;
         Lr = Lr < P ? Lr : P;
@@ -1188,11 +1207,10 @@ __device__ inline void unit_body(
       }
     }
   }
+  LFX_WAVE_SYNC();        // the x / y slab is dead from here on: the curvature slab takes its place
   // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
-  double cq[kWaveChunks];
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
-    cq[k] = 0.;
     if (k < K) {
       const int q = 64 * k + lane;
       int qq = q < P ? P : q;                                            // keep the window inside the slab
@@ -1210,58 +1228,49 @@ __device__ inline void unit_body(
           sum += (d == 0) ? v * (-2. * P) : v;
         }
       }
-      cq[k] = ((inblk >> k) & 1u) ? sum * sum : 0.;
-      U.c[q] = cq[k];
+      U.c[kSlabPad + q] = ((inblk >> k) & 1u) ? sum * sum : 0.;
     }
   }
   LFX_WAVE_SYNC();
   // ---- F. block labelling
   uint32_t selE = 0, covE = 0, selS = 0, covS = 0;
-  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, 0u, selE, covE);}
-  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c, prm, span, inblk, K, lane, hi, sh, cq, reach, covE, selS, covS);}
+  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, 0u, selE, covE);}
+  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, covE, selS, covS);}
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
-  int pbres[kWaveChunks];
-  {
-    bool unsure = false;
+  uint32_t pb_yes = 0, pb_unsure = 0;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    if (k < K) {
+      const int q = 64 * k + lane, i = g0 + q;
+      const int qm = q > 0 ? q - 1 : 0;
+      const double ri = U.r[q];
+      const double a1 = fabs(U.r[qm] - ri), a2 = fabs(U.r[q + 1] - ri);
+      const double yb = rcp_approx(ri);
+      // parallel_beam.hpp:43-49: (float)(a / ri) > ratio; 2^-18 covers the float rounding too
+      const int t1 = quotient_test(a1, yb, prm.pb_ratio, 0x1p-18), t2 = quotient_test(a2, yb, prm.pb_ratio, 0x1p-18);
+      int res = (t1 == 1 && t2 == 1) ? 1 : 0;
+      if ((t1 == 2 && t2 != 0) || (t2 == 2 && t1 != 0)) {res = 2;}
+      if (!(i >= 1 && i + 1 < N) || !((owned >> k) & 1u)) {res = 0;}
+      pb_yes |= (res == 1 ? 1u : 0u) << k;
+      pb_unsure |= (res == 2 ? 1u : 0u) << k;
+    }
+  }
+  if (__ballot(pb_unsure != 0u) != 0ull) {
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
-      pbres[k] = 0;
-      if (k < K) {
-        const int q = 64 * k + lane, i = g0 + q;
+      if (k < K && ((pb_unsure >> k) & 1u)) {
+        const int q = 64 * k + lane;
         const int qm = q > 0 ? q - 1 : 0;
-        const double ri = r[k];
-        const double a1 = fabs(U.r[qm] - ri), a2 = fabs(U.r[q + 1] - ri);
-        const double yb = rcp_approx(ri);
-        // parallel_beam.hpp:43-49: (float)(a / ri) > ratio; 2^-18 covers the float rounding too
-        const int t1 = quotient_test(a1, yb, prm.pb_ratio, 0x1p-18), t2 = quotient_test(a2, yb, prm.pb_ratio, 0x1p-18);
-        int res = (t1 == 1 && t2 == 1) ? 1 : 0;
-        if ((t1 == 2 && t2 != 0) || (t2 == 2 && t1 != 0)) {res = 2;}
-        if (!(i >= 1 && i + 1 < N) || !((owned >> k) & 1u)) {res = 0;}
-        pbres[k] = res;
-        unsure = unsure || res == 2;
-      }
-    }
-    if (__ballot(unsure) != 0ull) {
-#pragma unroll
-      for (int k = 0; k < kWaveChunks; k++) {
-        if (k < K && pbres[k] == 2) {
-          const int q = 64 * k + lane;
-          const int qm = q > 0 ? q - 1 : 0;
-          const double ri = r[k];
-          const float ratio1 = (float)(fabs(U.r[qm] - ri) / ri);
-          const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
-          pbres[k] = ((double)ratio1 > prm.pb_ratio && (double)ratio2 > prm.pb_ratio) ? 1 : 0;
-        }
+        const double ri = U.r[q];
+        const float ratio1 = (float)(fabs(U.r[qm] - ri) / ri);
+        const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
+        pb_yes |= (((double)ratio1 > prm.pb_ratio && (double)ratio2 > prm.pb_ratio) ? 1u : 0u) << k;
       }
     }
   }
-  uint8_t lab[kWaveChunks];
-  uint64_t FE[kWaveChunks], FS[kWaveChunks];
+  uint32_t is_edge = 0, is_surf = 0, pe = 0, ps = 0;
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
-    lab[k] = kDefault;
-    FE[k] = 0;
-    FS[k] = 0;
     if (k < K) {
       const int q = 64 * k + lane, i = g0 + q;
       const bool own = (owned >> k) & 1u;
@@ -1271,37 +1280,29 @@ __device__ inline void unit_body(
       l = ((selS >> k) & 1u) ? (uint8_t)kSurface : l;
       l = ((selE >> k) & 1u) ? (uint8_t)kEdge : l;
       l = ((occ >> k) & 1u) ? (uint8_t)kOccluded : l;
-      const double ri = r[k];
+      const double ri = U.r[q];
       l = !(prm.min_range <= ri && ri <= prm.max_range) ? (uint8_t)kOutOfRange : l;        // range.hpp:40-43
-      l = pbres[k] == 1 ? (uint8_t)kParallelBeam : l;
+      l = ((pb_yes >> k) & 1u) ? (uint8_t)kParallelBeam : l;
       l = own ? l : (uint8_t)kDefault;
+      const double cv = U.c[kSlabPad + q];
       if (own) {
         label_s[off + i] = l;
-        curv_s[off + i] = cq[k];
+        curv_s[off + i] = cv;
       }
-      lab[k] = l;
-      FE[k] = __ballot(l == kEdge);
-      FS[k] = __ballot(l == kSurface);
-    }
-  }
-  uint32_t pe = 0, ps = 0;
-  const uint64_t below = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
-    if (k < K) {
-      if (lab[k] == kEdge || lab[k] == kSurface) {
-        const int q = 64 * k + lane, i = g0 + q;
+      const uint64_t fe = __ballot(l == kEdge), fs = __ballot(l == kSurface);
+      if (l == kEdge || l == kSurface) {
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-        const float4 rec = make_float4(x[k], y[k], sz[off + i], (float)cq[k]);
-        const size_t at = lab[k] == kEdge ? off + o0 + pe + __popcll(FE[k] & below)
-                                          : off + o1 - 1 - (ps + __popcll(FS[k] & below));
+        const float2 xy = sxy[off + i];
+        const float4 rec = make_float4(xy.x, xy.y, sz[off + i], (float)cv);
+        const size_t at = l == kEdge ? off + o0 + pe + ubelow(fe, lane) : off + o1 - 1 - (ps + ubelow(fs, lane));
         rec_pts[at] = rec;
         rec_idx[at] = sidx[off + i];
       }
-      pe += __popcll(FE[k]);
-      ps += __popcll(FS[k]);
+      pe += __popcll(fe);
+      ps += __popcll(fs);
     }
   }
+  (void)is_edge; (void)is_surf;
   if (lane == 0) {
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
     unit_ne[ui] = pe;
@@ -1311,7 +1312,7 @@ __device__ inline void unit_body(
 #undef LFX_DEFER
 }
 
-__global__ __launch_bounds__(64 * kUnitWaves) void ring_unit_kernel(
+__global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ scan_begin,
   const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
   const uint32_t * __restrict__ ring_offset, const float2 * __restrict__ sxy, const float * __restrict__ sz,
@@ -1494,18 +1495,22 @@ __global__ __launch_bounds__(kRings) void ring_totals_kernel(
 }
 
 // K4b: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
-// ring angle ascending (units ascending; a slow-path ring is one segment).
+// ring angle ascending (units ascending; a slow-path ring is one segment).  One wave per unit.
 __global__ __launch_bounds__(256) void feature_compact_kernel(
-  Params prm, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
-  const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_offset,
-  const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf,
-  const uint32_t * __restrict__ ring_ebase, const uint32_t * __restrict__ ring_sbase,
-  const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
-  const uint32_t * __restrict__ ring_flags, const float4 * __restrict__ rec_pts,
-  const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts, uint32_t * __restrict__ edge_idx,
-  float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx, uint32_t max_rings)
+  Params prm, uint32_t n_units /* units per ring the grid covers */, const uint32_t * __restrict__ scan_begin,
+  const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
+  const uint32_t * __restrict__ ring_offset, const uint32_t * __restrict__ ring_nedge,
+  const uint32_t * __restrict__ ring_nsurf, const uint32_t * __restrict__ ring_ebase,
+  const uint32_t * __restrict__ ring_sbase, const uint32_t * __restrict__ unit_ne,
+  const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ ring_flags,
+  const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
+  uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
+  uint32_t max_rings)
 {
-  const uint32_t slot = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const uint32_t s = blockIdx.y, lane = threadIdx.x & 63;
+  const uint32_t u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t slot = u / n_units;
+  const int j = (int)(u % n_units);
   uint32_t nr = scan_info[s * 4 + kInfoRings];
   nr = nr < max_rings ? nr : max_rings;
   if (slot >= nr) {return;}
@@ -1514,28 +1519,34 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const size_t off = b + ring_offset[s * kRings + slot];
   uint32_t eb = ring_ebase[s * kRings + slot], fb = ring_sbase[s * kRings + slot];
   const bool one_segment = ring_flags[s * kRings + slot] != 0u;
-  const int n_units = one_segment ? 1 : prm.B;
   const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
-  for (int j = 0; j < n_units; j++) {
-    int o0 = 0, o1 = N;
-    if (!one_segment) {
-      o0 = j == 0 ? 0 : block_boundary(N, prm.P, prm.B, j);
-      o1 = j == prm.B - 1 ? N : block_boundary(N, prm.P, prm.B, j + 1);
+  int o0 = 0, o1 = N;
+  uint32_t ne, ns;
+  if (one_segment) {
+    if (j != 0) {return;}
+    ne = ring_nedge[s * kRings + slot];
+    ns = ring_nsurf[s * kRings + slot];
+  } else {
+    // this unit's records start after those of the ring's earlier units
+    uint32_t pe = 0, ps = 0;
+    for (int t = (int)lane; t < j; t += 64) {pe += unit_ne[ui + t]; ps += unit_ns[ui + t];}
+    for (int d = 32; d > 0; d >>= 1) {pe += __shfl_xor(pe, d); ps += __shfl_xor(ps, d);}
+    eb += pe;
+    fb += ps;
+    o0 = j == 0 ? 0 : block_boundary(N, prm.P, prm.B, j);
+    o1 = j == prm.B - 1 ? N : block_boundary(N, prm.P, prm.B, j + 1);
+    ne = unit_ne[ui + j];
+    ns = unit_ns[ui + j];
+  }
+  for (uint32_t k = lane; k < ne + ns; k += 64) {
+    if (k < ne) {
+      edge_pts[b + eb + k] = rec_pts[off + o0 + k];
+      edge_idx[b + eb + k] = rec_idx[off + o0 + k];
+    } else {
+      const uint32_t q = k - ne;
+      surf_pts[b + fb + q] = rec_pts[off + o1 - 1 - q];
+      surf_idx[b + fb + q] = rec_idx[off + o1 - 1 - q];
     }
-    const uint32_t ne = one_segment ? ring_nedge[s * kRings + slot] : unit_ne[ui + j];
-    const uint32_t ns = one_segment ? ring_nsurf[s * kRings + slot] : unit_ns[ui + j];
-    for (uint32_t k = tid; k < ne + ns; k += blockDim.x) {
-      if (k < ne) {
-        edge_pts[b + eb + k] = rec_pts[off + o0 + k];
-        edge_idx[b + eb + k] = rec_idx[off + o0 + k];
-      } else {
-        const uint32_t q = k - ne;
-        surf_pts[b + fb + q] = rec_pts[off + o1 - 1 - q];
-        surf_idx[b + fb + q] = rec_idx[off + o1 - 1 - q];
-      }
-    }
-    eb += ne;
-    fb += ns;
   }
 }
 
