@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams (each with its own context and scratch) the steps alternate over")
     return ap.parse_args()
 
 
@@ -81,9 +83,16 @@ def main():
     d_points = torch.from_numpy(host).to(dev)
     n_list = np.array([len(c) for c in tiled], np.uint32)
     cap = 1 << int(np.ceil(np.log2(max(a.cols, 64))))
-    fx = FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
-                           max_points_per_ring=cap, max_rings=a.rings)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one context (= one set of device scratch) per stream: consecutive steps run on alternating
+    # streams, so the HBM-bound ring bucketing of one batch overlaps the latency-bound ring kernel of
+    # the previous one
+    n_streams = max(1, a.streams)
+    fxs = [FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
+                             max_points_per_ring=cap, max_rings=a.rings) for _ in range(n_streams)]
+    fx = fxs[0]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    stream = streams[0].cuda_stream
+    step_no = [0]
 
     use_gather = world > 1 and not a.no_gather
     if use_gather:
@@ -93,9 +102,13 @@ def main():
         offs = torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)
 
     def step():
-        fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
+        k = step_no[0] % n_streams
+        step_no[0] += 1
         if use_gather:
-            fx.pack_features(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
+            k = 0                      # the gather runs on torch's current stream
+        fxs[k].extract_batch_device(d_points.data_ptr(), n_list, streams[k].cuda_stream)
+        if use_gather:
+            fxs[k].pack_features(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
             gather_clouds(edge_buf, surf_buf, offs, a.batch, dst=0)
 
     def fence():
@@ -185,12 +198,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hdl64-64x1800 (BASELINE.json configs[2])", "rings": a.rings, "cols": a.cols,
                        "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": "code defaults",
+                       "streams": 1 if use_gather else n_streams,
                        "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_spot_check": parity,
         }
         print(json.dumps(out))
         sys.stdout.flush()
-    fx.close()
+    for f in fxs:
+        f.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
