@@ -56,7 +56,7 @@ typedef struct lfx_config {
   uint32_t max_points_per_scan;   /* capacity of one scan                                   */
   uint32_t max_batch;             /* scans per lfx_extract_batch* call                      */
   uint32_t max_points_per_ring;   /* 0 = LFX_MAX_RING_POINTS; rounded up to a power of two  */
-  uint32_t max_rings;             /* rings a scan may hold (workgroups launched per scan); 0 = 256 */
+  uint32_t max_rings;             /* ring ids are 0 .. max_rings-1 (a sensor's ring count); 0 = 256 */
   lfx_layout layout;              /* all-zero = PointXYZIR                                  */
 } lfx_config;
 
@@ -112,20 +112,22 @@ typedef struct lfx_scan_result {
 } lfx_scan_result;
 
 /* Device-resident results of the last lfx_extract_batch_device call (device pointers owned by
- * the context).  Scan s owns positions [scan_begin[s], scan_begin[s+1]) of every per-point
- * array; its features occupy the first n_edge[s] / n_surface[s] records from scan_begin[s]. */
+ * the context).  Per-point outputs are RING-MAJOR with a fixed capacity per ring id: ring r of
+ * scan s owns positions [(s * max_rings + r) * ring_capacity, + ring_count[s][r]) of labels_sorted,
+ * curvature_sorted and sorted_index, angle ascending.  The feature clouds are dense: scan s owns the
+ * first n_edge / n_surface records from scan_begin[s] (scan_info[s][2], [3]). */
 typedef struct lfx_device_view {
   uint32_t batch;
-  const uint32_t *scan_begin;     /* device [batch+1]                                           */
-  const uint8_t *labels_sorted;   /* device: label of sorted position k (see sorted_index)      */
-  const double *curvature_sorted; /* device                                                     */
-  const uint32_t *sorted_index;   /* device: original index (within its scan) of sorted position k */
-  const uint32_t *scan_info;      /* device [batch][4]: n_rings, error bits, n_edge, n_surface  */
-  const uint16_t *ring_id;        /* device [batch][256] by slot                                */
-  const uint32_t *ring_count;     /* device [batch][256] by slot                                */
-  const uint32_t *ring_offset;    /* device [batch][256] by slot                                */
-  const uint8_t *ring_status;     /* device [batch][256] by slot                                */
-  const float *edge_points;       /* device [total][4]                                          */
+  uint32_t max_rings;             /* ring ids the layout has room for                            */
+  uint32_t ring_capacity;         /* positions per ring (max_points_per_ring rounded up to 64)   */
+  const uint32_t *scan_begin;     /* device [batch+1] (in points)                                */
+  const uint8_t *labels_sorted;   /* device: label of ring position k                            */
+  const double *curvature_sorted; /* device                                                      */
+  const uint32_t *sorted_index;   /* device: original index (within its scan) of ring position k */
+  const uint32_t *scan_info;      /* device [batch][4]: occupied rings, error bits, n_edge, n_surface */
+  const uint32_t *ring_count;     /* device [batch][256] by ring id                              */
+  const uint8_t *ring_status;     /* device [batch][256] by ring id (valid where ring_count > 0) */
+  const float *edge_points;       /* device [total][4]                                           */
   const uint32_t *edge_index;
   const float *surface_points;
   const uint32_t *surface_index;
@@ -192,7 +194,7 @@ int lfx_stage_ring_projection(lfx_ctx *ctx, const void *points, size_t n_points,
                               uint32_t *n_rings, uint16_t *ring_id /* [256] */, uint32_t *ring_count /* [256] */);
 
 /* --- measurement ------------------------------------------------------------------------- */
-#define LFX_N_KERNELS 7   /* ring_histogram, ring_scan, ring_scatter, ring_unit, ring_extract, ring_totals, feature_compact */
+#define LFX_N_KERNELS 7   /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_extract, ring_totals, feature_compact */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);
 /* Sum of HIP-event durations per kernel since profiling was enabled, and launches counted. */
 int lfx_kernel_times(lfx_ctx *ctx, double ms[LFX_N_KERNELS], uint64_t launches[LFX_N_KERNELS]);

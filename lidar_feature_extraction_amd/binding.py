@@ -52,10 +52,10 @@ class ScanResult(C.Structure):
 
 
 class DeviceView(C.Structure):
-    _fields_ = [("batch", C.c_uint32)] + [(n, C.c_void_p) for n in (
-        "scan_begin", "labels_sorted", "curvature_sorted", "sorted_index", "scan_info", "ring_id",
-        "ring_count", "ring_offset", "ring_status", "edge_points", "edge_index", "surface_points",
-        "surface_index")]
+    _fields_ = [("batch", C.c_uint32), ("max_rings", C.c_uint32), ("ring_capacity", C.c_uint32)] + \
+        [(n, C.c_void_p) for n in (
+            "scan_begin", "labels_sorted", "curvature_sorted", "sorted_index", "scan_info",
+            "ring_count", "ring_status", "edge_points", "edge_index", "surface_points", "surface_index")]
 
 
 EXPORTS = [

@@ -96,15 +96,17 @@ struct lfx_ctx
   uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
   uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
+  bool single_pass = true;               // look-back bucketing; LFX_DEBUG_TWO_PASS selects histogram + scan + scatter
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
 
   // device scratch
-  DevBuf<uint32_t> scan_begin, scan_info, chunk_base, ring_off_by_id, ring_count, ring_offset, ring_nedge,
+  DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
     ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, slow_list, sidx, rec_idx, edge_idx,
-    surf_idx;
-  DevBuf<uint16_t> chunk_hist, ring_id;
-  DevBuf<uint8_t> ring_status, label_s, staging;
+    surf_idx, d_sidx;
+  DevBuf<uint16_t> chunk_hist;
+  DevBuf<uint8_t> ring_status, label_s, staging, d_label;
+  DevBuf<double> d_curv;
   DevBuf<float2> sxy;
   DevBuf<float> sz;
   DevBuf<double> curv_s;
@@ -261,25 +263,36 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   const uint8_t * pts = static_cast<const uint8_t *>(d_points);
   const uint32_t chunks = (longest + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
   if (chunks == 0) {return LFX_OK;}
-  {
-    Timed t(c, 0, st);
-    hipLaunchKernelGGL(lfx::ring_histogram_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
-      pts, c->layout, c->scan_begin.p, c->chunk_hist.p, c->scan_info.p, c->max_chunks);
-  }
-  {
-    Timed t(c, 1, st);
-    hipLaunchKernelGGL(lfx::ring_scan_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
-      c->scan_begin.p, c->chunk_hist.p, c->chunk_base.p, c->ring_off_by_id.p, c->ring_id.p, c->ring_count.p,
-      c->ring_offset.p, c->scan_info.p, c->max_chunks);
-  }
-  {
+  LFX_HIP(c, hipMemsetAsync(c->ring_count.p, 0, (size_t)batch * lfx::kRings * 4, st));
+  const bool canon = c->layout.step == 32 && c->layout.ox == 0 && c->layout.oy == 4 && c->layout.oz == 8 &&
+    c->layout.oring == 20 && (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
+  if (c->single_pass) {
+    LFX_HIP(c, hipMemsetAsync(c->chunk_flags.p, 0, (size_t)batch * c->max_chunks * 4, st));
     Timed t(c, 2, st);
-    const bool canon = c->layout.step == 32 && c->layout.ox == 0 && c->layout.oy == 4 && c->layout.oz == 8 &&
-      c->layout.oring == 20 && (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
-    hipLaunchKernelGGL(canon ? lfx::ring_scatter_kernel<true> : lfx::ring_scatter_kernel<false>,
-      dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
-      pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->ring_off_by_id.p, c->sxy.p, c->sz.p,
-      c->sidx.p, c->max_chunks);
+    auto kern = &lfx::ring_scatter_kernel<false, true>;
+    if (canon) {kern = &lfx::ring_scatter_kernel<true, true>;}
+    hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
+      pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
+      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap);
+  } else {
+    {
+      Timed t(c, 0, st);
+      hipLaunchKernelGGL(lfx::ring_histogram_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
+        pts, c->layout, c->scan_begin.p, c->chunk_hist.p, c->scan_info.p, c->max_chunks, c->max_rings);
+    }
+    {
+      Timed t(c, 1, st);
+      hipLaunchKernelGGL(lfx::ring_scan_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
+        c->scan_begin.p, c->chunk_hist.p, c->chunk_base.p, c->ring_count.p, c->scan_info.p, c->max_chunks);
+    }
+    {
+      Timed t(c, 2, st);
+      auto kern = &lfx::ring_scatter_kernel<false, false>;
+      if (canon) {kern = &lfx::ring_scatter_kernel<true, false>;}
+      hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
+        pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
+        c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap);
+    }
   }
   // ring_flags[max_batch][256], then the slow-list counter
   uint32_t * slow_count = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;
@@ -290,30 +303,29 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
     hipLaunchKernelGGL(lfx::ring_unit_kernel, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
       dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-      c->dev, c->cap, c->unit_flags, c->max_rings, c->scan_begin.p, c->scan_info.p, c->ring_count.p,
-      c->ring_offset.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
+      c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->ring_flags.p, slow_count, c->slow_list.p);
   }
   {
     Timed t(c, 4, st);
     const dim3 grid = c->fast_path ? dim3(c->slow_grid) : dim3(c->max_rings, batch);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
-      c->dev, c->cap, c->stage_flags, c->fast_path ? 1u : 0u, pts, c->layout, c->scan_begin.p, c->scan_info.p,
-      c->ring_count.p, c->ring_offset.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
+      c->dev, c->cap, c->stage_flags, c->fast_path ? 1u : 0u, pts, c->layout, c->scan_begin.p,
+      c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
       c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->ring_flags.p, slow_count, c->slow_list.p,
       c->max_rings);
   }
   {
     Timed t(c, 5, st);
     hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
-      c->scan_info.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p, c->ring_ebase.p,
-      c->ring_sbase.p, c->fast_path ? (uint32_t)c->dev.B : 1u, c->max_rings);
+      c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
+      c->ring_ebase.p, c->ring_sbase.p, c->fast_path ? (uint32_t)c->dev.B : 1u, c->max_rings);
   }
   {
     Timed t(c, 6, st);
     const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
     hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings * n_units + 3) / 4, batch), dim3(256), 0, st,
-      c->dev, n_units, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_offset.p, c->ring_nedge.p,
+      c->dev, n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_nedge.p,
       c->ring_nsurf.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p, c->unit_ns.p, c->ring_flags.p,
       c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p, c->surf_idx.p, c->max_rings);
   }
@@ -328,29 +340,45 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
   HostScan & h = c->host[s];
   const uint32_t b = c->h_scan_begin[s], n = c->h_scan_begin[s + 1] - b;
   uint32_t info[4] = {0, 0, 0, 0};
-  uint16_t rid[lfx::kRings];
-  uint32_t rcount[lfx::kRings], roff[lfx::kRings];
+  uint32_t rcount[lfx::kRings];
   uint8_t rstat[lfx::kRings];
   LFX_HIP(c, hipMemcpyAsync(info, c->scan_info.p + (size_t)s * 4, 16, hipMemcpyDeviceToHost, st));
-  LFX_HIP(c, hipMemcpyAsync(rid, c->ring_id.p + (size_t)s * lfx::kRings, sizeof(rid), hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipMemcpyAsync(rcount, c->ring_count.p + (size_t)s * lfx::kRings, sizeof(rcount), hipMemcpyDeviceToHost, st));
-  LFX_HIP(c, hipMemcpyAsync(roff, c->ring_offset.p + (size_t)s * lfx::kRings, sizeof(roff), hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipMemcpyAsync(rstat, c->ring_status.p + (size_t)s * lfx::kRings, sizeof(rstat), hipMemcpyDeviceToHost, st));
   h.labels_sorted.resize(n);
   h.curvature_sorted.resize(n);
   h.sorted_index.resize(n);
   if (n) {
-    LFX_HIP(c, hipMemcpyAsync(h.labels_sorted.data(), c->label_s.p + b, n, hipMemcpyDeviceToHost, st));
-    LFX_HIP(c, hipMemcpyAsync(h.curvature_sorted.data(), c->curv_s.p + b, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    LFX_HIP(c, hipMemcpyAsync(h.sorted_index.data(), c->sidx.p + b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    // ring-major (fixed capacity per ring) -> dense, rings ascending; then one copy per array
+    hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings), dim3(256), 0, st,
+      s, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p, c->d_curv.p,
+      c->d_sidx.p);
+    LFX_HIP(c, hipGetLastError());
+    LFX_HIP(c, hipMemcpyAsync(h.labels_sorted.data(), c->d_label.p, n, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.curvature_sorted.data(), c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.sorted_index.data(), c->d_sidx.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   }
   LFX_HIP(c, hipStreamSynchronize(st));
   if (info[lfx::kInfoError] & 1u) {
-    return fail(c, LFX_ERR_RING_ID, "a point carries a ring id above LFX_MAX_RING_ID");
+    return fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)");
   }
-  const uint32_t nr = info[lfx::kInfoRings];
-  if (nr > c->max_rings) {
-    return fail(c, LFX_ERR_CAPACITY, "scan holds more rings than the context's max_rings");
+  if (info[lfx::kInfoError] & 4u) {
+    return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
+  }
+  uint32_t nr = 0;
+  h.ring_id.clear(); h.ring_count.clear(); h.ring_offset.clear(); h.ring_status.clear();
+  {
+    uint32_t dense = 0;
+    for (uint32_t r = 0; r < c->max_rings; r++) {
+      if (rcount[r] == 0) {continue;}
+      h.ring_id.push_back((uint16_t)r);
+      h.ring_count.push_back(rcount[r]);
+      h.ring_offset.push_back(dense);
+      h.ring_status.push_back(rstat[r]);
+      dense += rcount[r];
+      nr++;
+    }
+    if (dense != n) {return fail(c, LFX_ERR_HIP, "internal: ring counts do not add up to the scan");}
   }
   const uint32_t ne = info[lfx::kInfoEdge], ns = info[lfx::kInfoSurface];
   h.edge_points.resize((size_t)ne * 4);
@@ -366,10 +394,6 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
     LFX_HIP(c, hipMemcpyAsync(h.surface_index.data(), c->surf_idx.p + b, (size_t)ns * 4, hipMemcpyDeviceToHost, st));
   }
   LFX_HIP(c, hipStreamSynchronize(st));
-  h.ring_id.assign(rid, rid + nr);
-  h.ring_count.assign(rcount, rcount + nr);
-  h.ring_offset.assign(roff, roff + nr);
-  h.ring_status.assign(rstat, rstat + nr);
   // back to the caller's point order (labels[k] / curvature[k] belong to input point k)
   h.labels.assign(n, LFX_LABEL_DEFAULT);
   h.curvature.assign(n, 0.0);
@@ -487,6 +511,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->ring_threads = ring_threads_for(c->cap);
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
+  c->single_pass = std::getenv("LFX_DEBUG_TWO_PASS") == nullptr;
   c->slow_grid = 1024;
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_FLAGS")) {c->unit_flags = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}
@@ -505,13 +530,15 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   auto ok = [&](hipError_t r) {if (e == hipSuccess) {e = r;}};
   ok(c->scan_begin.alloc(nb + 1)); ok(c->scan_info.alloc(nb * 4));
   ok(c->chunk_hist.alloc(chunk_tab)); ok(c->chunk_base.alloc(chunk_tab));
-  ok(c->ring_off_by_id.alloc(tables)); ok(c->ring_id.alloc(tables)); ok(c->ring_count.alloc(tables));
-  ok(c->ring_offset.alloc(tables)); ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
+  ok(c->ring_count.alloc(tables)); ok(c->chunk_flags.alloc(nb * c->max_chunks));
+  ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
   ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
   ok(c->ring_flags.alloc(tables + 1)); ok(c->slow_list.alloc(tables));
   ok(c->unit_ne.alloc(tables * lfx::kUnitMaxBlocks)); ok(c->unit_ns.alloc(tables * lfx::kUnitMaxBlocks));
-  ok(c->sxy.alloc(tc)); ok(c->sz.alloc(tc)); ok(c->sidx.alloc(tc)); ok(c->rec_pts.alloc(tc)); ok(c->rec_idx.alloc(tc));
-  ok(c->label_s.alloc(tc)); ok(c->curv_s.alloc(tc));
+  const size_t rc = nb * c->max_rings * c->cap;      // ring-major arrays: fixed capacity per ring id
+  ok(c->sxy.alloc(rc)); ok(c->sz.alloc(rc)); ok(c->sidx.alloc(rc)); ok(c->rec_pts.alloc(rc)); ok(c->rec_idx.alloc(rc));
+  ok(c->label_s.alloc(rc)); ok(c->curv_s.alloc(rc));
+  ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
   if (e == hipSuccess) {
@@ -539,7 +566,7 @@ void lfx_destroy(lfx_ctx * c)
   for (auto & sp : c->spans) {(void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);}
   for (auto & ev : c->free_events) {(void)hipEventDestroy(ev);}
   c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
-  c->ring_off_by_id.release(); c->ring_id.release(); c->ring_count.release(); c->ring_offset.release();
+  c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
   c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->unit_ne.release(); c->unit_ns.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
@@ -559,14 +586,14 @@ int lfx_device_results(const lfx_ctx * c, lfx_device_view * v)
 {
   if (!c || !v) {return LFX_ERR_INVALID_ARGUMENT;}
   v->batch = c->last_batch;
+  v->max_rings = c->max_rings;
+  v->ring_capacity = c->cap;
   v->scan_begin = c->scan_begin.p;
   v->labels_sorted = c->label_s.p;
   v->curvature_sorted = c->curv_s.p;
   v->sorted_index = c->sidx.p;
   v->scan_info = c->scan_info.p;
-  v->ring_id = c->ring_id.p;
   v->ring_count = c->ring_count.p;
-  v->ring_offset = c->ring_offset.p;
   v->ring_status = c->ring_status.p;
   v->edge_points = reinterpret_cast<const float *>(c->edge_pts.p);
   v->edge_index = c->edge_idx.p;

@@ -72,7 +72,7 @@ enum Label : uint8_t
 // K0: ring histogram per 1024-point chunk.
 __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
-  uint16_t * __restrict__ chunk_hist, uint32_t * __restrict__ scan_info, uint32_t max_chunks)
+  uint16_t * __restrict__ chunk_hist, uint32_t * __restrict__ scan_info, uint32_t max_chunks, uint32_t max_rings)
 {
   const uint32_t s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
     const uint32_t e = chunk * kChunkPoints + i * kChunkThreads + tid;
     if (e < n) {
       const uint32_t ring = *reinterpret_cast<const uint16_t *>(pts + (size_t)(b + e) * L.step + L.oring);
-      if (ring >= kRings) {bad = true;} else {atomicAdd(&h[ring], 1u);}
+      if (ring >= max_rings) {bad = true;} else {atomicAdd(&h[ring], 1u);}
     }
   }
   __syncthreads();
@@ -95,13 +95,11 @@ __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: per scan, prefix the chunk histograms per ring, lay the rings out in ascending id, and
-// list the non-empty rings (the "slots" ring_extract is launched over).
+// K1 (two-pass bucketing only): per scan, prefix the chunk histograms per ring.
 __global__ __launch_bounds__(kRings) void ring_scan_kernel(
   const uint32_t * __restrict__ scan_begin, const uint16_t * __restrict__ chunk_hist,
-  uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ ring_off_by_id,
-  uint16_t * __restrict__ ring_id, uint32_t * __restrict__ ring_count, uint32_t * __restrict__ ring_offset,
-  uint32_t * __restrict__ scan_info, uint32_t max_chunks)
+  uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ ring_count, uint32_t * __restrict__ scan_info,
+  uint32_t max_chunks)
 {
   const uint32_t s = blockIdx.x, r = threadIdx.x;
   const uint32_t n = scan_begin[s + 1] - scan_begin[s];
@@ -113,40 +111,37 @@ __global__ __launch_bounds__(kRings) void ring_scan_kernel(
     chunk_base[k] = acc;
     acc += v;
   }
-  __shared__ uint32_t cnt[kRings], occ[kRings];
-  cnt[r] = acc;
-  occ[r] = acc ? 1u : 0u;
-  __syncthreads();
-  // inclusive Hillis-Steele scans over 256 entries (count -> offset, occupancy -> slot)
-  for (uint32_t d = 1; d < kRings; d <<= 1) {
-    const uint32_t a = r >= d ? cnt[r - d] : 0u, o = r >= d ? occ[r - d] : 0u;
-    __syncthreads();
-    cnt[r] += a;
-    occ[r] += o;
-    __syncthreads();
-  }
-  const uint32_t offset = cnt[r] - acc;
-  ring_off_by_id[s * kRings + r] = offset;
-  if (acc) {
-    const uint32_t slot = occ[r] - 1;
-    ring_id[s * kRings + slot] = (uint16_t)r;
-    ring_count[s * kRings + slot] = acc;
-    ring_offset[s * kRings + slot] = offset;
-  }
-  if (r == kRings - 1) {scan_info[s * 4 + kInfoRings] = occ[r];}
+  ring_count[s * kRings + r] = acc;
+  const uint32_t occupied = __syncthreads_count(acc != 0u);
+  if (r == 0) {scan_info[s * 4 + kInfoRings] = occupied;}
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: stable scatter of (x, y | z | original index) into ring-major arrays.  The rank of a point
+// Ring-major layout: ring `r` of scan `s` owns positions [((s * max_rings) + r) * cap, + cap) of every
+// per-point array (fixed capacity per ring id, so no global prefix over rings is needed).
+__host__ __device__ inline size_t ring_base(uint32_t s, uint32_t ring, uint32_t max_rings, uint32_t cap)
+{
+  return ((size_t)s * max_rings + ring) * cap;
+}
+
+constexpr uint32_t kSpinLimit = 200000;   // ~50 ms of s_sleep polls before a look-back gives up
+
+// K2: stable scatter of (x, y | z | original index) into ring-major arrays.
+// LOOKBACK (default): the only pass over the input.  A chunk publishes its per-ring counts, waits
+// for the counts of the scan's earlier chunks (lower block index: already dispatched) and sums
+// them -- no separate histogram pass.  Release / acquire at agent scope as
+// cdna_hip_programming.md Guideline 16 prescribes; the spin is bounded and a timeout marks the
+// scan as failed instead of hanging.  Without LOOKBACK the prefixes come from ring_scan_kernel.  The rank of a point
 // among the points of its ring inside the chunk comes from wave ballots (one per key bit), so the
 // order of arrival is kept.  The chunk is first laid out ring-major in LDS; the stores to HBM then
 // walk that layout, so a wave writes runs of consecutive positions (one run per ring) instead of
 // 64 scattered dwords.
-template<bool CANON>
+template<bool CANON, bool LOOKBACK>
 __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
-  const uint32_t * __restrict__ chunk_base, const uint32_t * __restrict__ ring_off_by_id,
-  float2 * __restrict__ sxy, float * __restrict__ sz, uint32_t * __restrict__ sidx, uint32_t max_chunks)
+  uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
+  uint32_t * __restrict__ scan_info, float2 * __restrict__ sxy, float * __restrict__ sz,
+  uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap)
 {
   const uint32_t s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
@@ -156,7 +151,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   constexpr int kGroups = kChunkSlots * (kChunkThreads / 64);      // (slot, wave) pairs in arrival order
   __shared__ uint16_t wcnt[kGroups][kRings];
   __shared__ uint32_t cstart[kRings];                              // start of each ring inside the staged chunk
-  __shared__ uint32_t gbase[kRings];                               // where that run starts in the scan's arrays
+  __shared__ uint32_t gfill[kRings];                               // points of the ring in earlier chunks
   __shared__ uint32_t staged;                                      // points with a valid ring id in this chunk
   // staging, skewed by one element per 32 (kSkew): with column-major input a wave's 64 points go to 64
   // different rings, i.e. to staged positions one run length apart -- a power-of-two stride
@@ -170,6 +165,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
 
   float x[kChunkSlots], y[kChunkSlots], z[kChunkSlots];
   uint32_t key[kChunkSlots], rank[kChunkSlots];
+  bool bad_ring = false;
 #pragma unroll
   for (int i = 0; i < kChunkSlots; i++) {
     const uint32_t e = chunk * kChunkPoints + i * kChunkThreads + tid;
@@ -189,7 +185,29 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
         z[i] = *reinterpret_cast<const float *>(p + L.oz);
         ring = *reinterpret_cast<const uint16_t *>(p + L.oring);
       }
-      key[i] = ring < kRings ? ring : kRings;
+      key[i] = ring < max_rings ? ring : kRings;
+      if (LOOKBACK && ring >= max_rings) {bad_ring = true;}
+    }
+  }
+  const size_t row = (size_t)s * max_chunks;
+  if (LOOKBACK) {
+    // the per-ring counts are all the later chunks need: count with LDS atomics and publish them
+    // before the ranking work, with write-through (sc1) stores, drain, then ONE lane sets the flag.
+    // No L2 write-back fence: a release fence would flush every dirty line of the XCD's L2, i.e. the
+    // other workgroups' scattered output (cdna_hip_programming.md Guideline 16, form R1).
+    cstart[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kChunkSlots; i++) {
+      if (key[i] < kRings) {atomicAdd(&cstart[key[i]], 1u);}
+    }
+    __syncthreads();
+    if (bad_ring) {atomicOr(&scan_info[s * 4 + kInfoError], 1u);}
+    __hip_atomic_store(&chunk_base[(row + chunk) * kRings + tid], cstart[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(&chunk_flags[row + chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #pragma unroll
@@ -216,6 +234,61 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     mine = acc;                            // points of ring `tid` in this chunk
     cstart[tid] = acc;
   }
+  uint32_t before = 0;                     // points of ring `tid` in the scan's earlier chunks
+  if (LOOKBACK) {
+    bool timeout = false;
+    for (uint32_t p = tid; p < chunk; p += kChunkThreads) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&chunk_flags[row + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kSpinLimit) {timeout = true; break;}
+      }
+    }
+    if (timeout) {atomicOr(&scan_info[s * 4 + kInfoError], 4u);}
+    __syncthreads();
+    // every load of the published counts is an sc1 (L1-bypassing, agent-scope) load; four 16-byte
+    // loads are kept in flight per thread (thread = 4 consecutive rings x one quarter of the chunks)
+    {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const uint32_t grp = tid >> 6, quad = tid & 63;
+      u32x4 acc = {0u, 0u, 0u, 0u};
+      for (uint32_t p0 = 0; p0 < chunk; p0 += 16) {
+        const uint32_t pa = p0 + grp, pb = pa + 4, pc = pa + 8, pd = pa + 12;
+        const uint32_t * qa = chunk_base + (row + (pa < chunk ? pa : 0u)) * kRings + 4 * quad;
+        const uint32_t * qb = chunk_base + (row + (pb < chunk ? pb : 0u)) * kRings + 4 * quad;
+        const uint32_t * qc = chunk_base + (row + (pc < chunk ? pc : 0u)) * kRings + 4 * quad;
+        const uint32_t * qd = chunk_base + (row + (pd < chunk ? pd : 0u)) * kRings + 4 * quad;
+        u32x4 va, vb, vc, vd;
+        asm volatile(
+          "global_load_dwordx4 %0, %4, off sc1\n\t"
+          "global_load_dwordx4 %1, %5, off sc1\n\t"
+          "global_load_dwordx4 %2, %6, off sc1\n\t"
+          "global_load_dwordx4 %3, %7, off sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(va), "=&v"(vb), "=&v"(vc), "=&v"(vd)
+          : "v"(qa), "v"(qb), "v"(qc), "v"(qd)
+          : "memory");
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        acc += (pa < chunk ? va : zero) + (pb < chunk ? vb : zero) + (pc < chunk ? vc : zero) + (pd < chunk ? vd : zero);
+      }
+      __syncthreads();                       // wcnt is done with (prefixes taken above); reuse it as scratch
+      uint32_t * part = reinterpret_cast<uint32_t *>(&st_xy[0]);      // [4][256] u32, staging not yet in use
+      part[grp * kRings + 4 * quad + 0] = acc.x;
+      part[grp * kRings + 4 * quad + 1] = acc.y;
+      part[grp * kRings + 4 * quad + 2] = acc.z;
+      part[grp * kRings + 4 * quad + 3] = acc.w;
+      __syncthreads();
+      before = part[tid] + part[kRings + tid] + part[2 * kRings + tid] + part[3 * kRings + tid];
+      __syncthreads();
+    }
+    if ((chunk + 1) * (uint32_t)kChunkPoints >= n) {     // the scan's last chunk knows the ring totals
+      ring_count[s * kRings + tid] = before + mine;
+      const uint32_t occupied = __syncthreads_count(before + mine != 0u);
+      if (tid == 0) {scan_info[s * 4 + kInfoRings] = occupied;}
+    }
+  } else {
+    before = chunk_base[(row + chunk) * kRings + tid];
+  }
   __syncthreads();
   for (uint32_t d = 1; d < kRings; d <<= 1) {       // inclusive scan of the ring counts
     const uint32_t a = tid >= d ? cstart[tid - d] : 0u;
@@ -228,7 +301,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     if (tid == kRings - 1) {staged = cstart[tid];}
     __syncthreads();
     cstart[tid] = start;
-    gbase[tid] = b + ring_off_by_id[s * kRings + tid] + chunk_base[((size_t)s * max_chunks + chunk) * kRings + tid];
+    gfill[tid] = before;
   }
   __syncthreads();
 #pragma unroll
@@ -248,10 +321,13 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   for (uint32_t o = tid; o < n_staged; o += kChunkThreads) {
     const uint32_t os = o + (o >> 5);
     const uint32_t r = st_ring[os];
-    const uint32_t pos = gbase[r] + (o - cstart[r]);
-    sxy[pos] = st_xy[os];
-    sz[pos] = st_z[os];
-    sidx[pos] = chunk * kChunkPoints + st_src[os];
+    const uint32_t k = gfill[r] + (o - cstart[r]);       // position inside the ring
+    if (k < cap) {                                       // a ring longer than its capacity is reported, not stored
+      const size_t pos = ring_base(s, r, max_rings, cap) + k;
+      sxy[pos] = st_xy[os];
+      sz[pos] = st_z[os];
+      sidx[pos] = chunk * kChunkPoints + st_src[os];
+    }
   }
 }
 
@@ -1019,9 +1095,9 @@ __device__ inline int quotient_test(double a, double yb /* rcp_approx(b) */, dou
 
 template<int PT>
 __device__ inline void unit_body(
-  const Params & prm, UnitLds & U, uint32_t ring_cap, uint32_t dbg_flags, uint32_t s, uint32_t slot, int j,
-  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ ring_count,
-  const uint32_t * __restrict__ ring_offset, const float2 * __restrict__ sxy, const float * __restrict__ sz,
+  const Params & prm, UnitLds & U, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
+  uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
+  const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
   float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
   uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags,
@@ -1032,7 +1108,8 @@ __device__ inline void unit_body(
   const int sh = (lane + 48) & 63;
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
   const int N = (int)ring_count[s * kRings + slot];
-  const size_t off = (size_t)scan_begin[s] + ring_offset[s * kRings + slot];
+  if (N == 0) {return;}                                  // no such ring in this scan
+  const size_t off = ring_base(s, slot, max_rings, ring_cap);
   uint32_t * flag = ring_flags + s * kRings + slot;
 #define LFX_DEFER() \
   do { \
@@ -1313,9 +1390,8 @@ __device__ inline void unit_body(
 }
 
 __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
-  Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ scan_begin,
-  const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
-  const uint32_t * __restrict__ ring_offset, const float2 * __restrict__ sxy, const float * __restrict__ sz,
+  Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
+  const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
   float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
   uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags,
@@ -1326,18 +1402,16 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   const uint32_t u = blockIdx.x * kUnitWaves + (threadIdx.x >> 6);
   const uint32_t slot = u / (uint32_t)prm.B;
   const int j = (int)(u % (uint32_t)prm.B);
-  uint32_t nr = scan_info[s * 4 + kInfoRings];
-  nr = nr < max_rings ? nr : max_rings;
-  if (slot >= nr) {return;}
+  if (slot >= max_rings) {return;}
   UnitLds & U = lds[threadIdx.x >> 6];
   if (prm.P == 5) {
-    unit_body<5>(prm, U, ring_cap, dbg_flags, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+    unit_body<5>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
   } else if (prm.P == 2) {
-    unit_body<2>(prm, U, ring_cap, dbg_flags, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+    unit_body<2>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
   } else {
-    unit_body<0>(prm, U, ring_cap, dbg_flags, s, slot, j, scan_begin, ring_count, ring_offset, sxy, sz, sidx, label_s, curv_s,
+    unit_body<0>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
   }
 }
@@ -1349,8 +1423,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
 // marks the ring so that feature_compact_kernel reads it that way.
 __global__ __launch_bounds__(512) void ring_extract_kernel(
   Params prm, uint32_t cap, uint32_t stage_flags, uint32_t use_list, const uint8_t * __restrict__ pts, Layout L,
-  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
-  const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_offset,
+  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ ring_count,
   float2 * __restrict__ sxy, const float * __restrict__ sz, uint32_t * __restrict__ sidx,
   uint8_t * __restrict__ label_s, double * __restrict__ curv_s, float4 * __restrict__ rec_pts,
   uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status, uint32_t * __restrict__ unit_ne,
@@ -1369,13 +1442,11 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
     } else {
       slot = blockIdx.x;
       s = blockIdx.y;
-      uint32_t nr = scan_info[s * 4 + kInfoRings];
-      nr = nr < max_rings ? nr : max_rings;
-      if (slot >= nr) {return;}
+      if (slot >= max_rings || ring_count[s * kRings + slot] == 0u) {return;}
     }
     const int N = (int)ring_count[s * kRings + slot];
     const size_t sb = scan_begin[s];
-    const size_t off = sb + ring_offset[s * kRings + slot];
+    const size_t off = ring_base(s, slot, max_rings, cap);
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
     uint8_t status = kOk;
     bool resorted = false;
@@ -1396,7 +1467,8 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
     if (tid == 0) {ring_flags[s * kRings + slot] = 1u;}      // "one segment" layout of the records
     if (status != kOk) {
       // the ring contributes nothing (feature_extraction.cpp:116,154-156)
-      for (int i = tid; i < N; i += T) {
+      const int stored = (uint32_t)N < cap ? N : (int)cap;
+      for (int i = tid; i < stored; i += T) {
         label_s[off + i] = kDefault;
         curv_s[off + i] = 0.;
       }
@@ -1461,15 +1533,14 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
 // ------------------------------------------------------------------------------------------
 // K4a: per scan, ring totals and their exclusive prefix (rings ascending).
 __global__ __launch_bounds__(kRings) void ring_totals_kernel(
-  uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
+  uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
+  const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
   uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf, uint32_t * __restrict__ ring_ebase,
   uint32_t * __restrict__ ring_sbase, uint32_t n_units, uint32_t max_rings)
 {
   const uint32_t s = blockIdx.x, slot = threadIdx.x;
-  uint32_t nr = scan_info[s * 4 + kInfoRings];
-  nr = nr < max_rings ? nr : max_rings;
   uint32_t e = 0, f = 0;
-  if (slot < nr) {
+  if (slot < max_rings && ring_count[s * kRings + slot] != 0u) {
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
     for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ui + j]; f += unit_ns[ui + j];}
   }
@@ -1497,9 +1568,9 @@ __global__ __launch_bounds__(kRings) void ring_totals_kernel(
 // K4b: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
 // ring angle ascending (units ascending; a slow-path ring is one segment).  One wave per unit.
 __global__ __launch_bounds__(256) void feature_compact_kernel(
-  Params prm, uint32_t n_units /* units per ring the grid covers */, const uint32_t * __restrict__ scan_begin,
-  const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
-  const uint32_t * __restrict__ ring_offset, const uint32_t * __restrict__ ring_nedge,
+  Params prm, uint32_t n_units /* units per ring the grid covers */, uint32_t cap,
+  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ ring_count,
+  const uint32_t * __restrict__ ring_nedge,
   const uint32_t * __restrict__ ring_nsurf, const uint32_t * __restrict__ ring_ebase,
   const uint32_t * __restrict__ ring_sbase, const uint32_t * __restrict__ unit_ne,
   const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ ring_flags,
@@ -1511,12 +1582,11 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t slot = u / n_units;
   const int j = (int)(u % n_units);
-  uint32_t nr = scan_info[s * 4 + kInfoRings];
-  nr = nr < max_rings ? nr : max_rings;
-  if (slot >= nr) {return;}
+  if (slot >= max_rings) {return;}
   const int N = (int)ring_count[s * kRings + slot];
+  if (N == 0) {return;}
   const size_t b = scan_begin[s];
-  const size_t off = b + ring_offset[s * kRings + slot];
+  const size_t off = ring_base(s, slot, max_rings, cap);
   uint32_t eb = ring_ebase[s * kRings + slot], fb = ring_sbase[s * kRings + slot];
   const bool one_segment = ring_flags[s * kRings + slot] != 0u;
   const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
@@ -1547,6 +1617,35 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       surf_pts[b + fb + q] = rec_pts[off + o1 - 1 - q];
       surf_idx[b + fb + q] = rec_idx[off + o1 - 1 - q];
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Download path: one scan's per-point outputs from the ring-major layout to dense arrays, rings
+// ascending (the order of lfx_scan_result::sorted_index).  One workgroup per ring id.
+__global__ __launch_bounds__(256) void densify_kernel(
+  uint32_t s, uint32_t max_rings, uint32_t cap, const uint32_t * __restrict__ ring_count,
+  const uint8_t * __restrict__ label_s, const double * __restrict__ curv_s, const uint32_t * __restrict__ sidx,
+  uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx)
+{
+  const uint32_t ring = blockIdx.x, tid = threadIdx.x;
+  __shared__ uint32_t part[256];
+  part[tid] = (tid < ring && tid < max_rings) ? ring_count[s * kRings + tid] : 0u;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)tid < d) {part[tid] += part[tid + d];}
+    __syncthreads();
+  }
+  const uint32_t dense = part[0];
+  uint32_t N = ring_count[s * kRings + ring];
+  N = N < cap ? N : cap;                       // an over-long ring holds only `cap` stored points
+  const size_t off = ring_base(s, ring, max_rings, cap);
+  const uint32_t Nfull = ring_count[s * kRings + ring];
+  for (uint32_t i = tid; i < Nfull; i += blockDim.x) {
+    const bool stored = i < N;
+    d_label[dense + i] = stored ? label_s[off + i] : (uint8_t)kDefault;
+    d_curv[dense + i] = stored ? curv_s[off + i] : 0.;
+    d_sidx[dense + i] = stored ? sidx[off + i] : 0xFFFFFFFFu;
   }
 }
 
