@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--force-gather", action="store_true", help="run the pack + gather step even with one rank (rehearsal)")
+    ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (each with its own context and scratch) the steps alternate over")
     return ap.parse_args()
 
@@ -64,8 +65,9 @@ def main():
         a.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if not os.path.exists(os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx.so")):
@@ -83,9 +85,10 @@ def main():
     d_points = torch.from_numpy(host).to(dev)
     n_list = np.array([len(c) for c in tiled], np.uint32)
     cap = 1 << int(np.ceil(np.log2(max(a.cols, 64))))
-    # one context (= one set of device scratch) per stream: consecutive steps run on alternating
-    # streams, so the HBM-bound ring bucketing of one batch overlaps the latency-bound ring kernel of
-    # the previous one
+    # one context (= one set of device scratch) per stream.  --streams > 1 alternates consecutive
+    # steps over streams, so the HBM-bound ring bucketing of one batch overlaps the latency-bound ring
+    # kernel of the previous one (+8 % scans/s at 3 streams); the default is 1 so that the per-kernel
+    # durations in "roofline" are those of undisturbed kernels
     n_streams = max(1, a.streams)
     fxs = [FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
                              max_points_per_ring=cap, max_rings=a.rings) for _ in range(n_streams)]
@@ -94,7 +97,7 @@ def main():
     stream = streams[0].cuda_stream
     step_no = [0]
 
-    use_gather = world > 1 and not a.no_gather
+    use_gather = (world > 1 and not a.no_gather) or a.force_gather
     if use_gather:
         feat_cap = int(a.batch * n_pts * 0.35) + 1024
         edge_buf = torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev)
@@ -113,13 +116,18 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or a.force_gather:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
     fence()
+    # per-kernel durations: HIP events recorded around every launch of the timed region, on the
+    # stream the kernel is launched on (lfx_set_profiling); with one stream they are what
+    # rocprofv3 --kernel-trace --stats reports for the same command
+    for f in fxs:
+        f.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -132,13 +140,11 @@ def main():
     scans_total = a.batch * a.steps * world
     value = scans_total / dt
 
-    # ---- per-kernel durations: HIP events on the launch stream, same steps again
-    fx.set_profiling(True)
-    for _ in range(a.steps):
-        fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
-    torch.cuda.synchronize()
-    kt = fx.kernel_times()
-    fx.set_profiling(False)
+    kt = {}
+    for f in fxs:
+        for k, (ms, cnt) in f.kernel_times().items():
+            kt[k] = (kt.get(k, (0.0, 0))[0] + ms, kt.get(k, (0.0, 0))[1] + cnt)
+        f.set_profiling(False)
     per_launch_us = {k: (1e3 * ms / max(cnt, 1)) for k, (ms, cnt) in kt.items()}
     dominant = max(per_launch_us, key=per_launch_us.get)
     sum_us = sum(per_launch_us.values())
@@ -206,7 +212,7 @@ def main():
         sys.stdout.flush()
     for f in fxs:
         f.close()
-    if world > 1:
+    if world > 1 or a.force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

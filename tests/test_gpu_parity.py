@@ -230,6 +230,43 @@ def test_long_blocks_take_the_lds_labelling_path(fx):
     f.close()
 
 
+@pytest.mark.parametrize("env", ["LFX_DEBUG_TWO_PASS", "LFX_DEBUG_NO_FAST_PATH"])
+def test_fallback_paths_give_the_same_results(env):
+    """The two-pass ring bucketing (histogram + scan + scatter) and the workgroup-per-ring kernel for
+    every ring are kept as fallbacks of the look-back bucketing / wave-per-unit kernel."""
+    import os
+    clouds = [make_scan(16, 1200, seed=70), make_scan(16, 1200, seed=71, drop_fraction=0.1), make_scan(8, 700, seed=72, shuffle=True)]
+    os.environ[env] = "1"
+    try:
+        f = FeatureExtraction(device=0, max_points_per_scan=16 * 1200, max_batch=3, max_rings=16)
+    finally:
+        del os.environ[env]
+    got = f.extract_batch(clouds)
+    for i, c in enumerate(clouds):
+        assert_scan_equal(got[i], OB.extract(c, canonical_ties=False), "%s/%d" % (env, i))
+    f.close()
+
+
+def test_ring_id_beyond_max_rings_is_an_error():
+    c = make_scan(8, 300, seed=3)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=4)
+    with pytest.raises(LB.LfxError) as e:
+        f.ExtractFeatures(c)
+    assert e.value.code == -5
+    f.close()
+
+
+def test_many_chunks_look_back():
+    """A long scan (128 chunks of 2048 points) exercises the look-back over many predecessors."""
+    c = make_scan(128, 2048, seed=90, vfov_deg=22.5)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=2, max_points_per_ring=2048, max_rings=128)
+    got = f.extract_batch([c, c[:100000]])
+    assert_scan_equal(got[0], OB.extract(c, canonical_ties=False), "128x2048")
+    c2 = np.ascontiguousarray(c[:100000])
+    assert_scan_equal(got[1], OB.extract(c2, canonical_ties=False), "128x2048-truncated")
+    f.close()
+
+
 def test_f64_sqrt_and_divide_are_correctly_rounded(fx):
     """Range (math.hpp:36-39) and the link cosine feed orderings: they must equal IEEE results."""
     rng = np.random.default_rng(2)
