@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "liblfx.so")
+LIB_PATH = os.environ.get("LFX_LIB_PATH") or os.path.join(_HERE, "_lib", "liblfx.so")   # override: A/B builds only
 
 LFX_N_KERNELS = 7
 MAX_RINGS = 256

@@ -609,6 +609,44 @@ __device__ inline uint32_t ubelow(uint64_t w, int lane)
   return lane < 32 ? __popc(lo & m) : __popc(lo) + __popc(up & m);
 }
 
+// Order masks: bit 16+d of lt[k] (d = -P..P, d != 0) says that the neighbour at q+d comes BEFORE
+// position q = 64k+lane in ascending curvature order with ties broken by the lower index -- the
+// visiting order of the surface pass; the edge pass visits in exactly the reverse order
+// (label.hpp:85-89 iterates the same argsort backwards), so its mask is the complement.
+// cl[q] is the curvature at local position q; it may be read up to P positions outside [0, nloc):
+// callers keep that addressable and the bits are masked by reach / candidates later.
+template<int PT>
+__device__ inline void order_masks(
+  const double * cl_, const Params & prm, int nloc, int K, int lane, uint32_t (&lt)[kWaveChunks])
+{
+  const int P = PT > 0 ? PT : prm.P;
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    lt[k] = 0;
+    if (k < K) {
+      const int q = 64 * k + lane;
+      const int qc = q < nloc ? q : nloc - 1;
+      const double ci = cl_[qc];
+      uint32_t m = 0;
+      if (PT > 0) {
+#pragma unroll
+        for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {
+          const double cl = cl_[qc - d], cr = cl_[qc + d];
+          m |= (cl <= ci) ? (1u << (16 - d)) : 0u;        // left neighbour: lower index wins a tie
+          m |= (cr < ci) ? (1u << (16 + d)) : 0u;
+        }
+      } else {
+        for (int d = 1; d <= P; d++) {
+          const double cl = cl_[qc - d], cr = cl_[qc + d];
+          m |= (cl <= ci) ? (1u << (16 - d)) : 0u;
+          m |= (cr < ci) ? (1u << (16 + d)) : 0u;
+        }
+      }
+      lt[k] = m;
+    }
+  }
+}
+
 // One pass over one block.  `taken` (bit k = local position 64k+lane is no longer Default) is the
 // per-lane state handed from the edge pass to the surface pass; the pass returns which of the
 // lane's positions it picked (`sel`) and which it reached (`cov`, picks included).
@@ -617,9 +655,9 @@ __device__ inline uint32_t ubelow(uint64_t w, int lane)
 template<bool EDGE, int PT>
 __device__ inline void wave_pass(
   const double * cl_, const Params & prm, int nloc, uint32_t inblk, int K, int lane, bool hi, int sh,
-  const uint32_t (&reach)[kWaveChunks], uint32_t taken, uint32_t & sel, uint32_t & cov)
+  const uint32_t (&reach)[kWaveChunks], const uint32_t (&lt)[kWaveChunks], uint32_t taken, uint32_t & sel,
+  uint32_t & cov)
 {
-  const int P = PT > 0 ? PT : prm.P;
   uint64_t A[kWaveChunks + 2], S[kWaveChunks + 2];
   uint32_t H[kWaveChunks];
   sel = 0;
@@ -645,36 +683,13 @@ __device__ inline void wave_pass(
     }
   }
   if (any == 0) {return;}
-  // priority masks: which candidates in reach come first (curvature, then index).  The slab may be
-  // read up to P positions outside [0, nloc): callers keep that addressable; the values are masked.
+  // priority masks: which candidates in reach are visited first
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
     H[k] = 0;
     if (k < K && A[k + 1] != 0) {
-      const int q = 64 * k + lane;
-      const int qc = q < nloc ? q : nloc - 1;
       const uint32_t m = uwindow(A, k, hi, sh) & reach[k] & ~(1u << 16);
-      const double ci = cl_[qc];
-      uint32_t higher = 0;
-      if (PT > 0) {
-#pragma unroll
-        for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {
-          const double cl = cl_[qc - d], cr = cl_[qc + d];
-          const bool fl = EDGE ? (cl > ci) : (cl <= ci);                  // left neighbour: lower index
-          const bool fr = EDGE ? (cr >= ci) : (cr < ci);                  // right neighbour: higher index
-          higher |= fl ? (1u << (16 - d)) : 0u;
-          higher |= fr ? (1u << (16 + d)) : 0u;
-        }
-      } else {
-        for (int d = 1; d <= P; d++) {
-          const double cl = cl_[qc - d], cr = cl_[qc + d];
-          const bool fl = EDGE ? (cl > ci) : (cl <= ci);
-          const bool fr = EDGE ? (cr >= ci) : (cr < ci);
-          higher |= fl ? (1u << (16 - d)) : 0u;
-          higher |= fr ? (1u << (16 + d)) : 0u;
-        }
-      }
-      H[k] = higher & m;
+      H[k] = (EDGE ? ~lt[k] : lt[k]) & m;
     }
   }
   // rounds: a live candidate with no live candidate of higher priority in reach is picked;
@@ -754,8 +769,10 @@ __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {inblk |= (64 * k + lane < nb ? 1u : 0u) << k;}
     uint32_t selE, covE, selS, covS;
-    wave_pass<true, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, 0u, selE, covE);
-    wave_pass<false, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, covE, selS, covS);
+    uint32_t lt[kWaveChunks];
+    order_masks<PT>(w.c + b0, prm, nb, K, lane, lt);
+    wave_pass<true, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, lt, 0u, selE, covE);
+    wave_pass<false, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, lt, covE, selS, covS);
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
@@ -1232,10 +1249,10 @@ __device__ inline void unit_body(
   uint32_t occ = 0, inblk = 0, owned = 0;
   uint32_t reach[kWaveChunks];
   {
-    uint64_t JL[kWaveChunks + 2], JR[kWaveChunks + 2], JRs[kWaveChunks + 2], LL[kWaveChunks + 2];
+    uint64_t JL[kWaveChunks + 2], JR[kWaveChunks + 2], JRs[kWaveChunks + 2];
     uint32_t lkw[kWaveChunks];
 #pragma unroll
-    for (int k = 0; k < kWaveChunks + 2; k++) {JL[k] = 0; JR[k] = 0; JRs[k] = 0; LL[k] = 0;}
+    for (int k = 0; k < kWaveChunks + 2; k++) {JL[k] = 0; JR[k] = 0; JRs[k] = 0;}
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {lkw[k] = 0;}
 #pragma unroll
@@ -1252,7 +1269,6 @@ __device__ inline void unit_body(
         const bool jr = lk_prev && i >= P + 1 && q < qhi && U.r[qm] > rq + prm.dist_diff;    // occlusion.hpp:67-79
         JL[k + 1] = __ballot(jl);
         JR[k + 1] = __ballot(jr);
-        LL[k + 1] = LK[k + 1] & range_word(k, qb0, qb1 - 1);
       }
     }
 #pragma unroll
@@ -1275,11 +1291,9 @@ __device__ inline void unit_body(
         const bool ib = q >= qb0 && q < qb1;
         inblk |= (ib ? 1u : 0u) << k;
         owned |= ((q >= qo0 && q < qo1) ? 1u : 0u) << k;
-        const uint32_t ll = uwindow(LL, k, hi, sh);
-        int Lb = __clz((int)~(ll << 16));
-        int Rb = __ffs((int)~(ll >> 16)) - 1;
-        Lb = Lb < P ? Lb : P;
-        Rb = Rb < P ? Rb : P;
+        // inside the block the links are cut at its ends (label.hpp:157-159): clamp the runs
+        const int Lb = Lr < q - qb0 ? Lr : q - qb0;
+        const int Rb = Rr < qb1 - 1 - q ? Rr : qb1 - 1 - q;
         reach[k] = ib ? (((1u << (Lb + Rb + 1)) - 1u) << (16 - Lb)) : 0u;
       }
     }
@@ -1311,8 +1325,10 @@ __device__ inline void unit_body(
   LFX_WAVE_SYNC();
   // ---- F. block labelling
   uint32_t selE = 0, covE = 0, selS = 0, covS = 0;
-  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, 0u, selE, covE);}
-  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, covE, selS, covS);}
+  uint32_t lt[kWaveChunks];
+  order_masks<PT>(U.c + kSlabPad, prm, span, K, lane, lt);
+  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, lt, 0u, selE, covE);}
+  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, lt, covE, selS, covS);}
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
   uint32_t pb_yes = 0, pb_unsure = 0;
 #pragma unroll
