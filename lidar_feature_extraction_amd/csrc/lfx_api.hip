@@ -221,8 +221,10 @@ lfx::Params device_params(const lfx_params & p)
   d.P = p.padding;
   d.B = p.n_blocks;
   d.cos_bound = cos_bound(p.neighbor_degree_threshold * M_PI / 180.0);   // degree_to_radian.hpp:34-37
+  d.cos_bound_f = (float)d.cos_bound;
   d.dist_diff = p.distance_diff_threshold;
   d.pb_ratio = p.parallel_beam_min_range_ratio;
+  d.pb_ratio_f = (float)d.pb_ratio;
   d.edge_thr = p.edge_threshold;
   d.surf_thr = p.surface_threshold;
   d.min_range = p.min_range;

@@ -47,8 +47,10 @@ struct Params
   int P;                 // convolution_padding
   int B;                 // n_blocks
   double cos_bound;      // IsNeighborXY(i,i+1)  <=>  cos_bound <= cos_angle <= 1   (neighbor.hpp:44-48)
+  float cos_bound_f;     // (float)cos_bound, +-inf kept: the f32 pre-filter of the same test
   double dist_diff;      // distance_diff_threshold
   double pb_ratio;       // parallel_beam_min_range_ratio
+  float pb_ratio_f;      // (float)pb_ratio for the f32 pre-filter
   double edge_thr, surf_thr;
   double min_range, max_range;
 };
@@ -1212,15 +1214,18 @@ __device__ inline void unit_body(
         const bool pair = q >= qlo && q + 1 < qhi;
         const double rn = U.r[q + 1];
         zero_pair = zero_pair || (pair && q >= qo0 && q < qo1 && r[k] == 0. && rn == 0.);   // math.cpp:40-42 throws
-        const double dot = (double)x[k] * (double)U.p.x[q + 1] + (double)y[k] * (double)U.p.y[q + 1];
-        const double den = r[k] * rn;
-        const double yb = rcp_approx(den);
-        // cos_bound <= cos <= 1: both ends classified without the division when clear of them
-        const int above = quotient_test(dot, yb, prm.cos_bound, 0x1p-20);
-        const int over1 = quotient_test(dot, yb, 1.0, 0x1p-20);
-        int res = (above == 1 && over1 == 0) ? 1 : 0;
-        if (above == 2 || over1 == 2) {res = 2;}
-        if (above == 0 || over1 == 1) {res = 0;}
+        // cos_bound <= cos <= 1 (neighbor.hpp:44-48 via the cosine bound): classified in f32 first.
+        // |dot| <= r0*r1, so the f32 cosine is within ~4 ulp(1) = 5e-7 of the exact one; a value more
+        // than 2^-19 (1.9e-6) away from both ends decides the test, anything closer (or not finite)
+        // takes the exact f64 division below.
+        const float dotf = x[k] * U.p.x[q + 1] + y[k] * U.p.y[q + 1];
+        const float denf = (float)r[k] * (float)rn;
+        const float cosf = dotf * __builtin_amdgcn_rcpf(denf);
+        const float cbf = prm.cos_bound_f;
+        int res = 2;
+        if (cosf > cbf + 0x1p-19f && cosf < 1.0f - 0x1p-19f) {res = 1;}
+        if (cosf < cbf - 0x1p-19f || cosf > 1.0f + 0x1p-19f) {res = 0;}
+        if (!(fabsf(cosf) < 4.0f)) {res = 2;}
         if (!pair) {res = 0;}
         lk_yes |= (res == 1 ? 1u : 0u) << k;
         lk_unsure |= (res == 2 ? 1u : 0u) << k;
@@ -1336,11 +1341,20 @@ __device__ inline void unit_body(
     if (k < K) {
       const int q = 64 * k + lane, i = g0 + q;
       const int qm = q > 0 ? q - 1 : 0;
-      const double ri = U.r[q];
-      const double a1 = fabs(U.r[qm] - ri), a2 = fabs(U.r[q + 1] - ri);
-      const double yb = rcp_approx(ri);
-      // parallel_beam.hpp:43-49: (float)(a / ri) > ratio; 2^-18 covers the float rounding too
-      const int t1 = quotient_test(a1, yb, prm.pb_ratio, 0x1p-18), t2 = quotient_test(a2, yb, prm.pb_ratio, 0x1p-18);
+      // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
+      // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
+      // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
+      // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
+      const float rf = (float)U.r[q], rmf = (float)U.r[qm], rpf = (float)U.r[q + 1];
+      const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
+      const float thr = prm.pb_ratio_f * rf;
+      const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
+      int t1 = 2, t2 = 2;
+      if (a1 > hi_t) {t1 = 1;}
+      if (a1 < lo_t) {t1 = 0;}
+      if (a2 > hi_t) {t2 = 1;}
+      if (a2 < lo_t) {t2 = 0;}
+      if (!(prm.pb_ratio_f >= 0x1p-9f) || !(rf > 0.f) || !(rf < 1e30f)) {t1 = 2; t2 = 2;}
       int res = (t1 == 1 && t2 == 1) ? 1 : 0;
       if ((t1 == 2 && t2 != 0) || (t2 == 2 && t1 != 0)) {res = 2;}
       if (!(i >= 1 && i + 1 < N) || !((owned >> k) & 1u)) {res = 0;}

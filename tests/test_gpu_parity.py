@@ -267,6 +267,51 @@ def test_many_chunks_look_back():
     f.close()
 
 
+@pytest.mark.parametrize("smallest_step", [1e-6, 1e-9])
+def test_values_next_to_the_thresholds(fx, smallest_step):
+    """The link and parallel-beam tests are pre-classified with cheap f32 arithmetic and only values
+    next to a threshold take the exact f64 division.  Rings built to sit next to every threshold:
+    angular steps around neighbor_degree_threshold and around zero, range ratios around
+    parallel_beam_min_range_ratio, range jumps around distance_diff_threshold, ranges around min/max."""
+    rng = np.random.default_rng(123)
+    hp = HyperParameters()
+    theta = math.radians(hp.neighbor_degree_threshold)
+    rings = []
+    for rid in range(12):
+        n = 1500
+        steps = np.full(n, math.radians(0.2))
+        k = rng.integers(0, n, 500)
+        # steps within a few 1e-8 rad of the threshold angle, and tiny steps down to 1e-9 rad
+        steps[k[:250]] = theta + rng.integers(-40, 41, 250) * 1e-9
+        steps[k[250:]] = 10.0 ** rng.uniform(math.log10(smallest_step), -4, 250)
+        az = -3.0 + np.cumsum(steps)
+        az = az[az < 3.1]
+        n = len(az)
+        r = np.full(n, 8.0) + 0.01 * rng.standard_normal(n)
+        j = rng.integers(1, n - 1, 300)
+        # both neighbours differ by ratio * (1 + tiny) -> parallel-beam test next to its threshold
+        eps = rng.integers(-30, 31, 300) * 1e-8
+        r[j] = r[j - 1] / (1.0 + hp.parallel_beam_min_range_ratio * (1.0 + eps))
+        r[j + 1] = r[j - 1]
+        j2 = rng.integers(1, n - 1, 200)
+        r[j2] = r[j2 - 1] + hp.distance_diff_threshold + rng.integers(-20, 21, 200) * 1e-8     # occlusion jumps
+        j3 = rng.integers(0, n, 100)
+        r[j3[:50]] = hp.min_range + rng.integers(-20, 21, 50) * 1e-9
+        r[j3[50:]] = hp.max_range + rng.integers(-20, 21, 50) * 1e-7
+        rings.append((rid, (r * np.cos(az)).astype(np.float32), (r * np.sin(az)).astype(np.float32)))
+    ring = np.concatenate([np.full(len(x), rid, np.uint16) for rid, x, _y in rings])
+    c = _cloud(ring, np.concatenate([x for _r, x, _y in rings]), np.concatenate([y for _r, _x, y in rings]))
+    want = OB.extract(c, oracle_params(hp), canonical_ties=True)
+    if smallest_step >= 1e-6:
+        assert want["angle_ties"] == 0          # every ring is strictly angle-sorted: the wave-per-unit path takes them
+    else:
+        assert want["angle_ties"] > 0           # directions that coincide in f32: the sorting (slow) path takes those rings
+    got = fx.ExtractFeatures(c)
+    assert_scan_equal(got, want, "thresholds[ties]")
+    counts = np.bincount(got.labels, minlength=8)
+    assert counts[5] > 0 and counts[6] > 0 and counts[7] > 0      # out-of-range, occluded, parallel-beam all hit
+
+
 def test_f64_sqrt_and_divide_are_correctly_rounded(fx):
     """Range (math.hpp:36-39) and the link cosine feed orderings: they must equal IEEE results."""
     rng = np.random.default_rng(2)
