@@ -261,15 +261,16 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   c->last_batch = batch;
   c->last_points = d_points;
-  LFX_HIP(c, hipMemsetAsync(c->scan_info.p, 0, (size_t)batch * 16, st));
+  uint32_t * slow_count = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;   // behind ring_flags[max_batch][256]
+  hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
+    c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
+    c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, slow_count);
   const uint8_t * pts = static_cast<const uint8_t *>(d_points);
   const uint32_t chunks = (longest + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
   if (chunks == 0) {return LFX_OK;}
-  LFX_HIP(c, hipMemsetAsync(c->ring_count.p, 0, (size_t)batch * lfx::kRings * 4, st));
   const bool canon = c->layout.step == 32 && c->layout.ox == 0 && c->layout.oy == 4 && c->layout.oz == 8 &&
     c->layout.oring == 20 && (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
   if (c->single_pass) {
-    LFX_HIP(c, hipMemsetAsync(c->chunk_flags.p, 0, (size_t)batch * c->max_chunks * 4, st));
     Timed t(c, 2, st);
     auto kern = &lfx::ring_scatter_kernel<false, true>;
     if (canon) {kern = &lfx::ring_scatter_kernel<true, true>;}
@@ -296,10 +297,6 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
         c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap);
     }
   }
-  // ring_flags[max_batch][256], then the slow-list counter
-  uint32_t * slow_count = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;
-  LFX_HIP(c, hipMemsetAsync(c->ring_flags.p, 0, (size_t)batch * lfx::kRings * 4, st));
-  LFX_HIP(c, hipMemsetAsync(slow_count, 0, 4, st));
   if (c->fast_path) {
     Timed t(c, 3, st);
     const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
