@@ -193,6 +193,16 @@ int lfx_stage_convolution1d(lfx_ctx *ctx, const double *input, uint32_t n, const
 int lfx_stage_ring_projection(lfx_ctx *ctx, const void *points, size_t n_points, uint32_t *sorted_index,
                               uint32_t *n_rings, uint16_t *ring_id /* [256] */, uint32_t *ring_count /* [256] */);
 
+/* --- colored_scan (debug cloud of the node, feature_extraction.cpp:153,161) ---------------- */
+/* LabelToColor, extraction/src/color_points.cpp:39-68: rgb of one PointLabel; returns
+ * LFX_ERR_INVALID_ARGUMENT for a value that is not a label (the reference throws). */
+int lfx_label_to_color(uint8_t label, uint8_t rgb[3]);
+/* ColorPointsByLabel (color_points.hpp:60-74) for a whole scan on the host: out[i] = {x, y, z, rgb packed
+ * as PCL does (r << 16 | g << 8 | b, bit-cast to float)} for input point i, from the labels lfx_extract
+ * returned.  points: the scan's records (layout as given to lfx_create); out: n_points * 4 floats. */
+int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_points, const uint8_t *labels,
+                              float *out);
+
 /* --- measurement ------------------------------------------------------------------------- */
 #define LFX_N_KERNELS 7   /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_extract, ring_totals, feature_compact */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);

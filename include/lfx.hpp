@@ -103,6 +103,14 @@ public:
   {
     return ExtractFeatures(cloud.data(), cloud.size());
   }
+  // colored_scan of the node (feature_extraction.cpp:153): x, y, z + packed rgb per input point.
+  std::vector<float> ColorPointsByLabel(const PointXYZIR * points, std::size_t n, const Features & f) const
+  {
+    std::vector<float> out(4 * n);
+    const int rc = lfx_color_points_by_label(ctx_, points, n, f.labels.data(), out.data());
+    if (rc != LFX_OK) {throw Error(rc, "invalid label");}
+    return out;
+  }
   lfx_ctx * handle() const {return ctx_;}
 
 private:

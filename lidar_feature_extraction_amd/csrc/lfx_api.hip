@@ -769,6 +769,40 @@ int lfx_stage_ring_projection(
   return LFX_OK;
 }
 
+// ---------------------------------------------------------------------------- colored_scan
+int lfx_label_to_color(uint8_t label, uint8_t rgb[3])   // color_points.cpp:39-68
+{
+  static const uint8_t table[8][3] = {
+    {255, 255, 255},   // Default
+    {255, 0, 0},       // Edge
+    {255, 63, 0},      // EdgeNeighbor
+    {255, 0, 0},       // Surface
+    {255, 63, 0},      // SurfaceNeighbor
+    {127, 127, 127},   // OutOfRange
+    {255, 0, 255},     // Occluded
+    {0, 255, 0}};      // ParallelBeam
+  if (!rgb || label > LFX_LABEL_PARALLEL_BEAM) {return LFX_ERR_INVALID_ARGUMENT;}
+  rgb[0] = table[label][0]; rgb[1] = table[label][1]; rgb[2] = table[label][2];
+  return LFX_OK;
+}
+
+int lfx_color_points_by_label(const lfx_ctx * c, const void * points, size_t n_points, const uint8_t * labels, float * out)
+{
+  if (!c || (!points && n_points) || !labels || !out) {return LFX_ERR_INVALID_ARGUMENT;}
+  const uint8_t * p = static_cast<const uint8_t *>(points);
+  for (size_t i = 0; i < n_points; i++) {
+    uint8_t rgb[3];
+    if (lfx_label_to_color(labels[i], rgb) != LFX_OK) {return LFX_ERR_INVALID_ARGUMENT;}
+    const uint8_t * q = p + i * c->layout.step;
+    std::memcpy(&out[4 * i + 0], q + c->layout.ox, 4);
+    std::memcpy(&out[4 * i + 1], q + c->layout.oy, 4);
+    std::memcpy(&out[4 * i + 2], q + c->layout.oz, 4);
+    const uint32_t packed = ((uint32_t)rgb[0] << 16) | ((uint32_t)rgb[1] << 8) | (uint32_t)rgb[2];
+    std::memcpy(&out[4 * i + 3], &packed, 4);
+  }
+  return LFX_OK;
+}
+
 // ---------------------------------------------------------------------------- measurement
 int lfx_set_profiling(lfx_ctx * c, int enabled)
 {

@@ -206,6 +206,16 @@ class FeatureExtraction:
             off += int(cnt[k])
         return out
 
+    def ColorPointsByLabel(self, cloud, labels):
+        """colored_scan (color_points.hpp:60-74): [n,4] f32 = x, y, z, packed rgb (as PCL's PointXYZRGB)."""
+        cloud = np.ascontiguousarray(cloud)
+        labels = np.ascontiguousarray(labels, np.uint8)
+        out = np.zeros((len(cloud), 4), np.float32)
+        B.check(self._ctx, self._L.lfx_color_points_by_label(
+            self._ctx, C.c_void_p(cloud.ctypes.data), len(cloud), C.c_void_p(labels.ctypes.data),
+            C.c_void_p(out.ctypes.data)))
+        return out
+
     # --- measurement ---------------------------------------------------------------------
     def set_profiling(self, on):
         B.check(self._ctx, self._L.lfx_set_profiling(self._ctx, int(bool(on))))

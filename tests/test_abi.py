@@ -60,6 +60,16 @@ def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     assert lib.lfx_kernel_name(3) == b"ring_unit_kernel"
 
 
+def test_label_to_color_table(lib, refvec):
+    """LabelToColor vectors: test_color_points.cpp:40-78 + color_points.cpp:39-68 (host-side helper, no device)."""
+    names = ["Default", "Edge", "EdgeNeighbor", "Surface", "SurfaceNeighbor", "OutOfRange", "Occluded", "ParallelBeam"]
+    for k, name in enumerate(names):
+        rgb = (C.c_uint8 * 3)()
+        assert lib.lfx_label_to_color(k, rgb) == 0
+        assert list(rgb) == refvec["label_to_color"]["expect_rgb"][name]
+    assert lib.lfx_label_to_color(8, (C.c_uint8 * 3)()) == -1      # ThrowIfInvalidLabelDetected
+
+
 def test_no_cpu_fallback_without_a_device(lib):
     import torch
     if torch.cuda.device_count() > 0:
