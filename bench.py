@@ -74,7 +74,7 @@ def main():
         import __graft_entry__
         __graft_entry__.build()
     from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, concat
-    from lidar_feature_extraction_amd.gather import gather_clouds
+    from lidar_feature_extraction_amd.gather import CloudGather
 
     # ---- synthetic stream: scan i -> rank i mod world; seeds 1234 + scan id
     n_unique = max(1, min(a.unique, a.batch))
@@ -99,10 +99,13 @@ def main():
 
     use_gather = (world > 1 and not a.no_gather) or a.force_gather
     if use_gather:
+        # two sets of packed-cloud buffers: while the clouds of step k-1 travel to rank 0 on a side
+        # stream, step k extracts and packs into the other set (gather.py: CloudGather)
         feat_cap = int(a.batch * n_pts * 0.35) + 1024
-        edge_buf = torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev)
-        surf_buf = torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev)
-        offs = torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)
+        bufs = [(torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev),
+                 torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev),
+                 torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(2)]
+        gather = CloudGather(dst=0, device=dev)
 
     def step():
         k = step_no[0] % n_streams
@@ -111,10 +114,14 @@ def main():
             k = 0                      # the gather runs on torch's current stream
         fxs[k].extract_batch_device(d_points.data_ptr(), n_list, streams[k].cuda_stream)
         if use_gather:
+            edge_buf, surf_buf, offs = bufs[step_no[0] % 2]
+            gather.wait_buffer(edge_buf)       # the gather that last read this set must be done
             fxs[k].pack_features(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
-            gather_clouds(edge_buf, surf_buf, offs, a.batch, dst=0)
+            gather.submit(edge_buf, surf_buf, offs, a.batch)
 
     def fence():
+        if use_gather:
+            gather.flush()             # the last step's clouds
         torch.cuda.synchronize()
         if world > 1 or a.force_gather:
             dist.barrier()
