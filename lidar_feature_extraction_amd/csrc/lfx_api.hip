@@ -102,7 +102,7 @@ struct lfx_ctx
 
   // device scratch
   DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
-    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, slow_list, sidx, rec_idx, edge_idx,
+    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, sidx, rec_idx, edge_idx,
     surf_idx, d_sidx;
   DevBuf<uint16_t> chunk_hist;
   DevBuf<uint8_t> ring_status, label_s, staging, d_label;
@@ -303,7 +303,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     hipLaunchKernelGGL(lfx::ring_unit_kernel, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
       dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
       c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
-      c->unit_ns.p, c->ring_flags.p, slow_count, c->slow_list.p);
+      c->unit_ns.p, c->unit_span.p, c->ring_flags.p, slow_count, c->slow_list.p);
   }
   {
     Timed t(c, 4, st);
@@ -311,8 +311,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
       c->dev, c->cap, c->stage_flags, c->fast_path ? 1u : 0u, pts, c->layout, c->scan_begin.p,
       c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
-      c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->ring_flags.p, slow_count, c->slow_list.p,
-      c->max_rings);
+      c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p, c->ring_flags.p, slow_count,
+      c->slow_list.p, c->max_rings);
   }
   {
     Timed t(c, 5, st);
@@ -323,10 +323,10 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   {
     Timed t(c, 6, st);
     const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
-    hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings * n_units + 3) / 4, batch), dim3(256), 0, st,
-      c->dev, n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_nedge.p,
-      c->ring_nsurf.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p, c->unit_ns.p, c->ring_flags.p,
-      c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p, c->surf_idx.p, c->max_rings);
+    hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
+      n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
+      c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
+      c->surf_idx.p, c->max_rings);
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -534,6 +534,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
   ok(c->ring_flags.alloc(tables + 1)); ok(c->slow_list.alloc(tables));
   ok(c->unit_ne.alloc(tables * lfx::kUnitMaxBlocks)); ok(c->unit_ns.alloc(tables * lfx::kUnitMaxBlocks));
+  ok(c->unit_span.alloc(tables * lfx::kUnitMaxBlocks));
   const size_t rc = nb * c->max_rings * c->cap;      // ring-major arrays: fixed capacity per ring id
   ok(c->sxy.alloc(rc)); ok(c->sz.alloc(rc)); ok(c->sidx.alloc(rc)); ok(c->rec_pts.alloc(rc)); ok(c->rec_idx.alloc(rc));
   ok(c->label_s.alloc(rc)); ok(c->curv_s.alloc(rc));
@@ -567,7 +568,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
-  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->unit_ne.release(); c->unit_ns.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();

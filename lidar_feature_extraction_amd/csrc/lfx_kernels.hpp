@@ -1134,8 +1134,8 @@ __device__ inline void unit_body(
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
   float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
-  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags,
-  uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
+  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span,
+  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
 {
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 16;
@@ -1429,6 +1429,7 @@ __device__ inline void unit_body(
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
     unit_ne[ui] = pe;
     unit_ns[ui] = ps;
+    unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
     if (j == 0) {ring_status[s * kRings + slot] = kOk;}
   }
 #undef LFX_DEFER
@@ -1439,8 +1440,8 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
   float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
-  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags,
-  uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
+  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span,
+  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
 {
   __shared__ UnitLds lds[kUnitWaves];
   const uint32_t s = blockIdx.y;
@@ -1451,13 +1452,13 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   UnitLds & U = lds[threadIdx.x >> 6];
   if (prm.P == 5) {
     unit_body<5>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, slow_count, slow_list);
   } else if (prm.P == 2) {
     unit_body<2>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, slow_count, slow_list);
   } else {
     unit_body<0>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, ring_flags, slow_count, slow_list);
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, slow_count, slow_list);
   }
 }
 
@@ -1472,8 +1473,8 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
   float2 * __restrict__ sxy, const float * __restrict__ sz, uint32_t * __restrict__ sidx,
   uint8_t * __restrict__ label_s, double * __restrict__ curv_s, float4 * __restrict__ rec_pts,
   uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status, uint32_t * __restrict__ unit_ne,
-  uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ ring_flags, const uint32_t * __restrict__ slow_count,
-  const uint32_t * __restrict__ slow_list, uint32_t max_rings)
+  uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span, uint32_t * __restrict__ ring_flags,
+  const uint32_t * __restrict__ slow_count, const uint32_t * __restrict__ slow_list, uint32_t max_rings)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int T = blockDim.x, tid = threadIdx.x;
@@ -1508,8 +1509,12 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
       resorted = angle_sort(w, N, sxy + off, sidx + off);
       status = process_ring(w, prm, N, stage_flags, nullptr, nullptr, nullptr);
     }
-    if (tid < kUnitMaxBlocks) {unit_ne[ui + tid] = 0; unit_ns[ui + tid] = 0;}
-    if (tid == 0) {ring_flags[s * kRings + slot] = 1u;}      // "one segment" layout of the records
+    // the whole ring is ONE unit with one segment of records: [0, N)
+    if (tid < kUnitMaxBlocks) {unit_ne[ui + tid] = 0; unit_ns[ui + tid] = 0; unit_span[ui + tid] = 0;}
+    if (tid == 0) {
+      ring_flags[s * kRings + slot] = 1u;
+      unit_span[ui] = ((uint32_t)((uint32_t)N < cap ? N : (int)cap) << 16);
+    }
     if (status != kOk) {
       // the ring contributes nothing (feature_extraction.cpp:116,154-156)
       const int stored = (uint32_t)N < cap ? N : (int)cap;
@@ -1611,57 +1616,38 @@ __global__ __launch_bounds__(kRings) void ring_totals_kernel(
 }
 
 // K4b: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
-// ring angle ascending (units ascending; a slow-path ring is one segment).  One wave per unit.
+// ring angle ascending (units ascending; a slow-path ring is one unit).  One wave per ring.
 __global__ __launch_bounds__(256) void feature_compact_kernel(
-  Params prm, uint32_t n_units /* units per ring the grid covers */, uint32_t cap,
-  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ ring_count,
-  const uint32_t * __restrict__ ring_nedge,
-  const uint32_t * __restrict__ ring_nsurf, const uint32_t * __restrict__ ring_ebase,
+  uint32_t n_units, uint32_t cap, const uint32_t * __restrict__ scan_begin,
+  const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_ebase,
   const uint32_t * __restrict__ ring_sbase, const uint32_t * __restrict__ unit_ne,
-  const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ ring_flags,
+  const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ unit_span,
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
   uint32_t max_rings)
 {
   const uint32_t s = blockIdx.y, lane = threadIdx.x & 63;
-  const uint32_t u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const uint32_t slot = u / n_units;
-  const int j = (int)(u % n_units);
-  if (slot >= max_rings) {return;}
-  const int N = (int)ring_count[s * kRings + slot];
-  if (N == 0) {return;}
+  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= max_rings || ring_count[s * kRings + slot] == 0u) {return;}
   const size_t b = scan_begin[s];
   const size_t off = ring_base(s, slot, max_rings, cap);
-  uint32_t eb = ring_ebase[s * kRings + slot], fb = ring_sbase[s * kRings + slot];
-  const bool one_segment = ring_flags[s * kRings + slot] != 0u;
+  size_t eb = b + ring_ebase[s * kRings + slot], fb = b + ring_sbase[s * kRings + slot];
   const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
-  int o0 = 0, o1 = N;
-  uint32_t ne, ns;
-  if (one_segment) {
-    if (j != 0) {return;}
-    ne = ring_nedge[s * kRings + slot];
-    ns = ring_nsurf[s * kRings + slot];
-  } else {
-    // this unit's records start after those of the ring's earlier units
-    uint32_t pe = 0, ps = 0;
-    for (int t = (int)lane; t < j; t += 64) {pe += unit_ne[ui + t]; ps += unit_ns[ui + t];}
-    for (int d = 32; d > 0; d >>= 1) {pe += __shfl_xor(pe, d); ps += __shfl_xor(ps, d);}
-    eb += pe;
-    fb += ps;
-    o0 = j == 0 ? 0 : block_boundary(N, prm.P, prm.B, j);
-    o1 = j == prm.B - 1 ? N : block_boundary(N, prm.P, prm.B, j + 1);
-    ne = unit_ne[ui + j];
-    ns = unit_ns[ui + j];
-  }
-  for (uint32_t k = lane; k < ne + ns; k += 64) {
-    if (k < ne) {
-      edge_pts[b + eb + k] = rec_pts[off + o0 + k];
-      edge_idx[b + eb + k] = rec_idx[off + o0 + k];
-    } else {
-      const uint32_t q = k - ne;
-      surf_pts[b + fb + q] = rec_pts[off + o1 - 1 - q];
-      surf_idx[b + fb + q] = rec_idx[off + o1 - 1 - q];
+  for (uint32_t j = 0; j < n_units; j++) {
+    const uint32_t ne = unit_ne[ui + j], ns = unit_ns[ui + j], span = unit_span[ui + j];
+    const size_t first = off + (span & 0xFFFFu), last = off + (span >> 16);
+    for (uint32_t k = lane; k < ne + ns; k += 64) {
+      if (k < ne) {
+        edge_pts[eb + k] = rec_pts[first + k];
+        edge_idx[eb + k] = rec_idx[first + k];
+      } else {
+        const uint32_t q = k - ne;
+        surf_pts[fb + q] = rec_pts[last - 1 - q];
+        surf_idx[fb + q] = rec_idx[last - 1 - q];
+      }
     }
+    eb += ne;
+    fb += ns;
   }
 }
 
