@@ -57,6 +57,8 @@ typedef struct lfx_config {
   uint32_t max_batch;             /* scans per lfx_extract_batch* call                      */
   uint32_t max_points_per_ring;   /* 0 = LFX_MAX_RING_POINTS; rounded up to a power of two  */
   uint32_t max_rings;             /* ring ids are 0 .. max_rings-1 (a sensor's ring count); 0 = 256 */
+  uint32_t drop_zero_points;      /* 1: points with x = y = z = 0 are not part of the scan -- the filter the
+                                   * upstream converter applies (point_type_converter/convert.py:162-163,192) */
   lfx_layout layout;              /* all-zero = PointXYZIR                                  */
 } lfx_config;
 
@@ -97,7 +99,8 @@ typedef struct lfx_scan_result {
   uint32_t n_points;
   const uint8_t *labels;          /* [n_points] lfx_label, addressed by ORIGINAL point index   */
   const double *curvature;        /* [n_points] f64, original index (curvature.cpp:44-50)      */
-  const uint32_t *sorted_index;   /* [n_points] rings ascending, angle ascending inside a ring (ring.hpp:141-147) */
+  const uint32_t *sorted_index;   /* [n_sorted] rings ascending, angle ascending inside a ring (ring.hpp:141-147) */
+  uint32_t n_sorted;              /* = n_points, less the points drop_zero_points removed                  */
   uint32_t n_rings;
   const uint16_t *ring_id;        /* [n_rings] ascending                                        */
   const uint32_t *ring_count;     /* [n_rings] points of the ring                               */

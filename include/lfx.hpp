@@ -88,7 +88,7 @@ public:
     Features f;
     f.labels.assign(r.labels, r.labels + r.n_points);
     f.curvature.assign(r.curvature, r.curvature + r.n_points);
-    f.sorted_index.assign(r.sorted_index, r.sorted_index + r.n_points);
+    f.sorted_index.assign(r.sorted_index, r.sorted_index + r.n_sorted);
     f.edge_index.assign(r.edge_index, r.edge_index + r.n_edge);
     f.surface_index.assign(r.surface_index, r.surface_index + r.n_surface);
     fill(f.edge, r.edge_points, r.edge_index, r.n_edge, points);

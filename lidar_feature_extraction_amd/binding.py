@@ -38,12 +38,13 @@ class Layout(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("max_points_per_scan", C.c_uint32), ("max_batch", C.c_uint32),
-                ("max_points_per_ring", C.c_uint32), ("max_rings", C.c_uint32), ("layout", Layout)]
+                ("max_points_per_ring", C.c_uint32), ("max_rings", C.c_uint32), ("drop_zero_points", C.c_uint32),
+                ("layout", Layout)]
 
 
 class ScanResult(C.Structure):
     _fields_ = [("n_points", C.c_uint32), ("labels", C.POINTER(C.c_uint8)), ("curvature", C.POINTER(C.c_double)),
-                ("sorted_index", C.POINTER(C.c_uint32)), ("n_rings", C.c_uint32),
+                ("sorted_index", C.POINTER(C.c_uint32)), ("n_sorted", C.c_uint32), ("n_rings", C.c_uint32),
                 ("ring_id", C.POINTER(C.c_uint16)), ("ring_count", C.POINTER(C.c_uint32)),
                 ("ring_offset", C.POINTER(C.c_uint32)), ("ring_status", C.POINTER(C.c_uint8)),
                 ("n_edge", C.c_uint32), ("edge_points", C.POINTER(C.c_float)), ("edge_index", C.POINTER(C.c_uint32)),

@@ -96,6 +96,7 @@ struct lfx_ctx
   uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
   uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
+  uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
   bool single_pass = true;               // look-back bucketing; LFX_DEBUG_TWO_PASS selects histogram + scan + scatter
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
@@ -276,12 +277,12 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     if (canon) {kern = &lfx::ring_scatter_kernel<true, true>;}
     hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
       pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
-      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap);
+      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero);
   } else {
     {
       Timed t(c, 0, st);
       hipLaunchKernelGGL(lfx::ring_histogram_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
-        pts, c->layout, c->scan_begin.p, c->chunk_hist.p, c->scan_info.p, c->max_chunks, c->max_rings);
+        pts, c->layout, c->scan_begin.p, c->chunk_hist.p, c->scan_info.p, c->max_chunks, c->max_rings, c->drop_zero);
     }
     {
       Timed t(c, 1, st);
@@ -294,7 +295,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       if (canon) {kern = &lfx::ring_scatter_kernel<true, false>;}
       hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
         pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
-        c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap);
+        c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero);
     }
   }
   if (c->fast_path) {
@@ -364,7 +365,7 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
   if (info[lfx::kInfoError] & 4u) {
     return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
   }
-  uint32_t nr = 0;
+  uint32_t nr = 0, n_kept = n;
   h.ring_id.clear(); h.ring_count.clear(); h.ring_offset.clear(); h.ring_status.clear();
   {
     uint32_t dense = 0;
@@ -377,7 +378,10 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
       dense += rcount[r];
       nr++;
     }
-    if (dense != n) {return fail(c, LFX_ERR_HIP, "internal: ring counts do not add up to the scan");}
+    if (dense > n || (dense != n && !c->drop_zero)) {
+      return fail(c, LFX_ERR_HIP, "internal: ring counts do not add up to the scan");
+    }
+    n_kept = dense;
   }
   const uint32_t ne = info[lfx::kInfoEdge], ns = info[lfx::kInfoSurface];
   h.edge_points.resize((size_t)ne * 4);
@@ -393,10 +397,12 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
     LFX_HIP(c, hipMemcpyAsync(h.surface_index.data(), c->surf_idx.p + b, (size_t)ns * 4, hipMemcpyDeviceToHost, st));
   }
   LFX_HIP(c, hipStreamSynchronize(st));
-  // back to the caller's point order (labels[k] / curvature[k] belong to input point k)
+  // back to the caller's point order (labels[k] / curvature[k] belong to input point k); points the
+  // zero filter dropped keep Default / 0 and do not appear in sorted_index
   h.labels.assign(n, LFX_LABEL_DEFAULT);
   h.curvature.assign(n, 0.0);
-  for (uint32_t k = 0; k < n; k++) {
+  h.sorted_index.resize(n_kept);
+  for (uint32_t k = 0; k < n_kept; k++) {
     const uint32_t o = h.sorted_index[k];
     if (o < n) {
       h.labels[o] = h.labels_sorted[k];
@@ -405,6 +411,7 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
   }
   if (out) {
     out->n_points = n;
+    out->n_sorted = n_kept;
     out->labels = h.labels.data();
     out->curvature = h.curvature.data();
     out->sorted_index = h.sorted_index.data();
@@ -496,6 +503,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     }
     c->layout = lfx::Layout{L.point_step, L.off_x, L.off_y, L.off_z, L.off_ring};
   }
+  c->drop_zero = config->drop_zero_points ? 1u : 0u;
   c->max_points = config->max_points_per_scan;
   c->max_batch = config->max_batch;
   uint32_t ring_cap = config->max_points_per_ring ? config->max_points_per_ring : LFX_MAX_RING_POINTS;

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void batch_reset_kernel(
 // K0: ring histogram per 1024-point chunk.
 __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
-  uint16_t * __restrict__ chunk_hist, uint32_t * __restrict__ scan_info, uint32_t max_chunks, uint32_t max_rings)
+  uint16_t * __restrict__ chunk_hist, uint32_t * __restrict__ scan_info, uint32_t max_chunks, uint32_t max_rings,
+  uint32_t drop_zero)
 {
   const uint32_t s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
@@ -102,8 +103,11 @@ __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
   for (int i = 0; i < kChunkSlots; i++) {
     const uint32_t e = chunk * kChunkPoints + i * kChunkThreads + tid;
     if (e < n) {
-      const uint32_t ring = *reinterpret_cast<const uint16_t *>(pts + (size_t)(b + e) * L.step + L.oring);
-      if (ring >= max_rings) {bad = true;} else {atomicAdd(&h[ring], 1u);}
+      const uint8_t * p = pts + (size_t)(b + e) * L.step;
+      const uint32_t ring = *reinterpret_cast<const uint16_t *>(p + L.oring);
+      const bool zero = drop_zero && *reinterpret_cast<const float *>(p + L.ox) == 0.f &&
+        *reinterpret_cast<const float *>(p + L.oy) == 0.f && *reinterpret_cast<const float *>(p + L.oz) == 0.f;
+      if (ring >= max_rings) {bad = true;} else if (!zero) {atomicAdd(&h[ring], 1u);}
     }
   }
   __syncthreads();
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
   uint32_t * __restrict__ scan_info, float2 * __restrict__ sxy, float * __restrict__ sz,
-  uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap)
+  uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero)
 {
   const uint32_t s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
@@ -204,6 +208,9 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
       }
       key[i] = ring < max_rings ? ring : kRings;
       if (LOOKBACK && ring >= max_rings) {bad_ring = true;}
+      // the upstream converter's filter (point_type_converter/convert.py:162-163,192): all-zero points
+      // are not part of the scan
+      if (drop_zero && x[i] == 0.f && y[i] == 0.f && z[i] == 0.f) {key[i] = kRings;}
     }
   }
   const size_t row = (size_t)s * max_chunks;

@@ -79,7 +79,7 @@ def _result(r):
     ne, ns, n, nr = r.n_edge, r.n_surface, r.n_points, r.n_rings
     return ScanFeatures(
         labels=_np(r.labels, n, np.uint8), curvature=_np(r.curvature, n, np.float64),
-        sorted_index=_np(r.sorted_index, n, np.uint32),
+        sorted_index=_np(r.sorted_index, r.n_sorted, np.uint32),
         ring_id=_np(r.ring_id, nr, np.uint16), ring_count=_np(r.ring_count, nr, np.uint32),
         ring_offset=_np(r.ring_offset, nr, np.uint32), ring_status=_np(r.ring_status, nr, np.uint8),
         edge_points=_np(r.edge_points, ne, np.float32, (ne, 4)) if ne else np.zeros((0, 4), np.float32),
@@ -92,11 +92,12 @@ class FeatureExtraction:
     """One context = one GPU = one calling thread (feature_extraction.cpp:65-87,185)."""
 
     def __init__(self, params=None, device=0, max_points_per_scan=262144, max_batch=1,
-                 max_points_per_ring=0, max_rings=0):
+                 max_points_per_ring=0, max_rings=0, drop_zero_points=False):
         self._L = B.load()
         self.params = params or HyperParameters()
         self._ctx = C.c_void_p()
-        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, B.Layout(0, 0, 0, 0, 0))
+        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)),
+                       B.Layout(0, 0, 0, 0, 0))
         cp = self.params.to_c()
         rc = self._L.lfx_create(C.byref(self._ctx), device, C.byref(cp), C.byref(cfg))
         if rc != 0:

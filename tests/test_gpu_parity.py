@@ -247,6 +247,34 @@ def test_fallback_paths_give_the_same_results(env):
     f.close()
 
 
+def test_zero_point_filter_matches_the_upstream_converter():
+    """drop_zero_points: all-zero points are dropped before extraction, as point_type_converter does
+    (convert.py:162-163,192; pinned there by test_convert.py).  Result = oracle on the filtered cloud."""
+    rng = np.random.default_rng(8)
+    c = make_scan(16, 1000, seed=55)
+    zero = rng.uniform(0, 1, len(c)) < 0.03
+    c["x"][zero] = 0.0
+    c["y"][zero] = 0.0
+    c["z"][zero] = 0.0
+    keep = np.nonzero(~zero)[0]
+    filtered = np.ascontiguousarray(c[keep])
+    want = OB.extract(filtered, canonical_ties=False)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=16, drop_zero_points=True)
+    got = f.ExtractFeatures(c)
+    f.close()
+    assert len(got.sorted_index) == len(keep)
+    assert np.array_equal(got.sorted_index, keep[want["sorted_index"]].astype(np.uint32))
+    assert np.array_equal(got.labels[keep], want["labels"]) and not got.labels[zero].any()
+    assert got.curvature[keep].tobytes() == want["curvature"].tobytes()
+    assert np.array_equal(got.edge_index, keep[want["edge_index"]].astype(np.uint32))
+    assert np.array_equal(got.surface_index, keep[want["surface_index"]].astype(np.uint32))
+    assert got.edge_points.tobytes() == want["edge_points"].tobytes()
+    # without the option the zero points stay in (and make their rings' adjacent zero pairs skip conditions)
+    f2 = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=16)
+    assert len(f2.ExtractFeatures(c).sorted_index) == len(c)
+    f2.close()
+
+
 def test_ring_id_beyond_max_rings_is_an_error():
     c = make_scan(8, 300, seed=3)
     f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=4)
