@@ -731,7 +731,12 @@ __device__ inline void wave_pass(
         S[k + 1] = s;
       }
     }
-    uint64_t left = 0;
+    uint64_t left = 0, picked = 0;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {picked |= S[k + 1];}
+    // With a total order the live candidate of highest priority is always picked.  No pick at all
+    // means the order is inconsistent (NaN curvature from non-finite input): stop instead of spinning.
+    if (picked == 0) {break;}
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
@@ -910,6 +915,7 @@ __device__ inline void label_pass(
   }
   __syncthreads();
   for (;; ) {
+    int picked = 0;
     for (int i0 = 0; i0 < Npad; i0 += T) {
       const int i = i0 + tid;
       bool s = false;
@@ -917,8 +923,10 @@ __device__ inline void label_pass(
       const int w0 = i0 + (tid & ~63);
       store_word(w.sel, w0, Npad, s);
       or_word(selAll, w0, Npad, s);
+      picked |= s;
     }
-    __syncthreads();
+    // no pick at all = inconsistent order (NaN curvature from non-finite input): stop, do not spin
+    if (!__syncthreads_or(picked)) {break;}
     int any = 0;
     for (int i0 = 0; i0 < Npad; i0 += T) {
       const int i = i0 + tid;
@@ -1294,8 +1302,10 @@ __device__ inline void unit_body(
         const double rq = U.r[q];
         const bool jl = lk_here && i < N - P - 1 && U.r[q + 1] > rq + prm.dist_diff;         // occlusion.hpp:44-57
         const bool jr = lk_prev && i >= P + 1 && q < qhi && U.r[qm] > rq + prm.dist_diff;    // occlusion.hpp:67-79
-        JL[k + 1] = __ballot(jl);
-        JR[k + 1] = __ballot(jr);
+        if (!(dbg_flags & 256u)) {
+          JL[k + 1] = __ballot(jl);
+          JR[k + 1] = __ballot(jr);
+        }
       }
     }
 #pragma unroll
@@ -1313,8 +1323,10 @@ __device__ inline void unit_body(
         Rr = Rr < P ? Rr : P;
         const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
         const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
-        const bool o = (uwindow(JL, k, hi, sh) & left) || (uwindow(JRs, k, hi, sh) & right);
-        occ |= (o ? 1u : 0u) << k;
+        if (!(dbg_flags & 256u)) {
+          const bool o = (uwindow(JL, k, hi, sh) & left) || (uwindow(JRs, k, hi, sh) & right);
+          occ |= (o ? 1u : 0u) << k;
+        }
         const bool ib = q >= qb0 && q < qb1;
         inblk |= (ib ? 1u : 0u) << k;
         owned |= ((q >= qo0 && q < qo1) ? 1u : 0u) << k;
@@ -1360,7 +1372,7 @@ __device__ inline void unit_body(
   uint32_t pb_yes = 0, pb_unsure = 0;
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
-    if (k < K) {
+    if (k < K && !(dbg_flags & 512u)) {
       const int q = 64 * k + lane, i = g0 + q;
       const int qm = q > 0 ? q - 1 : 0;
       // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
@@ -1419,7 +1431,7 @@ __device__ inline void unit_body(
         curv_s[off + i] = cv;
       }
       const uint64_t fe = __ballot(l == kEdge), fs = __ballot(l == kSurface);
-      if (l == kEdge || l == kSurface) {
+      if ((l == kEdge || l == kSurface) && !(dbg_flags & 1024u)) {
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
         const float2 xy = sxy[off + i];
         const float4 rec = make_float4(xy.x, xy.y, sz[off + i], (float)cv);

@@ -275,6 +275,25 @@ def test_zero_point_filter_matches_the_upstream_converter():
     f2.close()
 
 
+@pytest.mark.timeout(120)
+def test_non_finite_input_terminates_and_leaves_other_rings_alone(fx):
+    """The node requires a dense cloud (feature_extraction.cpp:96-101); NaN / inf coordinates make the
+    curvature order inconsistent.  The kernels must still terminate (the pick rounds stop when a round
+    picks nothing) and rings without such points must be unaffected."""
+    c = make_scan(8, 900, seed=61)
+    bad = c.copy()
+    r3 = np.nonzero(bad["ring"] == 3)[0]
+    r5 = np.nonzero(bad["ring"] == 5)[0]
+    bad["x"][r3[100:140]] = np.nan
+    bad["y"][r3[400]] = np.inf
+    bad["x"][r5[10:700:7]] = np.nan           # NaN curvature almost everywhere in ring 5
+    got = fx.ExtractFeatures(bad)             # must return
+    ref = fx.ExtractFeatures(c)
+    clean = ~np.isin(bad["ring"], [3, 5])
+    assert np.array_equal(got.labels[clean], ref.labels[clean])
+    assert got.curvature[clean].tobytes() == ref.curvature[clean].tobytes()
+
+
 def test_ring_id_beyond_max_rings_is_an_error():
     c = make_scan(8, 300, seed=3)
     f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=4)
