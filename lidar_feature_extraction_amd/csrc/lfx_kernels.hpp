@@ -313,19 +313,25 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   } else {
     before = chunk_base[(row + chunk) * kRings + tid];
   }
-  __syncthreads();
-  for (uint32_t d = 1; d < kRings; d <<= 1) {       // inclusive scan of the ring counts
-    const uint32_t a = tid >= d ? cstart[tid - d] : 0u;
-    __syncthreads();
-    cstart[tid] += a;
-    __syncthreads();
-  }
   {
-    const uint32_t start = cstart[tid] - mine;
-    if (tid == kRings - 1) {staged = cstart[tid];}
+    // exclusive scan of the 256 ring counts: shuffles inside each wave, one exchange of the four wave
+    // totals through LDS (two barriers instead of sixteen)
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(incl, d);
+      if (lane >= (uint32_t)d) {incl += t;}
+    }
+    __syncthreads();                      // every thread has read its cstart[] entry (LOOKBACK) by now
+    if (lane == 63) {gfill[wave] = incl;} // wave totals, parked in gfill[0..3] for a moment
     __syncthreads();
-    cstart[tid] = start;
+    uint32_t base = 0;
+    for (uint32_t v = 0; v < wave; v++) {base += gfill[v];}
+    const uint32_t total = gfill[0] + gfill[1] + gfill[2] + gfill[3];
+    __syncthreads();
+    cstart[tid] = base + incl - mine;
     gfill[tid] = before;
+    if (tid == 0) {staged = total;}
   }
   __syncthreads();
 #pragma unroll
