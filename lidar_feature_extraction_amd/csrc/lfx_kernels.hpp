@@ -170,17 +170,24 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t n_here = (n - chunk * kChunkPoints) < (uint32_t)kChunkPoints ? (n - chunk * kChunkPoints) : (uint32_t)kChunkPoints;
   constexpr int kGroups = kChunkSlots * (kChunkThreads / 64);      // (slot, wave) pairs in arrival order
-  __shared__ uint16_t wcnt[kGroups][kRings];
   __shared__ uint32_t cstart[kRings];                              // start of each ring inside the staged chunk
   __shared__ uint32_t gfill[kRings];                               // points of the ring in earlier chunks
   __shared__ uint32_t staged;                                      // points with a valid ring id in this chunk
-  // staging, skewed by one element per 32 (kSkew): with column-major input a wave's 64 points go to 64
-  // different rings, i.e. to staged positions one run length apart -- a power-of-two stride
+  // staging, skewed by one element per 32: with column-major input a wave's 64 points go to 64
+  // different rings, i.e. to staged positions one run length apart -- a power-of-two stride.
+  // One LDS block serves two phases: first the (slot, wave) count table `wcnt` (16 KB) and the
+  // look-back scratch `part` (4 KB behind it); then, once every thread holds its staging positions in
+  // registers, the staging arrays over the same bytes (33 KB in all: four workgroups per CU).
   constexpr int kStage = kChunkPoints + kChunkPoints / 32 + 1;
-  __shared__ float2 st_xy[kStage];
-  __shared__ float st_z[kStage];
-  __shared__ uint16_t st_src[kStage];
-  __shared__ uint8_t st_ring[kStage];
+  constexpr int kStageBytes = kStage * (8 + 4 + 2 + 1) + 16;
+  __shared__ __attribute__((aligned(16))) uint8_t block[kStageBytes];
+  uint16_t (*wcnt)[kRings] = reinterpret_cast<uint16_t (*)[kRings]>(block);
+  uint32_t * part = reinterpret_cast<uint32_t *>(block + kGroups * kRings * 2);
+  float2 * st_xy = reinterpret_cast<float2 *>(block);
+  float * st_z = reinterpret_cast<float *>(block + kStage * 8);
+  uint16_t * st_src = reinterpret_cast<uint16_t *>(block + kStage * 12);
+  uint8_t * st_ring = block + kStage * 14;
+  static_assert(kGroups * kRings * 2 + 4 * kRings * 4 <= kStageBytes, "count table + look-back scratch must fit the staging block");
   for (int i = tid; i < kGroups * kRings; i += kChunkThreads) {(&wcnt[0][0])[i] = 0;}
   __syncthreads();
 
@@ -295,8 +302,8 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
         const u32x4 zero = {0u, 0u, 0u, 0u};
         acc += (pa < chunk ? va : zero) + (pb < chunk ? vb : zero) + (pc < chunk ? vc : zero) + (pd < chunk ? vd : zero);
       }
-      __syncthreads();                       // wcnt is done with (prefixes taken above); reuse it as scratch
-      uint32_t * part = reinterpret_cast<uint32_t *>(&st_xy[0]);      // [4][256] u32, staging not yet in use
+      __syncthreads();
+      // part: [4][256] u32 behind the count table
       part[grp * kRings + 4 * quad + 0] = acc.x;
       part[grp * kRings + 4 * quad + 1] = acc.y;
       part[grp * kRings + 4 * quad + 2] = acc.z;
@@ -334,15 +341,23 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     if (tid == 0) {staged = total;}
   }
   __syncthreads();
+  uint32_t lp[kChunkSlots];
+#pragma unroll
+  for (int i = 0; i < kChunkSlots; i++) {
+    lp[i] = 0;
+    if (key[i] < kRings) {
+      lp[i] = cstart[key[i]] + wcnt[i * (kChunkThreads / 64) + wave][key[i]] + rank[i];
+      lp[i] += lp[i] >> 5;
+    }
+  }
+  __syncthreads();                          // the count table is dead: its bytes become staging
 #pragma unroll
   for (int i = 0; i < kChunkSlots; i++) {
     if (key[i] < kRings) {
-      uint32_t lp = cstart[key[i]] + wcnt[i * (kChunkThreads / 64) + wave][key[i]] + rank[i];
-      lp += lp >> 5;
-      st_xy[lp] = make_float2(x[i], y[i]);
-      st_z[lp] = z[i];
-      st_src[lp] = (uint16_t)(i * kChunkThreads + tid);
-      st_ring[lp] = (uint8_t)key[i];
+      st_xy[lp[i]] = make_float2(x[i], y[i]);
+      st_z[lp[i]] = z[i];
+      st_src[lp[i]] = (uint16_t)(i * kChunkThreads + tid);
+      st_ring[lp[i]] = (uint8_t)key[i];
     }
   }
   __syncthreads();
