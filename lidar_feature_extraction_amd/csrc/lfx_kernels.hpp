@@ -1,14 +1,19 @@
 // lfx_kernels.hpp -- hand-written HIP kernels (gfx950 / MI355X) for the per-scan lidar feature
 // extraction path.  Semantics follow /root/reference/extraction (file:line cited per routine);
 // the structure does not: the reference walks rings and blocks sequentially on one CPU thread
-// and decides edge/surface points by argsort + greedy suppression; here
+// and decides edge/surface points by argsort + greedy suppression.  Per batch of scans:
 //
-//   ring_histogram / ring_scan / ring_scatter   stable counting sort of the scan's points by ring
-//                                               (MakePointIndices, ring.hpp:114-125) into SoA x,y,index
-//   ring_extract    one workgroup per ring: angle order check (+ LDS bitonic sort fallback),
-//                   range, curvature, neighbour links, block labelling, occlusion / out-of-range /
-//                   parallel-beam masks, in-ring compaction -- everything LDS resident
-//   feature_compact packs the per-ring edge / surface lists into the scan's clouds
+//   ring_scatter_kernel     the ONE pass over the input: stable counting sort of the points by ring
+//                           (MakePointIndices, ring.hpp:114-125) into ring-major arrays, the prefix
+//                           over earlier chunks obtained by look-back inside the launch
+//   ring_unit_kernel        fast path: one WAVE per (ring, block): angle-order check, range,
+//                           curvature, links, block labelling, occlusion / out-of-range /
+//                           parallel-beam masks, per-unit feature records; no workgroup barrier
+//   ring_extract_kernel     slow path for the rings the fast path defers (unsorted as bucketed ->
+//                           LDS bitonic sort with the exact predicate; skip conditions; long blocks):
+//                           one workgroup per ring, the ring resident in LDS
+//   ring_totals_kernel, feature_compact_kernel   per-unit records -> the scan's edge / surface clouds
+//   (ring_histogram_kernel, ring_scan_kernel: two-pass bucketing kept as a fallback)
 //
 // Labelling without a sort.  The reference's per-block pass (label.hpp:72-95,113-134) visits
 // points in curvature order and lets every pick suppress what its link-aware +-P fill reaches
@@ -16,14 +21,16 @@
 // them intact), so the picked set is the lexicographically first maximal independent set of the
 // candidates in priority order.  That set is computed exactly by rounds of "a live candidate
 // with no live higher-priority candidate in reach is picked; everything a pick reaches dies":
-// each round is a few AND/shift operations on 32-bit windows of LDS bit arrays, and the
-// priority comparisons (f64 curvature, index as tie-break) are done once per candidate.
+// each round is a few AND/shift operations on 32-bit windows of point-set bit masks, and the
+// priority comparisons (f64 curvature, index as tie-break) are done once per point.
 //
 // Floating point: every operation the reference performs in IEEE f64/f32 is performed here in the
 // same type and order, unfused (contract off), so integer results (labels, index sets) are
-// bit-exact and curvature is bit-equal.  The only libm call on the path, acos() in CalcRadian
-// (math.cpp:34-46), is only ever compared with a threshold; the host turns that threshold into
-// the equivalent bound on the cosine with the host's own acos (lfx_api.hip: cos_bound()).
+// bit-exact and curvature is bit-equal.  Threshold tests on quotients are pre-classified with
+// cheaper arithmetic and fall back to the exact division next to the threshold (unit_body).  The
+// only libm call on the path, acos() in CalcRadian (math.cpp:34-46), is only ever compared with a
+// threshold; the host turns that threshold into the equivalent bound on the cosine with the host's
+// own acos (lfx_api.hip: cos_bound()).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256) void batch_reset_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K0: ring histogram per 1024-point chunk.
+// Two-pass bucketing only (LFX_DEBUG_TWO_PASS): ring histogram per chunk.
 __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint16_t * __restrict__ chunk_hist, uint32_t * __restrict__ scan_info, uint32_t max_chunks, uint32_t max_rings,
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K1 (two-pass bucketing only): per scan, prefix the chunk histograms per ring.
+// Two-pass bucketing only: per scan, prefix the chunk histograms per ring.
 __global__ __launch_bounds__(kRings) void ring_scan_kernel(
   const uint32_t * __restrict__ scan_begin, const uint16_t * __restrict__ chunk_hist,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ ring_count, uint32_t * __restrict__ scan_info,
@@ -147,7 +154,7 @@ __host__ __device__ inline size_t ring_base(uint32_t s, uint32_t ring, uint32_t 
 
 constexpr uint32_t kSpinLimit = 200000;   // ~50 ms of s_sleep polls before a look-back gives up
 
-// K2: stable scatter of (x, y | z | original index) into ring-major arrays.
+// Ring bucketing: stable scatter of (x, y | z | original index) into ring-major arrays.
 // LOOKBACK (default): the only pass over the input.  A chunk publishes its per-ring counts, waits
 // for the counts of the scan's earlier chunks (lower block index: already dispatched) and sums
 // them -- no separate histogram pass.  Release / acquire at agent scope as
@@ -630,7 +637,7 @@ constexpr int kWaveChunks = 6;            // blocks of up to 384 points take the
 // In 32-bit halves U[2j], U[2j+1] of W[j]: the window starts at half 2(k+1)-1, 2(k+1) or 2(k+1)+1
 // for lanes < 16, 16..47, >= 48, at bit (lane+16)&31 -- two selects between wave-uniform halves
 // and one v_alignbit.
-__device__ inline uint32_t uwindow(const uint64_t (&W)[kWaveChunks + 2], int k, bool hi, int sh)
+__device__ inline uint32_t uwindow(const uint64_t (&W)[kWaveChunks + 2], int k)
 {
   const int lane = threadIdx.x & 63;
   const uint32_t u0 = (uint32_t)(W[k] >> 32), u1 = (uint32_t)W[k + 1], u2 = (uint32_t)(W[k + 1] >> 32),
@@ -699,7 +706,7 @@ __device__ inline void order_masks(
 // lane's position 64k+lane belongs to the block being labelled.
 template<bool EDGE, int PT>
 __device__ inline void wave_pass(
-  const double * cl_, const Params & prm, int nloc, uint32_t inblk, int K, int lane, bool hi, int sh,
+  const double * cl_, const Params & prm, int nloc, uint32_t inblk, int K, int lane,
   const uint32_t (&reach)[kWaveChunks], const uint32_t (&lt)[kWaveChunks], uint32_t taken, uint32_t & sel,
   uint32_t & cov)
 {
@@ -733,7 +740,7 @@ __device__ inline void wave_pass(
   for (int k = 0; k < kWaveChunks; k++) {
     H[k] = 0;
     if (k < K && A[k + 1] != 0) {
-      const uint32_t m = uwindow(A, k, hi, sh) & reach[k] & ~(1u << 16);
+      const uint32_t m = uwindow(A, k) & reach[k] & ~(1u << 16);
       H[k] = (EDGE ? ~lt[k] : lt[k]) & m;
     }
   }
@@ -745,7 +752,7 @@ __device__ inline void wave_pass(
       if (k < K) {
         uint64_t s = 0;
         if (A[k + 1] != 0) {
-          const bool pick = ((alive >> k) & 1u) && (uwindow(A, k, hi, sh) & H[k]) == 0;
+          const bool pick = ((alive >> k) & 1u) && (uwindow(A, k) & H[k]) == 0;
           s = __ballot(pick);
           sel |= (pick ? 1u : 0u) << k;
         }
@@ -762,7 +769,7 @@ __device__ inline void wave_pass(
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
         if ((S[k] | S[k + 1] | S[k + 2]) != 0) {
-          const bool hit = (uwindow(S, k, hi, sh) & reach[k]) != 0;
+          const bool hit = (uwindow(S, k) & reach[k]) != 0;
           const uint32_t hb = (hit ? 1u : 0u) << k;
           cov |= hb;
           alive &= ~hb;
@@ -779,8 +786,6 @@ template<int PT>
 __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N, bool single_block)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const bool hi = lane >= 16;
-  const int sh = (lane + 48) & 63;
   const int P = PT > 0 ? PT : prm.P;
   const int nblocks = single_block ? 1 : prm.B;
   for (int j = wave; j < nblocks; j += nwaves) {
@@ -806,7 +811,7 @@ __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N
       for (int k = 0; k < kWaveChunks; k++) {
         reach[k] = 0;
         if (k < K) {
-          const uint32_t ll = uwindow(LL, k, hi, sh);                    // bit 16+d: link between q+d and q+d+1
+          const uint32_t ll = uwindow(LL, k);                    // bit 16+d: link between q+d and q+d+1
           int L = __clz((int)~(ll << 16));
           int R = __ffs((int)~(ll >> 16)) - 1;
           L = L < P ? L : P;
@@ -821,8 +826,8 @@ __device__ inline void label_blocks_wave(RingWork & w, const Params & prm, int N
     uint32_t selE, covE, selS, covS;
     uint32_t lt[kWaveChunks];
     order_masks<PT>(w.c + b0, prm, nb, K, lane, lt);
-    wave_pass<true, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, lt, 0u, selE, covE);
-    wave_pass<false, PT>(w.c + b0, prm, nb, inblk, K, lane, hi, sh, reach, lt, covE, selS, covS);
+    wave_pass<true, PT>(w.c + b0, prm, nb, inblk, K, lane, reach, lt, 0u, selE, covE);
+    wave_pass<false, PT>(w.c + b0, prm, nb, inblk, K, lane, reach, lt, covE, selS, covS);
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
@@ -1084,7 +1089,7 @@ __device__ inline uint8_t process_ring(
 }
 
 // ==========================================================================================
-// K3 (fast path): one WAVE per (ring, block) unit; no workgroup barrier anywhere.
+// Ring kernel, fast path: one WAVE per (ring, block) unit; no workgroup barrier anywhere.
 //
 // Unit j of a ring owns the output positions of block j (the first / last unit also own the ring's
 // P-wide borders) and loads them with a halo of P+1 positions on either side: enough for the
@@ -1174,8 +1179,6 @@ __device__ inline void unit_body(
   uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
 {
   const int lane = threadIdx.x & 63;
-  const bool hi = lane >= 16;
-  const int sh = (lane + 48) & 63;
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
   const int N = (int)ring_count[s * kRings + slot];
   if (N == 0) {return;}                                  // no such ring in this scan
@@ -1315,7 +1318,7 @@ __device__ inline void unit_body(
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
         const int q = 64 * k + lane, i = g0 + q;
-        const uint32_t lw = uwindow(LK, k, hi, sh);
+        const uint32_t lw = uwindow(LK, k);
         lkw[k] = lw;
         const bool lk_here = (lw >> 16) & 1u;                            // pair (q, q+1)
         const bool lk_prev = (lw >> 15) & 1u;                            // pair (q-1, q)
@@ -1345,7 +1348,7 @@ __device__ inline void unit_body(
         const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
         const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
         if (!(dbg_flags & 256u)) {
-          const bool o = (uwindow(JL, k, hi, sh) & left) || (uwindow(JRs, k, hi, sh) & right);
+          const bool o = (uwindow(JL, k) & left) || (uwindow(JRs, k) & right);
           occ |= (o ? 1u : 0u) << k;
         }
         const bool ib = q >= qb0 && q < qb1;
@@ -1387,8 +1390,8 @@ __device__ inline void unit_body(
   uint32_t selE = 0, covE = 0, selS = 0, covS = 0;
   uint32_t lt[kWaveChunks];
   order_masks<PT>(U.c + kSlabPad, prm, span, K, lane, lt);
-  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, lt, 0u, selE, covE);}
-  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, hi, sh, reach, lt, covE, selS, covS);}
+  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, reach, lt, 0u, selE, covE);}
+  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, reach, lt, covE, selS, covS);}
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
   uint32_t pb_yes = 0, pb_unsure = 0;
 #pragma unroll
@@ -1430,7 +1433,7 @@ __device__ inline void unit_body(
       }
     }
   }
-  uint32_t is_edge = 0, is_surf = 0, pe = 0, ps = 0;
+  uint32_t pe = 0, ps = 0;
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
     if (k < K) {
@@ -1464,7 +1467,6 @@ __device__ inline void unit_body(
       ps += __popcll(fs);
     }
   }
-  (void)is_edge; (void)is_surf;
   if (lane == 0) {
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
     unit_ne[ui] = pe;
@@ -1503,7 +1505,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K3 (slow path): one workgroup per ring, ring resident in LDS.  Takes the rings the fast path
+// Ring kernel, slow path: one workgroup per ring, ring resident in LDS.  Takes the rings the fast path
 // deferred (use_list) or every ring of the batch (n_blocks > 64, debugging).  Writes the ring's
 // feature records as ONE segment (edge from the front of the ring, surface from its back) and
 // marks the ring so that feature_compact_kernel reads it that way.
@@ -1621,7 +1623,7 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K4a: per scan, ring totals and their exclusive prefix (rings ascending).
+// Compaction, step 1: per scan, ring totals and their exclusive prefix (rings ascending).
 __global__ __launch_bounds__(kRings) void ring_totals_kernel(
   uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
   const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
@@ -1655,7 +1657,7 @@ __global__ __launch_bounds__(kRings) void ring_totals_kernel(
   }
 }
 
-// K4b: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
+// Compaction, step 2: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
 // ring angle ascending (units ascending; a slow-path ring is one unit).  One wave per ring.
 __global__ __launch_bounds__(256) void feature_compact_kernel(
   uint32_t n_units, uint32_t cap, const uint32_t * __restrict__ scan_begin,
