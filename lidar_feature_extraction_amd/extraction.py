@@ -92,12 +92,14 @@ class FeatureExtraction:
     """One context = one GPU = one calling thread (feature_extraction.cpp:65-87,185)."""
 
     def __init__(self, params=None, device=0, max_points_per_scan=262144, max_batch=1,
-                 max_points_per_ring=0, max_rings=0, drop_zero_points=False):
+                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None):
         self._L = B.load()
         self.params = params or HyperParameters()
         self._ctx = C.c_void_p()
-        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)),
-                       B.Layout(0, 0, 0, 0, 0))
+        # layout: (point_step, off_x, off_y, off_z, off_ring) of the records, None = PointXYZIR
+        lay = B.Layout(*layout) if layout is not None else B.Layout(0, 0, 0, 0, 0)
+        self._step = lay.point_step or 32
+        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay)
         cp = self.params.to_c()
         rc = self._L.lfx_create(C.byref(self._ctx), device, C.byref(cp), C.byref(cfg))
         if rc != 0:
@@ -124,8 +126,8 @@ class FeatureExtraction:
     def extract_batch(self, clouds):
         clouds = [np.ascontiguousarray(c) for c in clouds]
         for c in clouds:
-            if c.dtype != POINT_DTYPE:
-                raise TypeError("clouds must be POINT_DTYPE (32-byte PointXYZIR) arrays")
+            if c.dtype.itemsize != self._step:
+                raise TypeError("clouds must be arrays of %d-byte records (POINT_DTYPE for PointXYZIR)" % self._step)
         nb = len(clouds)
         ptrs = (C.c_void_p * nb)(*[c.ctypes.data for c in clouds])
         ns = (C.c_size_t * nb)(*[len(c) for c in clouds])

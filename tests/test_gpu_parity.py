@@ -294,6 +294,30 @@ def test_non_finite_input_terminates_and_leaves_other_rings_alone(fx):
     assert got.curvature[clean].tobytes() == ref.curvature[clean].tobytes()
 
 
+def test_other_record_layouts():
+    """lfx_layout: any point_step / field offsets (what a PointCloud2 message describes), not only the
+    32-byte PointXYZIR record."""
+    c = make_scan(16, 800, seed=66, drop_fraction=0.05, shuffle=True)     # shuffled: the sorting path reads z by index
+    want = OB.extract(c, canonical_ties=False)
+    wide = np.dtype({"names": ["t", "ring", "z", "y", "junk", "x"], "formats": ["<f8", "<u2", "<f4", "<f4", "<u4", "<f4"],
+                     "offsets": [0, 10, 12, 20, 28, 40], "itemsize": 48})
+    w = np.zeros(len(c), wide)
+    w["x"], w["y"], w["z"], w["ring"] = c["x"], c["y"], c["z"], c["ring"]
+    w["t"], w["junk"] = np.arange(len(c)), 0xDEADBEEF
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=16, layout=(48, 40, 20, 12, 10))
+    assert_scan_equal(f.ExtractFeatures(w), want, "48-byte records")
+    f.close()
+    tight = np.dtype({"names": ["x", "y", "z", "ring"], "formats": ["<f4", "<f4", "<f4", "<u2"], "offsets": [0, 4, 8, 12],
+                      "itemsize": 16})
+    t = np.zeros(len(c), tight)
+    t["x"], t["y"], t["z"], t["ring"] = c["x"], c["y"], c["z"], c["ring"]
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=16, layout=(16, 0, 4, 8, 12))
+    assert_scan_equal(f.ExtractFeatures(t), want, "16-byte records")
+    f.close()
+    with pytest.raises(LB.LfxError):
+        FeatureExtraction(device=0, max_points_per_scan=100, layout=(32, 0, 4, 8, 31))      # ring field leaves the record
+
+
 def test_ring_id_beyond_max_rings_is_an_error():
     c = make_scan(8, 300, seed=3)
     f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=4)
