@@ -207,7 +207,7 @@ int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_p
                               float *out);
 
 /* --- measurement ------------------------------------------------------------------------- */
-#define LFX_N_KERNELS 7   /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_extract, ring_totals, feature_compact */
+#define LFX_N_KERNELS 9   /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);
 /* Sum of HIP-event durations per kernel since profiling was enabled, and launches counted. */
 int lfx_kernel_times(lfx_ctx *ctx, double ms[LFX_N_KERNELS], uint64_t launches[LFX_N_KERNELS]);

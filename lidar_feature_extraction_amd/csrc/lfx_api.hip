@@ -24,7 +24,8 @@ std::string g_create_error;
 
 const char * kKernelNames[LFX_N_KERNELS] = {
   "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_unit_kernel",
-  "ring_extract_kernel", "ring_totals_kernel", "feature_compact_kernel"};
+  "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel", "ring_totals_kernel",
+  "feature_compact_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -92,7 +93,7 @@ struct lfx_ctx
   lfx::Params dev{};
   lfx::Layout layout{};
   uint32_t max_points = 0, max_batch = 0, cap = 0, max_chunks = 0, max_rings = 0, ring_threads = 0, slow_grid = 0;
-  size_t total_cap = 0, ring_lds = 0;
+  size_t total_cap = 0, ring_lds = 0, order_lds = 0;
   uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
   uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
@@ -103,7 +104,8 @@ struct lfx_ctx
 
   // device scratch
   DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
-    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, sidx, rec_idx, edge_idx,
+    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list,
+    sidx, rec_idx, edge_idx,
     surf_idx, d_sidx;
   DevBuf<uint16_t> chunk_hist;
   DevBuf<uint8_t> ring_status, label_s, staging, d_label;
@@ -262,10 +264,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   c->last_batch = batch;
   c->last_points = d_points;
-  uint32_t * slow_count = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;   // behind ring_flags[max_batch][256]
+  uint32_t * counters = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;     // behind ring_flags[max_batch][256]
+  uint32_t * defer_count = counters, * redo_count = counters + 1, * slow_count = counters + 2;
   hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
     c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
-    c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, slow_count);
+    c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters);
   const uint8_t * pts = static_cast<const uint8_t *>(d_points);
   const uint32_t chunks = (longest + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
   if (chunks == 0) {return LFX_OK;}
@@ -299,15 +302,35 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     }
   }
   if (c->fast_path) {
-    Timed t(c, 3, st);
-    const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
-    hipLaunchKernelGGL(lfx::ring_unit_kernel, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
-      dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-      c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
-      c->unit_ns.p, c->unit_span.p, c->ring_flags.p, slow_count, c->slow_list.p);
+    const uint32_t * no_list = nullptr;
+    {
+      Timed t(c, 3, st);
+      const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
+      hipLaunchKernelGGL(lfx::ring_unit_kernel<false>, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
+        dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
+        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p,
+        c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p,
+        c->ring_flags.p, defer_count, c->defer_list.p, no_list, no_list);
+    }
+    {
+      // rings out of angle order: repaired in place, then a second pass of the unit kernel over them
+      Timed t(c, 4, st);
+      hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(c->slow_grid), dim3(512), c->order_lds, st,
+        c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
+        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p);
+    }
+    {
+      Timed t(c, 5, st);
+      const uint32_t units = c->max_rings * (uint32_t)c->dev.B * batch;
+      hipLaunchKernelGGL(lfx::ring_unit_kernel<true>, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves),
+        dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
+        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p,
+        c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p,
+        c->ring_flags.p, slow_count, c->slow_list.p, redo_count, c->redo_list.p);
+    }
   }
   {
-    Timed t(c, 4, st);
+    Timed t(c, 6, st);
     const dim3 grid = c->fast_path ? dim3(c->slow_grid) : dim3(c->max_rings, batch);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
       c->dev, c->cap, c->stage_flags, c->fast_path ? 1u : 0u, pts, c->layout, c->scan_begin.p,
@@ -316,13 +339,13 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       c->slow_list.p, c->max_rings);
   }
   {
-    Timed t(c, 5, st);
+    Timed t(c, 7, st);
     hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
       c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
       c->ring_ebase.p, c->ring_sbase.p, c->fast_path ? (uint32_t)c->dev.B : 1u, c->max_rings);
   }
   {
-    Timed t(c, 6, st);
+    Timed t(c, 8, st);
     const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
     hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
       n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
@@ -524,6 +547,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
   c->ring_lds = lfx::ring_lds_bytes(c->cap);
+  c->order_lds = lfx::order_lds_bytes(c->cap);
   c->max_chunks = (c->max_points + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
   c->total_cap = (size_t)c->max_points * c->max_batch;
   if (c->total_cap >= (1ull << 32)) {
@@ -540,7 +564,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->ring_count.alloc(tables)); ok(c->chunk_flags.alloc(nb * c->max_chunks));
   ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
   ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
-  ok(c->ring_flags.alloc(tables + 1)); ok(c->slow_list.alloc(tables));
+  ok(c->ring_flags.alloc(tables + 4)); ok(c->slow_list.alloc(tables)); ok(c->defer_list.alloc(tables));
+  ok(c->redo_list.alloc(tables));
   ok(c->unit_ne.alloc(tables * lfx::kUnitMaxBlocks)); ok(c->unit_ns.alloc(tables * lfx::kUnitMaxBlocks));
   ok(c->unit_span.alloc(tables * lfx::kUnitMaxBlocks));
   const size_t rc = nb * c->max_rings * c->cap;      // ring-major arrays: fixed capacity per ring id
@@ -552,6 +577,10 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_extract_kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ring_lds);
+  }
+  if (e == hipSuccess) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_order_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->order_lds);
   }
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_stage_kernel),
@@ -576,7 +605,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
-  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();

@@ -82,14 +82,14 @@ enum Label : uint8_t
 __global__ __launch_bounds__(256) void batch_reset_kernel(
   uint32_t * __restrict__ scan_info, uint32_t n_info, uint32_t * __restrict__ ring_count, uint32_t n_count,
   uint32_t * __restrict__ chunk_flags, uint32_t n_flags, uint32_t * __restrict__ ring_flags, uint32_t n_rflags,
-  uint32_t * __restrict__ slow_count)
+  uint32_t * __restrict__ counters /* [4]: deferred, redo, slow, spare */)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t k = i; k < n_info; k += stride) {scan_info[k] = 0;}
   for (uint32_t k = i; k < n_count; k += stride) {ring_count[k] = 0;}
   for (uint32_t k = i; k < n_flags; k += stride) {chunk_flags[k] = 0;}
   for (uint32_t k = i; k < n_rflags; k += stride) {ring_flags[k] = 0;}
-  if (i == 0) {*slow_count = 0;}
+  if (i < 4) {counters[i] = 0;}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1101,6 +1101,7 @@ __device__ inline uint8_t process_ring(
 constexpr int kUnitWaves = 4;
 constexpr int kUnitSpan = 64 * kWaveChunks;
 constexpr int kUnitMaxBlocks = 64;        // per-unit count tables are sized for n_blocks <= 64
+enum { kDeferOrder = 1u, kDeferOther = 2u, kDeferMask = 3u, kRingSorted = 4u /* put in order by ring_order_kernel */ };
 
 constexpr int kSlabPad = 16;               // positions readable on either side of the curvature slab
 struct UnitLds
@@ -1176,7 +1177,8 @@ __device__ inline void unit_body(
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
   float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
   uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span,
-  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
+  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list,
+  bool second_pass)
 {
   const int lane = threadIdx.x & 63;
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
@@ -1184,20 +1186,25 @@ __device__ inline void unit_body(
   if (N == 0) {return;}                                  // no such ring in this scan
   const size_t off = ring_base(s, slot, max_rings, ring_cap);
   uint32_t * flag = ring_flags + s * kRings + slot;
-#define LFX_DEFER() \
+  // A deferred ring goes on `defer_list` once (the first unit to flag it appends it); the flag keeps
+  // the reasons: kDeferOrder = not angle-sorted as bucketed (ring_order_kernel repairs that and the
+  // ring gets a second pass here), kDeferOther = anything only the workgroup-per-ring kernel handles.
+#define LFX_DEFER(reason) \
   do { \
-    if (lane == 0 && atomicOr(flag, 1u) == 0u) {slow_list[atomicAdd(slow_count, 1u)] = s * kRings + slot;} \
+    if (lane == 0 && (atomicOr(flag, (reason)) & kDeferMask) == 0u) { \
+      defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
+    } \
     return; \
   } while (0)
   // skip conditions and over-long rings are the slow path's business (it also reports them)
   if (N < 2 * P + 1 || N - 2 * P < B || (uint32_t)N > ring_cap) {
-    if (j == 0) {LFX_DEFER();}
+    if (j == 0) {LFX_DEFER(kDeferOther);}
     return;
   }
   const int b0 = block_boundary(N, P, B, j), b1 = block_boundary(N, P, B, j + 1);
   const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? N : b1;
   const int H = P + 1, g0 = o0 - H, span = o1 + H - g0;
-  if (b1 - b0 < 2 || span > kUnitSpan) {LFX_DEFER();}
+  if (b1 - b0 < 2 || span > kUnitSpan) {LFX_DEFER(kDeferOther);}
   const int K = (span + 63) >> 6;
   const int qb0 = b0 - g0, qb1 = b1 - g0;          // the block in span coordinates
   const int qo0 = o0 - g0, qo1 = o1 - g0;          // the owned positions
@@ -1251,7 +1258,7 @@ __device__ inline void unit_body(
         if (pair && !polar_less(x[k], y[k], U.p.x[q + 1], U.p.y[q + 1])) {really = true;}
       }
     }
-    if (__ballot(really) != 0ull) {LFX_DEFER();}
+    if (__ballot(really) != 0ull) {LFX_DEFER(second_pass ? kDeferOther : kDeferOrder);}
   }
   LFX_WAVE_SYNC();
   // ---- C. links (neighbor.hpp:44-48) as wave-uniform words; bit q <-> pair (q, q+1)
@@ -1301,7 +1308,7 @@ __device__ inline void unit_body(
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {LK[k + 1] = __ballot((lk_yes >> k) & 1u);}
     }
-    if (__ballot(zero_pair) != 0ull) {LFX_DEFER();}
+    if (__ballot(zero_pair) != 0ull) {LFX_DEFER(kDeferOther);}
   }
   // ---- D. everything that needs the link words: occlusion (occlusion.hpp:37-91) and the reach of a
   //         pick inside the block (fill.hpp:101-117)
@@ -1477,31 +1484,185 @@ __device__ inline void unit_body(
 #undef LFX_DEFER
 }
 
+// SECOND = false: first pass, grid = (units of a scan / 4, batch); rings it cannot take go on
+// `defer_list` with the reason.  SECOND = true: second pass over the rings ring_order_kernel
+// repaired (redo_list, grid-stride); what still cannot be taken goes on the slow list.
+template<bool SECOND>
 __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
   float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
   uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span,
-  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ slow_count, uint32_t * __restrict__ slow_list)
+  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list,
+  const uint32_t * __restrict__ redo_count, const uint32_t * __restrict__ redo_list)
 {
   __shared__ UnitLds lds[kUnitWaves];
-  const uint32_t s = blockIdx.y;
-  const uint32_t u = blockIdx.x * kUnitWaves + (threadIdx.x >> 6);
-  const uint32_t slot = u / (uint32_t)prm.B;
-  const int j = (int)(u % (uint32_t)prm.B);
-  if (slot >= max_rings) {return;}
   UnitLds & U = lds[threadIdx.x >> 6];
+  const uint32_t B = (uint32_t)prm.B;
+  uint32_t u = blockIdx.x * kUnitWaves + (threadIdx.x >> 6);
+  uint32_t s, slot;
+  if (SECOND) {
+    // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
+    // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
+    if (u >= *redo_count * B) {return;}
+    const uint32_t e = redo_list[u / B];
+    s = e / kRings;
+    slot = e % kRings;
+  } else {
+    s = blockIdx.y;
+    slot = u / B;
+    if (slot >= max_rings) {return;}
+  }
+  const int j = (int)(u % B);
   if (prm.P == 5) {
     unit_body<5>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, slow_count, slow_list);
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
   } else if (prm.P == 2) {
     unit_body<2>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, slow_count, slow_list);
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
   } else {
     unit_body<0>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, slow_count, slow_list);
+      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Order repair.  One workgroup per ring the first pass found out of angle order.  A ring that is a
+// ROTATION of its sorted order (a driver starting the scan at another azimuth), its REVERSE (a
+// clockwise sensor) or both is put in order by index arithmetic; anything else by a bitonic sort
+// in LDS with the exact predicate and the arrival index as tie-break (ring.hpp:54-112; canonical
+// order where the reference's unstable std::sort leaves ties open).  The ring's slices of
+// sxy / sz / sidx are rewritten in sorted order; rings whose only problem was the order go on the
+// redo list (second pass of ring_unit_kernel), the others on the slow list.
+__global__ __launch_bounds__(512) void ring_order_kernel(
+  uint32_t cap, uint32_t max_rings, const uint32_t * __restrict__ ring_count, float2 * __restrict__ sxy,
+  float * __restrict__ sz, uint32_t * __restrict__ sidx, uint32_t * __restrict__ ring_flags,
+  const uint32_t * __restrict__ defer_count, const uint32_t * __restrict__ defer_list,
+  uint32_t * __restrict__ redo_count, uint32_t * __restrict__ redo_list, uint32_t * __restrict__ slow_count,
+  uint32_t * __restrict__ slow_list)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  const int T = blockDim.x, tid = threadIdx.x;
+  uint32_t M = 1;                                     // power of two >= cap: room for the sort
+  while (M < cap) {M <<= 1;}
+  float * lx = reinterpret_cast<float *>(lds_raw);
+  float * ly = lx + M;
+  uint32_t * li = reinterpret_cast<uint32_t *>(ly + M);   // arrival index (tie-break)
+  uint32_t * lp = li + M;                                 // position in the ring as bucketed
+  float * lz = reinterpret_cast<float *>(lp + M);
+  uint32_t * ls = reinterpret_cast<uint32_t *>(lz + M);   // sidx as bucketed
+  int * cnt = reinterpret_cast<int *>(ls + M);            // [8] counters
+  const uint32_t n_items = *defer_count;
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t e = defer_list[item];
+    const uint32_t s = e / kRings, slot = e % kRings;
+    const int N = (int)ring_count[e];
+    const uint32_t reason = ring_flags[e];
+    const size_t off = ring_base(s, slot, max_rings, cap);
+    const bool fixable = (reason & kDeferOrder) && N >= 2 && (uint32_t)N <= cap;
+    if (fixable) {
+      if (tid < 8) {cnt[tid] = tid == 1 || tid == 3 ? -1 : 0;}
+      for (int i = tid; i < N; i += T) {
+        const float2 v = sxy[off + i];
+        lx[i] = v.x;
+        ly[i] = v.y;
+        lz[i] = sz[off + i];
+        ls[i] = sidx[off + i];
+      }
+      __syncthreads();
+      // cnt[0] / cnt[1]: number / position of pairs that are not strictly increasing,
+      // cnt[2] / cnt[3]: the same for not strictly decreasing
+      for (int i = tid; i + 1 < N; i += T) {
+        if (!polar_less(lx[i], ly[i], lx[i + 1], ly[i + 1])) {atomicAdd(&cnt[0], 1); atomicMax(&cnt[1], i);}
+        if (!polar_less(lx[i + 1], ly[i + 1], lx[i], ly[i])) {atomicAdd(&cnt[2], 1); atomicMax(&cnt[3], i);}
+      }
+      __syncthreads();
+      const int up_breaks = cnt[0], up_at = cnt[1], down_breaks = cnt[2], down_at = cnt[3];
+      int mode = 0;                                     // 0 sort, 1 rotation, 2 reverse, 3 reversed rotation
+      int cut = 0;
+      if (up_breaks == 1 && polar_less(lx[up_at + 1], ly[up_at + 1], lx[up_at], ly[up_at]) &&
+        polar_less(lx[N - 1], ly[N - 1], lx[0], ly[0]))
+      {
+        mode = 1; cut = up_at + 1;                      // sorted = [cut .. N-1] then [0 .. cut-1]
+      } else if (down_breaks == 0) {
+        mode = 2;                                       // strictly decreasing: sorted = reverse
+      } else if (down_breaks == 1 && polar_less(lx[down_at], ly[down_at], lx[down_at + 1], ly[down_at + 1]) &&
+        polar_less(lx[0], ly[0], lx[N - 1], ly[N - 1]))
+      {
+        mode = 3; cut = down_at + 1;                    // two decreasing runs: sorted = reverse([0..cut-1]) then reverse([cut..N-1])
+      }
+      if (mode == 0) {
+        uint32_t Ms = 1;
+        while (Ms < (uint32_t)N) {Ms <<= 1;}
+        for (uint32_t i = tid; i < Ms; i += T) {
+          const bool in = i < (uint32_t)N;
+          li[i] = in ? ls[i] : kSentinel;
+          lp[i] = i;
+          if (!in) {lx[i] = 0.f; ly[i] = 0.f;}
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= Ms; k <<= 1) {
+          for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < Ms / 2; t += T) {
+              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const uint32_t p = i | j;
+              const bool asc = (i & k) == 0;
+              const float ax = lx[i], ay = ly[i], bx = lx[p], by = ly[p];
+              const uint32_t ai = li[i], bi = li[p];
+              const bool swap = asc ? sort_less(bx, by, bi, ax, ay, ai) : sort_less(ax, ay, ai, bx, by, bi);
+              if (swap) {
+                const uint32_t pa = lp[i], pb = lp[p];
+                lx[i] = bx; ly[i] = by; li[i] = bi; lp[i] = pb;
+                lx[p] = ax; ly[p] = ay; li[p] = ai; lp[p] = pa;
+              }
+            }
+            __syncthreads();
+          }
+        }
+        for (int i = tid; i < N; i += T) {
+          const uint32_t src = lp[i];
+          sxy[off + i] = make_float2(lx[i], ly[i]);
+          sz[off + i] = lz[src];
+          sidx[off + i] = li[i];
+        }
+      } else {
+        for (int i = tid; i < N; i += T) {
+          int src;
+          if (mode == 1) {
+            src = i + cut < N ? i + cut : i + cut - N;
+          } else if (mode == 2) {
+            src = N - 1 - i;
+          } else {
+            src = i < cut ? cut - 1 - i : N - 1 - (i - cut);
+          }
+          sxy[off + i] = make_float2(lx[src], ly[src]);
+          sz[off + i] = lz[src];
+          sidx[off + i] = ls[src];
+        }
+      }
+    }
+    if (tid == 0) {
+      // kRingSorted: the ring is sorted exactly once from its bucketed order, also when it ends up in
+      // the workgroup-per-ring kernel later (a second sort could differ where the float predicate is
+      // not a consistent order on nearly parallel points)
+      if (fixable && reason == kDeferOrder) {
+        ring_flags[e] = kRingSorted;
+        redo_list[atomicAdd(redo_count, 1u)] = e;
+      } else {
+        if (fixable) {ring_flags[e] = reason | kRingSorted;}
+        slow_list[atomicAdd(slow_count, 1u)] = e;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__host__ __device__ inline size_t order_lds_bytes(uint32_t cap)
+{
+  uint32_t M = 1;
+  while (M < cap) {M <<= 1;}
+  return (size_t)M * 24 + 64;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1548,7 +1709,9 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
         w.y[i] = v.y;
       }
       __syncthreads();
-      resorted = angle_sort(w, N, sxy + off, sidx + off);
+      if (!(use_list && (ring_flags[s * kRings + slot] & kRingSorted))) {
+        resorted = angle_sort(w, N, sxy + off, sidx + off);
+      }
       status = process_ring(w, prm, N, stage_flags, nullptr, nullptr, nullptr);
     }
     // the whole ring is ONE unit with one segment of records: [0, N)
