@@ -59,10 +59,13 @@ def test_scan_parity(shape, pname):
     f.close()
 
 
-@pytest.mark.parametrize("variant", ["ragged", "shuffled", "rotated", "reversed", "ragged_shuffled"])
+@pytest.mark.parametrize("variant", ["ragged", "shuffled", "rotated", "reversed", "reversed_rotated", "ragged_rotated",
+                                     "ragged_shuffled"])
 def test_scan_parity_input_orders(fx, variant):
     kw = {"ragged": dict(drop_fraction=0.13), "shuffled": dict(shuffle=True), "rotated": dict(start_col=517),
-          "reversed": dict(reverse=True), "ragged_shuffled": dict(drop_fraction=0.3, shuffle=True)}[variant]
+          "reversed": dict(reverse=True), "reversed_rotated": dict(reverse=True, start_col=333),
+          "ragged_rotated": dict(drop_fraction=0.2, start_col=901),
+          "ragged_shuffled": dict(drop_fraction=0.3, shuffle=True)}[variant]
     c = make_scan(32, 1024, seed=77, **kw)
     got = fx.ExtractFeatures(c)
     want = OB.extract(c, canonical_ties=False)
