@@ -202,6 +202,22 @@ def main():
                "ms_per_scan": round(1e3 * el / done, 3),
                "sample": "%d scans of %dx%d (the bench's own inputs, %d distinct), oracle/lfx_oracle.cpp, 1 thread, %.1f s"
                          % (done, a.rings, a.cols, n_unique, el)}
+        # the same port with one scan per host thread (the reference itself is single-threaded,
+        # feature_extraction.cpp:185; this is the "all host cores" figure of SURVEY.md 8d)
+        from concurrent.futures import ThreadPoolExecutor
+        n_thr = max(1, min(len(os.sched_getaffinity(0)), 64))
+        per_thread = max(2, int(done / max(el, 1e-9) * min(a.cpu_seconds, 8.0)))
+
+        def work(t):
+            for k in range(per_thread):
+                oracle.extract(clouds[(t + k) % n_unique], canonical_ties=False)
+            return per_thread
+        t2 = time.perf_counter()
+        with ThreadPoolExecutor(n_thr) as ex:
+            total = sum(ex.map(work, range(n_thr)))
+        el2 = time.perf_counter() - t2
+        cpu["all_cores"] = {"value": round(total / el2, 3), "unit": "scans/s", "cores": n_thr,
+                            "sample": "%d scans, one scan per thread, %.1f s" % (total, el2)}
 
     if rank == 0:
         out = {
