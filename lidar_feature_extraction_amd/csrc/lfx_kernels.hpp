@@ -1103,14 +1103,22 @@ constexpr int kUnitSpan = 64 * kWaveChunks;
 constexpr int kUnitMaxBlocks = 64;        // per-unit count tables are sized for n_blocks <= 64
 enum { kDeferOrder = 1u, kDeferOther = 2u, kDeferMask = 3u, kRingSorted = 4u /* put in order by ring_order_kernel */ };
 
-constexpr int kSlabPad = 16;               // positions readable on either side of the curvature slab
+// Wave-uniform bit arrays in LDS.  A 64-bit ballot word per chunk, stored by the whole wave (every lane
+// writes the same value to the same address, so each lane only ever reads back what it wrote itself:
+// no fence is needed).  A lane then gets the 32 positions around its own one with one two-dword LDS
+// read and one v_alignbit -- the words live neither in scalar registers (there are too few) nor in
+// four selects per window.
+enum { kBitLK, kBitJL, kBitJR, kBitA, kBitS, kBitSelE, kBitSelS, kUnitBitArrays };
+constexpr int kBitWords = 2 * (kWaveChunks + 2);      // dwords per array; position p is bit p + 64
+
 struct UnitLds
 {
   double r[kUnitSpan];
   union {
-    double c[kUnitSpan + 2 * kSlabPad];      // from stage E on
+    double c[kUnitSpan + 2];                                      // from stage E on
     struct {float x[kUnitSpan + 2]; float y[kUnitSpan + 2];} p;   // stages A-C
   };
+  uint32_t bits[kUnitBitArrays][kBitWords];
 };
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
@@ -1134,39 +1142,46 @@ __device__ inline uint64_t range_word(int k, int lo, int hi)
   return upto_b & ~upto_a;
 }
 
-// Branch-free form of polar_less for the common case; `special` is set when one of the
-// predicate's special cases applies (equal points, a zero point, a point on the x axis) and the
-// full predicate has to be evaluated instead.
-__device__ inline bool polar_less_fast(float ax, float ay, float bx, float by, bool & special)
+// Lane predicate <-> wave-uniform mask.  `bal` is meant for ONE comparison (it then is the
+// comparison's own result register); combine masks with & | ~ in scalar code.
+__device__ inline uint64_t bal(bool p) {return __builtin_amdgcn_ballot_w64(p);}
+__device__ inline bool lanes(uint64_t m) {return __builtin_amdgcn_inverse_ballot_w64(m);}
+// lanes whose position q lies in [lo, hi) (lo, hi wave-uniform): one subtract and one compare per lane --
+// the scalar unit is as busy as the vector unit in this kernel, so the mask is not built from shifts
+__device__ inline uint64_t in_span(int q, int lo, int hi)
+{
+  const int width = hi - lo;
+  return bal((uint32_t)(q - lo) < (uint32_t)(width > 0 ? width : 0));
+}
+
+struct UnitWin
+{
+  uint32_t ofs, sh;      // dword offset of the window's first dword inside a chunk pair; bit shift
+};
+
+__device__ inline void put_word(UnitLds & U, int arr, int k, uint64_t w)
+{
+  *reinterpret_cast<uint64_t *>(&U.bits[arr][2 * (k + 1)]) = w;
+}
+
+// bit 16 + d of the result <-> position q + d of array `arr`, q = 64k + lane (+1 for the shifted constants)
+__device__ inline uint32_t get_win(const UnitLds & U, int arr, int k, const UnitWin & w)
+{
+  const uint32_t * b = &U.bits[arr][2 * k + w.ofs];
+  return __builtin_amdgcn_alignbit(b[1], b[0], w.sh);
+}
+
+// Branch-free form of polar_less for the common case, as masks: `spec` = one of the predicate's
+// special cases applies (equal points, a zero point, a point on the x axis) and the full predicate
+// has to be evaluated instead.
+__device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float by, uint64_t & spec)
 {
   const float lena = ax * ax + ay * ay;
   const float lenb = bx * bx + by * by;
-  special = (ax == bx && ay == by) || lena == 0.f || lenb == 0.f || ay == 0.f || by == 0.f;
+  spec = (bal(ax == bx) & bal(ay == by)) | bal(lena == 0.f) | bal(lenb == 0.f) | bal(ay == 0.f) | bal(by == 0.f);
   const float det = ax * by - ay * bx;
-  return (ay * by > 0.f) ? (det > 0.f) : (ay < 0.f);
-}
-
-// Reciprocal of a positive finite double to ~2^-28 relative (v_rcp_f64 + one Newton step); used
-// only to decide threshold tests that are far from their threshold (see quotient_test).
-__device__ inline double rcp_approx(double d)
-{
-  const double y0 = __builtin_amdgcn_rcp(d);
-  return y0 * (2.0 - d * y0);
-}
-
-// Classifies (double)(a / b) against a threshold WITHOUT the IEEE division: returns 1 when the
-// quotient is certainly above thr, 0 when certainly below, 2 when it is within `band` (relative)
-// of thr or not finite -- the caller then performs the exact division.  band is far above the
-// error of a * rcp_approx(b), so a 0/1 answer equals the answer of the exact quotient.
-__device__ inline int quotient_test(double a, double yb /* rcp_approx(b) */, double thr, double band)
-{
-  const double q = a * yb;
-  const double lo = thr - fabs(thr) * band, hi = thr + fabs(thr) * band;
-  int res = 2;
-  if (q > hi) {res = 1;}
-  if (q < lo) {res = 0;}
-  if (!(fabs(q) < 1e300)) {res = 2;}       // inf / NaN: let the exact path decide
-  return res;
+  const uint64_t same = bal(ay * by > 0.f);
+  return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
 }
 
 template<int PT>
@@ -1210,8 +1225,16 @@ __device__ inline void unit_body(
   const int qo0 = o0 - g0, qo1 = o1 - g0;          // the owned positions
   const int qlo = g0 < 0 ? -g0 : 0;                // first / one-past-last position that is a ring point
   const int qhi = (N - g0) < span ? (N - g0) : span;
+  const UnitWin W0{(uint32_t)(lane + 48) >> 5, (uint32_t)(lane + 16) & 31u};   // window around q
+  const UnitWin W1{(uint32_t)(lane + 49) >> 5, (uint32_t)(lane + 17) & 31u};   // window around q + 1
 
   // ---- A. load; x, y also to the wave's LDS slab (neighbours are read by position)
+  {
+    uint32_t * z = &U.bits[0][0];
+    z[lane] = 0u;
+    if (lane + 64 < kUnitBitArrays * kBitWords) {z[lane + 64] = 0u;}
+    static_assert(kUnitBitArrays * kBitWords <= 128, "two stores per lane zero the bit arrays");
+  }
   float x[kWaveChunks], y[kWaveChunks];
   double r[kWaveChunks];
 #pragma unroll
@@ -1220,7 +1243,7 @@ __device__ inline void unit_body(
     if (k < K) {
       const int q = 64 * k + lane;
       int i = g0 + q;
-      const bool in = q >= qlo && q < qhi;
+      const bool in = lanes(in_span(q, qlo, qhi));
       i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
       const float2 v = sxy[off + i];
       x[k] = in ? v.x : 0.f;
@@ -1232,49 +1255,49 @@ __device__ inline void unit_body(
   LFX_WAVE_SYNC();
   // ---- B. angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, else
   //         slow path; range (math.hpp:36-39)
-  bool bad = false;
+  const int pair_end = qo1 < qhi - 1 ? qo1 : qhi - 1;                  // owned pairs (q, q+1): q in [qo0, pair_end)
+  uint64_t bad = 0;
 #pragma unroll
   for (int k = 0; k < kWaveChunks; k++) {
     if (k < K) {
       const int q = 64 * k + lane;
       const float xn = U.p.x[q + 1], yn = U.p.y[q + 1];
-      bool special;
-      const bool less = polar_less_fast(x[k], y[k], xn, yn, special);
-      const bool pair = q >= qo0 && q < qo1 && q + 1 < qhi;
-      bad = bad || (pair && (special || !less));
+      uint64_t spec;
+      const uint64_t less = polar_less_masks(x[k], y[k], xn, yn, spec);
+      bad |= in_span(q, qo0, pair_end) & (spec | ~less);
       const double xd = (double)x[k], yd = (double)y[k];
       r[k] = sqrt(xd * xd + yd * yd);
       U.r[q] = r[k];
     }
   }
-  if (__ballot(bad) != 0ull) {
+  if (bad != 0ull) {
     // re-evaluate with the full predicate: a special case is not necessarily out of order
     bool really = false;
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
       if (k < K) {
         const int q = 64 * k + lane;
-        const bool pair = q >= qo0 && q < qo1 && q + 1 < qhi;
+        const bool pair = q >= qo0 && q < pair_end;
         if (pair && !polar_less(x[k], y[k], U.p.x[q + 1], U.p.y[q + 1])) {really = true;}
       }
     }
     if (__ballot(really) != 0ull) {LFX_DEFER(second_pass ? kDeferOther : kDeferOrder);}
   }
   LFX_WAVE_SYNC();
-  // ---- C. links (neighbor.hpp:44-48) as wave-uniform words; bit q <-> pair (q, q+1)
-  uint64_t LK[kWaveChunks + 2];
-#pragma unroll
-  for (int k = 0; k < kWaveChunks + 2; k++) {LK[k] = 0;}
+  // ---- C. links (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the
+  //         occlusion test (occlusion.hpp:44-57, 67-79)
   {
-    bool zero_pair = false;
-    uint32_t lk_yes = 0, lk_unsure = 0;      // bit k: the pair at 64k+lane is a link / needs the exact division
+    uint64_t lky[kWaveChunks], uns[kWaveChunks];
+    uint64_t zero_pair = 0, any_uns = 0;
+    const float cbf = prm.cos_bound_f;
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
+      lky[k] = 0; uns[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
-        const bool pair = q >= qlo && q + 1 < qhi;
+        const uint64_t pair = in_span(q, qlo, qhi - 1);
         const double rn = U.r[q + 1];
-        zero_pair = zero_pair || (pair && q >= qo0 && q < qo1 && r[k] == 0. && rn == 0.);   // math.cpp:40-42 throws
+        zero_pair |= pair & in_span(q, qo0, qo1) & bal(r[k] == 0.) & bal(rn == 0.);       // math.cpp:40-42 throws
         // cos_bound <= cos <= 1 (neighbor.hpp:44-48 via the cosine bound): classified in f32 first.
         // |dot| <= r0*r1, so the f32 cosine is within ~4 ulp(1) = 5e-7 of the exact one; a value more
         // than 2^-19 (1.9e-6) away from both ends decides the test, anything closer (or not finite)
@@ -1282,90 +1305,71 @@ __device__ inline void unit_body(
         const float dotf = x[k] * U.p.x[q + 1] + y[k] * U.p.y[q + 1];
         const float denf = (float)r[k] * (float)rn;
         const float cosf = dotf * __builtin_amdgcn_rcpf(denf);
-        const float cbf = prm.cos_bound_f;
-        int res = 2;
-        if (cosf > cbf + 0x1p-19f && cosf < 1.0f - 0x1p-19f) {res = 1;}
-        if (cosf < cbf - 0x1p-19f || cosf > 1.0f + 0x1p-19f) {res = 0;}
-        if (!(fabsf(cosf) < 4.0f)) {res = 2;}
-        if (!pair) {res = 0;}
-        lk_yes |= (res == 1 ? 1u : 0u) << k;
-        lk_unsure |= (res == 2 ? 1u : 0u) << k;
+        const uint64_t yes = bal(cosf > cbf + 0x1p-19f) & bal(cosf < 1.0f - 0x1p-19f);
+        const uint64_t no = bal(cosf < cbf - 0x1p-19f) | bal(cosf > 1.0f + 0x1p-19f);
+        const uint64_t fin = bal(fabsf(cosf) < 4.0f);
+        lky[k] = yes & ~no & fin & pair;
+        uns[k] = (~(yes | no) | ~fin) & pair;
+        any_uns |= uns[k];
       }
     }
-    if (__ballot(lk_unsure != 0u) != 0ull) {
+    if (any_uns != 0ull) {
 #pragma unroll
       for (int k = 0; k < kWaveChunks; k++) {
-        if (k < K && ((lk_unsure >> k) & 1u)) {
+        if (k < K && uns[k] != 0ull) {
           const int q = 64 * k + lane;
           const double rn = U.r[q + 1];
           const double dot = (double)x[k] * (double)U.p.x[q + 1] + (double)y[k] * (double)U.p.y[q + 1];
           const double cosang = dot / (r[k] * rn);                       // math.cpp:44-45
-          lk_yes |= ((cosang >= prm.cos_bound && cosang <= 1.0) ? 1u : 0u) << k;   // acos(cos) < threshold; NaN -> false
+          lky[k] |= uns[k] & bal(cosang >= prm.cos_bound) & bal(cosang <= 1.0);   // acos(cos) < threshold; NaN -> false
         }
       }
     }
+    if (zero_pair != 0ull) {LFX_DEFER(kDeferOther);}
+    uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
-      if (k < K) {LK[k + 1] = __ballot((lk_yes >> k) & 1u);}
-    }
-    if (__ballot(zero_pair) != 0ull) {LFX_DEFER(kDeferOther);}
-  }
-  // ---- D. everything that needs the link words: occlusion (occlusion.hpp:37-91) and the reach of a
-  //         pick inside the block (fill.hpp:101-117)
-  uint32_t occ = 0, inblk = 0, owned = 0;
-  uint32_t reach[kWaveChunks];
-  {
-    uint64_t JL[kWaveChunks + 2], JR[kWaveChunks + 2], JRs[kWaveChunks + 2];
-    uint32_t lkw[kWaveChunks];
-#pragma unroll
-    for (int k = 0; k < kWaveChunks + 2; k++) {JL[k] = 0; JR[k] = 0; JRs[k] = 0;}
-#pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {lkw[k] = 0;}
-#pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
-      if (k < K) {
-        const int q = 64 * k + lane, i = g0 + q;
-        const uint32_t lw = uwindow(LK, k);
-        lkw[k] = lw;
-        const bool lk_here = (lw >> 16) & 1u;                            // pair (q, q+1)
-        const bool lk_prev = (lw >> 15) & 1u;                            // pair (q-1, q)
-        const int qm = q > 0 ? q - 1 : 0;
-        const double rq = U.r[q];
-        const bool jl = lk_here && i < N - P - 1 && U.r[q + 1] > rq + prm.dist_diff;         // occlusion.hpp:44-57
-        const bool jr = lk_prev && i >= P + 1 && q < qhi && U.r[qm] > rq + prm.dist_diff;    // occlusion.hpp:67-79
-        if (!(dbg_flags & 256u)) {
-          JL[k + 1] = __ballot(jl);
-          JR[k + 1] = __ballot(jr);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kWaveChunks + 1; k++) {JRs[k] = (JR[k] >> 1) | (JR[k + 1] << 63);}
-    JRs[kWaveChunks + 1] = JR[kWaveChunks + 1] >> 1;
-#pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
-      reach[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
-        const uint32_t lw = lkw[k];
-        int Lr = __clz((int)~(lw << 16));
-        int Rr = __ffs((int)~(lw >> 16)) - 1;
-        Lr = Lr < P ? Lr : P;
-        Rr = Rr < P ? Rr : P;
-        const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
-        const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
+        put_word(U, kBitLK, k, lky[k]);
+        const int qm = q > 0 ? q - 1 : 0;
+        const double rq = r[k] + prm.dist_diff;
+        // far side to the right of a linked pair (q, q+1), i in [0, N-P-1)
+        const uint64_t jl = lky[k] & in_span(q, 0, N - P - 1 - g0) & bal(U.r[q + 1] > rq);
+        // far side to the left of a linked pair (q-1, q), i in [P+1, N-1]
+        const uint64_t lk_prev = (lky[k] << 1) | prev_top;
+        const uint64_t jr = lk_prev & in_span(q, P + 1 - g0, qhi) & bal(U.r[qm] > rq);
+        prev_top = lky[k] >> 63;
         if (!(dbg_flags & 256u)) {
-          const bool o = (uwindow(JL, k) & left) || (uwindow(JRs, k) & right);
-          occ |= (o ? 1u : 0u) << k;
+          put_word(U, kBitJL, k, jl);
+          put_word(U, kBitJR, k, jr);
         }
-        const bool ib = q >= qb0 && q < qb1;
-        inblk |= (ib ? 1u : 0u) << k;
-        owned |= ((q >= qo0 && q < qo1) ? 1u : 0u) << k;
-        // inside the block the links are cut at its ends (label.hpp:157-159): clamp the runs
-        const int Lb = Lr < q - qb0 ? Lr : q - qb0;
-        const int Rb = Rr < qb1 - 1 - q ? Rr : qb1 - 1 - q;
-        reach[k] = ib ? (((1u << (Lb + Rb + 1)) - 1u) << (16 - Lb)) : 0u;
       }
+    }
+  }
+  // ---- D. occlusion fills (occlusion.hpp:37-91) and the reach of a pick inside the block (fill.hpp:101-117)
+  uint64_t occ[kWaveChunks];
+  uint32_t reach[kWaveChunks];
+#pragma unroll
+  for (int k = 0; k < kWaveChunks; k++) {
+    reach[k] = 0;
+    occ[k] = 0;
+    if (k < K) {
+      const int q = 64 * k + lane;
+      const uint32_t lw = get_win(U, kBitLK, k, W0);
+      int Lr = __clz((int)~(lw << 16));
+      int Rr = __ffs((int)~(lw >> 16)) - 1;
+      Lr = Lr < P ? Lr : P;
+      Rr = Rr < P ? Rr : P;
+      const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
+      const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
+      if (!(dbg_flags & 256u)) {
+        occ[k] = bal(((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u);
+      }
+      // inside the block the links are cut at its ends (label.hpp:157-159): clamp the runs
+      const int Lb = Lr < q - qb0 ? Lr : q - qb0;
+      const int Rb = Rr < qb1 - 1 - q ? Rr : qb1 - 1 - q;
+      reach[k] = lanes(in_span(q, qb0, qb1)) ? (((1u << (Lb + Rb + 1)) - 1u) << (16 - Lb)) : 0u;
     }
   }
   LFX_WAVE_SYNC();        // the x / y slab is dead from here on: the curvature slab takes its place
@@ -1389,54 +1393,156 @@ __device__ inline void unit_body(
           sum += (d == 0) ? v * (-2. * P) : v;
         }
       }
-      U.c[kSlabPad + q] = ((inblk >> k) & 1u) ? sum * sum : 0.;
+      U.c[q] = lanes(in_span(q, qb0, qb1)) ? sum * sum : 0.;
     }
   }
   LFX_WAVE_SYNC();
-  // ---- F. block labelling
-  uint32_t selE = 0, covE = 0, selS = 0, covS = 0;
+  // ---- F. block labelling (label.hpp:61-139): edge pass, then surface pass over what is still Default
   uint32_t lt[kWaveChunks];
-  order_masks<PT>(U.c + kSlabPad, prm, span, K, lane, lt);
-  if (dbg_flags & 1u) {wave_pass<true, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, reach, lt, 0u, selE, covE);}
-  if (dbg_flags & 64u) {wave_pass<false, PT>(U.c + kSlabPad, prm, span, inblk, K, lane, reach, lt, covE, selS, covS);}
-  // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
-  uint32_t pb_yes = 0, pb_unsure = 0;
-#pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
-    if (k < K && !(dbg_flags & 512u)) {
-      const int q = 64 * k + lane, i = g0 + q;
-      const int qm = q > 0 ? q - 1 : 0;
-      // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
-      // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
-      // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
-      // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
-      const float rf = (float)U.r[q], rmf = (float)U.r[qm], rpf = (float)U.r[q + 1];
-      const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
-      const float thr = prm.pb_ratio_f * rf;
-      const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
-      int t1 = 2, t2 = 2;
-      if (a1 > hi_t) {t1 = 1;}
-      if (a1 < lo_t) {t1 = 0;}
-      if (a2 > hi_t) {t2 = 1;}
-      if (a2 < lo_t) {t2 = 0;}
-      if (!(prm.pb_ratio_f >= 0x1p-9f) || !(rf > 0.f) || !(rf < 1e30f)) {t1 = 2; t2 = 2;}
-      int res = (t1 == 1 && t2 == 1) ? 1 : 0;
-      if ((t1 == 2 && t2 != 0) || (t2 == 2 && t1 != 0)) {res = 2;}
-      if (!(i >= 1 && i + 1 < N) || !((owned >> k) & 1u)) {res = 0;}
-      pb_yes |= (res == 1 ? 1u : 0u) << k;
-      pb_unsure |= (res == 2 ? 1u : 0u) << k;
-    }
-  }
-  if (__ballot(pb_unsure != 0u) != 0ull) {
+  {
+    // order masks, see order_masks(); the slab has no pad here: neighbours are read at clamped
+    // positions, and what a clamped read yields is masked by `reach` (zero outside the block)
 #pragma unroll
     for (int k = 0; k < kWaveChunks; k++) {
-      if (k < K && ((pb_unsure >> k) & 1u)) {
+      lt[k] = 0;
+      if (k < K) {
+        const int q = 64 * k + lane;
+        int qc = q < P ? P : q;
+        qc = qc > span - 1 - P ? span - 1 - P : qc;
+        const double ci = U.c[qc];
+        uint32_t m = 0;
+        if (PT > 0) {
+#pragma unroll
+          for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {
+            const double cl = U.c[qc - d], cr = U.c[qc + d];
+            m |= (cl <= ci) ? (1u << (16 - d)) : 0u;        // left neighbour: lower index wins a tie
+            m |= (cr < ci) ? (1u << (16 + d)) : 0u;
+          }
+        } else {
+          for (int d = 1; d <= P; d++) {
+            const double cl = U.c[qc - d], cr = U.c[qc + d];
+            m |= (cl <= ci) ? (1u << (16 - d)) : 0u;
+            m |= (cr < ci) ? (1u << (16 + d)) : 0u;
+          }
+        }
+        lt[k] = m;
+      }
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const bool edge = pass == 0;
+    if (!(dbg_flags & (edge ? 1u : 64u))) {continue;}
+    const int sel_arr = edge ? kBitSelE : kBitSelS;
+    uint64_t A[kWaveChunks], SEL[kWaveChunks];
+    uint32_t Hp[kWaveChunks];
+    uint64_t any = 0;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      A[k] = 0; SEL[k] = 0; Hp[k] = 0;
+      if (k < K) {
+        const int q = 64 * k + lane;
+        const double c0 = U.c[q < span ? q : span - 1];
+        uint64_t cd;
+        if (edge) {
+          // label.hpp:80-82; the slab is 0 outside the block and the threshold is > 0 (validated)
+          cd = bal(c0 >= prm.edge_thr);
+        } else {
+          // label.hpp:119-121: in the block and still Default, i.e. not reached by an edge pick
+          cd = in_span(q, qb0, qb1) & bal(c0 <= prm.surf_thr) & ~bal((get_win(U, kBitSelE, k, W0) & reach[k]) != 0u);
+        }
+        A[k] = cd;
+        put_word(U, kBitA, k, cd);
+        any |= cd;
+      }
+    }
+    if (any == 0ull) {continue;}
+    // priority masks: which candidates in reach are visited first; bit 16 = the position itself
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K && A[k] != 0ull) {
+        const uint32_t m = get_win(U, kBitA, k, W0) & reach[k] & ~(1u << 16);
+        Hp[k] = ((edge ? ~lt[k] : lt[k]) & m) | (1u << 16);
+      }
+    }
+    // rounds: a live candidate with no live candidate of higher priority in reach is picked;
+    // everything a pick reaches (the pick included) leaves the live set
+    for (;; ) {
+      uint64_t S[kWaveChunks + 2];
+      uint64_t picked = 0, left = 0;
+      S[0] = 0; S[kWaveChunks + 1] = 0;
+#pragma unroll
+      for (int k = 0; k < kWaveChunks; k++) {
+        S[k + 1] = 0;
+        if (k < K) {
+          if (A[k] != 0ull) {S[k + 1] = bal((get_win(U, kBitA, k, W0) & Hp[k]) == (1u << 16));}
+          put_word(U, kBitS, k, S[k + 1]);
+          SEL[k] |= S[k + 1];
+          picked |= S[k + 1];
+        }
+      }
+      // With a total order the live candidate of highest priority is always picked.  No pick at all
+      // means the order is inconsistent (NaN curvature from non-finite input): stop instead of spinning.
+      if (picked == 0ull) {break;}
+#pragma unroll
+      for (int k = 0; k < kWaveChunks; k++) {
+        if (k < K) {
+          if ((S[k] | S[k + 1] | S[k + 2]) != 0ull) {
+            A[k] &= ~bal((get_win(U, kBitS, k, W0) & reach[k]) != 0u);
+            put_word(U, kBitA, k, A[k]);
+          }
+          left |= A[k];
+        }
+      }
+      if (left == 0ull) {break;}
+    }
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      if (k < K) {put_word(U, sel_arr, k, SEL[k]);}
+    }
+  }
+  // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
+  uint64_t pby[kWaveChunks];
+  {
+    uint64_t pbu[kWaveChunks];
+    uint64_t any_uns = 0;
+    // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
+    // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
+    // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
+    // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
+    const bool ratio_ok = prm.pb_ratio_f >= 0x1p-9f;
+#pragma unroll
+    for (int k = 0; k < kWaveChunks; k++) {
+      pby[k] = 0; pbu[k] = 0;
+      if (k < K && !(dbg_flags & 512u)) {
         const int q = 64 * k + lane;
         const int qm = q > 0 ? q - 1 : 0;
-        const double ri = U.r[q];
-        const float ratio1 = (float)(fabs(U.r[qm] - ri) / ri);
-        const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
-        pb_yes |= (((double)ratio1 > prm.pb_ratio && (double)ratio2 > prm.pb_ratio) ? 1u : 0u) << k;
+        const float rf = (float)U.r[q], rmf = (float)U.r[qm], rpf = (float)U.r[q + 1];
+        const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
+        const float thr = prm.pb_ratio_f * rf;
+        const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
+        const uint64_t guard = ratio_ok ? (bal(rf > 0.f) & bal(rf < 1e30f)) : 0ull;
+        const uint64_t y1 = bal(a1 > hi_t) & guard, n1 = bal(a1 < lo_t) & guard;
+        const uint64_t y2 = bal(a2 > hi_t) & guard, n2 = bal(a2 < lo_t) & guard;
+        const uint64_t u1 = ~(y1 | n1), u2 = ~(y2 | n2);
+        // i in [1, N-1) and owned
+        const uint64_t valid = in_span(q, 1 - g0, N - 1 - g0) & in_span(q, qo0, qo1);
+        pby[k] = y1 & ~n1 & y2 & ~n2 & valid;
+        pbu[k] = ((u1 & ~n2) | (u2 & ~n1)) & valid;
+        any_uns |= pbu[k];
+      }
+    }
+    if (any_uns != 0ull) {
+#pragma unroll
+      for (int k = 0; k < kWaveChunks; k++) {
+        if (k < K && pbu[k] != 0ull) {
+          const int q = 64 * k + lane;
+          const int qm = q > 0 ? q - 1 : 0;
+          const double ri = U.r[q];
+          const float ratio1 = (float)(fabs(U.r[qm] - ri) / ri);
+          const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
+          pby[k] |= pbu[k] & bal((double)ratio1 > prm.pb_ratio) & bal((double)ratio2 > prm.pb_ratio);
+        }
       }
     }
   }
@@ -1445,28 +1551,31 @@ __device__ inline void unit_body(
   for (int k = 0; k < kWaveChunks; k++) {
     if (k < K) {
       const int q = 64 * k + lane, i = g0 + q;
-      const bool own = (owned >> k) & 1u;
+      const bool own = lanes(in_span(q, qo0, qo1));
+      const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
       uint8_t l = kDefault;
-      l = ((covE >> k) & 1u) ? (uint8_t)kEdgeNeighbor : l;
-      l = ((covS >> k) & 1u) ? (uint8_t)kSurfaceNeighbor : l;
-      l = ((selS >> k) & 1u) ? (uint8_t)kSurface : l;
-      l = ((selE >> k) & 1u) ? (uint8_t)kEdge : l;
-      l = ((occ >> k) & 1u) ? (uint8_t)kOccluded : l;
+      l = (wE & reach[k]) != 0u ? (uint8_t)kEdgeNeighbor : l;
+      l = (wS & reach[k]) != 0u ? (uint8_t)kSurfaceNeighbor : l;
+      l = (wS & (1u << 16)) != 0u ? (uint8_t)kSurface : l;
+      l = (wE & (1u << 16)) != 0u ? (uint8_t)kEdge : l;
+      l = lanes(occ[k]) ? (uint8_t)kOccluded : l;
       const double ri = U.r[q];
       l = !(prm.min_range <= ri && ri <= prm.max_range) ? (uint8_t)kOutOfRange : l;        // range.hpp:40-43
-      l = ((pb_yes >> k) & 1u) ? (uint8_t)kParallelBeam : l;
+      l = lanes(pby[k]) ? (uint8_t)kParallelBeam : l;
       l = own ? l : (uint8_t)kDefault;
-      const double cv = U.c[kSlabPad + q];
+      const double cv = U.c[q];
       if (own) {
         label_s[off + i] = l;
         curv_s[off + i] = cv;
       }
-      const uint64_t fe = __ballot(l == kEdge), fs = __ballot(l == kSurface);
-      if ((l == kEdge || l == kSurface) && !(dbg_flags & 1024u)) {
+      const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
+      if (lanes(fe | fs) && !(dbg_flags & 1024u)) {
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
         const float2 xy = sxy[off + i];
         const float4 rec = make_float4(xy.x, xy.y, sz[off + i], (float)cv);
-        const size_t at = l == kEdge ? off + o0 + pe + ubelow(fe, lane) : off + o1 - 1 - (ps + ubelow(fs, lane));
+        const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
+        const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
+        const size_t at = l == kEdge ? off + o0 + pe + be : off + o1 - 1 - (ps + bs);
         rec_pts[at] = rec;
         rec_idx[at] = sidx[off + i];
       }
@@ -1498,9 +1607,12 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   const uint32_t * __restrict__ redo_count, const uint32_t * __restrict__ redo_list)
 {
   __shared__ UnitLds lds[kUnitWaves];
-  UnitLds & U = lds[threadIdx.x >> 6];
+  // the wave index is the same in all 64 lanes: saying so keeps everything derived from it (unit,
+  // ring length, block boundaries, chunk count) in scalar registers and its branches scalar
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  UnitLds & U = lds[wave];
   const uint32_t B = (uint32_t)prm.B;
-  uint32_t u = blockIdx.x * kUnitWaves + (threadIdx.x >> 6);
+  uint32_t u = blockIdx.x * kUnitWaves + wave;
   uint32_t s, slot;
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
