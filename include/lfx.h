@@ -55,7 +55,8 @@ typedef struct lfx_layout {
 typedef struct lfx_config {
   uint32_t max_points_per_scan;   /* capacity of one scan                                   */
   uint32_t max_batch;             /* scans per lfx_extract_batch* call                      */
-  uint32_t max_points_per_ring;   /* 0 = LFX_MAX_RING_POINTS; rounded up to a power of two  */
+  uint32_t max_points_per_ring;   /* 0 = LFX_MAX_RING_POINTS; rounded up to a multiple of 64.  The sensor's real
+                                   * column count here lets the ring kernel run its smallest (fastest) variant */
   uint32_t max_rings;             /* ring ids are 0 .. max_rings-1 (a sensor's ring count); 0 = 256 */
   uint32_t drop_zero_points;      /* 1: points with x = y = z = 0 are not part of the scan -- the filter the
                                    * upstream converter applies (point_type_converter/convert.py:162-163,192) */

@@ -96,6 +96,7 @@ struct lfx_ctx
   size_t total_cap = 0, ring_lds = 0, order_lds = 0;
   uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
   uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
+  uint32_t unit_chunks = 6;              // chunks of 64 positions per unit wave (3..6), from the configured ring length
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
   bool single_pass = true;               // look-back bucketing; LFX_DEBUG_TWO_PASS selects histogram + scan + scatter
@@ -306,7 +307,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 3, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
-      hipLaunchKernelGGL(lfx::ring_unit_kernel<false>, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
+      auto kern = &lfx::ring_unit_kernel<false, 6>;
+      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<false, 5>;}
+      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<false, 4>;}
+      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3>;}
+      hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p,
         c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p,
@@ -322,7 +327,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 5, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B * batch;
-      hipLaunchKernelGGL(lfx::ring_unit_kernel<true>, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves),
+      auto kern = &lfx::ring_unit_kernel<true, 6>;
+      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<true, 5>;}
+      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<true, 4>;}
+      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<true, 3>;}
+      hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p,
         c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p,
@@ -539,6 +548,16 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   }
   c->max_rings = config->max_rings ? (config->max_rings > lfx::kRings ? lfx::kRings : config->max_rings) : lfx::kRings;
   c->ring_threads = ring_threads_for(c->cap);
+  {
+    // longest span (owned positions + halo) a unit of a ring of `ring_cap` points can have:
+    // block <= ceil((N - 2P) / B) + 1, plus a border of P for the first / last unit, plus 2 (P + 1) halo
+    const int P = c->dev.P, B = c->dev.B, N = (int)ring_cap;
+    const int span = (N - 2 * P + B - 1) / B + 1 + 3 * P + 2;
+    const int ch = (span + 63) / 64;
+    c->unit_chunks = (uint32_t)(ch < 3 ? 3 : (ch > 6 ? 6 : ch));
+    if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_CHUNKS")) {c->unit_chunks = (uint32_t)std::atoi(dbg);}
+    if (c->unit_chunks < 3 || c->unit_chunks > 6) {c->unit_chunks = 6;}
+  }
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
   c->single_pass = std::getenv("LFX_DEBUG_TWO_PASS") == nullptr;

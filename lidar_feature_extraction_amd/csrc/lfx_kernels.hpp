@@ -1109,17 +1109,22 @@ enum { kDeferOrder = 1u, kDeferOther = 2u, kDeferMask = 3u, kRingSorted = 4u /* 
 // read and one v_alignbit -- the words live neither in scalar registers (there are too few) nor in
 // four selects per window.
 enum { kBitLK, kBitJL, kBitJR, kBitA, kBitS, kBitSelE, kBitSelS, kUnitBitArrays };
-constexpr int kBitWords = 2 * (kWaveChunks + 2);      // dwords per array; position p is bit p + 64
 
+// CH = chunks of 64 positions a unit may span (block + halo); the host picks the smallest that fits
+// the longest ring it was configured for: less LDS and fewer registers per wave = more waves per CU.
+template<int CH>
 struct UnitLds
 {
-  double r[kUnitSpan];
+  static constexpr int kSpan = 64 * CH;
+  static constexpr int kBitWords = 2 * (CH + 2);      // dwords per array; position p is bit p + 64
+  double r[kSpan];
   union {
-    double c[kUnitSpan + 2];                                      // from stage E on
-    struct {float x[kUnitSpan + 2]; float y[kUnitSpan + 2];} p;   // stages A-C
+    double c[kSpan + 2];                                      // from stage E on
+    struct {float x[kSpan + 2]; float y[kSpan + 2];} p;       // stages A-C
   };
   uint32_t bits[kUnitBitArrays][kBitWords];
 };
+constexpr int unit_waves_per_simd(int ch) {return ch >= 6 ? 6 : (ch == 5 ? 7 : 8);}
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
 // lane's LDS read above another lane's LDS write of the same wave.
@@ -1159,13 +1164,15 @@ struct UnitWin
   uint32_t ofs, sh;      // dword offset of the window's first dword inside a chunk pair; bit shift
 };
 
-__device__ inline void put_word(UnitLds & U, int arr, int k, uint64_t w)
+template<int CH>
+__device__ inline void put_word(UnitLds<CH> & U, int arr, int k, uint64_t w)
 {
   *reinterpret_cast<uint64_t *>(&U.bits[arr][2 * (k + 1)]) = w;
 }
 
 // bit 16 + d of the result <-> position q + d of array `arr`, q = 64k + lane (+1 for the shifted constants)
-__device__ inline uint32_t get_win(const UnitLds & U, int arr, int k, const UnitWin & w)
+template<int CH>
+__device__ inline uint32_t get_win(const UnitLds<CH> & U, int arr, int k, const UnitWin & w)
 {
   const uint32_t * b = &U.bits[arr][2 * k + w.ofs];
   return __builtin_amdgcn_alignbit(b[1], b[0], w.sh);
@@ -1184,9 +1191,9 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
   return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
 }
 
-template<int PT>
+template<int PT, int CH>
 __device__ inline void unit_body(
-  const Params & prm, UnitLds & U, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
+  const Params & prm, UnitLds<CH> & U, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
@@ -1219,7 +1226,7 @@ __device__ inline void unit_body(
   const int b0 = block_boundary(N, P, B, j), b1 = block_boundary(N, P, B, j + 1);
   const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? N : b1;
   const int H = P + 1, g0 = o0 - H, span = o1 + H - g0;
-  if (b1 - b0 < 2 || span > kUnitSpan) {LFX_DEFER(kDeferOther);}
+  if (b1 - b0 < 2 || span > (64 * CH)) {LFX_DEFER(kDeferOther);}
   const int K = (span + 63) >> 6;
   const int qb0 = b0 - g0, qb1 = b1 - g0;          // the block in span coordinates
   const int qo0 = o0 - g0, qo1 = o1 - g0;          // the owned positions
@@ -1232,13 +1239,13 @@ __device__ inline void unit_body(
   {
     uint32_t * z = &U.bits[0][0];
     z[lane] = 0u;
-    if (lane + 64 < kUnitBitArrays * kBitWords) {z[lane + 64] = 0u;}
-    static_assert(kUnitBitArrays * kBitWords <= 128, "two stores per lane zero the bit arrays");
+    if (lane + 64 < kUnitBitArrays * UnitLds<CH>::kBitWords) {z[lane + 64] = 0u;}
+    static_assert(kUnitBitArrays * UnitLds<CH>::kBitWords <= 128, "two stores per lane zero the bit arrays");
   }
-  float x[kWaveChunks], y[kWaveChunks];
-  double r[kWaveChunks];
+  float x[CH], y[CH];
+  double r[CH];
 #pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
+  for (int k = 0; k < CH; k++) {
     x[k] = 0.f; y[k] = 0.f; r[k] = 0.;
     if (k < K) {
       const int q = 64 * k + lane;
@@ -1258,7 +1265,7 @@ __device__ inline void unit_body(
   const int pair_end = qo1 < qhi - 1 ? qo1 : qhi - 1;                  // owned pairs (q, q+1): q in [qo0, pair_end)
   uint64_t bad = 0;
 #pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
+  for (int k = 0; k < CH; k++) {
     if (k < K) {
       const int q = 64 * k + lane;
       const float xn = U.p.x[q + 1], yn = U.p.y[q + 1];
@@ -1274,7 +1281,7 @@ __device__ inline void unit_body(
     // re-evaluate with the full predicate: a special case is not necessarily out of order
     bool really = false;
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       if (k < K) {
         const int q = 64 * k + lane;
         const bool pair = q >= qo0 && q < pair_end;
@@ -1287,11 +1294,11 @@ __device__ inline void unit_body(
   // ---- C. links (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the
   //         occlusion test (occlusion.hpp:44-57, 67-79)
   {
-    uint64_t lky[kWaveChunks], uns[kWaveChunks];
+    uint64_t lky[CH], uns[CH];
     uint64_t zero_pair = 0, any_uns = 0;
     const float cbf = prm.cos_bound_f;
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       lky[k] = 0; uns[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
@@ -1315,7 +1322,7 @@ __device__ inline void unit_body(
     }
     if (any_uns != 0ull) {
 #pragma unroll
-      for (int k = 0; k < kWaveChunks; k++) {
+      for (int k = 0; k < CH; k++) {
         if (k < K && uns[k] != 0ull) {
           const int q = 64 * k + lane;
           const double rn = U.r[q + 1];
@@ -1328,7 +1335,7 @@ __device__ inline void unit_body(
     if (zero_pair != 0ull) {LFX_DEFER(kDeferOther);}
     uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       if (k < K) {
         const int q = 64 * k + lane;
         put_word(U, kBitLK, k, lky[k]);
@@ -1348,10 +1355,10 @@ __device__ inline void unit_body(
     }
   }
   // ---- D. occlusion fills (occlusion.hpp:37-91) and the reach of a pick inside the block (fill.hpp:101-117)
-  uint64_t occ[kWaveChunks];
-  uint32_t reach[kWaveChunks];
+  uint64_t occ[CH];
+  uint32_t reach[CH];
 #pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
+  for (int k = 0; k < CH; k++) {
     reach[k] = 0;
     occ[k] = 0;
     if (k < K) {
@@ -1375,11 +1382,11 @@ __device__ inline void unit_body(
   LFX_WAVE_SYNC();        // the x / y slab is dead from here on: the curvature slab takes its place
   // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
 #pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
+  for (int k = 0; k < CH; k++) {
     if (k < K) {
       const int q = 64 * k + lane;
       int qq = q < P ? P : q;                                            // keep the window inside the slab
-      qq = qq > 64 * kWaveChunks - 1 - P ? 64 * kWaveChunks - 1 - P : qq;
+      qq = qq > 64 * CH - 1 - P ? 64 * CH - 1 - P : qq;
       double sum = 0.;                                                   // math.hpp:46-52: left to right from 0
       if (PT > 0) {
 #pragma unroll
@@ -1398,12 +1405,12 @@ __device__ inline void unit_body(
   }
   LFX_WAVE_SYNC();
   // ---- F. block labelling (label.hpp:61-139): edge pass, then surface pass over what is still Default
-  uint32_t lt[kWaveChunks];
+  uint32_t lt[CH];
   {
     // order masks, see order_masks(); the slab has no pad here: neighbours are read at clamped
     // positions, and what a clamped read yields is masked by `reach` (zero outside the block)
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       lt[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
@@ -1434,11 +1441,11 @@ __device__ inline void unit_body(
     const bool edge = pass == 0;
     if (!(dbg_flags & (edge ? 1u : 64u))) {continue;}
     const int sel_arr = edge ? kBitSelE : kBitSelS;
-    uint64_t A[kWaveChunks], SEL[kWaveChunks];
-    uint32_t Hp[kWaveChunks];
+    uint64_t A[CH], SEL[CH];
+    uint32_t Hp[CH];
     uint64_t any = 0;
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       A[k] = 0; SEL[k] = 0; Hp[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
@@ -1459,7 +1466,7 @@ __device__ inline void unit_body(
     if (any == 0ull) {continue;}
     // priority masks: which candidates in reach are visited first; bit 16 = the position itself
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       if (k < K && A[k] != 0ull) {
         const uint32_t m = get_win(U, kBitA, k, W0) & reach[k] & ~(1u << 16);
         Hp[k] = ((edge ? ~lt[k] : lt[k]) & m) | (1u << 16);
@@ -1468,11 +1475,11 @@ __device__ inline void unit_body(
     // rounds: a live candidate with no live candidate of higher priority in reach is picked;
     // everything a pick reaches (the pick included) leaves the live set
     for (;; ) {
-      uint64_t S[kWaveChunks + 2];
+      uint64_t S[CH + 2];
       uint64_t picked = 0, left = 0;
-      S[0] = 0; S[kWaveChunks + 1] = 0;
+      S[0] = 0; S[CH + 1] = 0;
 #pragma unroll
-      for (int k = 0; k < kWaveChunks; k++) {
+      for (int k = 0; k < CH; k++) {
         S[k + 1] = 0;
         if (k < K) {
           if (A[k] != 0ull) {S[k + 1] = bal((get_win(U, kBitA, k, W0) & Hp[k]) == (1u << 16));}
@@ -1485,7 +1492,7 @@ __device__ inline void unit_body(
       // means the order is inconsistent (NaN curvature from non-finite input): stop instead of spinning.
       if (picked == 0ull) {break;}
 #pragma unroll
-      for (int k = 0; k < kWaveChunks; k++) {
+      for (int k = 0; k < CH; k++) {
         if (k < K) {
           if ((S[k] | S[k + 1] | S[k + 2]) != 0ull) {
             A[k] &= ~bal((get_win(U, kBitS, k, W0) & reach[k]) != 0u);
@@ -1497,14 +1504,14 @@ __device__ inline void unit_body(
       if (left == 0ull) {break;}
     }
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       if (k < K) {put_word(U, sel_arr, k, SEL[k]);}
     }
   }
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
-  uint64_t pby[kWaveChunks];
+  uint64_t pby[CH];
   {
-    uint64_t pbu[kWaveChunks];
+    uint64_t pbu[CH];
     uint64_t any_uns = 0;
     // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
     // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
@@ -1512,7 +1519,7 @@ __device__ inline void unit_body(
     // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
     const bool ratio_ok = prm.pb_ratio_f >= 0x1p-9f;
 #pragma unroll
-    for (int k = 0; k < kWaveChunks; k++) {
+    for (int k = 0; k < CH; k++) {
       pby[k] = 0; pbu[k] = 0;
       if (k < K && !(dbg_flags & 512u)) {
         const int q = 64 * k + lane;
@@ -1534,7 +1541,7 @@ __device__ inline void unit_body(
     }
     if (any_uns != 0ull) {
 #pragma unroll
-      for (int k = 0; k < kWaveChunks; k++) {
+      for (int k = 0; k < CH; k++) {
         if (k < K && pbu[k] != 0ull) {
           const int q = 64 * k + lane;
           const int qm = q > 0 ? q - 1 : 0;
@@ -1548,7 +1555,7 @@ __device__ inline void unit_body(
   }
   uint32_t pe = 0, ps = 0;
 #pragma unroll
-  for (int k = 0; k < kWaveChunks; k++) {
+  for (int k = 0; k < CH; k++) {
     if (k < K) {
       const int q = 64 * k + lane, i = g0 + q;
       const bool own = lanes(in_span(q, qo0, qo1));
@@ -1596,8 +1603,8 @@ __device__ inline void unit_body(
 // SECOND = false: first pass, grid = (units of a scan / 4, batch); rings it cannot take go on
 // `defer_list` with the reason.  SECOND = true: second pass over the rings ring_order_kernel
 // repaired (redo_list, grid-stride); what still cannot be taken goes on the slow list.
-template<bool SECOND>
-__global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
+template<bool SECOND, int CH>
+__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
@@ -1606,11 +1613,11 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list,
   const uint32_t * __restrict__ redo_count, const uint32_t * __restrict__ redo_list)
 {
-  __shared__ UnitLds lds[kUnitWaves];
+  __shared__ UnitLds<CH> lds[kUnitWaves];
   // the wave index is the same in all 64 lanes: saying so keeps everything derived from it (unit,
   // ring length, block boundaries, chunk count) in scalar registers and its branches scalar
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  UnitLds & U = lds[wave];
+  UnitLds<CH> & U = lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
   uint32_t s, slot;
@@ -1628,13 +1635,13 @@ __global__ __launch_bounds__(64 * kUnitWaves, 6) void ring_unit_kernel(
   }
   const int j = (int)(u % B);
   if (prm.P == 5) {
-    unit_body<5>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
+    unit_body<5, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
   } else if (prm.P == 2) {
-    unit_body<2>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
+    unit_body<2, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
   } else {
-    unit_body<0>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
+    unit_body<0, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
       rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
   }
 }
