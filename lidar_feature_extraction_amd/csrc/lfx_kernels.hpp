@@ -1242,17 +1242,23 @@ __device__ inline void unit_body(
     if (lane + 64 < kUnitBitArrays * UnitLds<CH>::kBitWords) {z[lane + 64] = 0u;}
     static_assert(kUnitBitArrays * UnitLds<CH>::kBitWords <= 128, "two stores per lane zero the bit arrays");
   }
-  float x[CH], y[CH];
+  // z and the original index are only needed for the feature records at the very end; loaded here,
+  // with x and y, their latency hides behind the whole computation instead of ending it (registers
+  // are not what limits the waves per CU of this kernel, LDS is)
+  float x[CH], y[CH], z[CH];
+  uint32_t src[CH];
   double r[CH];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
-    x[k] = 0.f; y[k] = 0.f; r[k] = 0.;
+    x[k] = 0.f; y[k] = 0.f; z[k] = 0.f; src[k] = 0u; r[k] = 0.;
     if (k < K) {
       const int q = 64 * k + lane;
       int i = g0 + q;
       const bool in = lanes(in_span(q, qlo, qhi));
       i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
       const float2 v = sxy[off + i];
+      z[k] = sz[off + i];
+      src[k] = sidx[off + i];
       x[k] = in ? v.x : 0.f;
       y[k] = in ? v.y : 0.f;
       U.p.x[q] = x[k];
@@ -1355,12 +1361,12 @@ __device__ inline void unit_body(
     }
   }
   // ---- D. occlusion fills (occlusion.hpp:37-91) and the reach of a pick inside the block (fill.hpp:101-117)
-  uint64_t occ[CH];
+  uint32_t over[CH];            // label that overrides the block labelling (masks, feature_extraction.cpp:135-138)
   uint32_t reach[CH];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
     reach[k] = 0;
-    occ[k] = 0;
+    over[k] = kDefault;
     if (k < K) {
       const int q = 64 * k + lane;
       const uint32_t lw = get_win(U, kBitLK, k, W0);
@@ -1371,7 +1377,7 @@ __device__ inline void unit_body(
       const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
       const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
       if (!(dbg_flags & 256u)) {
-        occ[k] = bal(((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u);
+        over[k] = ((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u ? (uint32_t)kOccluded : (uint32_t)kDefault;
       }
       // inside the block the links are cut at its ends (label.hpp:157-159): clamp the runs
       const int Lb = Lr < q - qb0 ? Lr : q - qb0;
@@ -1565,10 +1571,11 @@ __device__ inline void unit_body(
       l = (wS & reach[k]) != 0u ? (uint8_t)kSurfaceNeighbor : l;
       l = (wS & (1u << 16)) != 0u ? (uint8_t)kSurface : l;
       l = (wE & (1u << 16)) != 0u ? (uint8_t)kEdge : l;
-      l = lanes(occ[k]) ? (uint8_t)kOccluded : l;
       const double ri = U.r[q];
-      l = !(prm.min_range <= ri && ri <= prm.max_range) ? (uint8_t)kOutOfRange : l;        // range.hpp:40-43
-      l = lanes(pby[k]) ? (uint8_t)kParallelBeam : l;
+      uint32_t ov = over[k];
+      ov = !(prm.min_range <= ri && ri <= prm.max_range) ? (uint32_t)kOutOfRange : ov;      // range.hpp:40-43
+      ov = lanes(pby[k]) ? (uint32_t)kParallelBeam : ov;
+      l = ov != kDefault ? (uint8_t)ov : l;
       l = own ? l : (uint8_t)kDefault;
       const double cv = U.c[q];
       if (own) {
@@ -1578,13 +1585,12 @@ __device__ inline void unit_body(
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
       if (lanes(fe | fs) && !(dbg_flags & 1024u)) {
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-        const float2 xy = sxy[off + i];
-        const float4 rec = make_float4(xy.x, xy.y, sz[off + i], (float)cv);
+        const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
         const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
         const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
         const size_t at = l == kEdge ? off + o0 + pe + be : off + o1 - 1 - (ps + bs);
         rec_pts[at] = rec;
-        rec_idx[at] = sidx[off + i];
+        rec_idx[at] = src[k];
       }
       pe += __popcll(fe);
       ps += __popcll(fs);
