@@ -115,6 +115,7 @@ struct lfx_ctx
   DevBuf<float> sz;
   DevBuf<double> curv_s;
   DevBuf<float4> edge_pts, surf_pts, rec_pts;
+  DevBuf<lfx::UnitTables> unit_tab;      // the unit kernel's output pointers (one element)
 
   hipStream_t stream = nullptr;          // used by the synchronous host entry points
   std::vector<uint32_t> h_scan_begin;    // of the last batch
@@ -313,9 +314,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3>;}
       hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p,
-        c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p,
-        c->ring_flags.p, defer_count, c->defer_list.p, no_list, no_list);
+        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
+        defer_count, c->defer_list.p, no_list, no_list);
     }
     {
       // rings out of angle order: repaired in place, then a second pass of the unit kernel over them
@@ -333,9 +333,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<true, 3>;}
       hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p,
-        c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p,
-        c->ring_flags.p, slow_count, c->slow_list.p, redo_count, c->redo_list.p);
+        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
+        slow_count, c->slow_list.p, redo_count, c->redo_list.p);
     }
   }
   {
@@ -592,6 +591,12 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->label_s.alloc(rc)); ok(c->curv_s.alloc(rc));
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
+  ok(c->unit_tab.alloc(1));
+  if (e == hipSuccess) {
+    const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
+      c->unit_ns.p, c->unit_span.p, c->ring_flags.p};
+    e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_extract_kernel),
@@ -626,6 +631,7 @@ void lfx_destroy(lfx_ctx * c)
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
   c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
+  c->unit_tab.release();
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
   if (c->stream) {(void)hipStreamDestroy(c->stream);}

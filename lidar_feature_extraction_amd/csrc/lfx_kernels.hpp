@@ -1191,29 +1191,39 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
   return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
 }
 
+// Output tables of the unit kernel, read through one pointer: sixteen kernel-argument pointers held in
+// scalar registers from the first instruction on crowd out the wave-uniform masks the kernel works
+// with (the scalar file is the scarce one here).  The entries are fetched where they are first needed.
+struct UnitTables
+{
+  uint8_t * label_s;
+  double * curv_s;
+  float4 * rec_pts;
+  uint32_t * rec_idx;
+  uint8_t * ring_status;
+  uint32_t * unit_ne, * unit_ns, * unit_span;
+  uint32_t * ring_flags;
+};
+
 template<int PT, int CH>
 __device__ inline void unit_body(
   const Params & prm, UnitLds<CH> & U, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
-  const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
-  float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
-  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span,
-  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list,
-  bool second_pass)
+  const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
+  uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list, bool second_pass)
 {
   const int lane = threadIdx.x & 63;
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
   const int N = (int)ring_count[s * kRings + slot];
   if (N == 0) {return;}                                  // no such ring in this scan
   const size_t off = ring_base(s, slot, max_rings, ring_cap);
-  uint32_t * flag = ring_flags + s * kRings + slot;
   // A deferred ring goes on `defer_list` once (the first unit to flag it appends it); the flag keeps
   // the reasons: kDeferOrder = not angle-sorted as bucketed (ring_order_kernel repairs that and the
   // ring gets a second pass here), kDeferOther = anything only the workgroup-per-ring kernel handles.
 #define LFX_DEFER(reason) \
   do { \
-    if (lane == 0 && (atomicOr(flag, (reason)) & kDeferMask) == 0u) { \
+    if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
       defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
     } \
     return; \
@@ -1223,7 +1233,9 @@ __device__ inline void unit_body(
     if (j == 0) {LFX_DEFER(kDeferOther);}
     return;
   }
-  const int b0 = block_boundary(N, P, B, j), b1 = block_boundary(N, P, B, j + 1);
+  // both boundaries from one evaluation of the f64 formula: even lanes take j, odd lanes j + 1
+  const int bj = block_boundary(N, P, B, j + (lane & 1));
+  const int b0 = __builtin_amdgcn_readlane(bj, 0), b1 = __builtin_amdgcn_readlane(bj, 1);
   const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? N : b1;
   const int H = P + 1, g0 = o0 - H, span = o1 + H - g0;
   if (b1 - b0 < 2 || span > (64 * CH)) {LFX_DEFER(kDeferOther);}
@@ -1560,6 +1572,11 @@ __device__ inline void unit_body(
     }
   }
   uint32_t pe = 0, ps = 0;
+  asm volatile ("" ::: "memory");          // the table entries are not to be fetched (and held) any earlier
+  uint8_t * __restrict__ label_s = tab->label_s;
+  double * __restrict__ curv_s = tab->curv_s;
+  float4 * __restrict__ rec_pts = tab->rec_pts;
+  uint32_t * __restrict__ rec_idx = tab->rec_idx;
 #pragma unroll
   for (int k = 0; k < CH; k++) {
     if (k < K) {
@@ -1598,10 +1615,10 @@ __device__ inline void unit_body(
   }
   if (lane == 0) {
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
-    unit_ne[ui] = pe;
-    unit_ns[ui] = ps;
-    unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
-    if (j == 0) {ring_status[s * kRings + slot] = kOk;}
+    tab->unit_ne[ui] = pe;
+    tab->unit_ns[ui] = ps;
+    tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
+    if (j == 0) {tab->ring_status[s * kRings + slot] = kOk;}
   }
 #undef LFX_DEFER
 }
@@ -1613,10 +1630,8 @@ template<bool SECOND, int CH>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
-  const uint32_t * __restrict__ sidx, uint8_t * __restrict__ label_s, double * __restrict__ curv_s,
-  float4 * __restrict__ rec_pts, uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status,
-  uint32_t * __restrict__ unit_ne, uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span,
-  uint32_t * __restrict__ ring_flags, uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list,
+  const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
+  uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list,
   const uint32_t * __restrict__ redo_count, const uint32_t * __restrict__ redo_list)
 {
   __shared__ UnitLds<CH> lds[kUnitWaves];
@@ -1641,14 +1656,14 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   }
   const int j = (int)(u % B);
   if (prm.P == 5) {
-    unit_body<5, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
+    unit_body<5, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      defer_list, SECOND);
   } else if (prm.P == 2) {
-    unit_body<2, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
+    unit_body<2, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      defer_list, SECOND);
   } else {
-    unit_body<0, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, label_s, curv_s,
-      rec_pts, rec_idx, ring_status, unit_ne, unit_ns, unit_span, ring_flags, defer_count, defer_list, SECOND);
+    unit_body<0, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      defer_list, SECOND);
   }
 }
 
