@@ -1206,7 +1206,7 @@ struct UnitTables
 };
 
 template<int PT, int CH>
-__device__ inline void unit_body(
+__device__ __forceinline__ void unit_body(
   const Params & prm, UnitLds<CH> & U, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
