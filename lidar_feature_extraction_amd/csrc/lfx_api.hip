@@ -888,3 +888,16 @@ int lfx_kernel_times(lfx_ctx * c, double ms[LFX_N_KERNELS], uint64_t launches[LF
 }
 
 }  // extern "C"
+
+#ifdef LFX_STAMPS
+// Diagnostic build only: copy the unit kernel's stage stamps (see LFX_STAMP) to the host.
+extern "C" int lfx_debug_read_stamps(unsigned long long * out, int n)
+{
+  const int total = lfx::kStampUnits * lfx::kStampSlots;
+  if (!out || n < total) {return -total;}
+  if (hipDeviceSynchronize() != hipSuccess) {return LFX_ERR_HIP;}
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lfx::g_unit_stamps), sizeof(unsigned long long) * total) != hipSuccess) {return LFX_ERR_HIP;}
+  return total;
+}
+#endif
+

@@ -1191,6 +1191,26 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
   return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
 }
 
+// Diagnostic build only (-DLFX_STAMPS): shader-clock stamps at the stage boundaries of the unit kernel,
+// kept for the first kStampUnits units of scan LFX_STAMP_SCAN; read back with lfx_debug_read_stamps.  The product
+// build executes none of this.
+#ifdef LFX_STAMPS
+#ifndef LFX_STAMP_SCAN
+#define LFX_STAMP_SCAN 128
+#endif
+constexpr int kStampSlots = 16, kStampUnits = 384;
+__device__ unsigned long long g_unit_stamps[kStampUnits * kStampSlots];
+#define LFX_STAMP(n) \
+  do { \
+    if (s == (uint32_t)LFX_STAMP_SCAN && (uint32_t)(slot * B + j) < (uint32_t)kStampUnits) { \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+      if (lane == 0) {g_unit_stamps[(slot * B + j) * kStampSlots + (n)] = t_;} \
+    } \
+  } while (0)
+#else
+#define LFX_STAMP(n) do {} while (0)
+#endif
+
 // Output tables of the unit kernel, read through one pointer: sixteen kernel-argument pointers held in
 // scalar registers from the first instruction on crowd out the wave-uniform masks the kernel works
 // with (the scalar file is the scarce one here).  The entries are fetched where they are first needed.
@@ -1228,6 +1248,7 @@ __device__ __forceinline__ void unit_body(
     } \
     return; \
   } while (0)
+  LFX_STAMP(0);
   // skip conditions and over-long rings are the slow path's business (it also reports them)
   if (N < 2 * P + 1 || N - 2 * P < B || (uint32_t)N > ring_cap) {
     if (j == 0) {LFX_DEFER(kDeferOther);}
@@ -1247,6 +1268,7 @@ __device__ __forceinline__ void unit_body(
   const UnitWin W0{(uint32_t)(lane + 48) >> 5, (uint32_t)(lane + 16) & 31u};   // window around q
   const UnitWin W1{(uint32_t)(lane + 49) >> 5, (uint32_t)(lane + 17) & 31u};   // window around q + 1
 
+  LFX_STAMP(1);
   // ---- A. load; x, y also to the wave's LDS slab (neighbours are read by position)
   {
     uint32_t * z = &U.bits[0][0];
@@ -1278,6 +1300,7 @@ __device__ __forceinline__ void unit_body(
     }
   }
   LFX_WAVE_SYNC();
+  LFX_STAMP(2);
   // ---- B. angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, else
   //         slow path; range (math.hpp:36-39)
   const int pair_end = qo1 < qhi - 1 ? qo1 : qhi - 1;                  // owned pairs (q, q+1): q in [qo0, pair_end)
@@ -1309,6 +1332,7 @@ __device__ __forceinline__ void unit_body(
     if (__ballot(really) != 0ull) {LFX_DEFER(second_pass ? kDeferOther : kDeferOrder);}
   }
   LFX_WAVE_SYNC();
+  LFX_STAMP(3);
   // ---- C. links (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the
   //         occlusion test (occlusion.hpp:44-57, 67-79)
   {
@@ -1372,6 +1396,7 @@ __device__ __forceinline__ void unit_body(
       }
     }
   }
+  LFX_STAMP(4);
   // ---- D. occlusion fills (occlusion.hpp:37-91) and the reach of a pick inside the block (fill.hpp:101-117)
   uint32_t over[CH];            // label that overrides the block labelling (masks, feature_extraction.cpp:135-138)
   uint32_t reach[CH];
@@ -1398,6 +1423,7 @@ __device__ __forceinline__ void unit_body(
     }
   }
   LFX_WAVE_SYNC();        // the x / y slab is dead from here on: the curvature slab takes its place
+  LFX_STAMP(5);
   // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
 #pragma unroll
   for (int k = 0; k < CH; k++) {
@@ -1422,6 +1448,7 @@ __device__ __forceinline__ void unit_body(
     }
   }
   LFX_WAVE_SYNC();
+  LFX_STAMP(6);
   // ---- F. block labelling (label.hpp:61-139): edge pass, then surface pass over what is still Default
   uint32_t lt[CH];
   {
@@ -1454,9 +1481,11 @@ __device__ __forceinline__ void unit_body(
       }
     }
   }
+  LFX_STAMP(7);
 #pragma unroll
   for (int pass = 0; pass < 2; pass++) {
     const bool edge = pass == 0;
+    if (!edge) {LFX_STAMP(8);}
     if (!(dbg_flags & (edge ? 1u : 64u))) {continue;}
     const int sel_arr = edge ? kBitSelE : kBitSelS;
     uint64_t A[CH], SEL[CH];
@@ -1526,6 +1555,7 @@ __device__ __forceinline__ void unit_body(
       if (k < K) {put_word(U, sel_arr, k, SEL[k]);}
     }
   }
+  LFX_STAMP(9);
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
   uint64_t pby[CH];
   {
@@ -1571,6 +1601,7 @@ __device__ __forceinline__ void unit_body(
       }
     }
   }
+  LFX_STAMP(10);
   uint32_t pe = 0, ps = 0;
   asm volatile ("" ::: "memory");          // the table entries are not to be fetched (and held) any earlier
   uint8_t * __restrict__ label_s = tab->label_s;
@@ -1613,6 +1644,7 @@ __device__ __forceinline__ void unit_body(
       ps += __popcll(fs);
     }
   }
+  LFX_STAMP(11);
   if (lane == 0) {
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
     tab->unit_ne[ui] = pe;

@@ -1,0 +1,37 @@
+"""Diagnostic: where a unit wave's lifetime goes.  Build the kernels with -DLFX_STAMPS
+(make -C lidar_feature_extraction_amd/csrc stamps), run this on the GPU box:
+    LFX_LIB_PATH=$PWD/lidar_feature_extraction_amd/_lib/liblfx_stamps.so python tools_stamps.py
+It runs batches of 64x1800 scans and prints the median shader cycles between consecutive stage
+stamps of the unit kernel (units of scan 0).  Not part of the product or the tests."""
+import ctypes as C
+import numpy as np
+import torch
+from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, concat
+from lidar_feature_extraction_amd import binding as B
+
+NAMES = ["entry->checks", "boundaries", "A load", "B order+range", "C links+jumps", "D occlusion+reach",
+         "E curvature", "F order masks", "F edge pass", "F surface pass", "G parallel beam", "G labels+records"]
+batch, rings, cols = 256, 64, 1800
+clouds = [make_scan(rings, cols, seed=1234 + i) for i in range(8)]
+tiled = [clouds[i % 8] for i in range(batch)]
+d = torch.from_numpy(concat(tiled).view(np.uint8)).cuda()
+n = np.array([len(c) for c in tiled], np.uint32)
+fx = FeatureExtraction(HyperParameters(), device=0, max_points_per_scan=len(clouds[0]), max_batch=batch,
+                       max_points_per_ring=cols, max_rings=rings)
+for _ in range(5):
+    fx.extract_batch_device(d.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+L = B.load()
+L.lfx_debug_read_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+total = 384 * 16
+buf = (C.c_ulonglong * total)()
+assert L.lfx_debug_read_stamps(buf, total) == total
+t = np.frombuffer(buf, dtype=np.uint64).reshape(384, 16).astype(np.int64)
+ok = t[:, 11] > t[:, 0]
+t = t[ok]
+print("units stamped:", len(t))
+life = t[:, 11] - t[:, 0]
+print("lifetime (stamp 0 -> 11): median %d  p10 %d  p90 %d shader cycles" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
+for k in range(11):
+    dt = t[:, k + 1] - t[:, k]
+    print("%-22s median %6d  (%4.1f %%)" % (NAMES[k + 1], np.median(dt), 100.0 * np.median(dt) / np.median(life)))
