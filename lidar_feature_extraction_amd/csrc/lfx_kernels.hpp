@@ -1179,13 +1179,14 @@ __device__ inline uint32_t get_win(const UnitLds<CH> & U, int arr, int k, const 
 }
 
 // Branch-free form of polar_less for the common case, as masks: `spec` = one of the predicate's
-// special cases applies (equal points, a zero point, a point on the x axis) and the full predicate
+// special cases may apply (equal points, a zero point, a point on the x axis) and the full predicate
 // has to be evaluated instead.
 __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float by, uint64_t & spec)
 {
-  const float lena = ax * ax + ay * ay;
-  const float lenb = bx * bx + by * by;
-  spec = (bal(ax == bx) & bal(ay == by)) | bal(lena == 0.f) | bal(lenb == 0.f) | bal(ay == 0.f) | bal(by == 0.f);
+  // a SUPERSET of the special cases is enough (the caller re-evaluates flagged pairs with the full
+  // predicate): |y| < 1e-18 covers y == 0 and every point whose squared length rounds (or flushes) to
+  // zero in f32, which needs |x|, |y| < 1.1e-19
+  spec = (bal(ax == bx) & bal(ay == by)) | bal(fabsf(ay) < 1e-18f) | bal(fabsf(by) < 1e-18f);
   const float det = ax * by - ay * bx;
   const uint64_t same = bal(ay * by > 0.f);
   return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
