@@ -233,6 +233,25 @@ def test_long_blocks_take_the_lds_labelling_path(fx):
     f.close()
 
 
+@pytest.mark.parametrize("chunks", [3, 4, 5, 6])
+def test_every_unit_kernel_variant(chunks):
+    """The wave-per-unit kernel is instantiated for spans of 3..6 chunks of 64 positions and the host picks
+    one from max_points_per_ring; here each variant is forced in turn.  900-column rings fit all of them;
+    1800-column rings do not fit the 3- and 4-chunk variants, whose units then hand the ring to the
+    workgroup-per-ring kernel -- same results either way."""
+    import os
+    clouds = [make_scan(16, 900, seed=80), make_scan(16, 1800, seed=81), make_scan(16, 1500, seed=82, drop_fraction=0.07)]
+    os.environ["LFX_DEBUG_UNIT_CHUNKS"] = str(chunks)
+    try:
+        f = FeatureExtraction(device=0, max_points_per_scan=16 * 1800, max_batch=3, max_rings=16)
+    finally:
+        del os.environ["LFX_DEBUG_UNIT_CHUNKS"]
+    got = f.extract_batch(clouds)
+    for i, c in enumerate(clouds):
+        assert_scan_equal(got[i], OB.extract(c, canonical_ties=False), "chunks%d/%d" % (chunks, i))
+    f.close()
+
+
 @pytest.mark.parametrize("env", ["LFX_DEBUG_TWO_PASS", "LFX_DEBUG_NO_FAST_PATH"])
 def test_fallback_paths_give_the_same_results(env):
     """The two-pass ring bucketing (histogram + scan + scatter) and the workgroup-per-ring kernel for
