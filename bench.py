@@ -205,13 +205,15 @@ def main():
         # the same port with one scan per host thread (the reference itself is single-threaded,
         # feature_extraction.cpp:185; this is the "all host cores" figure of SURVEY.md 8d)
         from concurrent.futures import ThreadPoolExecutor
-        n_thr = max(1, min(len(os.sched_getaffinity(0)), 64))
-        per_thread = max(2, int(done / max(el, 1e-9) * min(a.cpu_seconds, 8.0)))
+        n_thr = max(1, min(len(os.sched_getaffinity(0)), 16))      # a 1-GPU box's CPU share is 16 cores
+        t_end = time.perf_counter() + min(a.cpu_seconds, 8.0)
 
         def work(t):
-            for k in range(per_thread):
+            k = 0
+            while time.perf_counter() < t_end:
                 oracle.extract(clouds[(t + k) % n_unique], canonical_ties=False)
-            return per_thread
+                k += 1
+            return k
         t2 = time.perf_counter()
         with ThreadPoolExecutor(n_thr) as ex:
             total = sum(ex.map(work, range(n_thr)))
