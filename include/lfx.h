@@ -46,11 +46,31 @@ typedef struct lfx_params {
   int32_t n_blocks;                       /*                                default 6    */
 } lfx_params;
 
-/* Where x, y, z (f32) and ring (u16) sit inside one point record.  PointXYZIR is
- * {32, 0, 4, 8, 20} (point_type.hpp:62-86; convert.py:134-145 of point_type_converter). */
+/* sensor_msgs/msg/PointField datatype codes (the upstream converter's table,
+ * point_type_converter/convert.py:41-53). */
+enum lfx_field_type {
+  LFX_FIELD_INT8 = 1, LFX_FIELD_UINT8 = 2, LFX_FIELD_INT16 = 3, LFX_FIELD_UINT16 = 4, LFX_FIELD_INT32 = 5,
+  LFX_FIELD_UINT32 = 6, LFX_FIELD_FLOAT32 = 7, LFX_FIELD_FLOAT64 = 8
+};
+
+/* Where x, y, z (f32) and ring sit inside one point record, as a PointCloud2 describes it.
+ * PointXYZIR is {32, 0, 4, 8, 20, LFX_FIELD_UINT16, 0} (point_type.hpp:62-86; convert.py:134-145 of
+ * point_type_converter).  ring_datatype: any integer PointField type (0 = UINT16; an Ouster driver
+ * publishes UINT8, test_convert.py:42-60); big_endian: the message's is_bigendian flag.  With these
+ * the library reads a driver's cloud directly -- the repack the upstream converter node does on the
+ * CPU (convert.py:183-212) is folded into the bucketing kernel's loads. */
 typedef struct lfx_layout {
   uint32_t point_step, off_x, off_y, off_z, off_ring;
+  uint32_t ring_datatype, big_endian;
 } lfx_layout;
+
+/* One entry of PointCloud2.fields */
+typedef struct lfx_point_field {
+  const char *name;
+  uint32_t offset;
+  uint8_t datatype;               /* lfx_field_type */
+  uint32_t count;
+} lfx_point_field;
 
 typedef struct lfx_config {
   uint32_t max_points_per_scan;   /* capacity of one scan                                   */
@@ -90,7 +110,10 @@ enum lfx_error {
   LFX_ERR_HIP = -3,
   LFX_ERR_CAPACITY = -4,          /* more points / scans than the context was created for     */
   LFX_ERR_RING_ID = -5,           /* a point carries ring > LFX_MAX_RING_ID                    */
-  LFX_ERR_OUT_OF_MEMORY = -6
+  LFX_ERR_OUT_OF_MEMORY = -6,
+  LFX_ERR_NO_RING_FIELD = -7,     /* the cloud has no "ring" field: RingIsAvailable (ring.cpp:36-44) is false and the
+                                   * node shuts down (feature_extraction.cpp:103-108)            */
+  LFX_ERR_UNSUPPORTED_FIELD = -8  /* x / y / z missing or not FLOAT32, ring not an integer, field outside point_step */
 };
 
 typedef struct lfx_ctx lfx_ctx;
@@ -160,6 +183,27 @@ int lfx_extract_batch(lfx_ctx *ctx, const void *const *points, const size_t *n_p
 int lfx_extract_batch_device(lfx_ctx *ctx, const void *d_points, const uint32_t *n_points, uint32_t batch,
                              void *stream);
 int lfx_device_results(const lfx_ctx *ctx, lfx_device_view *view);
+
+/* --- PointCloud2 on either side of the operator ---------------------------- */
+/* The record layout for lfx_config from a message's field list: what pcl::fromROSMsg<PointXYZIR>
+ * (ros_msg.hpp:72-78) needs from it -- x, y, z as FLOAT32 -- plus the ring channel the node insists on.
+ * Other fields (intensity, time, reflectivity ...) are skipped, as the upstream converter's field filter
+ * does (convert.py:113-121).  Returns LFX_ERR_NO_RING_FIELD / LFX_ERR_UNSUPPORTED_FIELD. */
+int lfx_layout_from_fields(const lfx_point_field *fields, uint32_t n_fields, uint32_t point_step, int is_bigendian,
+                           lfx_layout *out);
+/* The last device batch's edge and surface clouds as pcl::PointXYZ wire records (point_step 16:
+ * x, y, z, 1.0f -- what ToPointXYZ + toROSMsg publish as scan_edge / scan_surface,
+ * feature_extraction.cpp:163-170), packed back to back in scan order exactly as lfx_pack_features
+ * does (same offsets table). */
+int lfx_pack_xyz(lfx_ctx *ctx, float *d_edge_out, float *d_surface_out, uint32_t *d_offsets_out,
+                 size_t capacity_points, void *stream);
+/* colored_scan (feature_extraction.cpp:153,161) of the last device batch as pcl::PointXYZRGB wire records
+ * (point_step 32: x, y, z, 1.0f | rgb bit-cast to float, 0, 0, 0; rgb = 0xFF<<24 | r<<16 | g<<8 | b with the
+ * table of color_points.cpp:39-68): for every scan the points of each ring that was labelled (status
+ * LFX_RING_OK), rings ascending, angle ascending -- the reference appends ring by ring and skips a ring it
+ * abandons.  d_offsets_out u32 [batch+1]: exclusive prefix of the per-scan point counts. */
+int lfx_pack_colored(lfx_ctx *ctx, float *d_colored_out, uint32_t *d_offsets_out, size_t capacity_points,
+                     void *stream);
 /* Pack the last device batch's edge and surface clouds back to back, in scan order, into
  * caller-provided DEVICE buffers (what one rank hands to the multi-GPU gather):
  * d_edge_out / d_surface_out [capacity_points][4] floats (16-byte aligned); d_offsets_out u32
@@ -202,7 +246,7 @@ int lfx_stage_ring_projection(lfx_ctx *ctx, const void *points, size_t n_points,
  * LFX_ERR_INVALID_ARGUMENT for a value that is not a label (the reference throws). */
 int lfx_label_to_color(uint8_t label, uint8_t rgb[3]);
 /* ColorPointsByLabel (color_points.hpp:60-74) for a whole scan on the host: out[i] = {x, y, z, rgb packed
- * as PCL does (r << 16 | g << 8 | b, bit-cast to float)} for input point i, from the labels lfx_extract
+ * as PCL does (0xFF << 24 | r << 16 | g << 8 | b, bit-cast to float; a = 255 is PointXYZRGB's default)} for input point i, from the labels lfx_extract
  * returned.  points: the scan's records (layout as given to lfx_create); out: n_points * 4 floats. */
 int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_points, const uint8_t *labels,
                               float *out);

@@ -33,7 +33,16 @@ class Params(C.Structure):
 
 class Layout(C.Structure):
     _fields_ = [("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32),
-                ("off_z", C.c_uint32), ("off_ring", C.c_uint32)]
+                ("off_z", C.c_uint32), ("off_ring", C.c_uint32), ("ring_datatype", C.c_uint32),
+                ("big_endian", C.c_uint32)]
+
+
+class PointField(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint32), ("datatype", C.c_uint8), ("count", C.c_uint32)]
+
+
+# sensor_msgs/msg/PointField datatype codes
+INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64 = range(1, 9)
 
 
 class Config(C.Structure):
@@ -62,7 +71,7 @@ class DeviceView(C.Structure):
 EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
     "lfx_status_string", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
-    "lfx_device_results", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
+    "lfx_device_results", "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_kernel_times", "lfx_kernel_name",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
@@ -101,6 +110,9 @@ def load():
     L.lfx_extract_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), u32, C.POINTER(ScanResult)]
     L.lfx_extract_batch_device.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     L.lfx_device_results.argtypes = [vp, C.POINTER(DeviceView)]
+    L.lfx_layout_from_fields.argtypes = [C.POINTER(PointField), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Layout)]
+    L.lfx_pack_xyz.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
+    L.lfx_pack_colored.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.lfx_pack_features.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.lfx_download_scan.argtypes = [vp, u32, vp, C.POINTER(ScanResult)]
     L.lfx_stage_ring.argtypes = [vp, C.POINTER(Params), u32, u32] + [vp] * 10

@@ -275,7 +275,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   const uint32_t chunks = (longest + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
   if (chunks == 0) {return LFX_OK;}
   const bool canon = c->layout.step == 32 && c->layout.ox == 0 && c->layout.oy == 4 && c->layout.oz == 8 &&
-    c->layout.oring == 20 && (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
+    c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0 &&
+    (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
   if (c->single_pass) {
     Timed t(c, 2, st);
     auto kern = &lfx::ring_scatter_kernel<false, true>;
@@ -496,6 +497,44 @@ const char * lfx_kernel_name(int k) {return (k >= 0 && k < LFX_N_KERNELS) ? kKer
 
 const char * lfx_last_error(const lfx_ctx * ctx) {return ctx ? ctx->err.c_str() : g_create_error.c_str();}
 
+namespace
+{
+uint32_t field_size(uint32_t datatype)
+{
+  switch (datatype) {
+    case LFX_FIELD_INT8: case LFX_FIELD_UINT8: return 1;
+    case LFX_FIELD_INT16: case LFX_FIELD_UINT16: return 2;
+    case LFX_FIELD_INT32: case LFX_FIELD_UINT32: case LFX_FIELD_FLOAT32: return 4;
+    case LFX_FIELD_FLOAT64: return 8;
+    default: return 0;
+  }
+}
+}  // namespace
+
+int lfx_layout_from_fields(
+  const lfx_point_field * fields, uint32_t n_fields, uint32_t point_step, int is_bigendian, lfx_layout * out)
+{
+  if (!out || (!fields && n_fields) || point_step == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  const lfx_point_field * fx = nullptr, * fy = nullptr, * fz = nullptr, * fr = nullptr;
+  for (uint32_t i = 0; i < n_fields; i++) {
+    const lfx_point_field & f = fields[i];
+    if (!f.name) {return LFX_ERR_INVALID_ARGUMENT;}
+    if (!std::strcmp(f.name, "x")) {fx = &f;}
+    if (!std::strcmp(f.name, "y")) {fy = &f;}
+    if (!std::strcmp(f.name, "z")) {fz = &f;}
+    if (!std::strcmp(f.name, "ring")) {fr = &f;}       // RingIsAvailable, ring.cpp:36-44
+  }
+  if (!fr) {return LFX_ERR_NO_RING_FIELD;}
+  for (const lfx_point_field * f : {fx, fy, fz}) {
+    if (!f || f->datatype != LFX_FIELD_FLOAT32 || f->offset + 4 > point_step) {return LFX_ERR_UNSUPPORTED_FIELD;}
+  }
+  if (fr->datatype < LFX_FIELD_INT8 || fr->datatype > LFX_FIELD_UINT32 || fr->offset + field_size(fr->datatype) > point_step) {
+    return LFX_ERR_UNSUPPORTED_FIELD;
+  }
+  *out = lfx_layout{point_step, fx->offset, fy->offset, fz->offset, fr->offset, fr->datatype, is_bigendian ? 1u : 0u};
+  return LFX_OK;
+}
+
 int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const lfx_config * config)
 {
   if (!out) {return LFX_ERR_INVALID_ARGUMENT;}
@@ -522,17 +561,19 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->dev = device_params(*params);
   const lfx_layout & L = config->layout;
   if (L.point_step == 0) {
-    c->layout = lfx::Layout{32, 0, 4, 8, 20};     // PointXYZIR, point_type.hpp:62-86
+    c->layout = lfx::Layout{32, 0, 4, 8, 20, LFX_FIELD_UINT16, 0};     // PointXYZIR, point_type.hpp:62-86
   } else {
-    if (L.point_step % 4 || L.off_x % 4 || L.off_y % 4 || L.off_z % 4 || L.off_ring % 2 ||
+    const uint32_t rtype = L.ring_datatype ? L.ring_datatype : (uint32_t)LFX_FIELD_UINT16;
+    const uint32_t rsize = field_size(rtype);
+    if (rtype < LFX_FIELD_INT8 || rtype > LFX_FIELD_UINT32 ||
       L.off_x + 4 > L.point_step || L.off_y + 4 > L.point_step || L.off_z + 4 > L.point_step ||
-      L.off_ring + 2 > L.point_step)
+      L.off_ring + rsize > L.point_step)
     {
       delete c;
-      g_create_error = "layout: fields must be aligned and lie inside point_step";
+      g_create_error = "layout: x, y, z (FLOAT32) and ring (an integer type) must lie inside point_step";
       return LFX_ERR_INVALID_ARGUMENT;
     }
-    c->layout = lfx::Layout{L.point_step, L.off_x, L.off_y, L.off_z, L.off_ring};
+    c->layout = lfx::Layout{L.point_step, L.off_x, L.off_y, L.off_z, L.off_ring, rtype, L.big_endian ? 1u : 0u};
   }
   c->drop_zero = config->drop_zero_points ? 1u : 0u;
   c->max_points = config->max_points_per_scan;
@@ -664,9 +705,50 @@ int lfx_device_results(const lfx_ctx * c, lfx_device_view * v)
   return LFX_OK;
 }
 
+namespace
+{
+int pack_clouds(
+  lfx_ctx * c, float * d_edge_out, float * d_surface_out, uint32_t * d_offsets_out, size_t capacity_points,
+  void * stream, uint32_t xyz_wire);
+}
+
 int lfx_pack_features(
   lfx_ctx * c, float * d_edge_out, float * d_surface_out, uint32_t * d_offsets_out, size_t capacity_points,
   void * stream)
+{
+  return pack_clouds(c, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream, 0u);
+}
+
+int lfx_pack_xyz(
+  lfx_ctx * c, float * d_edge_out, float * d_surface_out, uint32_t * d_offsets_out, size_t capacity_points,
+  void * stream)
+{
+  return pack_clouds(c, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream, 1u);
+}
+
+int lfx_pack_colored(lfx_ctx * c, float * d_colored_out, uint32_t * d_offsets_out, size_t capacity_points, void * stream)
+{
+  if (!c || !d_colored_out || !d_offsets_out) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->last_batch == 0 || !c->last_points) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint32_t batch = c->last_batch;
+  const uint32_t capacity = capacity_points > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity_points;
+  hipLaunchKernelGGL(lfx::colored_offsets_kernel, dim3(1), dim3(256), 0, st, c->ring_count.p, c->ring_status.p, batch,
+    c->max_rings, d_offsets_out);
+  hipLaunchKernelGGL(lfx::colored_pack_kernel, dim3(c->max_rings, batch), dim3(256), 0, st,
+    c->ring_count.p, c->ring_status.p, d_offsets_out, c->sxy.p, c->sidx.p, c->label_s.p,
+    static_cast<const uint8_t *>(c->last_points), c->layout, c->scan_begin.p, c->max_rings, c->cap,
+    reinterpret_cast<float4 *>(d_colored_out), capacity);
+  LFX_HIP(c, hipGetLastError());
+  return LFX_OK;
+}
+
+namespace
+{
+int pack_clouds(
+  lfx_ctx * c, float * d_edge_out, float * d_surface_out, uint32_t * d_offsets_out, size_t capacity_points,
+  void * stream, uint32_t xyz_wire)
 {
   if (!c || !d_edge_out || !d_surface_out || !d_offsets_out) {return LFX_ERR_INVALID_ARGUMENT;}
   if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
@@ -677,10 +759,11 @@ int lfx_pack_features(
   hipLaunchKernelGGL(lfx::feature_offsets_kernel, dim3(1), dim3(256), 0, st, c->scan_info.p, batch, d_offsets_out);
   hipLaunchKernelGGL(lfx::feature_pack_kernel, dim3(8, batch), dim3(256), 0, st,
     c->scan_begin.p, c->scan_info.p, d_offsets_out, batch, c->edge_pts.p, c->surf_pts.p,
-    reinterpret_cast<float4 *>(d_edge_out), reinterpret_cast<float4 *>(d_surface_out), capacity);
+    reinterpret_cast<float4 *>(d_edge_out), reinterpret_cast<float4 *>(d_surface_out), capacity, xyz_wire);
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
 }
+}  // namespace
 
 int lfx_download_scan(lfx_ctx * c, uint32_t scan, void * stream, lfx_scan_result * out)
 {
@@ -857,10 +940,13 @@ int lfx_color_points_by_label(const lfx_ctx * c, const void * points, size_t n_p
     uint8_t rgb[3];
     if (lfx_label_to_color(labels[i], rgb) != LFX_OK) {return LFX_ERR_INVALID_ARGUMENT;}
     const uint8_t * q = p + i * c->layout.step;
-    std::memcpy(&out[4 * i + 0], q + c->layout.ox, 4);
-    std::memcpy(&out[4 * i + 1], q + c->layout.oy, 4);
-    std::memcpy(&out[4 * i + 2], q + c->layout.oz, 4);
-    const uint32_t packed = ((uint32_t)rgb[0] << 16) | ((uint32_t)rgb[1] << 8) | (uint32_t)rgb[2];
+    for (int a = 0; a < 3; a++) {
+      uint32_t v;
+      std::memcpy(&v, q + (a == 0 ? c->layout.ox : (a == 1 ? c->layout.oy : c->layout.oz)), 4);
+      if (c->layout.be) {v = __builtin_bswap32(v);}
+      std::memcpy(&out[4 * i + a], &v, 4);
+    }
+    const uint32_t packed = 0xFF000000u | ((uint32_t)rgb[0] << 16) | ((uint32_t)rgb[1] << 8) | (uint32_t)rgb[2];
     std::memcpy(&out[4 * i + 3], &packed, 4);
   }
   return LFX_OK;

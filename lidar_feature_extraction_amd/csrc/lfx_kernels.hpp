@@ -47,7 +47,28 @@ constexpr int kChunkSlots = kChunkPoints / kChunkThreads;
 constexpr int kRings = 256;            // ring ids 0..255
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 
-struct Layout { uint32_t step, ox, oy, oz, oring; };
+struct Layout { uint32_t step, ox, oy, oz, oring, rtype, be; };   // rtype: PointField datatype of ring; be: big-endian
+
+// One f32 field / the ring field of a record as a PointCloud2 describes them.  Byte-wise access to
+// fields that are not naturally aligned is left to the hardware (unaligned dword loads are legal).
+__device__ inline float load_f32(const uint8_t * p, uint32_t be)
+{
+  uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+  if (be) {v = __builtin_bswap32(v);}
+  return __uint_as_float(v);
+}
+
+__device__ inline uint32_t load_ring(const uint8_t * p, uint32_t rtype, uint32_t be)
+{
+  switch (rtype) {
+    case 1: return (uint32_t)(int32_t)*reinterpret_cast<const int8_t *>(p);          // negative ids end up >= max_rings
+    case 2: return *p;
+    case 3: {uint16_t v = *reinterpret_cast<const uint16_t *>(p); if (be) {v = __builtin_bswap16(v);} return (uint32_t)(int32_t)(int16_t)v;}
+    case 5:
+    case 6: {uint32_t v = *reinterpret_cast<const uint32_t *>(p); if (be) {v = __builtin_bswap32(v);} return v;}
+    default: {uint16_t v = *reinterpret_cast<const uint16_t *>(p); if (be) {v = __builtin_bswap16(v);} return v;}
+  }
+}
 
 struct Params
 {
@@ -111,9 +132,9 @@ __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
     const uint32_t e = chunk * kChunkPoints + i * kChunkThreads + tid;
     if (e < n) {
       const uint8_t * p = pts + (size_t)(b + e) * L.step;
-      const uint32_t ring = *reinterpret_cast<const uint16_t *>(p + L.oring);
-      const bool zero = drop_zero && *reinterpret_cast<const float *>(p + L.ox) == 0.f &&
-        *reinterpret_cast<const float *>(p + L.oy) == 0.f && *reinterpret_cast<const float *>(p + L.oz) == 0.f;
+      const uint32_t ring = load_ring(p + L.oring, L.rtype, L.be);
+      const bool zero = drop_zero && load_f32(p + L.ox, L.be) == 0.f && load_f32(p + L.oy, L.be) == 0.f &&
+        load_f32(p + L.oz, L.be) == 0.f;
       if (ring >= max_rings) {bad = true;} else if (!zero) {atomicAdd(&h[ring], 1u);}
     }
   }
@@ -215,10 +236,10 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
         x[i] = v.x; y[i] = v.y; z[i] = v.z;
         ring = *reinterpret_cast<const uint32_t *>(p + 20) & 0xFFFFu;
       } else {
-        x[i] = *reinterpret_cast<const float *>(p + L.ox);
-        y[i] = *reinterpret_cast<const float *>(p + L.oy);
-        z[i] = *reinterpret_cast<const float *>(p + L.oz);
-        ring = *reinterpret_cast<const uint16_t *>(p + L.oring);
+        x[i] = load_f32(p + L.ox, L.be);
+        y[i] = load_f32(p + L.oy, L.be);
+        z[i] = load_f32(p + L.oz, L.be);
+        ring = load_ring(p + L.oring, L.rtype, L.be);
       }
       key[i] = ring < max_rings ? ring : kRings;
       if (LOOKBACK && ring >= max_rings) {bad_ring = true;}
@@ -1941,7 +1962,7 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
         const uint64_t below = (1ull << (i & 63)) - 1ull;
         const uint32_t orig = sidx[off + i];
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-        const float z = resorted ? *reinterpret_cast<const float *>(pts + (sb + orig) * L.step + L.oz) : sz[off + i];
+        const float z = resorted ? load_f32(pts + (sb + orig) * L.step + L.oz, L.be) : sz[off + i];
         float x = w.x[i], y = w.y[i];
         if (reload_xy) {const float2 v = sxy[off + i]; x = v.x; y = v.y;}
         size_t at;
@@ -2097,19 +2118,86 @@ __global__ __launch_bounds__(256) void feature_pack_kernel(
   const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
   const uint32_t * __restrict__ offsets, uint32_t batch, const float4 * __restrict__ edge_pts,
   const float4 * __restrict__ surf_pts, float4 * __restrict__ edge_out, float4 * __restrict__ surf_out,
-  uint32_t capacity)
+  uint32_t capacity, uint32_t xyz_wire)
 {
   const uint32_t s = blockIdx.y;
   const uint32_t ne = scan_info[s * 4 + kInfoEdge], ns = scan_info[s * 4 + kInfoSurface];
   const size_t b = scan_begin[s];
   const uint32_t oe = offsets[s], os = offsets[batch + 1 + s];
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < ne + ns; k += gridDim.x * blockDim.x) {
-    if (k < ne) {
-      if (oe + k < capacity) {edge_out[oe + k] = edge_pts[b + k];}
+    const bool edge = k < ne;
+    const uint32_t q = edge ? k : k - ne;
+    float4 v = edge ? edge_pts[b + q] : surf_pts[b + q];
+    if (xyz_wire) {v.w = 1.0f;}          // pcl::PointXYZ: data[3] = 1 (the curvature travels in lfx_pack_features only)
+    if (edge) {
+      if (oe + q < capacity) {edge_out[oe + q] = v;}
     } else {
-      const uint32_t q = k - ne;
-      if (os + q < capacity) {surf_out[os + q] = surf_pts[b + q];}
+      if (os + q < capacity) {surf_out[os + q] = v;}
     }
+  }
+}
+
+// colored_scan (feature_extraction.cpp:153,161; color_points.hpp:60-74): per scan the points of every
+// labelled ring, rings ascending, angle ascending, as 32-byte pcl::PointXYZRGB wire records.
+__global__ __launch_bounds__(256) void colored_offsets_kernel(
+  const uint32_t * __restrict__ ring_count, const uint8_t * __restrict__ ring_status, uint32_t batch, uint32_t max_rings,
+  uint32_t * __restrict__ offsets /* [batch+1] */)
+{
+  __shared__ uint32_t part[256];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (batch + 255) / 256;
+  const uint32_t lo = tid * per, hi = (lo + per < batch) ? lo + per : batch;
+  auto scan_total = [&](uint32_t s) {
+      uint32_t t = 0;
+      for (uint32_t r = 0; r < max_rings; r++) {
+        if (ring_status[s * kRings + r] == kOk) {t += ring_count[s * kRings + r];}
+      }
+      return t;
+    };
+  uint32_t sum = 0;
+  for (uint32_t k = lo; k < hi; k++) {sum += scan_total(k);}
+  part[tid] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const uint32_t a = tid >= d ? part[tid - d] : 0u;
+    __syncthreads();
+    part[tid] += a;
+    __syncthreads();
+  }
+  uint32_t c = part[tid] - sum;
+  for (uint32_t k = lo; k < hi; k++) {
+    offsets[k] = c;
+    c += scan_total(k);
+  }
+  if (tid == 255) {offsets[batch] = part[255];}
+}
+
+__global__ __launch_bounds__(256) void colored_pack_kernel(
+  const uint32_t * __restrict__ ring_count, const uint8_t * __restrict__ ring_status,
+  const uint32_t * __restrict__ offsets, const float2 * __restrict__ sxy, const uint32_t * __restrict__ sidx,
+  const uint8_t * __restrict__ label_s, const uint8_t * __restrict__ pts, Layout L,
+  const uint32_t * __restrict__ scan_begin, uint32_t max_rings, uint32_t cap, float4 * __restrict__ out,
+  uint32_t capacity)
+{
+  const uint32_t s = blockIdx.y, ring = blockIdx.x, tid = threadIdx.x;
+  if (ring_status[s * kRings + ring] != kOk) {return;}
+  __shared__ uint32_t before;
+  if (tid == 0) {before = 0;}
+  __syncthreads();
+  if (tid < ring && ring_status[s * kRings + tid] == kOk) {atomicAdd(&before, ring_count[s * kRings + tid]);}
+  __syncthreads();
+  const uint32_t n = ring_count[s * kRings + ring];
+  const size_t off = ring_base(s, ring, max_rings, cap);
+  const uint32_t at = offsets[s] + before;
+  // color_points.cpp:39-68, indexed by label; a = 255 as in a default-constructed pcl::PointXYZRGB
+  const uint32_t table[8] = {0xFFFFFFFFu, 0xFFFF0000u, 0xFFFF3F00u, 0xFFFF0000u, 0xFFFF3F00u, 0xFF7F7F7Fu, 0xFFFF00FFu, 0xFF00FF00u};
+  for (uint32_t i = tid; i < n; i += blockDim.x) {
+    if (at + i >= capacity) {break;}
+    const float2 xy = sxy[off + i];
+    // z from the input record (the staged z of a ring the workgroup-per-ring kernel sorted itself is not re-ordered)
+    const float z = load_f32(pts + ((size_t)scan_begin[s] + sidx[off + i]) * L.step + L.oz, L.be);
+    out[2 * (size_t)(at + i)] = make_float4(xy.x, xy.y, z, 1.0f);
+    out[2 * (size_t)(at + i) + 1] = make_float4(__uint_as_float(table[label_s[off + i] & 7u]), 0.f, 0.f, 0.f);
   }
 }
 

@@ -96,8 +96,14 @@ class FeatureExtraction:
         self._L = B.load()
         self.params = params or HyperParameters()
         self._ctx = C.c_void_p()
-        # layout: (point_step, off_x, off_y, off_z, off_ring) of the records, None = PointXYZIR
-        lay = B.Layout(*layout) if layout is not None else B.Layout(0, 0, 0, 0, 0)
+        # layout: (point_step, off_x, off_y, off_z, off_ring[, ring_datatype, big_endian]) of the records or a
+        # B.Layout (layout_from_fields), None = PointXYZIR
+        if layout is None:
+            lay = B.Layout(0, 0, 0, 0, 0, 0, 0)
+        elif isinstance(layout, B.Layout):
+            lay = layout
+        else:
+            lay = B.Layout(*(tuple(layout) + (0, 0))[:7])
         self._step = lay.point_step or 32
         cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay)
         cp = self.params.to_c()
@@ -152,6 +158,18 @@ class FeatureExtraction:
         B.check(self._ctx, self._L.lfx_pack_features(
             self._ctx, C.c_void_p(int(d_edge_out)), C.c_void_p(int(d_surface_out)), C.c_void_p(int(d_offsets_out)),
             int(capacity_points), C.c_void_p(int(stream))))
+
+    def pack_xyz(self, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream=0):
+        """As pack_features, but pcl::PointXYZ wire records (x, y, z, 1.0f): scan_edge / scan_surface payloads."""
+        B.check(self._ctx, self._L.lfx_pack_xyz(
+            self._ctx, C.c_void_p(int(d_edge_out)), C.c_void_p(int(d_surface_out)), C.c_void_p(int(d_offsets_out)),
+            int(capacity_points), C.c_void_p(int(stream))))
+
+    def pack_colored(self, d_colored_out, d_offsets_out, capacity_points, stream=0):
+        """colored_scan of the last device batch as 32-byte pcl::PointXYZRGB wire records (see lfx.h)."""
+        B.check(self._ctx, self._L.lfx_pack_colored(
+            self._ctx, C.c_void_p(int(d_colored_out)), C.c_void_p(int(d_offsets_out)), int(capacity_points),
+            C.c_void_p(int(stream))))
 
     def download(self, scan, stream=0):
         r = B.ScanResult()
@@ -228,3 +246,16 @@ class FeatureExtraction:
         cnt = (C.c_uint64 * B.LFX_N_KERNELS)()
         B.check(self._ctx, self._L.lfx_kernel_times(self._ctx, ms, cnt))
         return {self._L.lfx_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(B.LFX_N_KERNELS)}
+
+
+def layout_from_fields(fields, point_step, is_bigendian=False):
+    """fields: iterable of (name, offset, datatype, count) as in PointCloud2.fields -> binding.Layout for
+    FeatureExtraction(layout=...).  Raises LfxError where the node would refuse the cloud (no ring channel)
+    or pcl::fromROSMsg could not map x / y / z."""
+    arr = (B.PointField * len(fields))(*[B.PointField(n.encode(), o, t, c) for (n, o, t, c) in fields])
+    out = B.Layout()
+    rc = B.load().lfx_layout_from_fields(arr, len(fields), point_step, int(bool(is_bigendian)), C.byref(out))
+    if rc != 0:
+        raise B.LfxError(rc, {-7: "the cloud has no ring field", -8: "x / y / z must be FLOAT32 and ring an integer field inside point_step"}.get(rc, "invalid field list"))
+    return out
+

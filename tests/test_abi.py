@@ -70,6 +70,40 @@ def test_label_to_color_table(lib, refvec):
     assert lib.lfx_label_to_color(8, (C.c_uint8 * 3)()) == -1      # ThrowIfInvalidLabelDetected
 
 
+def _layout(lib, fields, point_step, big=False):
+    arr = (LB.PointField * len(fields))(*[LB.PointField(n.encode(), o, t, c) for (n, o, t, c) in fields])
+    out = LB.Layout()
+    rc = lib.lfx_layout_from_fields(arr, len(fields), point_step, int(big), C.byref(out))
+    return rc, out
+
+
+def test_ring_channel_is_required(lib, refvec):
+    """RingIsAvailable (test_ring.cpp:129-144): a cloud without a "ring" field is refused."""
+    for case in refvec["ring_is_available"]["cases"]:
+        fields = [tuple(f) for f in case["fields"]] + [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1)]
+        rc, _ = _layout(lib, fields, 32)
+        assert (rc != -7) == case["available"]
+        assert rc == (0 if case["available"] else -7)
+
+
+def test_layout_from_point_cloud2_fields(lib, refvec):
+    """The field lists the upstream converter's tests use (test_convert.py) map to record layouts."""
+    for case in refvec["point_cloud2_layouts"]["cases"]:
+        rc, lay = _layout(lib, [tuple(f) for f in case["fields"]], case["point_step"])
+        assert rc == 0, case["name"]
+        got = [lay.point_step, lay.off_x, lay.off_y, lay.off_z, lay.off_ring, lay.ring_datatype]
+        assert got == case["layout"], case["name"]
+        assert lay.big_endian == 0
+    rc, lay = _layout(lib, [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1), ("ring", 12, 4, 1)], 16, big=True)
+    assert rc == 0 and lay.big_endian == 1
+    # what pcl::fromROSMsg<PointXYZIR> could not map, or what lies outside the record
+    assert _layout(lib, [("x", 0, 8, 1), ("y", 8, 7, 1), ("z", 12, 7, 1), ("ring", 16, 4, 1)], 24)[0] == -8   # x is FLOAT64
+    assert _layout(lib, [("x", 0, 7, 1), ("y", 4, 7, 1), ("ring", 12, 4, 1)], 16)[0] == -8                    # no z
+    assert _layout(lib, [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1), ("ring", 12, 7, 1)], 16)[0] == -8    # ring FLOAT32
+    assert _layout(lib, [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1), ("ring", 15, 4, 1)], 16)[0] == -8    # ring past the record
+    assert lib.lfx_layout_from_fields(None, 0, 16, 0, None) == -1
+
+
 def test_no_cpu_fallback_without_a_device(lib):
     import torch
     if torch.cuda.device_count() > 0:

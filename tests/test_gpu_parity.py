@@ -340,6 +340,100 @@ def test_other_record_layouts():
         FeatureExtraction(device=0, max_points_per_scan=100, layout=(32, 0, 4, 8, 31))      # ring field leaves the record
 
 
+def test_driver_clouds_are_read_directly():
+    """the repack of the upstream converter node (convert.py:183-212: any field order,
+    ring as UINT8, either byte order, all-zero points dropped) happens in the bucketing kernel's loads.
+    The expected result is the oracle on the PointXYZIR cloud the converter would have emitted."""
+    from lidar_feature_extraction_amd import layout_from_fields
+    c = make_scan(16, 900, seed=91, drop_fraction=0.03)
+    z = np.zeros(40, POINT_DTYPE)                       # invalid returns of the driver: (0, 0, 0)
+    z["ring"] = np.arange(40) % 16
+    raw = synth.concat([c[:5000], z, c[5000:]])
+    want = OB.extract(c, canonical_ties=False)          # the converter drops the zero points
+    # the Ouster-like record of test_convert.py:42-60: ring UINT8 at 26, point_step 48
+    ouster = np.dtype({"names": ["x", "y", "z", "intensity", "t", "reflectivity", "ring", "noise", "range"],
+                       "formats": ["<f4", "<f4", "<f4", "<f4", "<u4", "<u2", "u1", "<u2", "<u4"],
+                       "offsets": [0, 4, 8, 16, 20, 24, 26, 28, 32], "itemsize": 48})
+    fields = [("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1), ("intensity", 16, 7, 1), ("t", 20, 6, 1),
+              ("reflectivity", 24, 4, 1), ("ring", 26, 2, 1), ("noise", 28, 4, 1), ("range", 32, 6, 1)]
+    o = np.zeros(len(raw), ouster)
+    for k in ("x", "y", "z", "intensity", "ring"):
+        o[k] = raw[k]
+    o["t"], o["noise"] = np.arange(len(raw)), 7
+    f = FeatureExtraction(device=0, max_points_per_scan=len(raw), max_batch=1, max_rings=16, drop_zero_points=True,
+                          layout=layout_from_fields(fields, 48))
+    got = f.ExtractFeatures(o)
+    keep = np.nonzero(~((raw["x"] == 0) & (raw["y"] == 0) & (raw["z"] == 0)))[0]
+    assert np.array_equal(got.labels[keep], want["labels"])
+    assert got.curvature[keep].tobytes() == want["curvature"].tobytes()
+    assert np.array_equal(keep[want["edge_index"]], got.edge_index) and np.array_equal(keep[want["surface_index"]], got.surface_index)
+    f.close()
+    # big-endian message, 22-byte records (fields not naturally aligned), ring INT32
+    be = np.dtype({"names": ["x", "ring", "y", "z"], "formats": [">f4", ">i4", ">f4", ">f4"], "offsets": [0, 4, 10, 14],
+                   "itemsize": 22})
+    b = np.zeros(len(c), be)
+    for k in ("x", "y", "z", "ring"):
+        b[k] = c[k]
+    lay = layout_from_fields([("x", 0, 7, 1), ("ring", 4, 5, 1), ("y", 10, 7, 1), ("z", 14, 7, 1)], 22, is_bigendian=True)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=16, layout=lay)
+    assert_scan_equal(f.ExtractFeatures(b), want, "big-endian 22-byte records")
+    f.close()
+    with pytest.raises(LB.LfxError) as e:
+        layout_from_fields([("x", 0, 7, 1), ("y", 4, 7, 1), ("z", 8, 7, 1), ("intensity", 16, 7, 1)], 32)
+    assert e.value.code == -7                            # no ring channel: the node shuts down (feature_extraction.cpp:103-108)
+
+
+def test_wire_payloads_of_the_three_published_clouds(fx):
+    """scan_edge / scan_surface as pcl::PointXYZ records and colored_scan as pcl::PointXYZRGB records
+    (feature_extraction.cpp:153-170), built on the device; expected values from the oracle's labels."""
+    import torch
+    clouds = [make_scan(16, 900, seed=95), make_scan(16, 900, seed=96, drop_fraction=0.05)]
+    few = clouds[1]["ring"] == 7
+    clouds[1] = synth.concat([clouds[1][~few], clouds[1][few][:4]])    # ring 7: 4 points, removed as sparse
+    host = synth.concat(clouds).view(np.uint8)
+    dev = torch.from_numpy(host.copy()).to("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    fx.extract_batch_device(dev.data_ptr(), [len(c) for c in clouds], stream)
+    cap = sum(len(c) for c in clouds)
+    e = torch.zeros((cap, 4), dtype=torch.float32, device="cuda:0")
+    s = torch.zeros((cap, 4), dtype=torch.float32, device="cuda:0")
+    offs = torch.zeros(2 * 3, dtype=torch.int32, device="cuda:0")
+    col = torch.zeros((cap, 8), dtype=torch.float32, device="cuda:0")
+    coffs = torch.zeros(3, dtype=torch.int32, device="cuda:0")
+    fx.pack_xyz(e.data_ptr(), s.data_ptr(), offs.data_ptr(), cap, stream)
+    fx.pack_colored(col.data_ptr(), coffs.data_ptr(), cap, stream)
+    torch.cuda.synchronize()
+    e, s, offs, col, coffs = e.cpu().numpy(), s.cpu().numpy(), offs.cpu().numpy(), col.cpu().numpy(), coffs.cpu().numpy()
+    for i, c in enumerate(clouds):
+        want = OB.extract(c, canonical_ties=False)
+        for arr, o0, o1, idx in ((e, offs[i], offs[i + 1], want["edge_index"]), (s, offs[3 + i], offs[3 + i + 1], want["surface_index"])):
+            assert o1 - o0 == len(idx)
+            assert np.array_equal(arr[o0:o1, 0], c["x"][idx]) and np.array_equal(arr[o0:o1, 1], c["y"][idx])
+            assert np.array_equal(arr[o0:o1, 2], c["z"][idx]) and np.all(arr[o0:o1, 3] == 1.0)
+        # colored_scan: the labelled rings' points, rings ascending, angle ascending
+        order = []
+        at = 0
+        for rid, cnt, st in zip(want["ring_id"], want["ring_count"], want["ring_status"]):
+            if st == 0:
+                order.extend(want["sorted_index"][at:at + cnt])
+            at += cnt
+        order = np.asarray(order, dtype=np.int64)
+        got = col[coffs[i]:coffs[i + 1]]
+        assert len(got) == len(order)
+        assert np.array_equal(got[:, 0], c["x"][order]) and np.array_equal(got[:, 1], c["y"][order])
+        assert np.array_equal(got[:, 2], c["z"][order]) and np.all(got[:, 3] == 1.0) and np.all(got[:, 5:] == 0.0)
+        rgba = got[:, 4].copy().view(np.uint32)
+        assert np.all(rgba >> 24 == 255)
+        lab = want["labels"][order]
+        for v in np.unique(lab):
+            rgb = np.zeros(3, np.uint8)
+            assert LB.load().lfx_label_to_color(int(v), rgb.ctypes.data_as(LB.C.POINTER(LB.C.c_uint8))) == 0
+            m = lab == v
+            assert np.all((rgba[m] >> 16) & 255 == rgb[0]) and np.all((rgba[m] >> 8) & 255 == rgb[1]) and np.all(rgba[m] & 255 == rgb[2])
+    w1 = OB.extract(clouds[1], canonical_ties=False)
+    assert 7 not in [int(r) for r, st in zip(w1["ring_id"], w1["ring_status"]) if st == 0]    # the sparse ring is left out
+
+
 def test_ring_id_beyond_max_rings_is_an_error():
     c = make_scan(8, 300, seed=3)
     f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=4)
