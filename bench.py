@@ -130,11 +130,13 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    # per-kernel durations: HIP events recorded around every launch of the timed region, on the
+    # per-kernel durations: HIP events recorded around the launches inside the timed region, on the
     # stream the kernel is launched on (lfx_set_profiling); with one stream they are what
     # rocprofv3 --kernel-trace --stats reports for the same command
+    # The event pairs are recorded around the launches of every 4th step: around every step they cost
+    # ~7 % of the throughput being measured (0.815 vs 0.761 ms/step), which the sampled form avoids.
     for f in fxs:
-        f.set_profiling(True)
+        f.set_profiling(True, every=int(os.environ.get("LFX_BENCH_EVENT_EVERY", max(1, min(4, a.steps // 2)))))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -170,7 +172,7 @@ def main():
                           and np.array_equal(g.surface_index, w["surface_index"].astype(np.uint32)))
     feat_batch = sum(feats[j % n_unique] for j in range(a.batch))
     algo_bytes = 25 * n_pts * a.batch + 16 * feat_batch
-    achieved = algo_bytes / (per_launch_us[dominant] * 1e-6) / 1e9
+    achieved = algo_bytes / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -184,7 +186,7 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items()},
-                "whole_path_frac": round(algo_bytes / (sum_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+                "whole_path_frac": round(algo_bytes / (max(sum_us, 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
     cpu = None

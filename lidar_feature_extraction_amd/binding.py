@@ -72,7 +72,7 @@ EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
     "lfx_status_string", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
     "lfx_device_results", "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
-    "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_kernel_times", "lfx_kernel_name",
+    "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
 
@@ -121,6 +121,7 @@ def load():
     L.lfx_label_to_color.argtypes = [C.c_uint8, C.POINTER(C.c_uint8)]
     L.lfx_color_points_by_label.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.lfx_set_profiling.argtypes = [vp, i32]
+    L.lfx_set_profiling_interval.argtypes = [vp, C.c_uint32]
     L.lfx_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.lfx_kernel_name.argtypes = [i32]
     L.lfx_kernel_name.restype = C.c_char_p

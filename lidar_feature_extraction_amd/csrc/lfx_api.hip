@@ -125,6 +125,8 @@ struct lfx_ctx
   std::vector<HostScan> host;
 
   bool profiling = false;
+  uint32_t profile_every = 1, batch_no = 0;   // lfx_set_profiling_interval: events around every n-th batch only
+  bool profile_now = false;
   struct Span { hipEvent_t a, b; int k; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> free_events;
@@ -167,7 +169,7 @@ struct Timed
   Timed(lfx_ctx * c, int k, hipStream_t s)
   : c_(c), k_(k), s_(s)
   {
-    if (c_->profiling) {
+    if (c_->profile_now) {
       a_ = take_event(c_);
       b_ = take_event(c_);
       (void)hipEventRecord(a_, s_);
@@ -175,7 +177,7 @@ struct Timed
   }
   ~Timed()
   {
-    if (c_->profiling) {
+    if (c_->profile_now) {
       (void)hipEventRecord(b_, s_);
       c_->spans.push_back({a_, b_, k_});
     }
@@ -266,6 +268,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   c->last_batch = batch;
   c->last_points = d_points;
+  c->profile_now = c->profiling && (c->batch_no++ % c->profile_every) == 0u;
   uint32_t * counters = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;     // behind ring_flags[max_batch][256]
   uint32_t * defer_count = counters, * redo_count = counters + 1, * slow_count = counters + 2;
   hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
@@ -960,6 +963,14 @@ int lfx_set_profiling(lfx_ctx * c, int enabled)
   c->profiling = enabled != 0;
   for (int k = 0; k < LFX_N_KERNELS; k++) {c->ms[k] = 0; c->launches[k] = 0;}
   return rc;
+}
+
+int lfx_set_profiling_interval(lfx_ctx * c, uint32_t every_n_batches)
+{
+  if (!c || every_n_batches == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  c->profile_every = every_n_batches;
+  c->batch_no = 0;
+  return LFX_OK;
 }
 
 int lfx_kernel_times(lfx_ctx * c, double ms[LFX_N_KERNELS], uint64_t launches[LFX_N_KERNELS])

@@ -238,7 +238,9 @@ class FeatureExtraction:
         return out
 
     # --- measurement ---------------------------------------------------------------------
-    def set_profiling(self, on):
+    def set_profiling(self, on, every=1):
+        """HIP events around the kernels of every `every`-th batch (lfx_set_profiling_interval)."""
+        B.check(self._ctx, self._L.lfx_set_profiling_interval(self._ctx, int(every)))
         B.check(self._ctx, self._L.lfx_set_profiling(self._ctx, int(bool(on))))
 
     def kernel_times(self):
