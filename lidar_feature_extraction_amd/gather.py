@@ -95,23 +95,31 @@ class CloudGather:
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
                 all_totals = self._issue_totals(offsets, batch)
+                # the totals go to pinned host memory right behind their all-gather, with an event of their
+                # own: finishing this step later waits for THAT event only, not for whatever the side stream
+                # has been given since (the next step's collectives wait for the next step's extraction)
+                host_tot = torch.empty((len(all_totals), 2), dtype=torch.int64, pin_memory=True)
+                host_tot.copy_(torch.stack(all_totals), non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(self.side)
+            totals = (host_tot, landed)
         else:
-            all_totals = self._issue_totals(offsets, batch)
-        prev, self.pending = self.pending, (edge, surface, offsets, all_totals)
+            totals = (self._issue_totals(offsets, batch), None)
+        prev, self.pending = self.pending, (edge, surface, offsets, totals)
         return self._finish(prev) if prev is not None else None
 
     def _finish(self, p):
-        edge, surface, offsets, all_totals = p
+        edge, surface, offsets, (tot, landed) = p
         if self.cuda:
+            landed.synchronize()
             with torch.cuda.stream(self.side):
-                tot = torch.stack(all_totals).cpu()          # the host waits for THIS step's totals only
                 out = _gather_payload(edge, surface, offsets, tot, self.dst, self.group)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             for t in (edge, surface, offsets):
                 self.buffer_free[t.data_ptr()] = ev
             return out
-        tot = torch.stack(all_totals).cpu()
+        tot = torch.stack(tot).cpu()
         return _gather_payload(edge, surface, offsets, tot, self.dst, self.group)
 
     def flush(self):
