@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="scans per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="scans per step per GPU (118 M points, ~15 GB of device memory with all scratch)")
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--cols", type=int, default=1800)
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic scans per GPU (tiled to --batch)")
