@@ -1767,9 +1767,21 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
       __syncthreads();
       // cnt[0] / cnt[1]: number / position of pairs that are not strictly increasing,
       // cnt[2] / cnt[3]: the same for not strictly decreasing
-      for (int i = tid; i + 1 < N; i += T) {
-        if (!polar_less(lx[i], ly[i], lx[i + 1], ly[i + 1])) {atomicAdd(&cnt[0], 1); atomicMax(&cnt[1], i);}
-        if (!polar_less(lx[i + 1], ly[i + 1], lx[i], ly[i])) {atomicAdd(&cnt[2], 1); atomicMax(&cnt[3], i);}
+      // (counted per wave with ballots: in a sorted or reversed ring EVERY pair fails one of the two tests, and
+      // that many same-address LDS atomics serialise)
+      for (int i0 = 0; i0 + 1 < N; i0 += T) {
+        const int i = i0 + tid;
+        bool up = false, down = false;
+        if (i + 1 < N) {
+          up = !polar_less(lx[i], ly[i], lx[i + 1], ly[i + 1]);
+          down = !polar_less(lx[i + 1], ly[i + 1], lx[i], ly[i]);
+        }
+        const uint64_t mu = __ballot(up), md = __ballot(down);
+        if ((tid & 63) == 0) {
+          const int w0 = i0 + (tid & ~63);
+          if (mu) {atomicAdd(&cnt[0], __popcll(mu)); atomicMax(&cnt[1], w0 + 63 - __clzll(mu));}
+          if (md) {atomicAdd(&cnt[2], __popcll(md)); atomicMax(&cnt[3], w0 + 63 - __clzll(md));}
+        }
       }
       __syncthreads();
       const int up_breaks = cnt[0], up_at = cnt[1], down_breaks = cnt[2], down_at = cnt[3];
