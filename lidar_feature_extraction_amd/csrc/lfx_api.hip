@@ -100,6 +100,13 @@ struct lfx_ctx
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
   bool single_pass = true;               // look-back bucketing; LFX_DEBUG_TWO_PASS selects histogram + scan + scatter
+  // Order repair BEFORE the unit kernel (ring_order_kernel over every ring), switched on while the stream keeps
+  // arriving rotated / reversed: decided from the counters of earlier batches, which arrive in pinned host
+  // memory without anyone waiting for them.  LFX_DEBUG_PRE_ORDER=0/1 pins it.
+  int pre_order_env = -1;
+  bool pre_order = false;
+  uint32_t * h_counters = nullptr;       // pinned [4]: deferred, repaired after the first pass, slow, repaired before it
+  uint32_t h_rings_seen = 0;             // rings of the batch those counters belong to
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
 
@@ -309,6 +316,18 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   if (c->fast_path) {
     const uint32_t * no_list = nullptr;
+    if (c->pre_order_env >= 0) {
+      c->pre_order = c->pre_order_env != 0;
+    } else if (c->h_counters && c->h_rings_seen) {
+      // more than a twentieth of the rings of an earlier batch needed their order repaired: expect the same now
+      c->pre_order = 20u * (c->h_counters[1] + c->h_counters[3]) > c->h_rings_seen;
+    }
+    if (c->pre_order) {
+      Timed t(c, 4, st);
+      hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(4 * c->slow_grid), dim3(512), c->order_lds, st,
+        c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
+        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, batch, counters + 3);
+    }
     {
       Timed t(c, 3, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
@@ -326,7 +345,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       Timed t(c, 4, st);
       hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(c->slow_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
-        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p);
+        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 0u, counters + 3);
     }
     {
       Timed t(c, 5, st);
@@ -363,6 +382,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
       c->surf_idx.p, c->max_rings);
+  }
+  if (c->h_counters) {
+    // for the next batches' decision about the order pre-pass; nobody waits for this copy
+    LFX_HIP(c, hipMemcpyAsync(c->h_counters, counters, 16, hipMemcpyDeviceToHost, st));
+    c->h_rings_seen = batch * c->max_rings;
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -605,6 +629,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
   c->single_pass = std::getenv("LFX_DEBUG_TWO_PASS") == nullptr;
   c->slow_grid = 1024;
+  if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->pre_order_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_FLAGS")) {c->unit_flags = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
@@ -636,6 +661,10 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
+  if (e == hipSuccess) {
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 16, hipHostMallocDefault);
+    if (e == hipSuccess) {std::memset(c->h_counters, 0, 16);}
+  }
   if (e == hipSuccess) {
     const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p};
@@ -676,6 +705,7 @@ void lfx_destroy(lfx_ctx * c)
   c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
+  if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
   if (c->stream) {(void)hipStreamDestroy(c->stream);}

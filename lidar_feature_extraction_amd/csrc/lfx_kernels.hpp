@@ -1734,7 +1734,8 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
   float * __restrict__ sz, uint32_t * __restrict__ sidx, uint32_t * __restrict__ ring_flags,
   const uint32_t * __restrict__ defer_count, const uint32_t * __restrict__ defer_list,
   uint32_t * __restrict__ redo_count, uint32_t * __restrict__ redo_list, uint32_t * __restrict__ slow_count,
-  uint32_t * __restrict__ slow_list)
+  uint32_t * __restrict__ slow_list, uint32_t all_rings /* = batch: run BEFORE the unit kernel over every ring */,
+  uint32_t * __restrict__ pre_fixed)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int T = blockDim.x, tid = threadIdx.x;
@@ -1747,14 +1748,20 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
   float * lz = reinterpret_cast<float *>(lp + M);
   uint32_t * ls = reinterpret_cast<uint32_t *>(lz + M);   // sidx as bucketed
   int * cnt = reinterpret_cast<int *>(ls + M);            // [8] counters
-  const uint32_t n_items = *defer_count;
+  // Two uses.  After the first unit pass (all_rings = 0): the rings on the defer list.  Before it (all_rings =
+  // batch, switched on by the host while a stream keeps arriving rotated or reversed): every ring of the batch;
+  // a rotation / reversal is undone here, so that the first pass takes the ring and no second pass is needed;
+  // rings in order are only read, rings that need a real sort are left to the normal route.
+  const uint32_t n_items = all_rings ? all_rings * max_rings : *defer_count;
   for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t e = defer_list[item];
+    const uint32_t e = all_rings ? (item / max_rings) * kRings + item % max_rings : defer_list[item];
     const uint32_t s = e / kRings, slot = e % kRings;
     const int N = (int)ring_count[e];
-    const uint32_t reason = ring_flags[e];
+    const uint32_t reason = all_rings ? (uint32_t)kDeferOrder : ring_flags[e];
     const size_t off = ring_base(s, slot, max_rings, cap);
-    const bool fixable = (reason & kDeferOrder) && N >= 2 && (uint32_t)N <= cap;
+    // (a ring this kernel already put in order is not sorted a second time: where the float predicate is not a
+    // consistent order on nearly parallel points a second sort could differ)
+    const bool fixable = (reason & kDeferOrder) && !(reason & kRingSorted) && N >= 2 && (uint32_t)N <= cap;
     if (fixable) {
       if (tid < 8) {cnt[tid] = tid == 1 || tid == 3 ? -1 : 0;}
       for (int i = tid; i < N; i += T) {
@@ -1787,6 +1794,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
       const int up_breaks = cnt[0], up_at = cnt[1], down_breaks = cnt[2], down_at = cnt[3];
       int mode = 0;                                     // 0 sort, 1 rotation, 2 reverse, 3 reversed rotation
       int cut = 0;
+      __syncthreads();                                  // everyone has read cnt[0..3]; cnt[4] <- mode below
       if (up_breaks == 1 && polar_less(lx[up_at + 1], ly[up_at + 1], lx[up_at], ly[up_at]) &&
         polar_less(lx[N - 1], ly[N - 1], lx[0], ly[0]))
       {
@@ -1798,7 +1806,10 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
       {
         mode = 3; cut = down_at + 1;                    // two decreasing runs: sorted = reverse([0..cut-1]) then reverse([cut..N-1])
       }
-      if (mode == 0) {
+      if (tid == 0) {cnt[4] = mode;}
+      if (all_rings && (up_breaks == 0 || mode == 0)) {
+        // in order already, or in need of a real sort: not this pass's business
+      } else if (mode == 0) {
         uint32_t Ms = 1;
         while (Ms < (uint32_t)N) {Ms <<= 1;}
         for (uint32_t i = tid; i < Ms; i += T) {
@@ -1847,6 +1858,14 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
           sidx[off + i] = ls[src];
         }
       }
+    }
+    if (all_rings) {
+      if (tid == 0 && fixable && cnt[0] != 0 && cnt[4] != 0) {
+        ring_flags[e] = kRingSorted;
+        atomicAdd(pre_fixed, 1u);
+      }
+      __syncthreads();
+      continue;
     }
     if (tid == 0) {
       // kRingSorted: the ring is sorted exactly once from its bucketed order, also when it ends up in

@@ -72,6 +72,35 @@ def test_scan_parity_input_orders(fx, variant):
     assert_scan_equal(got, want, variant)
 
 
+INPUT_ORDER_KW = {"sorted": dict(), "ragged": dict(drop_fraction=0.13), "shuffled": dict(shuffle=True), "rotated": dict(start_col=517),
+                  "reversed": dict(reverse=True), "reversed_rotated": dict(reverse=True, start_col=333),
+                  "ragged_rotated": dict(drop_fraction=0.2, start_col=901)}
+
+
+@pytest.mark.parametrize("force", ["1", "0", None])
+def test_order_repair_before_the_first_pass(force):
+    """A stream that keeps arriving rotated / reversed gets its rings put in order BEFORE the unit kernel
+    (ring_order_kernel over every ring) instead of after a failed first pass; the library switches that on from
+    the repair counts of earlier batches (force=None: same context fed the same kind of batch three times, so the
+    later calls take the other route), LFX_DEBUG_PRE_ORDER pins it.  Same results on every route."""
+    import os
+    clouds = {k: make_scan(16, 1024, seed=85, **kw) for k, kw in INPUT_ORDER_KW.items()}
+    want = {k: OB.extract(c, canonical_ties=False) for k, c in clouds.items()}
+    if force is not None:
+        os.environ["LFX_DEBUG_PRE_ORDER"] = force
+    try:
+        f = FeatureExtraction(device=0, max_points_per_scan=16 * 1024, max_batch=4, max_points_per_ring=1024, max_rings=16)
+    finally:
+        os.environ.pop("LFX_DEBUG_PRE_ORDER", None)
+    for k, c in clouds.items():
+        for rep in range(3):
+            got = f.extract_batch([c, clouds["sorted"], c])
+            assert_scan_equal(got[0], want[k], "%s/pre-order %s/rep %d" % (k, force, rep))
+            assert_scan_equal(got[1], want["sorted"], "sorted beside %s/pre-order %s/rep %d" % (k, force, rep))
+            assert_scan_equal(got[2], want[k], "%s (second copy)/pre-order %s/rep %d" % (k, force, rep))
+    f.close()
+
+
 def _cloud(ring, x, y, z=None):
     c = np.zeros(len(ring), POINT_DTYPE)
     c["ring"], c["x"], c["y"] = ring, x, y
