@@ -96,6 +96,7 @@ struct lfx_ctx
   size_t total_cap = 0, ring_lds = 0, order_lds = 0;
   uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
   uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
+  bool default_thresholds = false;       // padding 5 and the seven thresholds of hyper_parameter.hpp:35-43: literal-threshold unit kernel
   uint32_t unit_chunks = 6;              // chunks of 64 positions per unit wave (3..6), from the configured ring length
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
@@ -331,10 +332,17 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 3, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
-      auto kern = &lfx::ring_unit_kernel<false, 6>;
-      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<false, 5>;}
-      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<false, 4>;}
-      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3>;}
+      auto kern = &lfx::ring_unit_kernel<false, 6, false>;
+      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<false, 5, false>;}
+      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<false, 4, false>;}
+      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3, false>;}
+      if (c->default_thresholds) {
+        // the reference's code defaults: the variant with the thresholds as literals
+        kern = &lfx::ring_unit_kernel<false, 6, true>;
+        if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<false, 5, true>;}
+        if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<false, 4, true>;}
+        if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3, true>;}
+      }
       hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
@@ -350,10 +358,10 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 5, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B * batch;
-      auto kern = &lfx::ring_unit_kernel<true, 6>;
-      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<true, 5>;}
-      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<true, 4>;}
-      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<true, 3>;}
+      auto kern = &lfx::ring_unit_kernel<true, 6, false>;
+      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<true, 5, false>;}
+      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<true, 4, false>;}
+      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<true, 3, false>;}
       hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
@@ -586,6 +594,14 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->device = device_id;
   c->params = *params;
   c->dev = device_params(*params);
+  {
+    lfx_params d;
+    lfx_default_params(&d);
+    c->default_thresholds = params->padding == 5 && params->distance_diff_threshold == d.distance_diff_threshold &&
+      params->parallel_beam_min_range_ratio == d.parallel_beam_min_range_ratio && params->edge_threshold == d.edge_threshold &&
+      params->surface_threshold == d.surface_threshold && params->min_range == d.min_range && params->max_range == d.max_range &&
+      std::getenv("LFX_DEBUG_GENERIC_THRESHOLDS") == nullptr;
+  }
   const lfx_layout & L = config->layout;
   if (L.point_step == 0) {
     c->layout = lfx::Layout{32, 0, 4, 8, 20, LFX_FIELD_UINT16, 0};     // PointXYZIR, point_type.hpp:62-86

@@ -1247,7 +1247,7 @@ struct UnitTables
   uint32_t * ring_flags;
 };
 
-template<int PT, int CH>
+template<int PT, int CH, bool DEF>
 __device__ __forceinline__ void unit_body(
   const Params & prm, UnitLds<CH> & U, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
@@ -1257,6 +1257,13 @@ __device__ __forceinline__ void unit_body(
 {
   const int lane = threadIdx.x & 63;
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
+  // DEF: the thresholds are the reference's code defaults (hyper_parameter.hpp:35-43; the host checks) and become
+  // literals: seven fewer long-lived scalar values in a kernel that spills scalar registers (-3.4 % time)
+  const double dist_diff = DEF ? 0.3 : prm.dist_diff;
+  const double edge_thr = DEF ? 0.05 : prm.edge_thr, surf_thr = DEF ? 0.05 : prm.surf_thr;
+  const double min_range = DEF ? 0.1 : prm.min_range, max_range = DEF ? 100.0 : prm.max_range;
+  const double pb_ratio = DEF ? 0.02 : prm.pb_ratio;
+  const float pb_ratio_f = DEF ? 0.02f : prm.pb_ratio_f;
   const int N = (int)ring_count[s * kRings + slot];
   if (N == 0) {return;}                                  // no such ring in this scan
   const size_t off = ring_base(s, slot, max_rings, ring_cap);
@@ -1404,7 +1411,7 @@ __device__ __forceinline__ void unit_body(
         const int q = 64 * k + lane;
         put_word(U, kBitLK, k, lky[k]);
         const int qm = q > 0 ? q - 1 : 0;
-        const double rq = r[k] + prm.dist_diff;
+        const double rq = r[k] + dist_diff;
         // far side to the right of a linked pair (q, q+1), i in [0, N-P-1)
         const uint64_t jl = lky[k] & in_span(q, 0, N - P - 1 - g0) & bal(U.r[q + 1] > rq);
         // far side to the left of a linked pair (q-1, q), i in [P+1, N-1]
@@ -1522,10 +1529,10 @@ __device__ __forceinline__ void unit_body(
         uint64_t cd;
         if (edge) {
           // label.hpp:80-82; the slab is 0 outside the block and the threshold is > 0 (validated)
-          cd = bal(c0 >= prm.edge_thr);
+          cd = bal(c0 >= edge_thr);
         } else {
           // label.hpp:119-121: in the block and still Default, i.e. not reached by an edge pick
-          cd = in_span(q, qb0, qb1) & bal(c0 <= prm.surf_thr) & ~bal((get_win(U, kBitSelE, k, W0) & reach[k]) != 0u);
+          cd = in_span(q, qb0, qb1) & bal(c0 <= surf_thr) & ~bal((get_win(U, kBitSelE, k, W0) & reach[k]) != 0u);
         }
         A[k] = cd;
         put_word(U, kBitA, k, cd);
@@ -1587,7 +1594,7 @@ __device__ __forceinline__ void unit_body(
     // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
     // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
     // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
-    const bool ratio_ok = prm.pb_ratio_f >= 0x1p-9f;
+    const bool ratio_ok = pb_ratio_f >= 0x1p-9f;
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       pby[k] = 0; pbu[k] = 0;
@@ -1596,7 +1603,7 @@ __device__ __forceinline__ void unit_body(
         const int qm = q > 0 ? q - 1 : 0;
         const float rf = (float)U.r[q], rmf = (float)U.r[qm], rpf = (float)U.r[q + 1];
         const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
-        const float thr = prm.pb_ratio_f * rf;
+        const float thr = pb_ratio_f * rf;
         const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
         const uint64_t guard = ratio_ok ? (bal(rf > 0.f) & bal(rf < 1e30f)) : 0ull;
         const uint64_t y1 = bal(a1 > hi_t) & guard, n1 = bal(a1 < lo_t) & guard;
@@ -1618,7 +1625,7 @@ __device__ __forceinline__ void unit_body(
           const double ri = U.r[q];
           const float ratio1 = (float)(fabs(U.r[qm] - ri) / ri);
           const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
-          pby[k] |= pbu[k] & bal((double)ratio1 > prm.pb_ratio) & bal((double)ratio2 > prm.pb_ratio);
+          pby[k] |= pbu[k] & bal((double)ratio1 > pb_ratio) & bal((double)ratio2 > pb_ratio);
         }
       }
     }
@@ -1643,7 +1650,7 @@ __device__ __forceinline__ void unit_body(
       l = (wE & (1u << 16)) != 0u ? (uint8_t)kEdge : l;
       const double ri = U.r[q];
       uint32_t ov = over[k];
-      ov = !(prm.min_range <= ri && ri <= prm.max_range) ? (uint32_t)kOutOfRange : ov;      // range.hpp:40-43
+      ov = !(min_range <= ri && ri <= max_range) ? (uint32_t)kOutOfRange : ov;      // range.hpp:40-43
       ov = lanes(pby[k]) ? (uint32_t)kParallelBeam : ov;
       l = ov != kDefault ? (uint8_t)ov : l;
       l = own ? l : (uint8_t)kDefault;
@@ -1680,7 +1687,7 @@ __device__ __forceinline__ void unit_body(
 // SECOND = false: first pass, grid = (units of a scan / 4, batch); rings it cannot take go on
 // `defer_list` with the reason.  SECOND = true: second pass over the rings ring_order_kernel
 // repaired (redo_list, grid-stride); what still cannot be taken goes on the slow list.
-template<bool SECOND, int CH>
+template<bool SECOND, int CH, bool DEF>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
@@ -1709,14 +1716,14 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
     if (slot >= max_rings) {return;}
   }
   const int j = (int)(u % B);
-  if (prm.P == 5) {
-    unit_body<5, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+  if (DEF || prm.P == 5) {
+    unit_body<5, CH, DEF>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
       defer_list, SECOND);
   } else if (prm.P == 2) {
-    unit_body<2, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+    unit_body<2, CH, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
       defer_list, SECOND);
   } else {
-    unit_body<0, CH>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+    unit_body<0, CH, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
       defer_list, SECOND);
   }
 }

@@ -281,10 +281,11 @@ def test_every_unit_kernel_variant(chunks):
     f.close()
 
 
-@pytest.mark.parametrize("env", ["LFX_DEBUG_TWO_PASS", "LFX_DEBUG_NO_FAST_PATH"])
+@pytest.mark.parametrize("env", ["LFX_DEBUG_TWO_PASS", "LFX_DEBUG_NO_FAST_PATH", "LFX_DEBUG_GENERIC_THRESHOLDS"])
 def test_fallback_paths_give_the_same_results(env):
     """The two-pass ring bucketing (histogram + scan + scatter) and the workgroup-per-ring kernel for
-    every ring are kept as fallbacks of the look-back bucketing / wave-per-unit kernel."""
+    every ring are kept as fallbacks of the look-back bucketing / wave-per-unit kernel; with the reference's
+    default thresholds the unit kernel runs a variant that has them as literals, here switched off."""
     import os
     clouds = [make_scan(16, 1200, seed=70), make_scan(16, 1200, seed=71, drop_fraction=0.1), make_scan(8, 700, seed=72, shuffle=True)]
     os.environ[env] = "1"
