@@ -1213,6 +1213,17 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
   return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
 }
 
+// Stage ablations of the unit kernel (tools_ablate.sh) exist in the diagnostic build only (-DLFX_ABLATE, `make
+// ablate`): LFX_DEBUG_UNIT_FLAGS then switches stages off (bits 256 occlusion, 512 parallel beam, 1024 records;
+// bits 1 / 64 = edge / surface pass kept).  The product build has no such tests in its instruction stream.
+#ifdef LFX_ABLATE
+#define LFX_STAGE_ON(bit) (!(dbg_flags & (bit)))
+#define LFX_STAGE_KEPT(bit) ((dbg_flags & (bit)) != 0u)
+#else
+#define LFX_STAGE_ON(bit) true
+#define LFX_STAGE_KEPT(bit) true
+#endif
+
 // Diagnostic build only (-DLFX_STAMPS): shader-clock stamps at the stage boundaries of the unit kernel,
 // kept for the first kStampUnits units of scan LFX_STAMP_SCAN; read back with lfx_debug_read_stamps.  The product
 // build executes none of this.
@@ -1418,7 +1429,7 @@ __device__ __forceinline__ void unit_body(
         const uint64_t lk_prev = (lky[k] << 1) | prev_top;
         const uint64_t jr = lk_prev & in_span(q, P + 1 - g0, qhi) & bal(U.r[qm] > rq);
         prev_top = lky[k] >> 63;
-        if (!(dbg_flags & 256u)) {
+        if (LFX_STAGE_ON(256u)) {
           put_word(U, kBitJL, k, jl);
           put_word(U, kBitJR, k, jr);
         }
@@ -1442,7 +1453,7 @@ __device__ __forceinline__ void unit_body(
       Rr = Rr < P ? Rr : P;
       const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
       const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
-      if (!(dbg_flags & 256u)) {
+      if (LFX_STAGE_ON(256u)) {
         over[k] = ((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u ? (uint32_t)kOccluded : (uint32_t)kDefault;
       }
       // inside the block the links are cut at its ends (label.hpp:157-159): clamp the runs
@@ -1515,7 +1526,7 @@ __device__ __forceinline__ void unit_body(
   for (int pass = 0; pass < 2; pass++) {
     const bool edge = pass == 0;
     if (!edge) {LFX_STAMP(8);}
-    if (!(dbg_flags & (edge ? 1u : 64u))) {continue;}
+    if (!LFX_STAGE_KEPT(edge ? 1u : 64u)) {continue;}
     const int sel_arr = edge ? kBitSelE : kBitSelS;
     uint64_t A[CH], SEL[CH];
     uint32_t Hp[CH];
@@ -1598,7 +1609,7 @@ __device__ __forceinline__ void unit_body(
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       pby[k] = 0; pbu[k] = 0;
-      if (k < K && !(dbg_flags & 512u)) {
+      if (k < K && LFX_STAGE_ON(512u)) {
         const int q = 64 * k + lane;
         const int qm = q > 0 ? q - 1 : 0;
         const float rf = (float)U.r[q], rmf = (float)U.r[qm], rpf = (float)U.r[q + 1];
@@ -1660,7 +1671,7 @@ __device__ __forceinline__ void unit_body(
         curv_s[off + i] = cv;
       }
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
-      if (lanes(fe | fs) && !(dbg_flags & 1024u)) {
+      if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
         const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
         const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
