@@ -2064,7 +2064,9 @@ __global__ __launch_bounds__(kRings) void ring_totals_kernel(
 }
 
 // Compaction, step 2: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
-// ring angle ascending (units ascending; a slow-path ring is one unit).  One wave per ring.
+// ring angle ascending (units ascending; a slow-path ring is one unit).  One wave per ring; the ring's records
+// are taken as ONE sequence over its units, four per lane in flight, so that the copy waits for memory once per
+// 256 records instead of once per unit.
 __global__ __launch_bounds__(256) void feature_compact_kernel(
   uint32_t n_units, uint32_t cap, const uint32_t * __restrict__ scan_begin,
   const uint32_t * __restrict__ ring_count, const uint32_t * __restrict__ ring_ebase,
@@ -2075,27 +2077,71 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   uint32_t max_rings)
 {
   const uint32_t s = blockIdx.y, lane = threadIdx.x & 63;
-  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (slot >= max_rings || ring_count[s * kRings + slot] == 0u) {return;}
   const size_t b = scan_begin[s];
   const size_t off = ring_base(s, slot, max_rings, cap);
-  size_t eb = b + ring_ebase[s * kRings + slot], fb = b + ring_sbase[s * kRings + slot];
+  const size_t eb = b + ring_ebase[s * kRings + slot], fb = b + ring_sbase[s * kRings + slot];
   const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
-  for (uint32_t j = 0; j < n_units; j++) {
-    const uint32_t ne = unit_ne[ui + j], ns = unit_ns[ui + j], span = unit_span[ui + j];
-    const size_t first = off + (span & 0xFFFFu), last = off + (span >> 16);
-    for (uint32_t k = lane; k < ne + ns; k += 64) {
-      if (k < ne) {
-        edge_pts[eb + k] = rec_pts[first + k];
-        edge_idx[eb + k] = rec_idx[first + k];
-      } else {
-        const uint32_t q = k - ne;
-        surf_pts[fb + q] = rec_pts[last - 1 - q];
-        surf_idx[fb + q] = rec_idx[last - 1 - q];
+  uint32_t ne_k = 0, ns_k = 0, span_k = 0;               // lane j holds unit j's entries (n_units <= 64)
+  if (lane < n_units) {
+    ne_k = unit_ne[ui + lane];
+    ns_k = unit_ns[ui + lane];
+    span_k = unit_span[ui + lane];
+  }
+  uint32_t total = ne_k + ns_k;
+  for (int o = 32; o > 0; o >>= 1) {total += __shfl_xor(total, o);}
+  for (uint32_t t0 = 0; t0 < total; t0 += 256) {
+    size_t src[4], dst[4];
+    bool edge[4], valid[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      valid[i] = t0 + 64 * i + lane < total;
+      edge[i] = false;
+      src[i] = off;
+      dst[i] = b;
+    }
+    uint32_t cum = 0, ecum = 0, scum = 0;
+    for (uint32_t u = 0; u < n_units; u++) {               // the units' counts are wave-uniform
+      const uint32_t ne = __builtin_amdgcn_readlane(ne_k, u), ns = __builtin_amdgcn_readlane(ns_k, u);
+      const uint32_t span = __builtin_amdgcn_readlane(span_k, u);
+      const size_t first = off + (span & 0xFFFFu), last = off + (span >> 16);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t q = t0 + 64 * i + lane - cum;       // index inside unit u (wraps when the record lies before it)
+        if (q < ne + ns) {
+          edge[i] = q < ne;
+          src[i] = edge[i] ? first + q : last - 1 - (q - ne);
+          dst[i] = edge[i] ? eb + ecum + q : fb + scum + (q - ne);
+        }
+      }
+      cum += ne + ns;
+      ecum += ne;
+      scum += ns;
+    }
+    float4 rp[4];
+    uint32_t ri[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ri[i] = 0;
+      if (valid[i]) {
+        rp[i] = rec_pts[src[i]];
+        ri[i] = rec_idx[src[i]];
       }
     }
-    eb += ne;
-    fb += ns;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (valid[i]) {
+        if (edge[i]) {
+          edge_pts[dst[i]] = rp[i];
+          edge_idx[dst[i]] = ri[i];
+        } else {
+          surf_pts[dst[i]] = rp[i];
+          surf_idx[dst[i]] = ri[i];
+        }
+      }
+    }
   }
 }
 
