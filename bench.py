@@ -102,8 +102,10 @@ def main():
         # two sets of packed-cloud buffers: while the clouds of step k-1 travel to rank 0 on a side
         # stream, step k extracts and packs into the other set (gather.py: CloudGather)
         feat_cap = int(a.batch * n_pts * 0.35) + 1024
-        bufs = [(torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev),
-                 torch.zeros((feat_cap, 4), dtype=torch.float32, device=dev),
+        # x, y, z only (12 bytes per point): what the node publishes (pcl::PointXYZ clouds,
+        # feature_extraction.cpp:163-166) and a quarter less to push through rank 0's links
+        bufs = [(torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
+                 torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
                  torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(2)]
         gather = CloudGather(dst=0, device=dev)
 
@@ -116,7 +118,7 @@ def main():
         if use_gather:
             edge_buf, surf_buf, offs = bufs[step_no[0] % 2]
             gather.wait_buffer(edge_buf)       # the gather that last read this set must be done
-            fxs[k].pack_features(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
+            fxs[k].pack_xyz12(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
             gather.submit(edge_buf, surf_buf, offs, a.batch)
 
     def fence():

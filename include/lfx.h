@@ -197,6 +197,10 @@ int lfx_layout_from_fields(const lfx_point_field *fields, uint32_t n_fields, uin
  * does (same offsets table). */
 int lfx_pack_xyz(lfx_ctx *ctx, float *d_edge_out, float *d_surface_out, uint32_t *d_offsets_out,
                  size_t capacity_points, void *stream);
+/* The same clouds as tight x, y, z triples (12 bytes per point, [capacity_points][3] floats): the least that has
+ * to cross xGMI when the clouds of several GPUs are gathered to one (gather.py, bench.py). */
+int lfx_pack_xyz12(lfx_ctx *ctx, float *d_edge_out, float *d_surface_out, uint32_t *d_offsets_out,
+                   size_t capacity_points, void *stream);
 /* colored_scan (feature_extraction.cpp:153,161) of the last device batch as pcl::PointXYZRGB wire records
  * (point_step 32: x, y, z, 1.0f | rgb bit-cast to float, 0, 0, 0; rgb = 0xFF<<24 | r<<16 | g<<8 | b with the
  * table of color_points.cpp:39-68): for every scan the points of each ring that was labelled (status

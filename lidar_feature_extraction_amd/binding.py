@@ -71,7 +71,7 @@ class DeviceView(C.Structure):
 EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
     "lfx_status_string", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
-    "lfx_device_results", "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
+    "lfx_device_results", "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
@@ -112,6 +112,7 @@ def load():
     L.lfx_device_results.argtypes = [vp, C.POINTER(DeviceView)]
     L.lfx_layout_from_fields.argtypes = [C.POINTER(PointField), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Layout)]
     L.lfx_pack_xyz.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
+    L.lfx_pack_xyz12.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.lfx_pack_colored.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.lfx_pack_features.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.lfx_download_scan.argtypes = [vp, u32, vp, C.POINTER(ScanResult)]

@@ -775,6 +775,13 @@ int lfx_pack_xyz(
   return pack_clouds(c, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream, 1u);
 }
 
+int lfx_pack_xyz12(
+  lfx_ctx * c, float * d_edge_out, float * d_surface_out, uint32_t * d_offsets_out, size_t capacity_points,
+  void * stream)
+{
+  return pack_clouds(c, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream, 2u);
+}
+
 int lfx_pack_colored(lfx_ctx * c, float * d_colored_out, uint32_t * d_offsets_out, size_t capacity_points, void * stream)
 {
   if (!c || !d_colored_out || !d_offsets_out) {return LFX_ERR_INVALID_ARGUMENT;}

@@ -2223,6 +2223,12 @@ __global__ __launch_bounds__(256) void feature_pack_kernel(
     const bool edge = k < ne;
     const uint32_t q = edge ? k : k - ne;
     float4 v = edge ? edge_pts[b + q] : surf_pts[b + q];
+    if (xyz_wire == 2u) {
+      // tight x, y, z (12 bytes per point): what has to travel when the clouds are gathered to one GPU
+      float * o = reinterpret_cast<float *>(edge ? edge_out : surf_out) + 3 * (size_t)((edge ? oe : os) + q);
+      if ((edge ? oe : os) + q < capacity) {o[0] = v.x; o[1] = v.y; o[2] = v.z;}
+      continue;
+    }
     if (xyz_wire) {v.w = 1.0f;}          // pcl::PointXYZ: data[3] = 1 (the curvature travels in lfx_pack_features only)
     if (edge) {
       if (oe + q < capacity) {edge_out[oe + q] = v;}

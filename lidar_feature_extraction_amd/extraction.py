@@ -165,6 +165,12 @@ class FeatureExtraction:
             self._ctx, C.c_void_p(int(d_edge_out)), C.c_void_p(int(d_surface_out)), C.c_void_p(int(d_offsets_out)),
             int(capacity_points), C.c_void_p(int(stream))))
 
+    def pack_xyz12(self, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream=0):
+        """As pack_features, but tight x, y, z triples ([capacity][3] floats): the gather payload."""
+        B.check(self._ctx, self._L.lfx_pack_xyz12(
+            self._ctx, C.c_void_p(int(d_edge_out)), C.c_void_p(int(d_surface_out)), C.c_void_p(int(d_offsets_out)),
+            int(capacity_points), C.c_void_p(int(stream))))
+
     def pack_colored(self, d_colored_out, d_offsets_out, capacity_points, stream=0):
         """colored_scan of the last device batch as 32-byte pcl::PointXYZRGB wire records (see lfx.h)."""
         B.check(self._ctx, self._L.lfx_pack_colored(

@@ -432,8 +432,14 @@ def test_wire_payloads_of_the_three_published_clouds(fx):
     coffs = torch.zeros(3, dtype=torch.int32, device="cuda:0")
     fx.pack_xyz(e.data_ptr(), s.data_ptr(), offs.data_ptr(), cap, stream)
     fx.pack_colored(col.data_ptr(), coffs.data_ptr(), cap, stream)
+    e12 = torch.zeros((cap, 3), dtype=torch.float32, device="cuda:0")
+    s12 = torch.zeros((cap, 3), dtype=torch.float32, device="cuda:0")
+    offs12 = torch.zeros(2 * 3, dtype=torch.int32, device="cuda:0")
+    fx.pack_xyz12(e12.data_ptr(), s12.data_ptr(), offs12.data_ptr(), cap, stream)
     torch.cuda.synchronize()
     e, s, offs, col, coffs = e.cpu().numpy(), s.cpu().numpy(), offs.cpu().numpy(), col.cpu().numpy(), coffs.cpu().numpy()
+    assert np.array_equal(offs12.cpu().numpy(), offs)                      # the tight gather payload: same points, 12 bytes each
+    assert np.array_equal(e12.cpu().numpy()[:offs[2]], e[:offs[2], :3]) and np.array_equal(s12.cpu().numpy()[:offs[5]], s[:offs[5], :3])
     for i, c in enumerate(clouds):
         want = OB.extract(c, canonical_ties=False)
         for arr, o0, o1, idx in ((e, offs[i], offs[i + 1], want["edge_index"]), (s, offs[3 + i], offs[3 + i + 1], want["surface_index"])):
