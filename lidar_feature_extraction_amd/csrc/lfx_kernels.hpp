@@ -1782,12 +1782,21 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
     const bool fixable = (reason & kDeferOrder) && !(reason & kRingSorted) && N >= 2 && (uint32_t)N <= cap;
     if (fixable) {
       if (tid < 8) {cnt[tid] = tid == 1 || tid == 3 ? -1 : 0;}
-      for (int i = tid; i < N; i += T) {
-        const float2 v = sxy[off + i];
-        lx[i] = v.x;
-        ly[i] = v.y;
-        lz[i] = sz[off + i];
-        ls[i] = sidx[off + i];
+      for (int i0 = 0; i0 < N; i0 += 4 * T) {           // twelve loads per thread in flight, then the LDS stores
+        float2 v[4];
+        float vz[4];
+        uint32_t vs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * T + tid;
+          v[u] = make_float2(0.f, 0.f); vz[u] = 0.f; vs[u] = 0u;
+          if (i < N) {v[u] = sxy[off + i]; vz[u] = sz[off + i]; vs[u] = sidx[off + i];}
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * T + tid;
+          if (i < N) {lx[i] = v[u].x; ly[i] = v[u].y; lz[i] = vz[u]; ls[i] = vs[u];}
+        }
       }
       __syncthreads();
       // cnt[0] / cnt[1]: number / position of pairs that are not strictly increasing,
