@@ -8,10 +8,16 @@
 //                           over earlier chunks obtained by look-back inside the launch
 //   ring_unit_kernel        fast path: one WAVE per (ring, block): angle-order check, range,
 //                           curvature, links, block labelling, occlusion / out-of-range /
-//                           parallel-beam masks, per-unit feature records; no workgroup barrier
-//   ring_extract_kernel     slow path for the rings the fast path defers (unsorted as bucketed ->
-//                           LDS bitonic sort with the exact predicate; skip conditions; long blocks):
-//                           one workgroup per ring, the ring resident in LDS
+//                           parallel-beam masks, per-unit feature records; no workgroup barrier;
+//                           point sets as ballot words in LDS bit arrays (one read + v_alignbit per
+//                           32-position window); instantiated per span (3..6 chunks of 64) and, for the
+//                           reference's default parameter set, with the thresholds as literals
+//   ring_order_kernel       order repair: a ring that arrives as a rotation / reversal of its angle order
+//                           is put in order by index arithmetic, anything else by an LDS bitonic sort;
+//                           after the first unit pass (then a second pass takes the repaired rings) or,
+//                           while a stream keeps arriving rotated, ahead of it over every ring
+//   ring_extract_kernel     slow path for what neither pass takes (skip conditions, blocks that do not
+//                           fit a wave, exactly tied directions): one workgroup per ring in LDS
 //   ring_totals_kernel, feature_compact_kernel   per-unit records -> the scan's edge / surface clouds
 //   (ring_histogram_kernel, ring_scan_kernel: two-pass bucketing kept as a fallback)
 //
@@ -1155,18 +1161,6 @@ constexpr int unit_waves_per_simd(int ch) {return ch >= 6 ? 6 : (ch == 5 ? 7 : 8
     __builtin_amdgcn_wave_barrier(); \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
-
-// bits of word k (positions 64k .. 64k+63) that lie in [lo, hi)
-__device__ inline uint64_t range_word(int k, int lo, int hi)
-{
-  int a = lo - 64 * k, b = hi - 64 * k;
-  a = a < 0 ? 0 : a;
-  b = b > 64 ? 64 : b;
-  if (b <= a) {return 0ull;}
-  const uint64_t upto_b = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
-  const uint64_t upto_a = (1ull << a) - 1ull;          // a <= 63 here
-  return upto_b & ~upto_a;
-}
 
 // Lane predicate <-> wave-uniform mask.  `bal` is meant for ONE comparison (it then is the
 // comparison's own result register); combine masks with & | ~ in scalar code.
