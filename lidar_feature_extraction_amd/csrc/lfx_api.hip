@@ -107,6 +107,7 @@ struct lfx_ctx
   int pre_order_env = -1;
   bool pre_order = false;
   uint32_t * h_counters = nullptr;       // pinned [4]: deferred, repaired after the first pass, slow, repaired before it
+  uint32_t redo_cap_env = 0;             // LFX_DEBUG_REDO_CAP: rings the second unit pass is launched for (tests)
   uint32_t h_rings_seen = 0;             // rings of the batch those counters belong to
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
@@ -327,7 +328,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       Timed t(c, 4, st);
       hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(4 * c->slow_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
-        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, batch, counters + 3);
+        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, batch, counters + 3, 0u);
     }
     {
       Timed t(c, 3, st);
@@ -346,18 +347,28 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
-        defer_count, c->defer_list.p, no_list, no_list);
+        defer_count, c->defer_list.p, no_list, no_list, 0u);
+    }
+    // The second pass is launched for as many rings as earlier batches had repaired after their first pass, twice
+    // over and at least 256 (a launch that covers every unit of a large batch costs ~20 us to find nothing to do);
+    // the order kernel hands what does not fit to the workgroup-per-ring kernel.
+    uint32_t redo_cap = batch * c->max_rings;
+    if (c->redo_cap_env) {
+      redo_cap = c->redo_cap_env;
+    } else if (c->h_counters && c->h_rings_seen) {
+      const uint32_t want = 2u * c->h_counters[1] + 256u;
+      redo_cap = want < redo_cap ? want : redo_cap;
     }
     {
       // rings out of angle order: repaired in place, then a second pass of the unit kernel over them
       Timed t(c, 4, st);
       hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(c->slow_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
-        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 0u, counters + 3);
+        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 0u, counters + 3, redo_cap);
     }
     {
       Timed t(c, 5, st);
-      const uint32_t units = c->max_rings * (uint32_t)c->dev.B * batch;
+      const uint32_t units = redo_cap * (uint32_t)c->dev.B;
       auto kern = &lfx::ring_unit_kernel<true, 6, false>;
       if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<true, 5, false>;}
       if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<true, 4, false>;}
@@ -365,7 +376,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
-        slow_count, c->slow_list.p, redo_count, c->redo_list.p);
+        slow_count, c->slow_list.p, redo_count, c->redo_list.p, redo_cap);
     }
   }
   {
@@ -645,6 +656,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
   c->single_pass = std::getenv("LFX_DEBUG_TWO_PASS") == nullptr;
   c->slow_grid = 1024;
+  if (const char * dbg = std::getenv("LFX_DEBUG_REDO_CAP")) {c->redo_cap_env = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->pre_order_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_FLAGS")) {c->unit_flags = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}

@@ -1698,7 +1698,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
   uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list,
-  const uint32_t * __restrict__ redo_count, const uint32_t * __restrict__ redo_list)
+  const uint32_t * __restrict__ redo_count, const uint32_t * __restrict__ redo_list, uint32_t redo_cap)
 {
   __shared__ UnitLds<CH> lds[kUnitWaves];
   // the wave index is the same in all 64 lanes: saying so keeps everything derived from it (unit,
@@ -1711,7 +1711,8 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
-    if (u >= *redo_count * B) {return;}
+    const uint32_t n_redo = *redo_count < redo_cap ? *redo_count : redo_cap;      // the order kernel sent the rest to the slow list
+    if (u >= n_redo * B) {return;}
     const uint32_t e = redo_list[u / B];
     s = e / kRings;
     slot = e % kRings;
@@ -1747,7 +1748,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
   const uint32_t * __restrict__ defer_count, const uint32_t * __restrict__ defer_list,
   uint32_t * __restrict__ redo_count, uint32_t * __restrict__ redo_list, uint32_t * __restrict__ slow_count,
   uint32_t * __restrict__ slow_list, uint32_t all_rings /* = batch: run BEFORE the unit kernel over every ring */,
-  uint32_t * __restrict__ pre_fixed)
+  uint32_t * __restrict__ pre_fixed, uint32_t redo_cap)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int T = blockDim.x, tid = threadIdx.x;
@@ -1892,9 +1893,13 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
       // kRingSorted: the ring is sorted exactly once from its bucketed order, also when it ends up in
       // the workgroup-per-ring kernel later (a second sort could differ where the float predicate is
       // not a consistent order on nearly parallel points)
-      if (fixable && reason == kDeferOrder) {
+      // (the second pass is launched for redo_cap rings -- what earlier batches needed, with room to spare;
+      // a ring beyond that takes the workgroup-per-ring kernel: slower, same result)
+      uint32_t at = 0xFFFFFFFFu;
+      if (fixable && reason == kDeferOrder) {at = atomicAdd(redo_count, 1u);}
+      if (at < redo_cap) {
         ring_flags[e] = kRingSorted;
-        redo_list[atomicAdd(redo_count, 1u)] = e;
+        redo_list[at] = e;
       } else {
         if (fixable) {ring_flags[e] = reason | kRingSorted;}
         slow_list[atomicAdd(slow_count, 1u)] = e;

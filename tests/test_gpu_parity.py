@@ -101,6 +101,25 @@ def test_order_repair_before_the_first_pass(force):
     f.close()
 
 
+def test_second_pass_capacity_overflow_goes_to_the_slow_path():
+    """The second unit pass is launched for a number of rings estimated from earlier batches; rings beyond it are
+    handed to the workgroup-per-ring kernel by the order-repair kernel.  Forced here to 3 rings."""
+    import os
+    c = make_scan(16, 1024, seed=86, start_col=300)
+    want = OB.extract(c, canonical_ties=False)
+    os.environ["LFX_DEBUG_REDO_CAP"] = "3"
+    os.environ["LFX_DEBUG_PRE_ORDER"] = "0"
+    try:
+        f = FeatureExtraction(device=0, max_points_per_scan=16 * 1024, max_batch=2, max_points_per_ring=1024, max_rings=16)
+    finally:
+        del os.environ["LFX_DEBUG_REDO_CAP"], os.environ["LFX_DEBUG_PRE_ORDER"]
+    for rep in range(2):
+        got = f.extract_batch([c, c])
+        assert_scan_equal(got[0], want, "redo cap 3, rep %d" % rep)
+        assert_scan_equal(got[1], want, "redo cap 3, second scan, rep %d" % rep)
+    f.close()
+
+
 def _cloud(ring, x, y, z=None):
     c = np.zeros(len(ring), POINT_DTYPE)
     c["ring"], c["x"], c["y"] = ring, x, y
