@@ -186,6 +186,8 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                # the kernel's real HBM rate: PMC bytes (profiles/pmc_traffic.json) over the live duration
+                "traffic_gbs": (round(traffic / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9, 1) if traffic else None),
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items()},
                 "whole_path_frac": round(algo_bytes / (max(sum_us, 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -225,6 +227,28 @@ def main():
         cpu["all_cores"] = {"value": round(total / el2, 3), "unit": "scans/s", "cores": n_thr,
                             "sample": "%d scans, one scan per thread, %.1f s" % (total, el2)}
 
+    # ---- end to end through the synchronous host API (pageable host buffers in, host results out: H2D, the
+    #      kernels, densify, D2H, un-permute to the caller's point order) -- the latency a ROS callback would see.
+    #      Reported beside `value`, never as it (device-resident and PCIe-inclusive separately).
+    end_to_end = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        fe = FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=16,
+                               max_points_per_ring=cap, max_rings=a.rings)
+        fe.ExtractFeatures(clouds[0])
+        t3 = time.perf_counter()
+        for j in range(16):
+            fe.ExtractFeatures(clouds[j % n_unique])
+        one = (time.perf_counter() - t3) / 16
+        some = [clouds[j % n_unique] for j in range(16)]
+        fe.extract_batch(some)
+        t3 = time.perf_counter()
+        for _ in range(3):
+            fe.extract_batch(some)
+        many = (time.perf_counter() - t3) / 48
+        fe.close()
+        end_to_end = {"ms_per_scan_one_at_a_time": round(1e3 * one, 3), "ms_per_scan_batches_of_16": round(1e3 * many, 3),
+                      "note": "lfx_extract / lfx_extract_batch with pageable host memory on both sides"}
+
     if rank == 0:
         out = {
             "metric": "scans/sec (64-ring x 1800 synthetic scans, extraction hot path, inputs resident in HBM)",
@@ -235,7 +259,7 @@ def main():
                        "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": "code defaults",
                        "streams": 1 if use_gather else n_streams,
                        "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_spot_check": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "parity_spot_check": parity,
         }
         print(json.dumps(out))
         sys.stdout.flush()
