@@ -1207,7 +1207,7 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
   return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
 }
 
-// Stage ablations of the unit kernel (tools_ablate.sh) exist in the diagnostic build only (-DLFX_ABLATE, `make
+// Stage ablations of the unit kernel (tools/ablate.sh) exist in the diagnostic build only (-DLFX_ABLATE, `make
 // ablate`): LFX_DEBUG_UNIT_FLAGS then switches stages off (bits 256 occlusion, 512 parallel beam, 1024 records;
 // bits 1 / 64 = edge / surface pass kept).  The product build has no such tests in its instruction stream.
 #ifdef LFX_ABLATE

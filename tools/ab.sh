@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_ab.sh REV  -- build the kernels of git revision REV as _lib/ab_A.so next to the working tree's
+# tools/ab.sh REV  -- build the kernels of git revision REV as _lib/ab_A.so next to the working tree's
 # build (_lib/liblfx.so) so that both can be timed on ONE device in one gpurun call:
 #   for i in 1 2 3; do LFX_LIB_PATH=$PWD/lidar_feature_extraction_amd/_lib/ab_A.so python bench.py ...; python bench.py ...; done
 set -e

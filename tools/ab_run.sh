@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_ab_run.sh [ROUNDS] [bench args...] -- on the GPU box: alternate _lib/ab_A.so (built by tools_ab.sh)
+# tools/ab_run.sh [ROUNDS] [bench args...] -- on the GPU box: alternate _lib/ab_A.so (built by tools/ab.sh)
 # and _lib/liblfx.so through bench.py, print scans/s and the per-kernel microseconds of each run.
 R=${1:-3}; shift
 mkdir -p gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_ablate.sh -- on the GPU box, after `make -C lidar_feature_extraction_amd/csrc ablate` here: unit-kernel time
+# tools/ablate.sh -- on the GPU box, after `make -C lidar_feature_extraction_amd/csrc ablate` here: unit-kernel time
 # with stages switched off (liblfx_ablate.so honours LFX_DEBUG_UNIT_FLAGS; results are
 # then wrong on purpose): 1 edge pass, 64 surface pass, 256 no occlusion, 512 no parallel-beam, 1024 no records.
 mkdir -p gpurun_out

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Throughput of the device-resident path for input orders other than "every ring arrives angle
 sorted": rotated scan start, clockwise sensor, shuffled points.  (bench.py measures the sorted case.)"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from anywhere: the repo root holds the packages
 import sys
 import time
 

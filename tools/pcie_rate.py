@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the synchronous host API (lfx_extract_batch: pageable host buffers in,
 host results out, incl. densify + un-permute).  Not bench.py's `value`; recorded in DESIGN.md."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from anywhere: the repo root holds the packages
 import sys
 import time
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_pmc.sh "COUNTER COUNTER ..." [kernel-name-substring] -- on the GPU box: one rocprofv3 --pmc pass over a
+# tools/pmc.sh "COUNTER COUNTER ..." [kernel-name-substring] -- on the GPU box: one rocprofv3 --pmc pass over a
 # short bench run; prints the per-dispatch average of each counter for the matching kernel.
 set -e
 C="$1"; KN="${2:-ring_unit_kernel}"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_profile.sh OUTDIR -- on the GPU box: the evidence behind bench.py's "roofline" object.
+# tools/profile.sh OUTDIR -- on the GPU box: the evidence behind bench.py's "roofline" object.
 #   1. rocprofv3 --kernel-trace --stats of `python3 bench.py` (per-kernel durations)       -> kernel_stats.csv
 #   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (HBM traffic)      -> pmc_traffic.json
 #   3. the plain bench line, CPU baseline included                                         -> bench.json

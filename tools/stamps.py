@@ -1,8 +1,11 @@
 """Diagnostic: where a unit wave's lifetime goes.  Build the kernels with -DLFX_STAMPS
 (make -C lidar_feature_extraction_amd/csrc stamps), run this on the GPU box:
-    LFX_LIB_PATH=$PWD/lidar_feature_extraction_amd/_lib/liblfx_stamps.so python tools_stamps.py
+    LFX_LIB_PATH=$PWD/lidar_feature_extraction_amd/_lib/liblfx_stamps.so python tools/stamps.py
 It runs batches of 64x1800 scans and prints the median shader cycles between consecutive stage
 stamps of the unit kernel (units of scan 0).  Not part of the product or the tests."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from anywhere: the repo root holds the packages
 import ctypes as C
 import numpy as np
 import torch

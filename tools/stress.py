@@ -1,6 +1,9 @@
 """Randomised parity sweep (not part of pytest: minutes of oracle time).  For N random (sensor shape, input order,
 hyper-parameter) draws: HIP path vs the CPU oracle, everything assert_scan_equal checks.  Run on the GPU box:
-    python tools_stress.py [N] [seed]"""
+    python tools/stress.py [N] [seed]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from anywhere: the repo root holds the packages
 import sys
 import time
 import numpy as np

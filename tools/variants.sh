@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_variants.sh LIB... -- on the GPU box: bench each _lib/<LIB> twice, print scans/s and per-kernel microseconds
+# tools/variants.sh LIB... -- on the GPU box: bench each _lib/<LIB> twice, print scans/s and per-kernel microseconds
 mkdir -p gpurun_out
 for i in 1 2; do
   for lib in "$@"; do
