@@ -77,8 +77,8 @@ struct DevBuf
 
 struct HostScan
 {
-  std::vector<uint8_t> labels, labels_sorted, ring_status;
-  std::vector<double> curvature, curvature_sorted;
+  std::vector<uint8_t> labels, ring_status;
+  std::vector<double> curvature;
   std::vector<uint32_t> sorted_index, ring_count, ring_offset, edge_index, surface_index;
   std::vector<uint16_t> ring_id;
   std::vector<float> edge_points, surface_points;
@@ -423,17 +423,20 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
   LFX_HIP(c, hipMemcpyAsync(info, c->scan_info.p + (size_t)s * 4, 16, hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipMemcpyAsync(rcount, c->ring_count.p + (size_t)s * lfx::kRings, sizeof(rcount), hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipMemcpyAsync(rstat, c->ring_status.p + (size_t)s * lfx::kRings, sizeof(rstat), hipMemcpyDeviceToHost, st));
-  h.labels_sorted.resize(n);
-  h.curvature_sorted.resize(n);
+  h.labels.resize(n);
+  h.curvature.resize(n);
   h.sorted_index.resize(n);
   if (n) {
-    // ring-major (fixed capacity per ring) -> dense, rings ascending; then one copy per array
+    // ring-major (fixed capacity per ring) -> the caller's point order (labels, curvature) and the dense list of
+    // angle-sorted indices, rings ascending; then one copy per array
+    LFX_HIP(c, hipMemsetAsync(c->d_label.p, 0, n, st));                  // LFX_LABEL_DEFAULT for points that are in no ring
+    LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, (size_t)n * 8, st));
     hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings), dim3(256), 0, st,
       s, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p, c->d_curv.p,
-      c->d_sidx.p);
+      c->d_sidx.p, n);
     LFX_HIP(c, hipGetLastError());
-    LFX_HIP(c, hipMemcpyAsync(h.labels_sorted.data(), c->d_label.p, n, hipMemcpyDeviceToHost, st));
-    LFX_HIP(c, hipMemcpyAsync(h.curvature_sorted.data(), c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.labels.data(), c->d_label.p, n, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(h.curvature.data(), c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     LFX_HIP(c, hipMemcpyAsync(h.sorted_index.data(), c->d_sidx.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   }
   LFX_HIP(c, hipStreamSynchronize(st));
@@ -475,18 +478,9 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
     LFX_HIP(c, hipMemcpyAsync(h.surface_index.data(), c->surf_idx.p + b, (size_t)ns * 4, hipMemcpyDeviceToHost, st));
   }
   LFX_HIP(c, hipStreamSynchronize(st));
-  // back to the caller's point order (labels[k] / curvature[k] belong to input point k); points the
-  // zero filter dropped keep Default / 0 and do not appear in sorted_index
-  h.labels.assign(n, LFX_LABEL_DEFAULT);
-  h.curvature.assign(n, 0.0);
+  // labels[k] / curvature[k] belong to input point k (densify_kernel); points the zero filter dropped keep
+  // Default / 0 and do not appear in sorted_index
   h.sorted_index.resize(n_kept);
-  for (uint32_t k = 0; k < n_kept; k++) {
-    const uint32_t o = h.sorted_index[k];
-    if (o < n) {
-      h.labels[o] = h.labels_sorted[k];
-      h.curvature[o] = h.curvature_sorted[k];
-    }
-  }
   if (out) {
     out->n_points = n;
     out->n_sorted = n_kept;

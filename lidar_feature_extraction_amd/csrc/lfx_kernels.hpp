@@ -2154,12 +2154,15 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Download path: one scan's per-point outputs from the ring-major layout to dense arrays, rings
-// ascending (the order of lfx_scan_result::sorted_index).  One workgroup per ring id.
+// Download path: one scan's per-point outputs from the ring-major layout.  sorted_index goes to a dense
+// array, rings ascending; labels and curvature go straight to the CALLER's point order (label of input point k
+// at [k]) -- the scatter by original index is done here rather than in a host loop after the copy.  The host
+// zeroes d_label / d_curv first: points the zero filter dropped, or beyond a ring's capacity, stay Default / 0.
+// One workgroup per ring id.
 __global__ __launch_bounds__(256) void densify_kernel(
   uint32_t s, uint32_t max_rings, uint32_t cap, const uint32_t * __restrict__ ring_count,
   const uint8_t * __restrict__ label_s, const double * __restrict__ curv_s, const uint32_t * __restrict__ sidx,
-  uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx)
+  uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx, uint32_t n_points)
 {
   const uint32_t ring = blockIdx.x, tid = threadIdx.x;
   __shared__ uint32_t part[256];
@@ -2176,9 +2179,12 @@ __global__ __launch_bounds__(256) void densify_kernel(
   const uint32_t Nfull = ring_count[s * kRings + ring];
   for (uint32_t i = tid; i < Nfull; i += blockDim.x) {
     const bool stored = i < N;
-    d_label[dense + i] = stored ? label_s[off + i] : (uint8_t)kDefault;
-    d_curv[dense + i] = stored ? curv_s[off + i] : 0.;
-    d_sidx[dense + i] = stored ? sidx[off + i] : 0xFFFFFFFFu;
+    const uint32_t orig = stored ? sidx[off + i] : 0xFFFFFFFFu;
+    d_sidx[dense + i] = orig;
+    if (orig < n_points) {
+      d_label[orig] = label_s[off + i];
+      d_curv[orig] = curv_s[off + i];
+    }
   }
 }
 
