@@ -13,7 +13,7 @@ out, kn = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(float); cnt = collections.Counter()
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if kn in row["Kernel_Name"] and "Lb1E" not in row["Kernel_Name"]:
+        if kn in row["Kernel_Name"] and "ring_unit_kernel<true" not in row["Kernel_Name"]:
             acc[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
 for k in sorted(acc):
     print("%-28s %14.0f per dispatch (%d dispatches)" % (k, acc[k] / cnt[k], cnt[k]))
