@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
   if (chunk * kChunkPoints >= n) {return;}
   __shared__ uint32_t h[kRings];
-  h[tid] = 0;
+  if (tid < kRings) {h[tid] = 0;}
   __syncthreads();
   bool bad = false;
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
     }
   }
   __syncthreads();
-  chunk_hist[((size_t)s * max_chunks + chunk) * kRings + tid] = (uint16_t)h[tid];
+  if (tid < kRings) {chunk_hist[((size_t)s * max_chunks + chunk) * kRings + tid] = (uint16_t)h[tid];}
   if (bad) {atomicOr(&scan_info[s * 4 + kInfoError], 1u);}
 }
 
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   float * st_z = reinterpret_cast<float *>(block + kStage * 8);
   uint16_t * st_src = reinterpret_cast<uint16_t *>(block + kStage * 12);
   uint8_t * st_ring = block + kStage * 14;
-  static_assert(kGroups * kRings * 2 + 4 * kRings * 4 <= kStageBytes, "count table + look-back scratch must fit the staging block");
+  static_assert(kGroups * kRings * 2 + (kChunkThreads / 64) * kRings * 4 <= kStageBytes, "count table + look-back scratch must fit the staging block");
+  static_assert(kChunkThreads >= kRings && kChunkThreads % 64 == 0, "one thread per ring id for the per-ring steps");
   for (int i = tid; i < kGroups * kRings; i += kChunkThreads) {(&wcnt[0][0])[i] = 0;}
   __syncthreads();
 
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     // before the ranking work, with write-through (sc1) stores, drain, then ONE lane sets the flag.
     // No L2 write-back fence: a release fence would flush every dirty line of the XCD's L2, i.e. the
     // other workgroups' scattered output (cdna_hip_programming.md Guideline 16, form R1).
-    cstart[tid] = 0;
+    if (tid < kRings) {cstart[tid] = 0;}
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kChunkSlots; i++) {
@@ -268,7 +269,9 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     }
     __syncthreads();
     if (bad_ring) {atomicOr(&scan_info[s * 4 + kInfoError], 1u);}
-    __hip_atomic_store(&chunk_base[(row + chunk) * kRings + tid], cstart[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < kRings) {
+      __hip_atomic_store(&chunk_base[(row + chunk) * kRings + tid], cstart[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
   }
   __syncthreads();
   uint32_t mine = 0;
-  {
+  if (tid < kRings) {
     uint32_t acc = 0;                      // thread = ring id: exclusive prefix over the arrival groups
     for (int g = 0; g < kGroups; g++) {
       const uint32_t v = wcnt[g][tid];
@@ -315,10 +318,11 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
     // loads are kept in flight per thread (thread = 4 consecutive rings x one quarter of the chunks)
     {
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      constexpr uint32_t kLb = kChunkThreads / 64;             // groups of 64 threads, each taking every kLb-th chunk
       const uint32_t grp = tid >> 6, quad = tid & 63;
       u32x4 acc = {0u, 0u, 0u, 0u};
-      for (uint32_t p0 = 0; p0 < chunk; p0 += 16) {
-        const uint32_t pa = p0 + grp, pb = pa + 4, pc = pa + 8, pd = pa + 12;
+      for (uint32_t p0 = 0; p0 < chunk; p0 += 4 * kLb) {
+        const uint32_t pa = p0 + grp, pb = pa + kLb, pc = pa + 2 * kLb, pd = pa + 3 * kLb;
         const uint32_t * qa = chunk_base + (row + (pa < chunk ? pa : 0u)) * kRings + 4 * quad;
         const uint32_t * qb = chunk_base + (row + (pb < chunk ? pb : 0u)) * kRings + 4 * quad;
         const uint32_t * qc = chunk_base + (row + (pc < chunk ? pc : 0u)) * kRings + 4 * quad;
@@ -337,22 +341,24 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
         acc += (pa < chunk ? va : zero) + (pb < chunk ? vb : zero) + (pc < chunk ? vc : zero) + (pd < chunk ? vd : zero);
       }
       __syncthreads();
-      // part: [4][256] u32 behind the count table
+      // part: [kLb][256] u32 behind the count table
       part[grp * kRings + 4 * quad + 0] = acc.x;
       part[grp * kRings + 4 * quad + 1] = acc.y;
       part[grp * kRings + 4 * quad + 2] = acc.z;
       part[grp * kRings + 4 * quad + 3] = acc.w;
       __syncthreads();
-      before = part[tid] + part[kRings + tid] + part[2 * kRings + tid] + part[3 * kRings + tid];
+      if (tid < kRings) {
+        for (uint32_t g = 0; g < kLb; g++) {before += part[g * kRings + tid];}
+      }
       __syncthreads();
     }
     if ((chunk + 1) * (uint32_t)kChunkPoints >= n) {     // the scan's last chunk knows the ring totals
-      ring_count[s * kRings + tid] = before + mine;
-      const uint32_t occupied = __syncthreads_count(before + mine != 0u);
+      if (tid < kRings) {ring_count[s * kRings + tid] = before + mine;}
+      const uint32_t occupied = __syncthreads_count(tid < kRings && before + mine != 0u);
       if (tid == 0) {scan_info[s * 4 + kInfoRings] = occupied;}
     }
   } else {
-    before = chunk_base[(row + chunk) * kRings + tid];
+    before = tid < kRings ? chunk_base[(row + chunk) * kRings + tid] : 0u;
   }
   {
     // exclusive scan of the 256 ring counts: shuffles inside each wave, one exchange of the four wave
@@ -364,14 +370,16 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
       if (lane >= (uint32_t)d) {incl += t;}
     }
     __syncthreads();                      // every thread has read its cstart[] entry (LOOKBACK) by now
-    if (lane == 63) {gfill[wave] = incl;} // wave totals, parked in gfill[0..3] for a moment
+    if (lane == 63 && wave < kRings / 64) {gfill[wave] = incl;} // wave totals, parked in gfill[0..3] for a moment
     __syncthreads();
     uint32_t base = 0;
-    for (uint32_t v = 0; v < wave; v++) {base += gfill[v];}
+    for (uint32_t v = 0; v < wave && v < kRings / 64; v++) {base += gfill[v];}
     const uint32_t total = gfill[0] + gfill[1] + gfill[2] + gfill[3];
     __syncthreads();
-    cstart[tid] = base + incl - mine;
-    gfill[tid] = before;
+    if (tid < kRings) {
+      cstart[tid] = base + incl - mine;
+      gfill[tid] = before;
+    }
     if (tid == 0) {staged = total;}
   }
   __syncthreads();
