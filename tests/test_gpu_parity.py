@@ -596,6 +596,60 @@ def test_full_size_properties():
     f.close()
 
 
+def _scan_properties(c, g, hp, ctx):
+    """Size-independent properties of one scan's outputs (no oracle)."""
+    n = len(c)
+    assert np.array_equal(np.sort(g.sorted_index), np.arange(n)), ctx                                   # a permutation
+    assert np.array_equal(np.nonzero(g.labels == 1)[0], np.sort(g.edge_index)), ctx
+    assert np.array_equal(np.nonzero(g.labels == 3)[0], np.sort(g.surface_index)), ctx
+    pos = np.empty(n, np.int64)
+    pos[g.sorted_index] = np.arange(n)
+    assert np.all(np.diff(pos[g.edge_index]) > 0) and np.all(np.diff(pos[g.surface_index]) > 0), ctx     # emission order
+    assert np.array_equal(c["ring"][g.sorted_index], np.repeat(g.ring_id, g.ring_count)), ctx           # ring-major
+    assert np.array_equal(g.edge_points[:, 0], c["x"][g.edge_index]) and np.array_equal(g.edge_points[:, 1], c["y"][g.edge_index]), ctx
+    assert np.array_equal(g.edge_points[:, 2], c["z"][g.edge_index]), ctx
+    assert np.array_equal(g.surface_points[:, 2], c["z"][g.surface_index]), ctx
+    assert np.array_equal(g.edge_points[:, 3], g.curvature[g.edge_index].astype(np.float32)), ctx
+    assert np.array_equal(g.surface_points[:, 3], g.curvature[g.surface_index].astype(np.float32)), ctx
+    assert np.all(g.curvature[g.edge_index] >= hp.edge_threshold) and np.all(g.curvature[g.surface_index] <= hp.surface_threshold), ctx
+
+
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_config_os1_128x2048_batch32(pname):
+    """BASELINE.json configs[3]: OS1-128-shaped 128-ring x 2048-column scans, batch = 32 scans in ONE call
+    (8.4 M points: 128 bucketing chunks per scan, ~3.7 GB of context scratch).  Both parameter sets.  Every scan:
+    size-independent properties and equality with a second run; scans 0, 9, 18, 27 and 31: the CPU oracle."""
+    hp = PARAM_SETS[pname]
+    rings, cols, batch = 128, 2048, 32
+    clouds = [make_scan(rings, cols, seed=4000 + i, vfov_deg=22.5) for i in range(batch)]
+    f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=batch, max_points_per_ring=cols,
+                          max_rings=rings)
+    got = f.extract_batch(clouds)
+    again = f.extract_batch(clouds)
+    f.close()
+    for i, (c, g, g2) in enumerate(zip(clouds, got, again)):
+        ctx = "128x2048x32/%s/scan%d" % (pname, i)
+        assert g.labels.tobytes() == g2.labels.tobytes() and g.curvature.tobytes() == g2.curvature.tobytes(), ctx
+        assert np.array_equal(g.edge_index, g2.edge_index) and np.array_equal(g.surface_index, g2.surface_index), ctx
+        assert len(g.ring_id) == rings and g.ring_count.tolist() == [cols] * rings and not g.ring_status.any(), ctx
+        _scan_properties(c, g, hp, ctx)
+        assert len(g.edge_index) > 0 and len(g.surface_index) > 0, ctx
+    for i in (0, 9, 18, 27, 31):
+        want = OB.extract(clouds[i], oracle_params(hp), canonical_ties=False)
+        assert want["angle_ties"] == 0 and want["curvature_ties"] == 0
+        assert_scan_equal(got[i], want, "128x2048x32/%s/scan%d" % (pname, i))
+
+
+@pytest.mark.timeout(900)
+def test_stress_slice():
+    """A seeded 200-draw slice of tools/stress.py: random sensor shapes (4-64 rings x 150-2600 columns), input
+    orders (sorted, rotated, reversed, both, shuffled, ragged), noise levels and all nine hyper-parameters; every
+    output against the oracle, each batch extracted twice (the second call may take another route)."""
+    from tests.stress_cases import ORDERS, run_cases
+    seen = run_cases(200, seed=20261004)
+    assert set(seen) == set(ORDERS), seen
+
+
 # ------------------------------------------------------------------ reference unit vectors on the device
 def test_refvec_curvature_convolution(fx, refvec):
     for c in refvec["calc_curvature"]["cases"]:
