@@ -256,7 +256,7 @@ int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_p
                               float *out);
 
 /* --- measurement ------------------------------------------------------------------------- */
-#define LFX_N_KERNELS 9   /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact */
+#define LFX_N_KERNELS 10  /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact, ring_unit_org (organised scans: loads the records itself) */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);
 /* Record the events around every n-th batch only (default 1).  The event pairs between the kernels of a batch
  * cost ~7 % of the device-resident throughput at 64x1800x256; sampled, the durations stay live and the cost goes. */

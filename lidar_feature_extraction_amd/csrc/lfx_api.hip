@@ -25,7 +25,7 @@ std::string g_create_error;
 const char * kKernelNames[LFX_N_KERNELS] = {
   "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_unit_kernel",
   "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel", "ring_totals_kernel",
-  "feature_compact_kernel"};
+  "feature_compact_kernel", "ring_unit_org_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -106,7 +106,16 @@ struct lfx_ctx
   // memory without anyone waiting for them.  LFX_DEBUG_PRE_ORDER=0/1 pins it.
   int pre_order_env = -1;
   bool pre_order = false;
-  uint32_t * h_counters = nullptr;       // pinned [4]: deferred, repaired after the first pass, slow, repaired before it
+  uint32_t * h_counters = nullptr;       // pinned [lfx::kCounters]: deferred, repaired after the first pass, slow, repaired before it,
+                                         // scans on the fall-back list, organised-scan kernel ran, scans of that batch
+  // The organised-scan kernel (lfx_kernels.hpp, unit_body<ORG>) reads a driver's column-major scan directly; scans that are
+  // not of that form fall back to the bucketing route inside the same call.  While most scans of a stream fall back the
+  // kernel is not launched at all (decided from the counters of earlier batches; every 16th batch tries again).
+  // LFX_DEBUG_FUSED=0/1 pins it.
+  bool fused_possible = false;
+  int fused_env = -1;
+  bool bucket_all = false;               // the stream is not organised: bucketing route for every scan
+  uint32_t retry_in = 0;
   uint32_t redo_cap_env = 0;             // LFX_DEBUG_REDO_CAP: rings the second unit pass is launched for (tests)
   uint32_t h_rings_seen = 0;             // rings of the batch those counters belong to
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
@@ -114,7 +123,7 @@ struct lfx_ctx
 
   // device scratch
   DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
-    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list,
+    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list,
     sidx, rec_idx, edge_idx,
     surf_idx, d_sidx;
   DevBuf<uint16_t> chunk_hist;
@@ -279,24 +288,69 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   c->last_points = d_points;
   c->profile_now = c->profiling && (c->batch_no++ % c->profile_every) == 0u;
   uint32_t * counters = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;     // behind ring_flags[max_batch][256]
-  uint32_t * defer_count = counters, * redo_count = counters + 1, * slow_count = counters + 2;
-  hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
-    c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
-    c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters);
+  uint32_t * defer_count = counters + lfx::kCntDefer, * redo_count = counters + lfx::kCntRedo,
+    * slow_count = counters + lfx::kCntSlow, * fb_count = counters + lfx::kCntFallback;
   const uint8_t * pts = static_cast<const uint8_t *>(d_points);
   const uint32_t chunks = (longest + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
-  if (chunks == 0) {return LFX_OK;}
   const bool canon = c->layout.step == 32 && c->layout.ox == 0 && c->layout.oy == 4 && c->layout.oz == 8 &&
     c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0 &&
     (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
+  // ---- which route: the organised-scan kernel first (scans it cannot take fall back inside this call), or
+  //      bucketing for every scan.  What earlier batches reported arrives in pinned memory unasked.
+  bool fused = c->fused_possible && canon && chunks != 0;
+  uint32_t fb_grid = batch;                            // list entries the bucketing kernels are launched for
+  if (fused) {
+    const uint32_t was_fused = c->h_counters[lfx::kCntFusedRan], fell = c->h_counters[lfx::kCntFallback],
+      of = c->h_counters[lfx::kCntBatch];
+    if (c->fused_env >= 0) {
+      fused = c->fused_env != 0;
+    } else {
+      if (was_fused && of) {
+        const bool mostly_not = 4u * fell > of;
+        if (mostly_not && !c->bucket_all) {c->retry_in = 16;}
+        c->bucket_all = mostly_not;
+      }
+      if (c->bucket_all) {
+        fused = false;
+        if (c->retry_in == 0 || --c->retry_in == 0) {fused = true; c->retry_in = 16;}     // the stream may have changed
+      }
+    }
+    if (fused) {
+      const uint32_t guess = (was_fused ? 2u * fell : 0u) + 8u;
+      fb_grid = guess < batch ? guess : batch;
+    }
+  }
+  hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
+    c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
+    c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
+    fused ? 0u : 1u);
+  if (chunks == 0) {return LFX_OK;}
+  if (fused) {
+    Timed t(c, 9, st);
+    const uint32_t groups = (c->max_rings + 3u) / 4u;
+    auto kern = &lfx::ring_unit_org_kernel<6, false>;
+    if (c->unit_chunks == 5) {kern = &lfx::ring_unit_org_kernel<5, false>;}
+    if (c->unit_chunks == 4) {kern = &lfx::ring_unit_org_kernel<4, false>;}
+    if (c->unit_chunks == 3) {kern = &lfx::ring_unit_org_kernel<3, false>;}
+    if (c->default_thresholds) {
+      kern = &lfx::ring_unit_org_kernel<6, true>;
+      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_org_kernel<5, true>;}
+      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_org_kernel<4, true>;}
+      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_org_kernel<3, true>;}
+    }
+    hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
+      c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p);
+  }
+  // ---- the bucketing route, over the scans on the fall-back list
   if (c->single_pass) {
     Timed t(c, 2, st);
     auto kern = &lfx::ring_scatter_kernel<false, true>;
     if (canon) {kern = &lfx::ring_scatter_kernel<true, true>;}
-    hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
+    hipLaunchKernelGGL(kern, dim3(chunks, fb_grid), dim3(lfx::kChunkThreads), 0, st,
       pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
-      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero);
+      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p);
   } else {
+    // (two-pass bucketing, LFX_DEBUG_TWO_PASS: never together with the organised-scan kernel, so the list is every scan in order)
     {
       Timed t(c, 0, st);
       hipLaunchKernelGGL(lfx::ring_histogram_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
@@ -313,22 +367,24 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       if (canon) {kern = &lfx::ring_scatter_kernel<true, false>;}
       hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
         pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
-        c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero);
+        c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p);
     }
   }
+  // the near-empty launches of the bucketing route are kept small while the organised-scan kernel takes the stream
+  const uint32_t list_grid = fused ? (c->slow_grid < 4u * fb_grid ? c->slow_grid : 4u * fb_grid) : c->slow_grid;
   if (c->fast_path) {
-    const uint32_t * no_list = nullptr;
     if (c->pre_order_env >= 0) {
       c->pre_order = c->pre_order_env != 0;
     } else if (c->h_counters && c->h_rings_seen) {
       // more than a twentieth of the rings of an earlier batch needed their order repaired: expect the same now
-      c->pre_order = 20u * (c->h_counters[1] + c->h_counters[3]) > c->h_rings_seen;
+      c->pre_order = 20u * (c->h_counters[lfx::kCntRedo] + c->h_counters[lfx::kCntPreFixed]) > c->h_rings_seen;
     }
     if (c->pre_order) {
       Timed t(c, 4, st);
-      hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(4 * c->slow_grid), dim3(512), c->order_lds, st,
+      hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(fused ? list_grid : 4 * c->slow_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
-        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, batch, counters + 3, 0u);
+        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 1u, counters + lfx::kCntPreFixed, 0u,
+        fb_count, c->fb_list.p, 0u);
     }
     {
       Timed t(c, 3, st);
@@ -344,10 +400,10 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
         if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<false, 4, true>;}
         if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3, true>;}
       }
-      hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, batch),
+      hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, fb_grid),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
-        defer_count, c->defer_list.p, no_list, no_list, 0u);
+        defer_count, c->defer_list.p, fb_count, c->fb_list.p, 0u);
     }
     // The second pass is launched for as many rings as earlier batches had repaired after their first pass, twice
     // over and at least 256 (a launch that covers every unit of a large batch costs ~20 us to find nothing to do);
@@ -356,15 +412,16 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     if (c->redo_cap_env) {
       redo_cap = c->redo_cap_env;
     } else if (c->h_counters && c->h_rings_seen) {
-      const uint32_t want = 2u * c->h_counters[1] + 256u;
+      const uint32_t want = 2u * c->h_counters[lfx::kCntRedo] + 256u;
       redo_cap = want < redo_cap ? want : redo_cap;
     }
     {
       // rings out of angle order: repaired in place, then a second pass of the unit kernel over them
       Timed t(c, 4, st);
-      hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(c->slow_grid), dim3(512), c->order_lds, st,
+      hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(list_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
-        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 0u, counters + 3, redo_cap);
+        c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 0u, counters + lfx::kCntPreFixed, redo_cap,
+        fb_count, c->fb_list.p, fb_grid);
     }
     {
       Timed t(c, 5, st);
@@ -381,7 +438,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   {
     Timed t(c, 6, st);
-    const dim3 grid = c->fast_path ? dim3(c->slow_grid) : dim3(c->max_rings, batch);
+    const dim3 grid = c->fast_path ? dim3(list_grid) : dim3(c->max_rings, batch);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
       c->dev, c->cap, c->stage_flags, c->fast_path ? 1u : 0u, pts, c->layout, c->scan_begin.p,
       c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
@@ -404,7 +461,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   if (c->h_counters) {
     // for the next batches' decision about the order pre-pass; nobody waits for this copy
-    LFX_HIP(c, hipMemcpyAsync(c->h_counters, counters, 16, hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipMemcpyAsync(c->h_counters, counters, 4 * lfx::kCounters, hipMemcpyDeviceToHost, st));
     c->h_rings_seen = batch * c->max_rings;
   }
   LFX_HIP(c, hipGetLastError());
@@ -433,7 +490,7 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
     LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, (size_t)n * 8, st));
     hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings), dim3(256), 0, st,
       s, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p, c->d_curv.p,
-      c->d_sidx.p, n);
+      c->d_sidx.p, n, c->scan_info.p);
     LFX_HIP(c, hipGetLastError());
     LFX_HIP(c, hipMemcpyAsync(h.labels.data(), c->d_label.p, n, hipMemcpyDeviceToHost, st));
     LFX_HIP(c, hipMemcpyAsync(h.curvature.data(), c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
@@ -649,6 +706,10 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
   c->single_pass = std::getenv("LFX_DEBUG_TWO_PASS") == nullptr;
+  // the organised-scan kernel needs to know the sensor's ring count (max_rings given) and reads PointXYZIR records
+  c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->layout.step == 32 && c->layout.ox == 0 &&
+    c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
+  if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->fused_env = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
   if (const char * dbg = std::getenv("LFX_DEBUG_REDO_CAP")) {c->redo_cap_env = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->pre_order_env = std::atoi(dbg) != 0 ? 1 : 0;}
@@ -673,7 +734,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->ring_count.alloc(tables)); ok(c->chunk_flags.alloc(nb * c->max_chunks));
   ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
   ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
-  ok(c->ring_flags.alloc(tables + 4)); ok(c->slow_list.alloc(tables)); ok(c->defer_list.alloc(tables));
+  ok(c->ring_flags.alloc(tables + lfx::kCounters)); ok(c->slow_list.alloc(tables)); ok(c->defer_list.alloc(tables));
+  ok(c->fb_list.alloc(nb));
   ok(c->redo_list.alloc(tables));
   ok(c->unit_ne.alloc(tables * lfx::kUnitMaxBlocks)); ok(c->unit_ns.alloc(tables * lfx::kUnitMaxBlocks));
   ok(c->unit_span.alloc(tables * lfx::kUnitMaxBlocks));
@@ -684,22 +746,25 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
   if (e == hipSuccess) {
-    e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 16, hipHostMallocDefault);
-    if (e == hipSuccess) {std::memset(c->h_counters, 0, 16);}
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 4 * lfx::kCounters, hipHostMallocDefault);
+    if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * lfx::kCounters);}
   }
   if (e == hipSuccess) {
     const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
-      c->unit_ns.p, c->unit_span.p, c->ring_flags.p};
+      c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
+      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p};
     e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
+  // (the attribute is per function, not per context: always the worst case, so that contexts of different ring
+  // capacities can live side by side)
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_extract_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->ring_lds);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx::ring_lds_bytes(LFX_MAX_RING_POINTS));
   }
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_order_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->order_lds);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx::order_lds_bytes(LFX_MAX_RING_POINTS));
   }
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_stage_kernel),
@@ -724,7 +789,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
-  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
@@ -801,7 +866,7 @@ int lfx_pack_colored(lfx_ctx * c, float * d_colored_out, uint32_t * d_offsets_ou
   hipLaunchKernelGGL(lfx::colored_pack_kernel, dim3(c->max_rings, batch), dim3(256), 0, st,
     c->ring_count.p, c->ring_status.p, d_offsets_out, c->sxy.p, c->sidx.p, c->label_s.p,
     static_cast<const uint8_t *>(c->last_points), c->layout, c->scan_begin.p, c->max_rings, c->cap,
-    reinterpret_cast<float4 *>(d_colored_out), capacity);
+    reinterpret_cast<float4 *>(d_colored_out), capacity, c->scan_info.p);
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
 }

@@ -91,6 +91,14 @@ struct Params
 
 // scan_info[s][4]
 enum { kInfoRings = 0, kInfoError = 1, kInfoEdge = 2, kInfoSurface = 3 };
+// bits of scan_info[s][kInfoError]: errors, and the route the scan took.  kScanFused: the organised-scan kernel took
+// the scan (ring r's position k IS input point k * rings + r: nothing was staged, sxy / sz / sidx hold nothing for
+// it); kScanFellBack: that kernel (or the host) handed the scan to the bucketing route, whose staged arrays are valid.
+enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u };
+__host__ __device__ inline bool scan_is_organised(uint32_t err) {return (err & (kScanFused | kScanFellBack)) == kScanFused;}
+// counters[8] behind ring_flags: rings deferred by the first unit pass, repaired after it, sent to the workgroup-per-ring
+// kernel, repaired before it; scans on the fall-back list; whether the organised-scan kernel ran; scans in the batch
+enum { kCntDefer = 0, kCntRedo = 1, kCntSlow = 2, kCntPreFixed = 3, kCntFallback = 4, kCntFusedRan = 5, kCntBatch = 6, kCounters = 8 };
 
 enum RingStatus : uint8_t
 {
@@ -109,14 +117,20 @@ enum Label : uint8_t
 __global__ __launch_bounds__(256) void batch_reset_kernel(
   uint32_t * __restrict__ scan_info, uint32_t n_info, uint32_t * __restrict__ ring_count, uint32_t n_count,
   uint32_t * __restrict__ chunk_flags, uint32_t n_flags, uint32_t * __restrict__ ring_flags, uint32_t n_rflags,
-  uint32_t * __restrict__ counters /* [4]: deferred, redo, slow, spare */)
+  uint32_t * __restrict__ counters /* [kCounters] */, uint32_t * __restrict__ fb_list, uint32_t batch,
+  uint32_t all_fall_back /* 1: every scan takes the bucketing route (the organised-scan kernel is not launched) */)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t k = i; k < n_info; k += stride) {scan_info[k] = 0;}
   for (uint32_t k = i; k < n_count; k += stride) {ring_count[k] = 0;}
   for (uint32_t k = i; k < n_flags; k += stride) {chunk_flags[k] = 0;}
   for (uint32_t k = i; k < n_rflags; k += stride) {ring_flags[k] = 0;}
-  if (i < 4) {counters[i] = 0;}
+  if (all_fall_back) {
+    for (uint32_t k = i; k < batch; k += stride) {fb_list[k] = k;}
+  }
+  if (i < kCounters) {
+    counters[i] = i == kCntFallback ? (all_fall_back ? batch : 0u) : (i == kCntFusedRan ? (all_fall_back ? 0u : 1u) : (i == kCntBatch ? batch : 0u));
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -192,13 +206,13 @@ constexpr uint32_t kSpinLimit = 200000;   // ~50 ms of s_sleep polls before a lo
 // walk that layout, so a wave writes runs of consecutive positions (one run per ring) instead of
 // 64 scattered dwords.
 template<bool CANON, bool LOOKBACK>
-__global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
-  const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
+__device__ __forceinline__ void scatter_chunk(
+  uint32_t s, const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
   uint32_t * __restrict__ scan_info, float2 * __restrict__ sxy, float * __restrict__ sz,
   uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero)
 {
-  const uint32_t s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
   if (chunk * kChunkPoints >= n) {return;}
   const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -415,6 +429,25 @@ __global__ __launch_bounds__(kChunkThreads) void ring_scatter_kernel(
       sz[pos] = st_z[os];
       sidx[pos] = chunk * kChunkPoints + st_src[os];
     }
+  }
+}
+
+// The scans to bucket are those on the fall-back list (every scan of the batch when the organised-scan kernel is
+// not in use): workgroup (x, y) takes chunk x of list entries y, y + gridDim.y, ...  A chunk only ever waits for
+// lower chunks of the same scan, i.e. for workgroups (x' < x, y) at the same step of their loop: no cycle.
+template<bool CANON, bool LOOKBACK>
+__global__ __launch_bounds__(kChunkThreads, 4) void ring_scatter_kernel(
+  const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
+  uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
+  uint32_t * __restrict__ scan_info, float2 * __restrict__ sxy, float * __restrict__ sz,
+  uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero,
+  const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
+{
+  const uint32_t n_list = *fb_count;
+  for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
+    scatter_chunk<CANON, LOOKBACK>(fb_list[it], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
+      sidx, max_chunks, max_rings, cap, drop_zero);
+    __syncthreads();                        // the LDS blocks are reused by the next entry
   }
 }
 
@@ -1152,13 +1185,20 @@ struct UnitLds
 {
   static constexpr int kSpan = 64 * CH;
   static constexpr int kBitWords = 2 * (CH + 2);      // dwords per array; position p is bit p + 64
-  double r[kSpan];
+  double r[kSpan];                                            // (organised-scan kernel: z of the hand-over until stage B)
   union {
     double c[kSpan + 2];                                      // from stage E on
-    struct {float x[kSpan + 2]; float y[kSpan + 2];} p;       // stages A-C
+    float2 pxy[kSpan + 2];                                    // stages A-C: x, y by position
   };
   uint32_t bits[kUnitBitArrays][kBitWords];
+  // slab stride = 8 dwords mod 32: the four slabs of a workgroup start 8 LDS banks apart, so the hand-over stores of the
+  // organised-scan kernel (16 lanes = 4 columns x 4 slabs, 8 bytes each) fall on 16 different bank pairs
+  static constexpr int kBaseDwords = (kSpan * 8 + (kSpan + 2) * 8 + kUnitBitArrays * kBitWords * 4) / 4;
+  static constexpr int kPadDwords = ((8 - kBaseDwords % 32) + 32) % 32;
+  uint32_t pad_[kPadDwords ? kPadDwords : 32];
 };
+static_assert(sizeof(UnitLds<5>) % 128 == 32 && sizeof(UnitLds<3>) % 128 == 32 && sizeof(UnitLds<4>) % 128 == 32 &&
+  sizeof(UnitLds<6>) % 128 == 32, "slab stride");
 constexpr int unit_waves_per_simd(int ch) {return ch >= 6 ? 6 : (ch == 5 ? 7 : 8);}
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
@@ -1258,17 +1298,45 @@ struct UnitTables
   uint8_t * ring_status;
   uint32_t * unit_ne, * unit_ns, * unit_span;
   uint32_t * ring_flags;
+  uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
 };
 
-template<int PT, int CH, bool DEF>
+// A scan the organised-scan kernel cannot take (ring pattern, point count, angle order, a skip condition, a unit that
+// does not fit a wave) is flagged once and appended to the fall-back list: the bucketing route then redoes it whole.
+__device__ inline void scan_falls_back(const UnitTables * __restrict__ tab, uint32_t s)
+{
+  if ((atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kScanFellBack) & kScanFellBack) == 0u) {
+    tab->fb_list[atomicAdd(tab->fb_count, 1u)] = s;
+  }
+}
+
+// ORG: the organised-scan form.  A driver's scan arrives column-major -- all rings of one firing, then the next
+// azimuth -- so that ring r's position k IS input point k * R + r (R = the sensor's ring count) and the rings are
+// angle-sorted as they stand.  Then nothing needs bucketing: the workgroup's four waves take the same block of four
+// ADJACENT rings and load the 32-byte records themselves, lane = (column, ring of the group), so that every 128-byte
+// line (one column of the four rings) is requested once by four neighbouring lanes; x, y (and z) are handed to the
+// ring's wave through its LDS slab (the workgroup's only barrier).  The pattern -- ring id of every record, point
+// count, angle order -- is verified on the way; a scan that breaks it is flagged and redone whole by the bucketing
+// route (scan_falls_back).  MakePointIndices / SortEachRingByAngle (ring.hpp:114-139) give exactly this order for
+// such a scan: arrival order inside a ring, which is already the angle order.
+struct OrgScan
+{
+  const uint8_t * __restrict__ pts;       // canonical 32-byte PointXYZIR records (point_type.hpp:62-86)
+  const uint32_t * __restrict__ scan_begin;
+  uint32_t * __restrict__ ring_count_out;
+  uint32_t R, r0, wave, drop_zero;
+};
+
+template<int PT, int CH, bool DEF, bool ORG>
 __device__ __forceinline__ void unit_body(
-  const Params & prm, UnitLds<CH> & U, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
+  const Params & prm, UnitLds<CH> * __restrict__ slabs, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
-  uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list, bool second_pass)
+  uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list, bool second_pass, const OrgScan & og)
 {
   const int lane = threadIdx.x & 63;
+  UnitLds<CH> & U = slabs[ORG ? og.wave : 0u];
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
   // DEF: the thresholds are the reference's code defaults (hyper_parameter.hpp:35-43; the host checks) and become
   // literals: seven fewer long-lived scalar values in a kernel that spills scalar registers (-3.4 % time)
@@ -1277,21 +1345,39 @@ __device__ __forceinline__ void unit_body(
   const double min_range = DEF ? 0.1 : prm.min_range, max_range = DEF ? 100.0 : prm.max_range;
   const double pb_ratio = DEF ? 0.02 : prm.pb_ratio;
   const float pb_ratio_f = DEF ? 0.02f : prm.pb_ratio_f;
-  const int N = (int)ring_count[s * kRings + slot];
-  if (N == 0) {return;}                                  // no such ring in this scan
+  int N;
+  uint32_t scan_first = 0;                 // ORG: index of the scan's first point
+  if (ORG) {
+    // the scan must be R rings x C columns, C within the ring capacity (every unit of the scan sees the same)
+    scan_first = og.scan_begin[s];
+    const uint32_t n = og.scan_begin[s + 1] - scan_first;
+    const uint32_t C = n / og.R;
+    N = (int)C;
+    if (C * og.R != n || C == 0u || C > ring_cap) {
+      if (blockIdx.x == 0 && og.wave == 0 && lane == 0) {scan_falls_back(tab, s);}
+      return;
+    }
+  } else {
+    N = (int)ring_count[s * kRings + slot];
+    if (N == 0) {return;}                                  // no such ring in this scan
+  }
   const size_t off = ring_base(s, slot, max_rings, ring_cap);
   // A deferred ring goes on `defer_list` once (the first unit to flag it appends it); the flag keeps
   // the reasons: kDeferOrder = not angle-sorted as bucketed (ring_order_kernel repairs that and the
   // ring gets a second pass here), kDeferOther = anything only the workgroup-per-ring kernel handles.
+  // ORG: the whole scan goes to the bucketing route instead.
 #define LFX_DEFER(reason) \
   do { \
-    if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
+    if (ORG) { \
+      if (lane == 0) {scan_falls_back(tab, s);} \
+    } else if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
       defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
     } \
     return; \
   } while (0)
   LFX_STAMP(0);
   // skip conditions and over-long rings are the slow path's business (it also reports them)
+  // (ORG: the same for the four waves of the workgroup, which therefore leave together -- before the barrier)
   if (N < 2 * P + 1 || N - 2 * P < B || (uint32_t)N > ring_cap) {
     if (j == 0) {LFX_DEFER(kDeferOther);}
     return;
@@ -1324,21 +1410,72 @@ __device__ __forceinline__ void unit_body(
   float x[CH], y[CH], z[CH];
   uint32_t src[CH];
   double r[CH];
+  if (ORG) {
+    // lane = (column cq of a 16-column piece, ring `sub` of the group): four neighbouring lanes read the four
+    // 32-byte records of one 128-byte line; wave w takes pieces w, w + 4, ... of the span
+    const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
+    const uint32_t rr = og.r0 + sub;
+    const uint32_t rload = rr < og.R ? rr : og.R - 1u;          // a group beyond the last ring loads nothing new
+    float4 rec[CH];
+    uint32_t rw[CH];
 #pragma unroll
-  for (int k = 0; k < CH; k++) {
-    x[k] = 0.f; y[k] = 0.f; z[k] = 0.f; src[k] = 0u; r[k] = 0.;
-    if (k < K) {
-      const int q = 64 * k + lane;
-      int i = g0 + q;
-      const bool in = lanes(in_span(q, qlo, qhi));
-      i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
-      const float2 v = sxy[off + i];
-      z[k] = sz[off + i];
-      src[k] = sidx[off + i];
-      x[k] = in ? v.x : 0.f;
-      y[k] = in ? v.y : 0.f;
-      U.p.x[q] = x[k];
-      U.p.y[q] = y[k];
+    for (int m = 0; m < CH; m++) {
+      rec[m] = make_float4(0.f, 0.f, 0.f, 0.f); rw[m] = 0u;
+      if (m < K) {
+        const int q = 64 * m + 16 * (int)og.wave + (int)cq;
+        int i = g0 + q;
+        i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+        const uint8_t * p = og.pts + ((size_t)scan_first + (size_t)i * og.R + rload) * 32u;
+        rec[m] = *reinterpret_cast<const float4 *>(p);
+        rw[m] = *reinterpret_cast<const uint32_t *>(p + 20);
+      }
+    }
+    uint64_t wrong = 0;
+    float * zex = reinterpret_cast<float *>(slabs[sub].r);
+#pragma unroll
+    for (int m = 0; m < CH; m++) {
+      if (m < K) {
+        const int q = 64 * m + 16 * (int)og.wave + (int)cq;
+        const uint64_t in = in_span(q, qlo, qhi);
+        // the record must carry the ring id its place implies; with the zero-point filter on, a (0, 0, 0) record
+        // would not be part of the scan (convert.py:162-163,192): not this kernel's case either
+        uint64_t bad = bal((rw[m] & 0xFFFFu) != rr);
+        if (og.drop_zero) {bad |= bal(rec[m].x == 0.f) & bal(rec[m].y == 0.f) & bal(rec[m].z == 0.f);}
+        wrong |= bad & in & bal(rr < og.R);
+        const bool inl = lanes(in);
+        slabs[sub].pxy[q] = make_float2(inl ? rec[m].x : 0.f, inl ? rec[m].y : 0.f);
+        zex[q] = rec[m].z;
+      }
+    }
+    __syncthreads();                                  // the only workgroup barrier: the slabs are handed over
+    if (wrong != 0ull) {LFX_DEFER(kDeferOther);}
+    if (slot >= og.R) {return;}                       // ring count not a multiple of four: no such ring
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      x[k] = 0.f; y[k] = 0.f; z[k] = 0.f; src[k] = 0u; r[k] = 0.;
+      if (k < K) {
+        const int q = 64 * k + lane;
+        const float2 v = U.pxy[q];
+        x[k] = v.x; y[k] = v.y;
+        z[k] = reinterpret_cast<const float *>(U.r)[q];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      x[k] = 0.f; y[k] = 0.f; z[k] = 0.f; src[k] = 0u; r[k] = 0.;
+      if (k < K) {
+        const int q = 64 * k + lane;
+        int i = g0 + q;
+        const bool in = lanes(in_span(q, qlo, qhi));
+        i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+        const float2 v = sxy[off + i];
+        z[k] = sz[off + i];
+        src[k] = sidx[off + i];
+        x[k] = in ? v.x : 0.f;
+        y[k] = in ? v.y : 0.f;
+        U.pxy[q] = make_float2(x[k], y[k]);
+      }
     }
   }
   LFX_WAVE_SYNC();
@@ -1351,7 +1488,8 @@ __device__ __forceinline__ void unit_body(
   for (int k = 0; k < CH; k++) {
     if (k < K) {
       const int q = 64 * k + lane;
-      const float xn = U.p.x[q + 1], yn = U.p.y[q + 1];
+      const float2 nb = U.pxy[q + 1];
+      const float xn = nb.x, yn = nb.y;
       uint64_t spec;
       const uint64_t less = polar_less_masks(x[k], y[k], xn, yn, spec);
       bad |= in_span(q, qo0, pair_end) & (spec | ~less);
@@ -1368,7 +1506,8 @@ __device__ __forceinline__ void unit_body(
       if (k < K) {
         const int q = 64 * k + lane;
         const bool pair = q >= qo0 && q < pair_end;
-        if (pair && !polar_less(x[k], y[k], U.p.x[q + 1], U.p.y[q + 1])) {really = true;}
+        const float2 nb = U.pxy[q + 1];
+        if (pair && !polar_less(x[k], y[k], nb.x, nb.y)) {really = true;}
       }
     }
     if (__ballot(really) != 0ull) {LFX_DEFER(second_pass ? kDeferOther : kDeferOrder);}
@@ -1393,7 +1532,8 @@ __device__ __forceinline__ void unit_body(
         // |dot| <= r0*r1, so the f32 cosine is within ~4 ulp(1) = 5e-7 of the exact one; a value more
         // than 2^-19 (1.9e-6) away from both ends decides the test, anything closer (or not finite)
         // takes the exact f64 division below.
-        const float dotf = x[k] * U.p.x[q + 1] + y[k] * U.p.y[q + 1];
+        const float2 nb = U.pxy[q + 1];
+        const float dotf = x[k] * nb.x + y[k] * nb.y;
         const float denf = (float)r[k] * (float)rn;
         const float cosf = dotf * __builtin_amdgcn_rcpf(denf);
         const uint64_t yes = bal(cosf > cbf + 0x1p-19f) & bal(cosf < 1.0f - 0x1p-19f);
@@ -1410,7 +1550,8 @@ __device__ __forceinline__ void unit_body(
         if (k < K && uns[k] != 0ull) {
           const int q = 64 * k + lane;
           const double rn = U.r[q + 1];
-          const double dot = (double)x[k] * (double)U.p.x[q + 1] + (double)y[k] * (double)U.p.y[q + 1];
+          const float2 nb = U.pxy[q + 1];
+          const double dot = (double)x[k] * (double)nb.x + (double)y[k] * (double)nb.y;
           const double cosang = dot / (r[k] * rn);                       // math.cpp:44-45
           lky[k] |= uns[k] & bal(cosang >= prm.cos_bound) & bal(cosang <= 1.0);   // acos(cos) < threshold; NaN -> false
         }
@@ -1680,7 +1821,7 @@ __device__ __forceinline__ void unit_body(
         const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
         const size_t at = l == kEdge ? off + o0 + pe + be : off + o1 - 1 - (ps + bs);
         rec_pts[at] = rec;
-        rec_idx[at] = src[k];
+        rec_idx[at] = ORG ? (uint32_t)i * og.R + slot : src[k];      // ORG: position i of ring `slot` is point i * R + slot
       }
       pe += __popcll(fe);
       ps += __popcll(fs);
@@ -1692,12 +1833,23 @@ __device__ __forceinline__ void unit_body(
     tab->unit_ne[ui] = pe;
     tab->unit_ns[ui] = ps;
     tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
-    if (j == 0) {tab->ring_status[s * kRings + slot] = kOk;}
+    if (j == 0) {
+      tab->ring_status[s * kRings + slot] = kOk;
+      if (ORG) {
+        // what the bucketing kernel would have counted (it overwrites both if the scan falls back after all)
+        og.ring_count_out[s * kRings + slot] = (uint32_t)N;
+        if (slot == 0) {
+          tab->scan_info[s * 4 + kInfoRings] = og.R;
+          atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kScanFused);
+        }
+      }
+    }
   }
 #undef LFX_DEFER
 }
 
-// SECOND = false: first pass, grid = (units of a scan / 4, batch); rings it cannot take go on
+// SECOND = false: first pass over the scans on the fall-back list (every scan of the batch when the organised-scan
+// kernel is not in use), grid = (units of a scan / 4, list entries or fewer); rings it cannot take go on
 // `defer_list` with the reason.  SECOND = true: second pass over the rings ring_order_kernel
 // repaired (redo_list, grid-stride); what still cannot be taken goes on the slow list.
 template<bool SECOND, int CH, bool DEF>
@@ -1712,33 +1864,76 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   // the wave index is the same in all 64 lanes: saying so keeps everything derived from it (unit,
   // ring length, block boundaries, chunk count) in scalar registers and its branches scalar
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  UnitLds<CH> & U = lds[wave];
+  UnitLds<CH> * U = &lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
-  uint32_t s, slot;
+  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u};
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
     const uint32_t n_redo = *redo_count < redo_cap ? *redo_count : redo_cap;      // the order kernel sent the rest to the slow list
     if (u >= n_redo * B) {return;}
     const uint32_t e = redo_list[u / B];
-    s = e / kRings;
-    slot = e % kRings;
+    const uint32_t s = e / kRings, slot = e % kRings;
+    const int j = (int)(u % B);
+    if (prm.P == 5) {
+      unit_body<5, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+        defer_list, true, none);
+    } else if (prm.P == 2) {
+      unit_body<2, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+        defer_list, true, none);
+    } else {
+      unit_body<0, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+        defer_list, true, none);
+    }
   } else {
-    s = blockIdx.y;
-    slot = u / B;
+    const uint32_t slot = u / B;
     if (slot >= max_rings) {return;}
+    const int j = (int)(u % B);
+    // (redo_count / redo_list double as the fall-back list here.)  One list entry per blockIdx.y and no loop -- a loop
+    // around unit_body costs it 60 spilled scalar registers; entries beyond the grid (the host's guess from earlier
+    // batches was too low) are handed to the workgroup-per-ring kernel by ring_order_kernel: slower, same result.
+    if (blockIdx.y >= *redo_count) {return;}
+    const uint32_t s = redo_list[blockIdx.y];
+    if (DEF || prm.P == 5) {
+      unit_body<5, CH, DEF, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+        defer_list, false, none);
+    } else if (prm.P == 2) {
+      unit_body<2, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+        defer_list, false, none);
+    } else {
+      unit_body<0, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+        defer_list, false, none);
+    }
   }
-  const int j = (int)(u % B);
+}
+
+// The organised-scan kernel (unit_body<ORG>): workgroup = block j of the four adjacent rings 4g .. 4g+3 of scan
+// blockIdx.y, one ring per wave.  blockIdx.x = j * groups + g: workgroups dispatched together take neighbouring ring
+// groups of the same block, i.e. neighbouring 128-byte lines of the same columns -- whole DRAM pages between them.
+template<int CH, bool DEF>
+__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_org_kernel(
+  Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
+  const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
+  const UnitTables * __restrict__ tab)
+{
+  __shared__ UnitLds<CH> lds[kUnitWaves];
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t groups = (max_rings + 3u) >> 2;
+  const uint32_t g = blockIdx.x % groups;
+  const int j = (int)(blockIdx.x / groups);
+  const uint32_t s = blockIdx.y;
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero};
+  const uint32_t slot = 4u * g + wave;
   if (DEF || prm.P == 5) {
-    unit_body<5, CH, DEF>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
-      defer_list, SECOND);
+    unit_body<5, CH, DEF, true>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+      nullptr, false, og);
   } else if (prm.P == 2) {
-    unit_body<2, CH, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
-      defer_list, SECOND);
+    unit_body<2, CH, false, true>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+      nullptr, false, og);
   } else {
-    unit_body<0, CH, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
-      defer_list, SECOND);
+    unit_body<0, CH, false, true>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+      nullptr, false, og);
   }
 }
 
@@ -1755,11 +1950,23 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
   float * __restrict__ sz, uint32_t * __restrict__ sidx, uint32_t * __restrict__ ring_flags,
   const uint32_t * __restrict__ defer_count, const uint32_t * __restrict__ defer_list,
   uint32_t * __restrict__ redo_count, uint32_t * __restrict__ redo_list, uint32_t * __restrict__ slow_count,
-  uint32_t * __restrict__ slow_list, uint32_t all_rings /* = batch: run BEFORE the unit kernel over every ring */,
-  uint32_t * __restrict__ pre_fixed, uint32_t redo_cap)
+  uint32_t * __restrict__ slow_list, uint32_t all_rings /* 1: run BEFORE the unit kernel over every ring of the scans on the fall-back list */,
+  uint32_t * __restrict__ pre_fixed, uint32_t redo_cap, const uint32_t * __restrict__ fb_count,
+  const uint32_t * __restrict__ fb_list, uint32_t list_cover /* all_rings = 0: list entries the first unit pass was launched for */)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int T = blockDim.x, tid = threadIdx.x;
+  if (!all_rings && fb_count != nullptr && tid == 0) {
+    // scans on the fall-back list beyond what the first unit pass covered: all their rings to the workgroup-per-ring kernel
+    const uint32_t n_list = *fb_count;
+    if (n_list > list_cover) {
+      const uint32_t extra = (n_list - list_cover) * max_rings;
+      for (uint32_t item = blockIdx.x; item < extra; item += gridDim.x) {
+        const uint32_t e = fb_list[list_cover + item / max_rings] * kRings + item % max_rings;
+        if (ring_count[e] != 0u) {slow_list[atomicAdd(slow_count, 1u)] = e;}
+      }
+    }
+  }
   uint32_t M = 1;                                     // power of two >= cap: room for the sort
   while (M < cap) {M <<= 1;}
   float * lx = reinterpret_cast<float *>(lds_raw);
@@ -1769,13 +1976,13 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
   float * lz = reinterpret_cast<float *>(lp + M);
   uint32_t * ls = reinterpret_cast<uint32_t *>(lz + M);   // sidx as bucketed
   int * cnt = reinterpret_cast<int *>(ls + M);            // [8] counters
-  // Two uses.  After the first unit pass (all_rings = 0): the rings on the defer list.  Before it (all_rings =
-  // batch, switched on by the host while a stream keeps arriving rotated or reversed): every ring of the batch;
+  // Two uses.  After the first unit pass (all_rings = 0): the rings on the defer list.  Before it (all_rings = 1,
+  // switched on by the host while a stream keeps arriving rotated or reversed): every ring of the listed scans;
   // a rotation / reversal is undone here, so that the first pass takes the ring and no second pass is needed;
   // rings in order are only read, rings that need a real sort are left to the normal route.
-  const uint32_t n_items = all_rings ? all_rings * max_rings : *defer_count;
+  const uint32_t n_items = all_rings ? *fb_count * max_rings : *defer_count;
   for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t e = all_rings ? (item / max_rings) * kRings + item % max_rings : defer_list[item];
+    const uint32_t e = all_rings ? fb_list[item / max_rings] * kRings + item % max_rings : defer_list[item];
     const uint32_t s = e / kRings, slot = e % kRings;
     const int N = (int)ring_count[e];
     const uint32_t reason = all_rings ? (uint32_t)kDeferOrder : ring_flags[e];
@@ -2170,9 +2377,11 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
 __global__ __launch_bounds__(256) void densify_kernel(
   uint32_t s, uint32_t max_rings, uint32_t cap, const uint32_t * __restrict__ ring_count,
   const uint8_t * __restrict__ label_s, const double * __restrict__ curv_s, const uint32_t * __restrict__ sidx,
-  uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx, uint32_t n_points)
+  uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx, uint32_t n_points,
+  const uint32_t * __restrict__ scan_info)
 {
   const uint32_t ring = blockIdx.x, tid = threadIdx.x;
+  const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]);     // position i of the ring is point i * rings + ring
   __shared__ uint32_t part[256];
   part[tid] = (tid < ring && tid < max_rings) ? ring_count[s * kRings + tid] : 0u;
   __syncthreads();
@@ -2187,7 +2396,7 @@ __global__ __launch_bounds__(256) void densify_kernel(
   const uint32_t Nfull = ring_count[s * kRings + ring];
   for (uint32_t i = tid; i < Nfull; i += blockDim.x) {
     const bool stored = i < N;
-    const uint32_t orig = stored ? sidx[off + i] : 0xFFFFFFFFu;
+    const uint32_t orig = stored ? (org ? i * max_rings + ring : sidx[off + i]) : 0xFFFFFFFFu;
     d_sidx[dense + i] = orig;
     if (orig < n_points) {
       d_label[orig] = label_s[off + i];
@@ -2300,10 +2509,11 @@ __global__ __launch_bounds__(256) void colored_pack_kernel(
   const uint32_t * __restrict__ offsets, const float2 * __restrict__ sxy, const uint32_t * __restrict__ sidx,
   const uint8_t * __restrict__ label_s, const uint8_t * __restrict__ pts, Layout L,
   const uint32_t * __restrict__ scan_begin, uint32_t max_rings, uint32_t cap, float4 * __restrict__ out,
-  uint32_t capacity)
+  uint32_t capacity, const uint32_t * __restrict__ scan_info)
 {
   const uint32_t s = blockIdx.y, ring = blockIdx.x, tid = threadIdx.x;
   if (ring_status[s * kRings + ring] != kOk) {return;}
+  const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]);     // nothing was staged: every field from the record
   __shared__ uint32_t before;
   if (tid == 0) {before = 0;}
   __syncthreads();
@@ -2316,9 +2526,11 @@ __global__ __launch_bounds__(256) void colored_pack_kernel(
   const uint32_t table[8] = {0xFFFFFFFFu, 0xFFFF0000u, 0xFFFF3F00u, 0xFFFF0000u, 0xFFFF3F00u, 0xFF7F7F7Fu, 0xFFFF00FFu, 0xFF00FF00u};
   for (uint32_t i = tid; i < n; i += blockDim.x) {
     if (at + i >= capacity) {break;}
-    const float2 xy = sxy[off + i];
+    const uint32_t orig = org ? i * max_rings + ring : sidx[off + i];
+    const uint8_t * rec = pts + ((size_t)scan_begin[s] + orig) * L.step;
+    const float2 xy = org ? make_float2(load_f32(rec + L.ox, L.be), load_f32(rec + L.oy, L.be)) : sxy[off + i];
     // z from the input record (the staged z of a ring the workgroup-per-ring kernel sorted itself is not re-ordered)
-    const float z = load_f32(pts + ((size_t)scan_begin[s] + sidx[off + i]) * L.step + L.oz, L.be);
+    const float z = load_f32(rec + L.oz, L.be);
     out[2 * (size_t)(at + i)] = make_float4(xy.x, xy.y, z, 1.0f);
     out[2 * (size_t)(at + i) + 1] = make_float4(__uint_as_float(table[label_s[off + i] & 7u]), 0.f, 0.f, 0.f);
   }

@@ -120,6 +120,121 @@ def test_second_pass_capacity_overflow_goes_to_the_slow_path():
     f.close()
 
 
+def _with_env(env, make):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return make()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("force", ["1", "0", None])
+def test_organised_scan_kernel_and_its_fall_back(force):
+    """A context that knows the sensor's ring count reads a driver's column-major scan directly (organised-scan
+    kernel: no bucketing pass); every scan that is not of that form -- ragged, rotated, reversed, shuffled, ring ids
+    that do not follow the column pattern, a zero-norm pair, a ring count that is not the sensor's -- falls back to
+    the bucketing route inside the same call.  Mixed batches, both routes pinned (LFX_DEBUG_FUSED) and the library's
+    own choice (None: the same context sees three kinds of stream); same results everywhere."""
+    R, Ccols = 12, 700                     # 12 rings: three groups of four; 10-ring scans below leave a group half empty
+    clouds = {k: make_scan(R, Ccols, seed=300 + i, **kw) for i, (k, kw) in enumerate(INPUT_ORDER_KW.items())}
+    swapped = make_scan(R, Ccols, seed=320)
+    col = swapped[R * 100:R * 101].copy()
+    swapped[R * 100], swapped[R * 100 + 1] = col[1], col[0]            # two records of one column change places
+    clouds["swapped_in_column"] = swapped
+    pair = make_scan(R, Ccols, seed=321)
+    k = np.nonzero(pair["ring"] == 5)[0]
+    for a in (k[200], k[201]):
+        pair["x"][a] = 0.0
+        pair["y"][a] = 0.0
+    clouds["zero_norm_pair"] = pair                                    # ring 5 is abandoned (math.cpp:40-42), the others are not
+    clouds["fewer_rings"] = make_scan(10, Ccols, seed=322)             # 7000 points: not a multiple of 12
+    clouds["other_shape_same_count"] = make_scan(6, 2 * Ccols, seed=323)   # 8400 points = 12 x 700, ring ids 0..5 only
+    clouds["short"] = make_scan(R, 9, seed=324, spikes=False)                        # 9 columns: too few for the convolution
+    want = {k: OB.extract(c, canonical_ties=False) for k, c in clouds.items()}
+    want["zero_norm_pair"] = OB.extract(pair, canonical_ties=True)      # the two (0, 0) points tie under the angle predicate
+    assert want["zero_norm_pair"]["ring_status"].tolist().count(0) == R - 1
+    env = {} if force is None else {"LFX_DEBUG_FUSED": force}
+    f = _with_env(env, lambda: FeatureExtraction(device=0, max_points_per_scan=R * 2 * Ccols, max_batch=6,
+                                                 max_points_per_ring=2 * Ccols, max_rings=R))
+    for name, c in clouds.items():
+        for rep in range(3):
+            got = f.extract_batch([c, clouds["sorted"], c, clouds["sorted"], clouds["sorted"]])
+            for i, key in enumerate([name, "sorted", name, "sorted", "sorted"]):
+                assert_scan_equal(got[i], want[key], "%s[%d]/fused %s/rep %d%s" % (key, i, force, rep, "[ties]" if want[key]["angle_ties"] else ""))
+    f.close()
+
+
+def test_organised_scan_kernel_more_fall_backs_than_expected():
+    """The bucketing route is launched for as many scans as earlier batches sent to it (plus a few); scans beyond
+    that are still bucketed, and their rings are handed to the workgroup-per-ring kernel.  32 rotated scans arrive
+    at a context that has seen nothing (room for 8), then again (room for all), then 32 organised ones."""
+    R, Ccols, nb = 8, 600, 32
+    rot = [make_scan(R, Ccols, seed=700 + i, start_col=37 + 11 * i) for i in range(nb)]
+    srt = [make_scan(R, Ccols, seed=800 + i) for i in range(nb)]
+    want_rot = [OB.extract(c, canonical_ties=False) for c in rot]
+    want_srt = [OB.extract(c, canonical_ties=False) for c in srt]
+    f = FeatureExtraction(device=0, max_points_per_scan=R * Ccols, max_batch=nb, max_points_per_ring=Ccols, max_rings=R)
+    for rep in range(3):
+        got = f.extract_batch(rot)
+        for i in range(nb):
+            assert_scan_equal(got[i], want_rot[i], "rotated %d, rep %d" % (i, rep))
+    for rep in range(2):
+        got = f.extract_batch(srt)
+        for i in range(nb):
+            assert_scan_equal(got[i], want_srt[i], "organised %d, rep %d" % (i, rep))
+    f.close()
+
+
+def test_organised_scan_kernel_zero_point_filter_and_colored_scan():
+    """With drop_zero_points a (0,0,0) record is not part of the scan, so a scan that holds one is not organised;
+    colored_scan of an organised scan is built from the input records (nothing was staged)."""
+    import torch
+    R, Ccols = 16, 500
+    c = make_scan(R, Ccols, seed=910)
+    z = c.copy()
+    for k in (R * 40 + 3, R * 41 + 3, R * 300 + 9):
+        z["x"][k] = 0.0
+        z["y"][k] = 0.0
+        z["z"][k] = 0.0
+    keep = np.nonzero(~((z["x"] == 0) & (z["y"] == 0) & (z["z"] == 0)))[0]
+    want_c = OB.extract(c, canonical_ties=False)
+    want_z = OB.extract(np.ascontiguousarray(z[keep]), canonical_ties=False)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=2, max_points_per_ring=Ccols, max_rings=R, drop_zero_points=True)
+    got = f.extract_batch([c, z])
+    assert_scan_equal(got[0], want_c, "organised, filter on")
+    assert np.array_equal(got[1].labels[keep], want_z["labels"]) and not got[1].labels[np.setdiff1d(np.arange(len(z)), keep)].any()
+    assert np.array_equal(got[1].edge_index, keep[want_z["edge_index"]].astype(np.uint32))
+    assert np.array_equal(got[1].surface_index, keep[want_z["surface_index"]].astype(np.uint32))
+    # colored_scan of the pair, on the device
+    host = synth.concat([c, z]).view(np.uint8)
+    dev = torch.from_numpy(host.copy()).to("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    f.extract_batch_device(dev.data_ptr(), [len(c), len(z)], stream)
+    cap = 2 * len(c)
+    col = torch.zeros((cap, 8), dtype=torch.float32, device="cuda:0")
+    coffs = torch.zeros(3, dtype=torch.int32, device="cuda:0")
+    f.pack_colored(col.data_ptr(), coffs.data_ptr(), cap, stream)
+    torch.cuda.synchronize()
+    col, coffs = col.cpu().numpy(), coffs.cpu().numpy()
+    order = want_c["sorted_index"]
+    assert coffs[1] - coffs[0] == len(c)
+    g = col[coffs[0]:coffs[1]]
+    assert np.array_equal(g[:, 0], c["x"][order]) and np.array_equal(g[:, 1], c["y"][order]) and np.array_equal(g[:, 2], c["z"][order])
+    rgba = g[:, 4].copy().view(np.uint32)
+    lab = want_c["labels"][order]
+    for v in np.unique(lab):
+        rgb = np.zeros(3, np.uint8)
+        assert LB.load().lfx_label_to_color(int(v), rgb.ctypes.data_as(LB.C.POINTER(LB.C.c_uint8))) == 0
+        assert np.all((rgba[lab == v] >> 16) & 255 == rgb[0]) and np.all(rgba[lab == v] & 255 == rgb[2])
+    f.close()
+
+
 def _cloud(ring, x, y, z=None):
     c = np.zeros(len(ring), POINT_DTYPE)
     c["ring"], c["x"], c["y"] = ring, x, y
