@@ -78,7 +78,7 @@ def main():
 
     # ---- synthetic stream: scan i -> rank i mod world; seeds 1234 + scan id
     n_unique = max(1, min(a.unique, a.batch))
-    clouds = [make_scan(a.rings, a.cols, seed=1234 + (j * world + rank)) for j in range(n_unique)]
+    clouds = [make_scan(a.rings, a.cols, seed=1234 + (j * world + rank), vfov_deg=22.5 if a.rings >= 128 else 15.0) for j in range(n_unique)]
     n_pts = len(clouds[0])
     tiled = [clouds[j % n_unique] for j in range(a.batch)]
     host = concat(tiled).view(np.uint8)
@@ -175,7 +175,7 @@ def main():
     feat_batch = sum(feats[j % n_unique] for j in range(a.batch))
     algo_bytes = 25 * n_pts * a.batch + 16 * feat_batch
     achieved = algo_bytes / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9
-    traffic = None
+    traffic = None                                    # not measured in this run: read from the committed PMC profile of this workload
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -188,6 +188,8 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 # the kernel's real HBM rate: PMC bytes (profiles/pmc_traffic.json) over the live duration
                 "traffic_gbs": (round(traffic / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9, 1) if traffic else None),
+                "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh, FETCH doubled), not this run"
+                                   if traffic else None),
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items()},
                 "whole_path_frac": round(algo_bytes / (max(sum_us, 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -250,12 +252,16 @@ def main():
                       "note": "lfx_extract / lfx_extract_batch with pageable host memory on both sides"}
 
     if rank == 0:
+        workload = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800): "vlp16-16x1800 (BASELINE.json configs[1])",
+                    (16, 900): "plumbing-16x900 (BASELINE.json configs[0])",
+                    (128, 2048): "os1-128x2048 (BASELINE.json configs[3]%s)" % (", batch = 32" if a.batch == 32 else "")}.get(
+                        (a.rings, a.cols), "%dx%d" % (a.rings, a.cols))
         out = {
-            "metric": "scans/sec (64-ring x 1800 synthetic scans, extraction hot path, inputs resident in HBM)",
+            "metric": "scans/sec (%d-ring x %d synthetic scans, extraction hot path, inputs resident in HBM)" % (a.rings, a.cols),
             "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 4), "ms_per_scan": round(1e3 * dt / (a.batch * a.steps), 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "hdl64-64x1800 (BASELINE.json configs[2])", "rings": a.rings, "cols": a.cols,
+            "config": {"workload": workload, "rings": a.rings, "cols": a.cols,
                        "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": "code defaults",
                        "streams": 1 if use_gather else n_streams,
                        "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "")},

@@ -1227,17 +1227,24 @@ struct UnitWin
   uint32_t ofs, sh;      // dword offset of the window's first dword inside a chunk pair; bit shift
 };
 
+// (the bit arrays are dwords read back in pairs and written as 64-bit words: both accesses are declared may_alias --
+// under the type-based aliasing rules a uint64_t store and a uint32_t load could otherwise be reordered, and in
+// straight-line code they were: a lane then read the live set of the round before and the pick rounds never ended)
+typedef uint64_t __attribute__((may_alias)) u64_alias_t;
+typedef uint32_t __attribute__((may_alias)) u32_alias_t;
+typedef float __attribute__((may_alias)) f32_alias_t;
+
 template<int CH>
 __device__ inline void put_word(UnitLds<CH> & U, int arr, int k, uint64_t w)
 {
-  *reinterpret_cast<uint64_t *>(&U.bits[arr][2 * (k + 1)]) = w;
+  *reinterpret_cast<u64_alias_t *>(&U.bits[arr][2 * (k + 1)]) = w;
 }
 
 // bit 16 + d of the result <-> position q + d of array `arr`, q = 64k + lane (+1 for the shifted constants)
 template<int CH>
 __device__ inline uint32_t get_win(const UnitLds<CH> & U, int arr, int k, const UnitWin & w)
 {
-  const uint32_t * b = &U.bits[arr][2 * k + w.ofs];
+  const u32_alias_t * b = reinterpret_cast<const u32_alias_t *>(&U.bits[arr][2 * k + w.ofs]);
   return __builtin_amdgcn_alignbit(b[1], b[0], w.sh);
 }
 
@@ -1327,7 +1334,13 @@ struct OrgScan
   uint32_t R, r0, wave, drop_zero;
 };
 
-template<int PT, int CH, bool DEF, bool ORG>
+// FULL (an experiment, off in every instantiation): all CH chunks are processed whatever the span (positions beyond it
+// are no ring points and are masked out everywhere) and no work is skipped for chunks without candidates, so that the
+// body is straight-line code per stage whose LDS reads the compiler can issue together -- a wave is parked in s_waitcnt
+// 43 % of its life (profiles/r02_org1/sq_counters.json).  Measured: the interleaved chunks need 42 more scalar and 24
+// more vector registers than the wave has (spilled), 1700 vs 1440 us per 1024 scans.  Kept because it is what exposed
+// the aliasing hazard described at put_word().
+template<int PT, int CH, bool DEF, bool ORG, bool FULL>
 __device__ __forceinline__ void unit_body(
   const Params & prm, UnitLds<CH> * __restrict__ slabs, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
@@ -1388,7 +1401,7 @@ __device__ __forceinline__ void unit_body(
   const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? N : b1;
   const int H = P + 1, g0 = o0 - H, span = o1 + H - g0;
   if (b1 - b0 < 2 || span > (64 * CH)) {LFX_DEFER(kDeferOther);}
-  const int K = (span + 63) >> 6;
+  const int K = FULL ? CH : (span + 63) >> 6;
   const int qb0 = b0 - g0, qb1 = b1 - g0;          // the block in span coordinates
   const int qo0 = o0 - g0, qo1 = o1 - g0;          // the owned positions
   const int qlo = g0 < 0 ? -g0 : 0;                // first / one-past-last position that is a ring point
@@ -1431,7 +1444,7 @@ __device__ __forceinline__ void unit_body(
       }
     }
     uint64_t wrong = 0;
-    float * zex = reinterpret_cast<float *>(slabs[sub].r);
+    f32_alias_t * zex = reinterpret_cast<f32_alias_t *>(slabs[sub].r);
 #pragma unroll
     for (int m = 0; m < CH; m++) {
       if (m < K) {
@@ -1457,7 +1470,7 @@ __device__ __forceinline__ void unit_body(
         const int q = 64 * k + lane;
         const float2 v = U.pxy[q];
         x[k] = v.x; y[k] = v.y;
-        z[k] = reinterpret_cast<const float *>(U.r)[q];
+        z[k] = reinterpret_cast<const f32_alias_t *>(U.r)[q];
       }
     }
   } else {
@@ -1697,7 +1710,7 @@ __device__ __forceinline__ void unit_body(
     // priority masks: which candidates in reach are visited first; bit 16 = the position itself
 #pragma unroll
     for (int k = 0; k < CH; k++) {
-      if (k < K && A[k] != 0ull) {
+      if (k < K && (FULL || A[k] != 0ull)) {
         const uint32_t m = get_win(U, kBitA, k, W0) & reach[k] & ~(1u << 16);
         Hp[k] = ((edge ? ~lt[k] : lt[k]) & m) | (1u << 16);
       }
@@ -1712,7 +1725,7 @@ __device__ __forceinline__ void unit_body(
       for (int k = 0; k < CH; k++) {
         S[k + 1] = 0;
         if (k < K) {
-          if (A[k] != 0ull) {S[k + 1] = bal((get_win(U, kBitA, k, W0) & Hp[k]) == (1u << 16));}
+          if (FULL || A[k] != 0ull) {S[k + 1] = bal((get_win(U, kBitA, k, W0) & Hp[k]) == (1u << 16));}
           put_word(U, kBitS, k, S[k + 1]);
           SEL[k] |= S[k + 1];
           picked |= S[k + 1];
@@ -1724,7 +1737,7 @@ __device__ __forceinline__ void unit_body(
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         if (k < K) {
-          if ((S[k] | S[k + 1] | S[k + 2]) != 0ull) {
+          if (FULL || (S[k] | S[k + 1] | S[k + 2]) != 0ull) {
             A[k] &= ~bal((get_win(U, kBitS, k, W0) & reach[k]) != 0u);
             put_word(U, kBitA, k, A[k]);
           }
@@ -1877,13 +1890,13 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
     const uint32_t s = e / kRings, slot = e % kRings;
     const int j = (int)(u % B);
     if (prm.P == 5) {
-      unit_body<5, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      unit_body<5, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
         defer_list, true, none);
     } else if (prm.P == 2) {
-      unit_body<2, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      unit_body<2, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
         defer_list, true, none);
     } else {
-      unit_body<0, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      unit_body<0, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
         defer_list, true, none);
     }
   } else {
@@ -1896,13 +1909,13 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
     if (blockIdx.y >= *redo_count) {return;}
     const uint32_t s = redo_list[blockIdx.y];
     if (DEF || prm.P == 5) {
-      unit_body<5, CH, DEF, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      unit_body<5, CH, DEF, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
         defer_list, false, none);
     } else if (prm.P == 2) {
-      unit_body<2, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      unit_body<2, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
         defer_list, false, none);
     } else {
-      unit_body<0, CH, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+      unit_body<0, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
         defer_list, false, none);
     }
   }
@@ -1926,13 +1939,13 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero};
   const uint32_t slot = 4u * g + wave;
   if (DEF || prm.P == 5) {
-    unit_body<5, CH, DEF, true>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+    unit_body<5, CH, DEF, true, false>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
       nullptr, false, og);
   } else if (prm.P == 2) {
-    unit_body<2, CH, false, true>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+    unit_body<2, CH, false, true, false>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
       nullptr, false, og);
   } else {
-    unit_body<0, CH, false, true>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+    unit_body<0, CH, false, true, false>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
       nullptr, false, og);
   }
 }

@@ -1,42 +1,62 @@
 #!/bin/bash
-# tools/profile.sh OUTDIR -- on the GPU box: the evidence behind bench.py's "roofline" object.
+# tools/profile.sh OUTDIR [bench args...] -- on the GPU box: the evidence behind bench.py's "roofline" object.
 #   1. rocprofv3 --kernel-trace --stats of `python3 bench.py` (per-kernel durations)       -> kernel_stats.csv
 #   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (HBM traffic)      -> pmc_traffic.json
-#   3. the plain bench line, CPU baseline included                                         -> bench.json
+#   3. rocprofv3 --pmc SQ_* (instruction mix, busy and wait cycles of the dominant kernel) -> sq_counters.json
+#   4. the plain bench line, CPU baseline included                                         -> bench.json
+# (counter passes carry --kernel-trace only; never a trace domain beside --pmc)
 set -e
 OUT=${1:-gpurun_out/profile}
+shift || true
+ARGS="$@"
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline > $OUT/trace_run.txt 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline $ARGS > $OUT/trace_run.txt 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > $OUT/pmc_fetch_run.txt 2>&1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > $OUT/pmc_write_run.txt 2>&1
-python3 - $OUT <<'PY'
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 $ARGS > $OUT/pmc_fetch_run.txt 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 $ARGS > $OUT/pmc_write_run.txt 2>&1
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 $ARGS > $OUT/pmc_sq1_run.txt 2>&1
+timeout -k 10 400 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 $ARGS > $OUT/pmc_sq2_run.txt 2>&1
+python3 - $OUT "$ARGS" <<'PY'
 import csv, glob, json, sys, collections, re
-out = sys.argv[1]
-def mean_per_kernel(d, counter):
-    acc = collections.defaultdict(float); cnt = collections.Counter()
+out, args = sys.argv[1], sys.argv[2].split()
+def opt(name, default):
+    return int(args[args.index(name) + 1]) if name in args else default
+def short(name):
+    m = re.search(r"lfx::(\w+)", name)
+    key = m.group(1) if m else name[:40]
+    if key == "ring_unit_kernel" and "<true" in name:
+        key = "ring_unit_kernel(second pass)"
+    return key
+def mean_per_kernel(d, counter=None):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] != counter:
+            if counter and row["Counter_Name"] != counter:
                 continue
-            name = row["Kernel_Name"]
-            m = re.search(r"lfx::(\w+)", name)
-            key = m.group(1) if m else name[:40]
-            if key == "ring_unit_kernel" and "<true" in name:
-                key = "ring_unit_kernel(second pass)"
-            acc[key] += float(row["Counter_Value"]); cnt[key] += 1
-    return {k: round(acc[k] / cnt[k], 1) for k in acc}
-fetch = mean_per_kernel(out + "/pmc_fetch", "FETCH_SIZE")
-write = mean_per_kernel(out + "/pmc_write", "WRITE_SIZE")
+            key = short(row["Kernel_Name"])
+            acc[key][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[key][row["Counter_Name"]] += 1
+    return {k: {c: round(acc[k][c] / cnt[k][c], 1) for c in acc[k]} for k in acc}
+fetch = {k: v["FETCH_SIZE"] for k, v in mean_per_kernel(out + "/pmc_fetch", "FETCH_SIZE").items()}
+write = {k: v["WRITE_SIZE"] for k, v in mean_per_kernel(out + "/pmc_write", "WRITE_SIZE").items()}
 hbm = {k: int(2 * fetch.get(k, 0) * 1024 + write.get(k, 0) * 1024) for k in set(fetch) | set(write)}
-json.dump({"batch": 1024, "rings": 64, "cols": 1800,
+json.dump({"batch": opt("--batch", 1024), "rings": opt("--rings", 64), "cols": opt("--cols", 1800),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB per dispatch, mean over dispatches); "
                    "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md: it counts 128-B requests at 64 B)",
-           "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": hbm}, open(out + "/pmc_traffic.json", "w"), indent=1)
+           "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": hbm,
+           "hbm_bytes_per_launch_total": sum(v for k, v in hbm.items() if k.startswith(("ring_", "feature_", "batch_")))},
+          open(out + "/pmc_traffic.json", "w"), indent=1)
+sq = mean_per_kernel(out + "/pmc_sq1")
+for k, v in mean_per_kernel(out + "/pmc_sq2").items():
+    sq.setdefault(k, {}).update(v)
+keep = {k: v for k, v in sq.items() if k.startswith(("ring_unit", "ring_scatter", "feature_compact"))}
+for k, v in keep.items():
+    w = v.get("SQ_WAVES", 0) or 1
+    v["per_wave"] = {c: round(v[c] / w, 1) for c in v if c.startswith(("SQ_INSTS", "SQ_WAVE_CYCLES", "SQ_ACTIVE", "SQ_WAIT"))}
+json.dump({"note": "rocprofv3 --pmc, two passes of eight SQ counters, mean per dispatch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)",
+           "kernels": keep}, open(out + "/sq_counters.json", "w"), indent=1)
 print(json.dumps(hbm))
 PY
-cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
-timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench_err.txt
+timeout -k 10 400 python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench_err.txt
 cat $OUT/bench.json
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2
