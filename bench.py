@@ -234,22 +234,39 @@ def main():
     #      Reported beside `value`, never as it (device-resident and PCIe-inclusive separately).
     end_to_end = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from lidar_feature_extraction_amd import binding as LB
+
+        def timed(fe, scans, reps):
+            fe.ExtractFeatures(scans[0])
+            t3 = time.perf_counter()
+            for j in range(reps):
+                fe.ExtractFeatures(scans[j % len(scans)])
+            one = (time.perf_counter() - t3) / reps
+            some = [scans[j % len(scans)] for j in range(16)]
+            fe.extract_batch(some)
+            t3 = time.perf_counter()
+            for _ in range(3):
+                fe.extract_batch(some)
+            return round(1e3 * one, 3), round(1e3 * (time.perf_counter() - t3) / 48, 3)
+
+        # what the node consumes (feature_extraction.cpp:161-170: the two clouds), point buffer in pinned memory
+        fe = FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=16,
+                               max_points_per_ring=cap, max_rings=a.rings, outputs=LB.OUT_FEATURES)
+        pinned = [fe.pinned_like(clouds[j]) for j in range(min(n_unique, 16))]
+        one, many = timed(fe, pinned, 32)
+        one_pg, many_pg = timed(fe, clouds, 16)
+        fe.close()
+        # every output (labels, curvature, sorted index: 13 more bytes per point over PCIe), pageable input
         fe = FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=16,
                                max_points_per_ring=cap, max_rings=a.rings)
-        fe.ExtractFeatures(clouds[0])
-        t3 = time.perf_counter()
-        for j in range(16):
-            fe.ExtractFeatures(clouds[j % n_unique])
-        one = (time.perf_counter() - t3) / 16
-        some = [clouds[j % n_unique] for j in range(16)]
-        fe.extract_batch(some)
-        t3 = time.perf_counter()
-        for _ in range(3):
-            fe.extract_batch(some)
-        many = (time.perf_counter() - t3) / 48
+        one_all, many_all = timed(fe, clouds, 16)
         fe.close()
-        end_to_end = {"ms_per_scan_one_at_a_time": round(1e3 * one, 3), "ms_per_scan_batches_of_16": round(1e3 * many, 3),
-                      "note": "lfx_extract / lfx_extract_batch with pageable host memory on both sides"}
+        end_to_end = {"ms_per_scan_one_at_a_time": one, "ms_per_scan_batches_of_16": many,
+                      "note": "lfx_extract / lfx_extract_batch through the Python binding: H2D of the 32-byte records, every kernel, the two "
+                              "clouds written into pinned host memory, one synchronise; input in pinned memory (lfx_host_alloc), outputs = the "
+                              "two clouds (what the node publishes)",
+                      "pageable_input": {"ms_per_scan_one_at_a_time": one_pg, "ms_per_scan_batches_of_16": many_pg},
+                      "pageable_input_all_outputs": {"ms_per_scan_one_at_a_time": one_all, "ms_per_scan_batches_of_16": many_all}}
 
     if rank == 0:
         workload = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800): "vlp16-16x1800 (BASELINE.json configs[1])",

@@ -81,7 +81,19 @@ typedef struct lfx_config {
   uint32_t drop_zero_points;      /* 1: points with x = y = z = 0 are not part of the scan -- the filter the
                                    * upstream converter applies (point_type_converter/convert.py:162-163,192) */
   lfx_layout layout;              /* all-zero = PointXYZIR                                  */
+  uint32_t outputs;               /* LFX_OUT_* mask: what lfx_extract / lfx_extract_batch bring back to the host.
+                                   * 0 = LFX_OUT_ALL.  The edge / surface clouds (with their index lists) and the ring
+                                   * table always come back; labels, curvature and sorted_index are per-point arrays
+                                   * (13 bytes per point over PCIe) that the node itself does not consume
+                                   * (feature_extraction.cpp:161-170 publishes the two clouds; labels only feed the
+                                   * colored_scan debug cloud): a caller that does not need them leaves them out     */
 } lfx_config;
+
+#define LFX_OUT_FEATURES 1u        /* always on */
+#define LFX_OUT_LABELS 2u
+#define LFX_OUT_CURVATURE 4u
+#define LFX_OUT_SORTED_INDEX 8u
+#define LFX_OUT_ALL 15u
 
 /* PointLabel values: extraction/include/lidar_feature_extraction/point_label.hpp:32-42 */
 enum lfx_label {
@@ -118,12 +130,12 @@ enum lfx_error {
 
 typedef struct lfx_ctx lfx_ctx;
 
-/* One scan's results in host memory (owned by the context, valid until its next call). */
+/* One scan's results in host memory (pinned, owned by the context, valid until its next call). */
 typedef struct lfx_scan_result {
   uint32_t n_points;
-  const uint8_t *labels;          /* [n_points] lfx_label, addressed by ORIGINAL point index   */
-  const double *curvature;        /* [n_points] f64, original index (curvature.cpp:44-50)      */
-  const uint32_t *sorted_index;   /* [n_sorted] rings ascending, angle ascending inside a ring (ring.hpp:141-147) */
+  const uint8_t *labels;          /* [n_points] lfx_label, addressed by ORIGINAL point index; NULL unless LFX_OUT_LABELS  */
+  const double *curvature;        /* [n_points] f64, original index (curvature.cpp:44-50); NULL unless LFX_OUT_CURVATURE  */
+  const uint32_t *sorted_index;   /* [n_sorted] rings ascending, angle ascending inside a ring (ring.hpp:141-147); NULL unless LFX_OUT_SORTED_INDEX */
   uint32_t n_sorted;              /* = n_points, less the points drop_zero_points removed                  */
   uint32_t n_rings;
   const uint16_t *ring_id;        /* [n_rings] ascending                                        */
@@ -142,7 +154,13 @@ typedef struct lfx_scan_result {
  * the context).  Per-point outputs are RING-MAJOR with a fixed capacity per ring id: ring r of
  * scan s owns positions [(s * max_rings + r) * ring_capacity, + ring_count[s][r]) of labels_sorted,
  * curvature_sorted and sorted_index, angle ascending.  The feature clouds are dense: scan s owns the
- * first n_edge / n_surface records from scan_begin[s] (scan_info[s][2], [3]). */
+ * first n_edge / n_surface records from scan_begin[s] (scan_info[s][2], [3]).
+ * scan_info[s][1] carries error bits (1: a ring id >= max_rings, 4: bucketing timed out -- lfx_batch_status turns
+ * them into a return code) and the route the scan took: (bits & LFX_SCAN_ROUTE_MASK) == LFX_SCAN_ORGANISED means the
+ * scan arrived column-major with ring == index mod max_rings and was read in place: position k of ring r IS input
+ * point k * max_rings + r and sorted_index holds nothing for that scan. */
+#define LFX_SCAN_ROUTE_MASK 0x300u
+#define LFX_SCAN_ORGANISED 0x100u
 typedef struct lfx_device_view {
   uint32_t batch;
   uint32_t max_rings;             /* ring ids the layout has room for                            */
@@ -183,6 +201,16 @@ int lfx_extract_batch(lfx_ctx *ctx, const void *const *points, const size_t *n_p
 int lfx_extract_batch_device(lfx_ctx *ctx, const void *d_points, const uint32_t *n_points, uint32_t batch,
                              void *stream);
 int lfx_device_results(const lfx_ctx *ctx, lfx_device_view *view);
+/* What lfx_extract reports through its return code, for callers of the device-resident path: waits for `stream`,
+ * reads the last batch's scan_info and returns LFX_ERR_RING_ID / LFX_ERR_HIP if any scan carries an error bit
+ * (the clouds of such a scan are not to be used), else LFX_OK.  first_bad (may be NULL): index of the first such scan. */
+int lfx_batch_status(lfx_ctx *ctx, void *stream, uint32_t *first_bad);
+
+/* Pinned host memory for the caller's point buffers: lfx_extract reads a buffer allocated here by DMA (3.7 MB in
+ * ~70 us for a 64 x 1800 scan); any other host pointer is first copied, chunk by chunk, through the context's own
+ * pinned staging buffer (CPU memcpy speed).  Free with lfx_host_free before or after lfx_destroy. */
+int lfx_host_alloc(lfx_ctx *ctx, size_t bytes, void **out);
+void lfx_host_free(lfx_ctx *ctx, void *ptr);
 
 /* --- PointCloud2 on either side of the operator ---------------------------- */
 /* The record layout for lfx_config from a message's field list: what pcl::fromROSMsg<PointXYZIR>

@@ -62,33 +62,61 @@ struct Features
 class FeatureExtraction
 {
 public:
+  // max_rings: the sensor's ring count (ring ids 0 .. max_rings-1).  Given, a driver's column-major scan is read in
+  // place by the organised-scan kernel (no bucketing pass); 0 = unknown (256 ring ids, every scan is bucketed).
+  // outputs: LFX_OUT_* mask of the per-point arrays to bring back besides the two clouds; what the node publishes
+  // (feature_extraction.cpp:161-170) needs none of them, its colored_scan debug cloud needs LFX_OUT_LABELS.
   explicit FeatureExtraction(
     const HyperParameters & params = HyperParameters(), int device = 0,
     std::uint32_t max_points_per_scan = 262144, std::uint32_t max_points_per_ring = 0,
-    std::uint32_t max_rings = 0)
+    std::uint32_t max_rings = 0, std::uint32_t outputs = LFX_OUT_ALL)
   {
     lfx_config cfg{};
     cfg.max_points_per_scan = max_points_per_scan;
     cfg.max_batch = 1;
     cfg.max_points_per_ring = max_points_per_ring;
     cfg.max_rings = max_rings;
+    cfg.outputs = outputs;
     const int rc = lfx_create(&ctx_, device, &params, &cfg);
     if (rc != LFX_OK) {throw Error(rc, lfx_last_error(nullptr));}
   }
-  ~FeatureExtraction() {lfx_destroy(ctx_);}
+  ~FeatureExtraction()
+  {
+    for (void * p : pinned_) {lfx_host_free(ctx_, p);}
+    lfx_destroy(ctx_);
+  }
   FeatureExtraction(const FeatureExtraction &) = delete;
   FeatureExtraction & operator=(const FeatureExtraction &) = delete;
 
-  // feature_extraction.cpp:114-157 for one cloud.
-  Features ExtractFeatures(const PointXYZIR * points, std::size_t n) const
+  // A point buffer in pinned host memory, owned by this object: lfx_extract reads it by DMA (a buffer from anywhere
+  // else is first copied through the context's staging buffer).  Let GetPointCloud fill it.
+  PointXYZIR * PinnedPoints(std::size_t capacity)
+  {
+    void * p = nullptr;
+    const int rc = lfx_host_alloc(ctx_, capacity * sizeof(PointXYZIR), &p);
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+    pinned_.push_back(p);
+    return static_cast<PointXYZIR *>(p);
+  }
+
+  // feature_extraction.cpp:114-157 for one cloud, results left where the library put them (pinned host memory owned by
+  // the context, valid until the next call): no copies.
+  lfx_scan_result ExtractFeaturesView(const PointXYZIR * points, std::size_t n) const
   {
     lfx_scan_result r{};
     const int rc = lfx_extract(ctx_, points, n, &r);
     if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+    return r;
+  }
+
+  // The same, copied into containers the caller keeps.
+  Features ExtractFeatures(const PointXYZIR * points, std::size_t n) const
+  {
+    const lfx_scan_result r = ExtractFeaturesView(points, n);
     Features f;
-    f.labels.assign(r.labels, r.labels + r.n_points);
-    f.curvature.assign(r.curvature, r.curvature + r.n_points);
-    f.sorted_index.assign(r.sorted_index, r.sorted_index + r.n_sorted);
+    if (r.labels) {f.labels.assign(r.labels, r.labels + r.n_points);}
+    if (r.curvature) {f.curvature.assign(r.curvature, r.curvature + r.n_points);}
+    if (r.sorted_index) {f.sorted_index.assign(r.sorted_index, r.sorted_index + r.n_sorted);}
     f.edge_index.assign(r.edge_index, r.edge_index + r.n_edge);
     f.surface_index.assign(r.surface_index, r.surface_index + r.n_surface);
     fill(f.edge, r.edge_points, r.edge_index, r.n_edge, points);
@@ -128,6 +156,7 @@ private:
     }
   }
   lfx_ctx * ctx_ = nullptr;
+  std::vector<void *> pinned_;
 };
 
 }  // namespace lfx

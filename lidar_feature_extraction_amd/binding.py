@@ -48,7 +48,10 @@ INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64 = range(1, 9)
 class Config(C.Structure):
     _fields_ = [("max_points_per_scan", C.c_uint32), ("max_batch", C.c_uint32),
                 ("max_points_per_ring", C.c_uint32), ("max_rings", C.c_uint32), ("drop_zero_points", C.c_uint32),
-                ("layout", Layout)]
+                ("layout", Layout), ("outputs", C.c_uint32)]
+
+
+OUT_FEATURES, OUT_LABELS, OUT_CURVATURE, OUT_SORTED_INDEX, OUT_ALL = 1, 2, 4, 8, 15
 
 
 class ScanResult(C.Structure):
@@ -71,7 +74,7 @@ class DeviceView(C.Structure):
 EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
     "lfx_status_string", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
-    "lfx_device_results", "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
+    "lfx_device_results", "lfx_batch_status", "lfx_host_alloc", "lfx_host_free", "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
@@ -110,6 +113,10 @@ def load():
     L.lfx_extract_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), u32, C.POINTER(ScanResult)]
     L.lfx_extract_batch_device.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     L.lfx_device_results.argtypes = [vp, C.POINTER(DeviceView)]
+    L.lfx_batch_status.argtypes = [vp, vp, C.POINTER(u32)]
+    L.lfx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.lfx_host_free.argtypes = [vp, vp]
+    L.lfx_host_free.restype = None
     L.lfx_layout_from_fields.argtypes = [C.POINTER(PointField), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Layout)]
     L.lfx_pack_xyz.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.lfx_pack_xyz12.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]

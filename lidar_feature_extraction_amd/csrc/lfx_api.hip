@@ -75,13 +75,35 @@ struct DevBuf
   }
 };
 
-struct HostScan
+struct HostScan          // the per-ring lists of one scan (the large arrays live in the pinned result block)
 {
-  std::vector<uint8_t> labels, ring_status;
-  std::vector<double> curvature;
-  std::vector<uint32_t> sorted_index, ring_count, ring_offset, edge_index, surface_index;
+  std::vector<uint8_t> ring_status;
+  std::vector<uint32_t> ring_count, ring_offset;
   std::vector<uint16_t> ring_id;
-  std::vector<float> edge_points, surface_points;
+};
+
+// Pinned host memory that only ever grows (the results handed to the caller stay valid until the next call).
+struct PinnedBuf
+{
+  uint8_t * p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t need)
+  {
+    if (need <= bytes) {return hipSuccess;}
+    if (p) {(void)hipHostFree(p);}
+    p = nullptr;
+    bytes = 0;
+    const size_t want = need + need / 4 + 4096;
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault);
+    if (e == hipSuccess) {bytes = want;}
+    return e;
+  }
+  void release()
+  {
+    if (p) {(void)hipHostFree(p);}
+    p = nullptr;
+    bytes = 0;
+  }
 };
 
 }  // namespace
@@ -141,6 +163,9 @@ struct lfx_ctx
   uint32_t last_batch = 0;
   const void * last_points = nullptr;
   std::vector<HostScan> host;
+  uint32_t outputs = LFX_OUT_ALL;        // lfx_config::outputs
+  PinnedBuf h_in, h_out;                 // staging of the synchronous host API (allocated on first use)
+  uint32_t * h_status = nullptr;         // pinned, lfx_batch_status
 
   bool profiling = false;
   uint32_t profile_every = 1, batch_no = 0;   // lfx_set_profiling_interval: events around every n-th batch only
@@ -468,45 +493,61 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   return LFX_OK;
 }
 
-int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
+size_t align16(size_t v) {return (v + 15u) & ~(size_t)15u;}
+
+// Results of scans [first, first + count) of the last batch to pinned host memory: everything is queued on `st`
+// (the pack kernel writes headers and clouds straight into the pinned block; labels / curvature / sorted_index, when
+// asked for, are un-permuted on the device and copied) and the host waits ONCE.
+int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t mask, lfx_scan_result * out)
 {
-  if (s >= c->last_batch) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "scan index outside the last batch");}
+  if (count == 0 || first + count > c->last_batch) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "scan index outside the last batch");}
   if (c->host.size() < c->last_batch) {c->host.resize(c->last_batch);}
-  HostScan & h = c->host[s];
-  const uint32_t b = c->h_scan_begin[s], n = c->h_scan_begin[s + 1] - b;
-  uint32_t info[4] = {0, 0, 0, 0};
-  uint32_t rcount[lfx::kRings];
-  uint8_t rstat[lfx::kRings];
-  LFX_HIP(c, hipMemcpyAsync(info, c->scan_info.p + (size_t)s * 4, 16, hipMemcpyDeviceToHost, st));
-  LFX_HIP(c, hipMemcpyAsync(rcount, c->ring_count.p + (size_t)s * lfx::kRings, sizeof(rcount), hipMemcpyDeviceToHost, st));
-  LFX_HIP(c, hipMemcpyAsync(rstat, c->ring_status.p + (size_t)s * lfx::kRings, sizeof(rstat), hipMemcpyDeviceToHost, st));
-  h.labels.resize(n);
-  h.curvature.resize(n);
-  h.sorted_index.resize(n);
-  if (n) {
-    // ring-major (fixed capacity per ring) -> the caller's point order (labels, curvature) and the dense list of
-    // angle-sorted indices, rings ascending; then one copy per array
-    LFX_HIP(c, hipMemsetAsync(c->d_label.p, 0, n, st));                  // LFX_LABEL_DEFAULT for points that are in no ring
-    LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, (size_t)n * 8, st));
-    hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings), dim3(256), 0, st,
-      s, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p, c->d_curv.p,
-      c->d_sidx.p, n, c->scan_info.p);
-    LFX_HIP(c, hipGetLastError());
-    LFX_HIP(c, hipMemcpyAsync(h.labels.data(), c->d_label.p, n, hipMemcpyDeviceToHost, st));
-    LFX_HIP(c, hipMemcpyAsync(h.curvature.data(), c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    LFX_HIP(c, hipMemcpyAsync(h.sorted_index.data(), c->d_sidx.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  const uint32_t p0 = c->h_scan_begin[first];
+  const size_t P = c->h_scan_begin[first + count] - p0;
+  const bool want_lab = mask & LFX_OUT_LABELS, want_curv = mask & LFX_OUT_CURVATURE, want_sidx = mask & LFX_OUT_SORTED_INDEX;
+  // pinned block: headers | edge_pts | surf_pts | curvature | edge_idx | surf_idx | sorted_index | labels
+  const size_t o_hdr = 0, o_ep = align16((size_t)count * lfx::kResultHeaderBytes), o_sp = o_ep + P * 16, o_cv = o_sp + P * 16,
+    o_ei = o_cv + (want_curv ? P * 8 : 0), o_si = o_ei + P * 4, o_sx = o_si + P * 4, o_lb = o_sx + (want_sidx ? P * 4 : 0),
+    total = o_lb + (want_lab ? P : 0) + 16;
+  if (c->h_out.reserve(total) != hipSuccess) {return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the pinned result block");}
+  uint8_t * H = c->h_out.p;
+  hipLaunchKernelGGL(lfx::result_pack_kernel, dim3(8, count), dim3(256), 0, st,
+    first, p0, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_status.p, c->edge_pts.p, c->edge_idx.p,
+    c->surf_pts.p, c->surf_idx.p, H + o_hdr, reinterpret_cast<float4 *>(H + o_ep), reinterpret_cast<float4 *>(H + o_sp),
+    reinterpret_cast<uint32_t *>(H + o_ei), reinterpret_cast<uint32_t *>(H + o_si));
+  LFX_HIP(c, hipGetLastError());
+  if (want_lab || want_curv || want_sidx) {
+    for (uint32_t k = 0; k < count; k++) {
+      const uint32_t s = first + k, b = c->h_scan_begin[s] - p0, n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
+      if (n == 0) {continue;}
+      // ring-major (fixed capacity per ring) -> the caller's point order (labels, curvature) and the dense list of
+      // angle-sorted indices, rings ascending; points that are in no ring (zero filter, over-long ring) stay Default / 0
+      LFX_HIP(c, hipMemsetAsync(c->d_label.p, 0, n, st));
+      LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, (size_t)n * 8, st));
+      hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings), dim3(256), 0, st,
+        s, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p, c->d_curv.p,
+        c->d_sidx.p, n, c->scan_info.p);
+      LFX_HIP(c, hipGetLastError());
+      if (want_lab) {LFX_HIP(c, hipMemcpyAsync(H + o_lb + b, c->d_label.p, n, hipMemcpyDeviceToHost, st));}
+      if (want_curv) {LFX_HIP(c, hipMemcpyAsync(H + o_cv + (size_t)b * 8, c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));}
+      if (want_sidx) {LFX_HIP(c, hipMemcpyAsync(H + o_sx + (size_t)b * 4, c->d_sidx.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));}
+    }
   }
   LFX_HIP(c, hipStreamSynchronize(st));
-  if (info[lfx::kInfoError] & 1u) {
-    return fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)");
-  }
-  if (info[lfx::kInfoError] & 4u) {
-    return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
-  }
-  uint32_t nr = 0, n_kept = n;
-  h.ring_id.clear(); h.ring_count.clear(); h.ring_offset.clear(); h.ring_status.clear();
-  {
-    uint32_t dense = 0;
+  for (uint32_t k = 0; k < count; k++) {
+    const uint32_t s = first + k, b = c->h_scan_begin[s] - p0, n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
+    const uint32_t * hdr = reinterpret_cast<const uint32_t *>(H + o_hdr + (size_t)k * lfx::kResultHeaderBytes);
+    const uint32_t * rcount = hdr + 4;
+    const uint8_t * rstat = reinterpret_cast<const uint8_t *>(hdr + 4 + lfx::kRings);
+    if (hdr[lfx::kInfoError] & lfx::kErrRingId) {
+      return fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)");
+    }
+    if (hdr[lfx::kInfoError] & lfx::kErrTimeout) {
+      return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
+    }
+    HostScan & h = c->host[s];
+    h.ring_id.clear(); h.ring_count.clear(); h.ring_offset.clear(); h.ring_status.clear();
+    uint32_t dense = 0, nr = 0;
     for (uint32_t r = 0; r < c->max_rings; r++) {
       if (rcount[r] == 0) {continue;}
       h.ring_id.push_back((uint16_t)r);
@@ -519,42 +560,23 @@ int download(lfx_ctx * c, uint32_t s, hipStream_t st, lfx_scan_result * out)
     if (dense > n || (dense != n && !c->drop_zero)) {
       return fail(c, LFX_ERR_HIP, "internal: ring counts do not add up to the scan");
     }
-    n_kept = dense;
-  }
-  const uint32_t ne = info[lfx::kInfoEdge], ns = info[lfx::kInfoSurface];
-  h.edge_points.resize((size_t)ne * 4);
-  h.edge_index.resize(ne);
-  h.surface_points.resize((size_t)ns * 4);
-  h.surface_index.resize(ns);
-  if (ne) {
-    LFX_HIP(c, hipMemcpyAsync(h.edge_points.data(), c->edge_pts.p + b, (size_t)ne * 16, hipMemcpyDeviceToHost, st));
-    LFX_HIP(c, hipMemcpyAsync(h.edge_index.data(), c->edge_idx.p + b, (size_t)ne * 4, hipMemcpyDeviceToHost, st));
-  }
-  if (ns) {
-    LFX_HIP(c, hipMemcpyAsync(h.surface_points.data(), c->surf_pts.p + b, (size_t)ns * 16, hipMemcpyDeviceToHost, st));
-    LFX_HIP(c, hipMemcpyAsync(h.surface_index.data(), c->surf_idx.p + b, (size_t)ns * 4, hipMemcpyDeviceToHost, st));
-  }
-  LFX_HIP(c, hipStreamSynchronize(st));
-  // labels[k] / curvature[k] belong to input point k (densify_kernel); points the zero filter dropped keep
-  // Default / 0 and do not appear in sorted_index
-  h.sorted_index.resize(n_kept);
-  if (out) {
-    out->n_points = n;
-    out->n_sorted = n_kept;
-    out->labels = h.labels.data();
-    out->curvature = h.curvature.data();
-    out->sorted_index = h.sorted_index.data();
-    out->n_rings = nr;
-    out->ring_id = h.ring_id.data();
-    out->ring_count = h.ring_count.data();
-    out->ring_offset = h.ring_offset.data();
-    out->ring_status = h.ring_status.data();
-    out->n_edge = ne;
-    out->edge_points = h.edge_points.data();
-    out->edge_index = h.edge_index.data();
-    out->n_surface = ns;
-    out->surface_points = h.surface_points.data();
-    out->surface_index = h.surface_index.data();
+    lfx_scan_result & o = out[k];
+    o.n_points = n;
+    o.n_sorted = dense;             // = n less the points the zero filter dropped
+    o.labels = want_lab ? H + o_lb + b : nullptr;
+    o.curvature = want_curv ? reinterpret_cast<const double *>(H + o_cv) + b : nullptr;
+    o.sorted_index = want_sidx ? reinterpret_cast<const uint32_t *>(H + o_sx) + b : nullptr;
+    o.n_rings = nr;
+    o.ring_id = h.ring_id.data();
+    o.ring_count = h.ring_count.data();
+    o.ring_offset = h.ring_offset.data();
+    o.ring_status = h.ring_status.data();
+    o.n_edge = hdr[lfx::kInfoEdge];
+    o.edge_points = reinterpret_cast<const float *>(H + o_ep) + (size_t)b * 4;
+    o.edge_index = reinterpret_cast<const uint32_t *>(H + o_ei) + b;
+    o.n_surface = hdr[lfx::kInfoSurface];
+    o.surface_points = reinterpret_cast<const float *>(H + o_sp) + (size_t)b * 4;
+    o.surface_index = reinterpret_cast<const uint32_t *>(H + o_si) + b;
   }
   return LFX_OK;
 }
@@ -681,6 +703,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     c->layout = lfx::Layout{L.point_step, L.off_x, L.off_y, L.off_z, L.off_ring, rtype, L.big_endian ? 1u : 0u};
   }
   c->drop_zero = config->drop_zero_points ? 1u : 0u;
+  c->outputs = (config->outputs ? config->outputs : (uint32_t)LFX_OUT_ALL) | LFX_OUT_FEATURES;
   c->max_points = config->max_points_per_scan;
   c->max_batch = config->max_batch;
   uint32_t ring_cap = config->max_points_per_ring ? config->max_points_per_ring : LFX_MAX_RING_POINTS;
@@ -795,6 +818,8 @@ void lfx_destroy(lfx_ctx * c)
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
+  c->h_in.release(); c->h_out.release();
+  if (c->h_status) {(void)hipHostFree(c->h_status); c->h_status = nullptr;}
   if (c->stream) {(void)hipStreamDestroy(c->stream);}
   delete c;
 }
@@ -823,6 +848,45 @@ int lfx_device_results(const lfx_ctx * c, lfx_device_view * v)
   v->surface_points = reinterpret_cast<const float *>(c->surf_pts.p);
   v->surface_index = c->surf_idx.p;
   return LFX_OK;
+}
+
+int lfx_batch_status(lfx_ctx * c, void * stream, uint32_t * first_bad)
+{
+  if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!c->h_status) {
+    LFX_HIP(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_status), (size_t)c->max_batch * 16, hipHostMallocDefault));
+  }
+  LFX_HIP(c, hipMemcpyAsync(c->h_status, c->scan_info.p, (size_t)c->last_batch * 16, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipStreamSynchronize(st));
+  for (uint32_t s = 0; s < c->last_batch; s++) {
+    const uint32_t e = c->h_status[s * 4 + lfx::kInfoError];
+    if (e & (lfx::kErrRingId | lfx::kErrTimeout)) {
+      if (first_bad) {*first_bad = s;}
+      return (e & lfx::kErrRingId) ?
+             fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)") :
+             fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
+    }
+  }
+  return LFX_OK;
+}
+
+int lfx_host_alloc(lfx_ctx * c, size_t bytes, void ** out)
+{
+  if (!c || !out || bytes == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  LFX_HIP(c, hipSetDevice(c->device));
+  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+    *out = nullptr;
+    return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate pinned host memory");
+  }
+  return LFX_OK;
+}
+
+void lfx_host_free(lfx_ctx *, void * ptr)
+{
+  if (ptr) {(void)hipHostFree(ptr);}
 }
 
 namespace
@@ -896,11 +960,13 @@ int lfx_download_scan(lfx_ctx * c, uint32_t scan, void * stream, lfx_scan_result
 {
   if (!c || !out) {return LFX_ERR_INVALID_ARGUMENT;}
   LFX_HIP(c, hipSetDevice(c->device));
-  return download(c, scan, static_cast<hipStream_t>(stream), out);
+  return fetch(c, scan, 1, static_cast<hipStream_t>(stream), LFX_OUT_ALL, out);
 }
 
-int lfx_extract_batch(
-  lfx_ctx * c, const void * const * points, const size_t * n_points, uint32_t batch, lfx_scan_result * out)
+namespace
+{
+int extract_batch_impl(
+  lfx_ctx * c, const void * const * points, const size_t * n_points, uint32_t batch, uint32_t mask, lfx_scan_result * out)
 {
   if (!c || !points || !n_points || !out || batch == 0) {return LFX_ERR_INVALID_ARGUMENT;}
   if (batch > c->max_batch) {return fail(c, LFX_ERR_CAPACITY, "batch exceeds max_batch");}
@@ -922,21 +988,48 @@ int lfx_extract_batch(
       return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the input staging buffer");
     }
   }
+  // Input: a pinned buffer (lfx_host_alloc, or anything the caller registered with HIP) goes to the device by DMA;
+  // pageable memory is copied through the context's pinned staging buffer in pieces, each piece's DMA running while
+  // the next is being copied.
   size_t at = 0;
   for (uint32_t s = 0; s < batch; s++) {
     const size_t bytes = n_points[s] * c->layout.step;
     if (bytes) {
-      LFX_HIP(c, hipMemcpyAsync(c->staging.p + at, points[s], bytes, hipMemcpyHostToDevice, c->stream));
+      hipPointerAttribute_t attr;
+      const bool pinned = hipPointerGetAttributes(&attr, points[s]) == hipSuccess && attr.type == hipMemoryTypeHost;
+      if (!pinned) {(void)hipGetLastError();}              // a plain pointer is "invalid value" to the query: not an error here
+      if (pinned) {
+        LFX_HIP(c, hipMemcpyAsync(c->staging.p + at, points[s], bytes, hipMemcpyHostToDevice, c->stream));
+      } else {
+        if (c->h_in.bytes < at + bytes) {
+          // (growing the staging buffer must not pull the rug from under copies already queued)
+          LFX_HIP(c, hipStreamSynchronize(c->stream));
+          if (c->h_in.reserve(total * c->layout.step) != hipSuccess) {
+            return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the pinned input staging buffer");
+          }
+        }
+        constexpr size_t kPiece = 1u << 20;
+        const uint8_t * src = static_cast<const uint8_t *>(points[s]);
+        for (size_t o = 0; o < bytes; o += kPiece) {
+          const size_t len = bytes - o < kPiece ? bytes - o : kPiece;
+          std::memcpy(c->h_in.p + at + o, src + o, len);
+          LFX_HIP(c, hipMemcpyAsync(c->staging.p + at + o, c->h_in.p + at + o, len, hipMemcpyHostToDevice, c->stream));
+        }
+      }
     }
     at += bytes;
   }
   const int rc = run_batch(c, c->staging.p, n32.data(), batch, c->stream);
   if (rc != LFX_OK) {return rc;}
-  for (uint32_t s = 0; s < batch; s++) {
-    const int r = download(c, s, c->stream, &out[s]);
-    if (r != LFX_OK) {return r;}
-  }
-  return LFX_OK;
+  return fetch(c, 0, batch, c->stream, mask, out);
+}
+}  // namespace
+
+int lfx_extract_batch(
+  lfx_ctx * c, const void * const * points, const size_t * n_points, uint32_t batch, lfx_scan_result * out)
+{
+  if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  return extract_batch_impl(c, points, n_points, batch, c->outputs, out);
 }
 
 int lfx_extract(lfx_ctx * c, const void * points, size_t n_points, lfx_scan_result * out)
@@ -1031,9 +1124,11 @@ int lfx_stage_ring_projection(
 {
   if (!c || !sorted_index) {return LFX_ERR_INVALID_ARGUMENT;}
   lfx_scan_result r;
-  const int rc = lfx_extract(c, points, n_points, &r);
+  const void * p[1] = {points};
+  const size_t n[1] = {n_points};
+  const int rc = extract_batch_impl(c, p, n, 1, LFX_OUT_SORTED_INDEX, &r);
   if (rc != LFX_OK) {return rc;}
-  std::memcpy(sorted_index, r.sorted_index, (size_t)r.n_points * 4);
+  if (r.n_sorted) {std::memcpy(sorted_index, r.sorted_index, (size_t)r.n_sorted * 4);}     // n_sorted <= n_points: the zero filter drops points
   if (n_rings) {*n_rings = r.n_rings;}
   for (uint32_t k = 0; k < r.n_rings; k++) {
     if (ring_id) {ring_id[k] = r.ring_id[k];}

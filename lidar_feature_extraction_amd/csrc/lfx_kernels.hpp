@@ -2419,6 +2419,40 @@ __global__ __launch_bounds__(256) void densify_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Synchronous host API: what the caller always gets back -- per scan the header (scan_info, ring counts, ring status)
+// and the edge / surface clouds with their index lists -- written by the device STRAIGHT INTO PINNED HOST MEMORY, so
+// that only the bytes that exist cross PCIe and the host waits once, for the stream, not for sizes first.
+// Host block: headers [count][kResultHeaderBytes], then edge_pts, surf_pts (float4), edge_idx, surf_idx (u32), each
+// addressed like the device arrays relative to the first scan's first point (p0).
+constexpr uint32_t kResultHeaderBytes = 16 + kRings * 4 + kRings;       // scan_info[4], ring_count[256], ring_status[256]
+__global__ __launch_bounds__(256) void result_pack_kernel(
+  uint32_t first, uint32_t p0, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ scan_info,
+  const uint32_t * __restrict__ ring_count, const uint8_t * __restrict__ ring_status,
+  const float4 * __restrict__ edge_pts, const uint32_t * __restrict__ edge_idx, const float4 * __restrict__ surf_pts,
+  const uint32_t * __restrict__ surf_idx, uint8_t * __restrict__ h_hdr, float4 * __restrict__ h_edge_pts,
+  float4 * __restrict__ h_surf_pts, uint32_t * __restrict__ h_edge_idx, uint32_t * __restrict__ h_surf_idx)
+{
+  const uint32_t k = blockIdx.y, s = first + k, tid = threadIdx.x;
+  if (blockIdx.x == 0) {
+    uint32_t * hdr = reinterpret_cast<uint32_t *>(h_hdr + (size_t)k * kResultHeaderBytes);
+    if (tid < 4) {hdr[tid] = scan_info[s * 4 + tid];}
+    hdr[4 + tid] = ring_count[s * kRings + tid];
+    reinterpret_cast<uint8_t *>(hdr + 4 + kRings)[tid] = ring_status[s * kRings + tid];
+  }
+  const uint32_t ne = scan_info[s * 4 + kInfoEdge], ns = scan_info[s * 4 + kInfoSurface];
+  const size_t b = scan_begin[s], hb = b - p0;
+  for (uint32_t i = blockIdx.x * blockDim.x + tid; i < ne + ns; i += gridDim.x * blockDim.x) {
+    if (i < ne) {
+      h_edge_pts[hb + i] = edge_pts[b + i];
+      h_edge_idx[hb + i] = edge_idx[b + i];
+    } else {
+      h_surf_pts[hb + i - ne] = surf_pts[b + i - ne];
+      h_surf_idx[hb + i - ne] = surf_idx[b + i - ne];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Batch-level packing for the multi-GPU gather: exclusive prefix of the per-scan feature counts
 // (one workgroup walks the batch), then a copy of every scan's clouds to its packed offset.
 __global__ __launch_bounds__(256) void feature_offsets_kernel(

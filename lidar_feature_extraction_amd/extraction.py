@@ -69,7 +69,7 @@ class ScanFeatures:
 
 
 def _np(ptr, n, dtype, shape=None):
-    if n == 0:
+    if n == 0 or not ptr:                  # (a NULL pointer: that output was not asked for, lfx_config.outputs)
         return np.zeros((0,) + tuple(shape[1:]) if shape else 0, dtype)
     a = np.ctypeslib.as_array(ptr, shape=(n,) if shape is None else shape).astype(dtype, copy=True)
     return a
@@ -92,7 +92,7 @@ class FeatureExtraction:
     """One context = one GPU = one calling thread (feature_extraction.cpp:65-87,185)."""
 
     def __init__(self, params=None, device=0, max_points_per_scan=262144, max_batch=1,
-                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None):
+                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None, outputs=0):
         self._L = B.load()
         self.params = params or HyperParameters()
         self._ctx = C.c_void_p()
@@ -105,7 +105,9 @@ class FeatureExtraction:
         else:
             lay = B.Layout(*(tuple(layout) + (0, 0))[:7])
         self._step = lay.point_step or 32
-        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay)
+        # outputs: B.OUT_* mask of what ExtractFeatures / extract_batch bring back (0 = everything); the two clouds always do
+        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay, int(outputs))
+        self._pinned = []
         cp = self.params.to_c()
         rc = self._L.lfx_create(C.byref(self._ctx), device, C.byref(cp), C.byref(cfg))
         if rc != 0:
@@ -115,6 +117,9 @@ class FeatureExtraction:
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
+            for ptr in getattr(self, "_pinned", []):
+                self._L.lfx_host_free(self._ctx, ptr)
+            self._pinned = []
             self._L.lfx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -140,6 +145,23 @@ class FeatureExtraction:
         res = (B.ScanResult * nb)()
         B.check(self._ctx, self._L.lfx_extract_batch(self._ctx, ptrs, ns, nb, res))
         return [_result(res[i]) for i in range(nb)]
+
+    def pinned_like(self, cloud):
+        """A copy of `cloud` in pinned host memory (lfx_host_alloc): lfx_extract reads such a buffer by DMA instead of
+        staging it.  Owned by this object (freed by close())."""
+        cloud = np.ascontiguousarray(cloud)
+        ptr = C.c_void_p()
+        B.check(self._ctx, self._L.lfx_host_alloc(self._ctx, max(cloud.nbytes, 1), C.byref(ptr)))
+        self._pinned.append(ptr)
+        buf = (C.c_uint8 * cloud.nbytes).from_address(ptr.value)
+        out = np.frombuffer(buf, dtype=cloud.dtype, count=len(cloud))
+        out[...] = cloud
+        return out
+
+    def batch_status(self, stream=0):
+        """lfx_batch_status: raises LfxError if a scan of the last device batch carries an error bit."""
+        bad = C.c_uint32(0)
+        B.check(self._ctx, self._L.lfx_batch_status(self._ctx, C.c_void_p(int(stream)), C.byref(bad)))
 
     def extract_batch_device(self, d_points, n_points, stream=0):
         """d_points: device address of the scans' records back to back; asynchronous on `stream`."""
