@@ -74,7 +74,7 @@ def main():
         import __graft_entry__
         __graft_entry__.build()
     from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, concat
-    from lidar_feature_extraction_amd.gather import CloudGather
+    from lidar_feature_extraction_amd.gather import CloudGather, RcclGather
 
     # ---- synthetic stream: scan i -> rank i mod world; seeds 1234 + scan id
     n_unique = max(1, min(a.unique, a.batch))
@@ -107,7 +107,15 @@ def main():
         bufs = [(torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
                  torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
                  torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(2)]
-        gather = CloudGather(dst=0, device=dev)
+        # RCCL through the library's own entry points (lfx_comm_*, lfx_gather_*); torch.distributed only carries the
+        # 128-byte communicator id from rank 0 to the others
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(idt, 0)
+        gather = CloudGather(fx, rank, world, bytes(idt.cpu().numpy().tobytes()), dst=0, device=dev,
+                             capacity_points=feat_cap * world, batch=a.batch)
 
     def step():
         k = step_no[0] % n_streams
@@ -286,6 +294,8 @@ def main():
         }
         print(json.dumps(out))
         sys.stdout.flush()
+    if use_gather:
+        gather.close()
     for f in fxs:
         f.close()
     if world > 1 or a.force_gather:

@@ -246,6 +246,39 @@ int lfx_pack_features(lfx_ctx *ctx, float *d_edge_out, float *d_surface_out, uin
 /* Copy scan `scan` of the last device batch to host memory (synchronises the stream). */
 int lfx_download_scan(lfx_ctx *ctx, uint32_t scan, void *stream, lfx_scan_result *out);
 
+/* --- multi-GPU: one process per GPU, scans sharded scan i -> rank i mod N, clouds gathered to one rank ------------- */
+/* The reference node is stateless per message (feature_extraction.cpp:173-179), so scans are independent units and the
+ * only exchange is the gather of the variable-length edge / surface clouds.  It runs over RCCL directly (librccl is
+ * opened at the first call; point-to-point send / recv over the direct xGMI links, no ring, no reduction).
+ * Bootstrap as with NCCL: rank 0 makes an id (lfx_comm_unique_id), the caller hands it to every rank by whatever means
+ * it has (MPI, a socket, torch.distributed ...), every rank calls lfx_comm_create with it. */
+#define LFX_COMM_ID_BYTES 128
+typedef struct lfx_comm lfx_comm;
+int lfx_comm_unique_id(uint8_t id[LFX_COMM_ID_BYTES]);
+int lfx_comm_create(lfx_ctx *ctx, const uint8_t id[LFX_COMM_ID_BYTES], int rank, int world, lfx_comm **out);
+void lfx_comm_destroy(lfx_comm *comm);
+/* Gather of one step, in two halves so that a caller can run it one step behind the extraction (bench.py, gather.py):
+ *   lfx_gather_counts   queues on `stream`: the all-gather of this rank's two totals (from d_offsets as written by
+ *                       lfx_pack_xyz12 / lfx_pack_xyz / lfx_pack_features: entries [batch] and [2*batch+1]) and their copy
+ *                       to pinned host memory.  Returns at once.
+ *   lfx_gather_payload  waits (host) for those totals, then queues on `stream` one grouped send / recv: every rank
+ *                       sends its first n_edge and n_surface records (floats_per_point floats each: 3 for xyz12, 4
+ *                       for xyz / features) and its offsets table to `dst`; dst receives them rank after rank into
+ *                       d_edge_all / d_surface_all (capacity_points records each; its own part is a device copy) and
+ *                       d_offsets_all [world][2][batch+1].  counts_out (host, [world][2], may be NULL) receives the
+ *                       totals of every rank on every rank; rank r's clouds start at the sum of the counts before it.
+ *                       capacity_points is the destination's, given by EVERY rank (the same value): if the gathered
+ *                       clouds do not fit, every rank returns LFX_ERR_CAPACITY and nothing is sent.
+ * lfx_gather = both, one after the other.  Every rank must make the same sequence of calls. */
+int lfx_gather_counts(lfx_ctx *ctx, lfx_comm *comm, const uint32_t *d_offsets, uint32_t batch, void *stream);
+int lfx_gather_payload(lfx_ctx *ctx, lfx_comm *comm, int dst, const float *d_edge, const float *d_surface,
+                       const uint32_t *d_offsets, uint32_t batch, uint32_t floats_per_point, float *d_edge_all,
+                       float *d_surface_all, uint32_t *d_offsets_all, size_t capacity_points, uint64_t *counts_out,
+                       void *stream);
+int lfx_gather(lfx_ctx *ctx, lfx_comm *comm, int dst, const float *d_edge, const float *d_surface,
+               const uint32_t *d_offsets, uint32_t batch, uint32_t floats_per_point, float *d_edge_all,
+               float *d_surface_all, uint32_t *d_offsets_all, size_t capacity_points, uint64_t *counts_out, void *stream);
+
 /* --- per-stage entry points (device-backed mirrors of the reference's free functions) ----- */
 /* One ring given as angle-sorted x[n], y[n] host arrays; every stage runs the same device
  * routines the fused ring kernel runs.  Optional inputs may be NULL.

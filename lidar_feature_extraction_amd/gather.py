@@ -2,29 +2,161 @@
 
 Scans are independent units (the reference node is stateless per message,
 /root/reference/extraction/app/feature_extraction.cpp:173-179): each rank extracts its own scans
-and rank `dst` collects the variable-length edge / surface clouds.  One process per GPU;
-`torch.distributed` backend "nccl" is RCCL over xGMI on the MI355X node, "gloo" on CPU (tests).
+and rank `dst` collects the variable-length edge / surface clouds.  One process per GPU.
 
-Message shape: the totals first (2 ints per rank, all-gather), then one padded gather per cloud
-kind -- rank dst receives over the direct links of all peers at once; no ring, no reduction.
+The exchange itself is the library's: lfx_comm_* / lfx_gather_counts / lfx_gather_payload (include/lfx.h) talk to
+RCCL directly -- the totals first (all-gather of two numbers per rank), then one grouped send / recv over the direct
+xGMI links; no ring, no reduction.  This module is the binding of those entry points (`RcclGather`) plus
+`CloudGather`, which runs them one step behind the extraction: while the device extracts batch k, the clouds of
+batch k-1 travel on a side stream, so rank dst's ingest (N-1 clouds per step) hides behind compute instead of adding
+to it.  Every rank issues the same sequence of calls whatever its data, so the ranks cannot get out of step.
 
-`gather_clouds` does that synchronously.  `CloudGather` pipelines it one step deep: while the
-device extracts batch k, the clouds of batch k-1 travel (on a side stream for GPU tensors), so
-rank dst's ingest (N-1 clouds per step) hides behind compute instead of adding to it.  Every rank
-issues the same sequence of collectives whatever its data, so the ranks cannot get out of step.
+`gather_clouds` is the same protocol over `torch.distributed` (gloo on CPU): a rehearsal for the tests that run without
+a GPU, never the product path.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import binding as B
 
+
+class RcclGather:
+    """One RCCL communicator (lfx_comm) tied to a FeatureExtraction context."""
+
+    def __init__(self, fx, rank, world, unique_id):
+        self._L = B.load()
+        self._fx = fx
+        self.rank, self.world = rank, world
+        self._comm = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        B.check(fx._ctx, self._L.lfx_comm_create(fx._ctx, C.cast(buf, C.c_void_p), rank, world, C.byref(self._comm)))
+
+    @staticmethod
+    def unique_id():
+        """Rank 0 makes it; hand the 128 bytes to every rank."""
+        buf = (C.c_uint8 * 128)()
+        rc = B.load().lfx_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise B.LfxError(rc, (B.load().lfx_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def close(self):
+        if self._comm.value:
+            self._L.lfx_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def counts(self, d_offsets, batch, stream=0):
+        B.check(self._fx._ctx, self._L.lfx_gather_counts(self._fx._ctx, self._comm, C.c_void_p(int(d_offsets)), batch,
+                                                         C.c_void_p(int(stream))))
+
+    def payload(self, dst, d_edge, d_surface, d_offsets, batch, floats_per_point, d_edge_all, d_surface_all, d_offsets_all,
+                capacity_points, stream=0):
+        """Returns the totals of every rank, [world, 2] (edge, surface)."""
+        counts = np.zeros((self.world, 2), np.uint64)
+        B.check(self._fx._ctx, self._L.lfx_gather_payload(
+            self._fx._ctx, self._comm, dst, C.c_void_p(int(d_edge)), C.c_void_p(int(d_surface)), C.c_void_p(int(d_offsets)),
+            batch, floats_per_point, C.c_void_p(int(d_edge_all or 0)), C.c_void_p(int(d_surface_all or 0)),
+            C.c_void_p(int(d_offsets_all or 0)), int(capacity_points), C.c_void_p(counts.ctypes.data), C.c_void_p(int(stream))))
+        return counts
+
+
+def split_gathered(edge_all, surface_all, offsets_all, counts, batch):
+    """Rank dst: the gathered buffers back into one dict per rank {edge, surface, offsets} (views)."""
+    out, at_e, at_s = [], 0, 0
+    for r in range(len(counts)):
+        ne, ns = int(counts[r][0]), int(counts[r][1])
+        out.append({"edge": edge_all[at_e:at_e + ne], "surface": surface_all[at_s:at_s + ns], "offsets": offsets_all[r]})
+        at_e += ne
+        at_s += ns
+    return out
+
+
+class CloudGather:
+    """One-step-deep pipeline of the gather on a side stream (GPU tensors, RCCL through the C ABI).
+
+    submit(edge, surface, offsets, batch) registers this step's packed clouds (they must stay untouched until the
+    NEXT submit returns: use two sets of buffers; `wait_buffer` orders their reuse), queues the all-gather of their
+    totals, and completes the previous step's gather, returning on rank dst the list split_gathered builds (views of
+    the receive buffers, valid once `done` has passed; None elsewhere).  flush() completes the last one."""
+
+    def __init__(self, fx, rank, world, unique_id, dst=0, device=None, capacity_points=0, batch=1, floats_per_point=3):
+        self.dst, self.rank, self.world = dst, rank, world
+        self.fpp, self.batch, self.cap = floats_per_point, batch, int(capacity_points)
+        self.rccl = RcclGather(fx, rank, world, unique_id)
+        self.side = torch.cuda.Stream(device=device)
+        self.pending = None
+        self.buffer_free = {}          # data_ptr of a send buffer -> event recorded after the gather that read it
+        self.done = None               # event after the last completed gather's receives
+        if rank == dst:
+            # two receive sets, so that a consumer may still read step k-2's clouds while step k-1's arrive
+            self.recv = [(torch.zeros((self.cap, self.fpp), dtype=torch.float32, device=device),
+                          torch.zeros((self.cap, self.fpp), dtype=torch.float32, device=device),
+                          torch.zeros((world, 2 * (batch + 1)), dtype=torch.int32, device=device)) for _ in range(2)]
+        else:
+            self.recv = [(None, None, None)] * 2
+        self.step = 0
+
+    def close(self):
+        self.rccl.close()
+
+    def wait_buffer(self, tensor):
+        """Make the caller's current stream wait until the last gather reading `tensor` is done."""
+        ev = self.buffer_free.pop(tensor.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def submit(self, edge, surface, offsets, batch):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        prev, self.pending = self.pending, (edge, surface, offsets, batch)
+        # the previous step's payload goes first: its totals landed long ago, and the side stream then does not sit on
+        # this step's `ready` before moving data that has been waiting since the step before
+        out = self._finish(prev) if prev is not None else None
+        self.side.wait_event(ready)
+        self.rccl.counts(offsets.data_ptr(), batch, self.side.cuda_stream)
+        return out
+
+    def _finish(self, p):
+        edge, surface, offsets, batch = p
+        ea, sa, oa = self.recv[self.step % 2]
+        self.step += 1
+        counts = self.rccl.payload(self.dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
+                                   ea.data_ptr() if ea is not None else 0, sa.data_ptr() if sa is not None else 0,
+                                   oa.data_ptr() if oa is not None else 0, self.cap, self.side.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        for t in (edge, surface, offsets):
+            self.buffer_free[t.data_ptr()] = ev
+        self.done = ev
+        if self.rank != self.dst:
+            return None
+        return split_gathered(ea, sa, oa, counts, batch)
+
+    def flush(self):
+        prev, self.pending = self.pending, None
+        out = self._finish(prev) if prev is not None else None
+        self.side.synchronize()
+        return out
+
+
+# --------------------------------------------------------------------------- CPU rehearsal (tests, gloo)
 def _totals(offsets, batch):
     return torch.stack([offsets[batch], offsets[2 * batch + 1]]).to(torch.int64)
 
 
-def _gather_payload(edge, surface, offsets, tot, dst, group):
-    """tot: [world, 2] int64 on the host.  Padded gather of both clouds and the offsets table."""
+def gather_clouds(edge, surface, offsets, batch, dst=0, group=None):
+    """The protocol of lfx_gather over torch.distributed (gloo): totals all-gathered first, then the clouds and the
+    offsets tables to rank dst.  edge, surface: [capacity, k] f32 packed clouds of this rank; offsets: int32
+    [2*(batch+1)].  Returns on rank dst what split_gathered returns, None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    totals = _totals(offsets, batch)
+    all_totals = [torch.zeros_like(totals) for _ in range(world)]
+    dist.all_gather(all_totals, totals, group=group)
+    tot = torch.stack(all_totals).cpu()
     me, ms = int(tot[:, 0].max()), int(tot[:, 1].max())
     if me > edge.shape[0] or ms > surface.shape[0]:
         raise RuntimeError("packed feature buffers are smaller than the gathered clouds")
@@ -44,92 +176,20 @@ def _gather_payload(edge, surface, offsets, tot, dst, group):
             for r in range(world)]
 
 
-def gather_clouds(edge, surface, offsets, batch, dst=0, group=None):
-    """edge, surface: [capacity, 4] f32 packed clouds of this rank (lfx_pack_features);
-    offsets: int32 [2*(batch+1)] exclusive prefixes of the per-scan counts (entry [batch] and
-    [2*batch+1] are the totals).  Returns on rank dst a list with one dict per rank
-    {edge [n_e,4], surface [n_s,4], offsets}, None elsewhere.  Synchronises the host once
-    (the totals decide the padded message length)."""
-    world = dist.get_world_size(group)
-    totals = _totals(offsets, batch)
-    all_totals = [torch.zeros_like(totals) for _ in range(world)]
-    dist.all_gather(all_totals, totals, group=group)
-    tot = torch.stack(all_totals).cpu()
-    return _gather_payload(edge, surface, offsets, tot, dst, group)
-
-
-class CloudGather:
-    """One-step-deep pipeline of gather_clouds.
-
-    submit(edge, surface, offsets, batch) registers this step's packed clouds (they must stay
-    untouched until the NEXT submit returns: use two sets of buffers) and completes the previous
-    step's gather, returning its result (rank dst) or None.  flush() completes the last one.
-    For GPU tensors everything is issued on a side stream that first waits for the work queued on
-    the caller's stream at submit time; `done_event` of the returned step lets the caller order the
-    reuse of a buffer after its gather."""
-
-    def __init__(self, dst=0, group=None, device=None):
-        self.dst, self.group = dst, group
-        self.cuda = device is not None and torch.device(device).type == "cuda"
-        self.side = torch.cuda.Stream(device=device) if self.cuda else None
-        self.pending = None
-        self.buffer_free = {}          # id(buffer) -> event recorded after the gather that read it
-
-    def wait_buffer(self, tensor):
-        """Make the caller's current stream wait until the last gather reading `tensor` is done."""
-        ev = self.buffer_free.pop(tensor.data_ptr(), None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
-    def _issue_totals(self, offsets, batch):
-        world = dist.get_world_size(self.group)
-        totals = _totals(offsets, batch)
-        all_totals = [torch.zeros_like(totals) for _ in range(world)]
-        dist.all_gather(all_totals, totals, group=self.group)
-        return all_totals
-
-    def submit(self, edge, surface, offsets, batch):
-        if self.cuda:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(ready)
-                all_totals = self._issue_totals(offsets, batch)
-                # the totals go to pinned host memory right behind their all-gather, with an event of their
-                # own: finishing this step later waits for THAT event only, not for whatever the side stream
-                # has been given since (the next step's collectives wait for the next step's extraction)
-                host_tot = torch.empty((len(all_totals), 2), dtype=torch.int64, pin_memory=True)
-                host_tot.copy_(torch.stack(all_totals), non_blocking=True)
-                landed = torch.cuda.Event()
-                landed.record(self.side)
-            totals = (host_tot, landed)
-        else:
-            totals = (self._issue_totals(offsets, batch), None)
-        prev, self.pending = self.pending, (edge, surface, offsets, totals)
-        return self._finish(prev) if prev is not None else None
-
-    def _finish(self, p):
-        edge, surface, offsets, (tot, landed) = p
-        if self.cuda:
-            landed.synchronize()
-            with torch.cuda.stream(self.side):
-                out = _gather_payload(edge, surface, offsets, tot, self.dst, self.group)
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-            for t in (edge, surface, offsets):
-                self.buffer_free[t.data_ptr()] = ev
-            return out
-        tot = torch.stack(tot).cpu()
-        return _gather_payload(edge, surface, offsets, tot, self.dst, self.group)
-
-    def flush(self):
-        prev, self.pending = self.pending, None
-        out = self._finish(prev) if prev is not None else None
-        if self.cuda:
-            self.side.synchronize()
-        return out
-
-
 def shard_scans(n_scans, rank, world):
     """scan i -> rank i mod world."""
     return list(range(rank, n_scans, world))
+
+
+def reassemble(per_rank, n_scans, world, batch):
+    """Rank dst: the gathered per-rank clouds back into stream order.  per_rank[r] = {edge, surface, offsets} with
+    offsets = [2][batch+1] exclusive prefixes of rank r's per-scan counts; scan i of the stream is rank i mod world's
+    local scan i // world.  Returns [(edge_i, surface_i)] for i in range(n_scans)."""
+    out = []
+    for i in range(n_scans):
+        r, k = i % world, i // world
+        offs = per_rank[r]["offsets"]
+        e0, e1 = int(offs[k]), int(offs[k + 1])
+        s0, s1 = int(offs[batch + 1 + k]), int(offs[batch + 1 + k + 1])
+        out.append((per_rank[r]["edge"][e0:e1], per_rank[r]["surface"][s0:s1]))
+    return out

@@ -1,5 +1,7 @@
-"""The multi-rank path on CPU: world_size 2 over gloo.  Covers the gather of variable-length
-clouds (what RCCL carries over xGMI on the GPU node) and the scan sharding."""
+"""The multi-rank path on CPU: world_size 2 over gloo.  `gather_clouds` is the rehearsal of lfx_gather's protocol
+(totals first, then the variable-length clouds and the offsets tables to one rank); the flow around it -- scans sharded
+scan i -> rank i mod N, each rank's clouds packed back to back, gather, reassembly into stream order -- is the one
+bench.py runs on the GPU node, here with the CPU oracle standing in for the device on every rank."""
 import os
 import socket
 
@@ -8,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lidar_feature_extraction_amd.gather import CloudGather, gather_clouds, shard_scans
+from lidar_feature_extraction_amd.gather import gather_clouds, reassemble, shard_scans
 
 
 def _free_port():
@@ -34,46 +36,6 @@ def _make_rank_data(rank, batch):
     edge[:ne.sum()] = rng.standard_normal((ne.sum(), 4))
     surf[:ns.sum()] = rng.standard_normal((ns.sum(), 4))
     return edge, surf, off, int(ne.sum()), int(ns.sum())
-
-
-def _check(out, world, batch, seed_shift=0):
-    ok = out is not None and len(out) == world
-    for r in range(world):
-        e, s, o, n_e, n_s = _make_rank_data(r + seed_shift, batch)
-        ok = ok and out[r]["edge"].shape[0] == n_e and out[r]["surface"].shape[0] == n_s
-        ok = ok and np.array_equal(out[r]["edge"].numpy(), e[:n_e]) and np.array_equal(out[r]["surface"].numpy(), s[:n_s])
-        ok = ok and np.array_equal(out[r]["offsets"].numpy(), o)
-    return bool(ok)
-
-
-def _pipelined_worker(rank, world, port, batch, ret):
-    """CloudGather: the result of step k arrives with submit(k+1) / flush(); three steps."""
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = CloudGather(dst=0)
-    outs = []
-    for step in range(3):
-        edge, surf, off, _ne, _ns = _make_rank_data(rank + 10 * step, batch)
-        outs.append(g.submit(torch.from_numpy(edge), torch.from_numpy(surf), torch.from_numpy(off), batch))
-    outs.append(g.flush())
-    ok = outs[0] is None
-    if rank == 0:
-        for step in range(3):
-            ok = ok and _check(outs[step + 1], world, batch, seed_shift=10 * step)
-    else:
-        ok = ok and all(o is None for o in outs)
-    ret[rank] = bool(ok)
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_pipelined_gather_two_ranks_gloo():
-    world, batch = 2, 5
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_pipelined_worker, args=(world, _free_port(), batch, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
 
 
 def _worker(rank, world, port, batch, ret):
@@ -102,6 +64,56 @@ def test_gather_two_ranks_gloo():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), batch, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def _stream_worker(rank, world, port, n_scans, ret):
+    """Scan i of a 7-scan stream goes to rank i mod 2; every rank extracts its scans (oracle), packs their clouds as
+    tight x, y, z triples with the offsets table lfx_pack_xyz12 writes, the clouds are gathered to rank 0 and put back
+    into stream order; rank 0 compares every scan's clouds with the oracle's for that scan."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lidar_feature_extraction_amd import make_scan
+    from oracle import binding as OB
+    mine = shard_scans(n_scans, rank, world)
+    batch = (n_scans + world - 1) // world                     # every rank packs `batch` scans (the last may be empty)
+    edges, surfs, off = [], [], np.zeros(2 * (batch + 1), np.int32)
+    for k in range(batch):
+        if k < len(mine):
+            w = OB.extract(make_scan(8, 300, seed=2000 + mine[k]), canonical_ties=False)
+            edges.append(w["edge_points"][:, :3])
+            surfs.append(w["surface_points"][:, :3])
+        else:
+            edges.append(np.zeros((0, 3), np.float32))
+            surfs.append(np.zeros((0, 3), np.float32))
+        off[k + 1] = off[k] + len(edges[-1])
+        off[batch + 1 + k + 1] = off[batch + 1 + k] + len(surfs[-1])
+    cap = 8 * 300 * batch
+    e = np.zeros((cap, 3), np.float32)
+    s = np.zeros((cap, 3), np.float32)
+    e[:off[batch]] = np.concatenate(edges)
+    s[:off[2 * batch + 1]] = np.concatenate(surfs)
+    out = gather_clouds(torch.from_numpy(e), torch.from_numpy(s), torch.from_numpy(off), batch, dst=0)
+    ok = True
+    if rank == 0:
+        per_rank = [{k: v.numpy() for k, v in o.items()} for o in out]
+        for i, (ge, gs) in enumerate(reassemble(per_rank, n_scans, world, batch)):
+            w = OB.extract(make_scan(8, 300, seed=2000 + i), canonical_ties=False)
+            ok = ok and np.array_equal(ge, w["edge_points"][:, :3]) and np.array_equal(gs, w["surface_points"][:, :3])
+            ok = ok and len(ge) > 0 and len(gs) > 0
+    else:
+        ok = out is None
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stream_sharded_over_two_ranks_reassembles_to_the_oracle_clouds():
+    world, n_scans = 2, 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_stream_worker, args=(world, _free_port(), n_scans, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 
