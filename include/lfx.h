@@ -189,6 +189,16 @@ int lfx_create(lfx_ctx **ctx, int device_id, const lfx_params *params, const lfx
 void lfx_destroy(lfx_ctx *ctx);
 const char *lfx_last_error(const lfx_ctx *ctx);   /* ctx may be NULL: error of the last failed lfx_create */
 const char *lfx_status_string(int ring_status);
+/* The text the reference's exception carries when it abandons a ring of n_points points for `ring_status` -- what the
+ * node logs with RCLCPP_WARN(e.what()), feature_extraction.cpp:154-156: convolution.cpp:40-41, index_range.cpp:36-38,
+ * neighbor.hpp:72-73, math.cpp:41.  Empty for LFX_RING_OK, LFX_RING_SPARSE (RemoveSparseRings drops the ring silently,
+ * ring.cpp:46-59) and LFX_RING_TOO_LARGE (no counterpart).  Returns the length written (snprintf semantics). */
+int lfx_ring_message(int ring_status, uint32_t n_points, const lfx_params *params, char *buf, size_t len);
+/* RangeMessage* of range_message.hpp:37-83, the texts of the reference's bounds errors ("i (which is 39) >= max (which
+ * is 30)"): kind 0 LargerThanOrEqualTo, 1 SmallerThanOrEqualTo, 2 LargerThan, 3 SmallerThan.  Returns the length, -1
+ * for an unknown kind. */
+int lfx_range_message(int kind, const char *value_name, const char *range_name, long long value, long long range,
+                      char *buf, size_t len);
 
 /* --- the operator: feature_extraction.cpp:114-157 ---------------------------------------- */
 /* Host points in, host results out (synchronous; H2D + kernels + D2H). */

@@ -73,7 +73,7 @@ class DeviceView(C.Structure):
 
 EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
-    "lfx_status_string", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
+    "lfx_status_string", "lfx_ring_message", "lfx_range_message", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
     "lfx_device_results", "lfx_batch_status", "lfx_host_alloc", "lfx_host_free", "lfx_comm_unique_id", "lfx_comm_create",
     "lfx_comm_destroy", "lfx_gather_counts", "lfx_gather_payload", "lfx_gather", "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
@@ -110,6 +110,8 @@ def load():
     L.lfx_last_error.restype = C.c_char_p
     L.lfx_status_string.argtypes = [i32]
     L.lfx_status_string.restype = C.c_char_p
+    L.lfx_ring_message.argtypes = [i32, u32, C.POINTER(Params), C.c_char_p, C.c_size_t]
+    L.lfx_range_message.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_size_t]
     L.lfx_extract.argtypes = [vp, vp, C.c_size_t, C.POINTER(ScanResult)]
     L.lfx_extract_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), u32, C.POINTER(ScanResult)]
     L.lfx_extract_batch_device.argtypes = [vp, vp, C.POINTER(u32), u32, vp]

@@ -614,6 +614,38 @@ const char * lfx_status_string(int s)
   }
 }
 
+int lfx_range_message(
+  int kind, const char * value_name, const char * range_name, long long value, long long range, char * buf, size_t len)
+{
+  static const char * const op[4] = {">=", "<=", ">", "<"};      // range_message.hpp:37-83
+  if (kind < 0 || kind > 3 || !value_name || !range_name || (!buf && len)) {return -1;}
+  return std::snprintf(buf, len, "%s (which is %lld) %s %s (which is %lld)", value_name, value, op[kind], range_name, range);
+}
+
+int lfx_ring_message(int ring_status, uint32_t n_points, const lfx_params * p, char * buf, size_t len)
+{
+  if (!p || (!buf && len)) {return -1;}
+  const int N = (int)n_points, P = p->padding, B = p->n_blocks;
+  switch (ring_status) {
+    case LFX_RING_TOO_FEW_CONV:       // convolution.cpp:40-41
+      return std::snprintf(buf, len, "Input array size %d cannot be smaller than weight size %d", N, 2 * P + 1);
+    case LFX_RING_TOO_FEW_BLOCKS:     // index_range.cpp:36-38 (the reference's text lacks the closing parenthesis)
+      return std::snprintf(buf, len, "end_index - start_index (which is %d) cannot be smaller than n_blocks (which is %d", N - 2 * P, B);
+    case LFX_RING_BLOCK_TOO_SMALL: {  // neighbor.hpp:72-73: the first block slice with fewer than two points
+      for (int j = 0; j < B; j++) {
+        const double s = (double)P, e = (double)(N - P), n = (double)B;     // index_range.cpp:60-66
+        const int size = (int)(s * (1. - (j + 1) / n) + e * (j + 1) / n) - (int)(s * (1. - j / n) + e * j / n);
+        if (size < 2) {return std::snprintf(buf, len, "The input point size (which is %d) cannot be smaller than 2", size);}
+      }
+      return std::snprintf(buf, len, "%s", "");
+    }
+    case LFX_RING_ZERO_NORM_PAIR:     // math.cpp:41
+      return std::snprintf(buf, len, "All input values are zero. Angle cannot be calculated");
+    default:
+      return std::snprintf(buf, len, "%s", "");
+  }
+}
+
 const char * lfx_kernel_name(int k) {return (k >= 0 && k < LFX_N_KERNELS) ? kKernelNames[k] : "";}
 
 const char * lfx_last_error(const lfx_ctx * ctx) {return ctx ? ctx->err.c_str() : g_create_error.c_str();}
@@ -647,9 +679,11 @@ int lfx_layout_from_fields(
   }
   if (!fr) {return LFX_ERR_NO_RING_FIELD;}
   for (const lfx_point_field * f : {fx, fy, fz}) {
-    if (!f || f->datatype != LFX_FIELD_FLOAT32 || f->offset + 4 > point_step) {return LFX_ERR_UNSUPPORTED_FIELD;}
+    if (!f || f->datatype != LFX_FIELD_FLOAT32 || (uint64_t)f->offset + 4u > point_step) {return LFX_ERR_UNSUPPORTED_FIELD;}
   }
-  if (fr->datatype < LFX_FIELD_INT8 || fr->datatype > LFX_FIELD_UINT32 || fr->offset + field_size(fr->datatype) > point_step) {
+  if (fr->datatype < LFX_FIELD_INT8 || fr->datatype > LFX_FIELD_UINT32 ||
+    (uint64_t)fr->offset + field_size(fr->datatype) > point_step)      // (64-bit sums: an offset near 2^32 must not wrap past the test)
+  {
     return LFX_ERR_UNSUPPORTED_FIELD;
   }
   *out = lfx_layout{point_step, fx->offset, fy->offset, fz->offset, fr->offset, fr->datatype, is_bigendian ? 1u : 0u};
@@ -671,7 +705,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     g_create_error = "no HIP device: this library has no CPU path";
     return LFX_ERR_NO_DEVICE;
   }
-  hipDeviceProp_t prop;
+  hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     g_create_error = std::string("device is not gfx950 (MI355X): ") + prop.gcnArchName;
     return LFX_ERR_NO_DEVICE;
@@ -695,8 +729,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     const uint32_t rtype = L.ring_datatype ? L.ring_datatype : (uint32_t)LFX_FIELD_UINT16;
     const uint32_t rsize = field_size(rtype);
     if (rtype < LFX_FIELD_INT8 || rtype > LFX_FIELD_UINT32 ||
-      L.off_x + 4 > L.point_step || L.off_y + 4 > L.point_step || L.off_z + 4 > L.point_step ||
-      L.off_ring + rsize > L.point_step)
+      (uint64_t)L.off_x + 4u > L.point_step || (uint64_t)L.off_y + 4u > L.point_step || (uint64_t)L.off_z + 4u > L.point_step ||
+      (uint64_t)L.off_ring + rsize > L.point_step)
     {
       delete c;
       g_create_error = "layout: x, y, z (FLOAT32) and ring (an integer type) must lie inside point_step";
@@ -1306,7 +1340,7 @@ int lfx_stage_convolution1d(lfx_ctx * c, const double * input, uint32_t n, const
 {
   if (!c || !input || !weight || !out || m == 0 || (m % 2) == 0) {return LFX_ERR_INVALID_ARGUMENT;}
   if (n < m) {   // convolution.cpp:39-43 throws std::invalid_argument
-    return fail(c, LFX_ERR_INVALID_ARGUMENT, "Input array size cannot be smaller than weight size");
+    return fail(c, LFX_ERR_INVALID_ARGUMENT, "Input array size " + std::to_string(n) + " cannot be smaller than weight size " + std::to_string(m));
   }
   LFX_HIP(c, hipSetDevice(c->device));
   double * di = nullptr, * dw = nullptr, * dout = nullptr;

@@ -77,6 +77,11 @@ def lib():
         L.orc_argsort.restype = None
         L.orc_index_range.argtypes = [_i, _i, _i, _pi]
         L.orc_padded_index_range.argtypes = [_i, _i, _i, _pi]
+        L.orc_range_message.argtypes = [_i, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_size_t]
+        L.orc_irange.argtypes = [_i, _pi]
+        L.orc_irange.restype = None
+        L.orc_mapped_points_at.argtypes = [_pd, _i, _pi, _i, _i, _i, _i, _pd, _pi]
+        L.orc_ring_message.argtypes = [_i, _i, C.POINTER(Params), C.c_char_p, C.c_size_t]
         L.orc_polar_less_f64.argtypes = [_d, _d, _d, _d]
         L.orc_polar_less_f32.argtypes = [_f, _f, _f, _f]
         L.orc_sort_by_atan2_f64.argtypes = [_pd, _pd, _i, _pi]

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -580,6 +581,56 @@ void orc_label_parallel_beam(uint8_t * labels, int n, const float * x, const flo
   Labels l(labels, labels + n);
   ParallelBeam(l, RangeOf(MapAll(x, y, n)), thr);
   std::copy(l.begin(), l.end(), labels);
+}
+
+// range_message.hpp:37-83: "{} (which is {}) OP {} (which is {})"
+int orc_range_message(int kind, const char * value_name, const char * range_name, long long value, long long range, char * buf, size_t len)
+{
+  static const char * const op[4] = {">=", "<=", ">", "<"};
+  if (kind < 0 || kind > 3) {return -1;}
+  return std::snprintf(buf, len, "%s (which is %lld) %s %s (which is %lld)", value_name, value, op[kind], range_name, range);
+}
+
+void orc_irange(int size, int * out)   // iterator.cpp:33-36
+{
+  for (int i = 0; i < size; i++) {out[i] = i;}
+}
+
+// mapped_points.hpp:40-72: a view cloud[indices[i]]; Slice(begin, end) copies indices[begin, end)
+int orc_mapped_points_at(const double * cloud_y, int n_cloud, const int * indices, int n_indices, int begin, int end, int i, double * out, int * size)
+{
+  if (begin < 0 || end > n_indices || begin > end) {return 1;}
+  const std::vector<int> sliced(indices + begin, indices + end);      // mapped_points.hpp:63-67
+  *size = static_cast<int>(sliced.size());                            // :69-71
+  if (i < 0 || i >= *size) {return 1;}
+  const int k = sliced[i];
+  if (k < 0 || k >= n_cloud) {return 1;}
+  *out = cloud_y[k];                                                  // :58-61
+  return 0;
+}
+
+// what() of the exception that makes the node abandon a ring (feature_extraction.cpp:154-156)
+int orc_ring_message(int status, int n, const orc_params * p, char * buf, size_t len)
+{
+  const int P = p->padding, B = p->n_blocks;
+  switch (status) {
+    case ORC_RING_TOO_FEW_CONV:      // convolution.cpp:40-41
+      return std::snprintf(buf, len, "Input array size %d cannot be smaller than weight size %d", n, 2 * P + 1);
+    case ORC_RING_TOO_FEW_BLOCKS:    // index_range.cpp:36-38 (the closing parenthesis is missing there too)
+      return std::snprintf(buf, len, "end_index - start_index (which is %d) cannot be smaller than n_blocks (which is %d", n - 2 * P, B);
+    case ORC_RING_BLOCK_TOO_SMALL: { // neighbor.hpp:72-73, on the first block slice with fewer than 2 points
+      const BlockRange r(P, n - P, B);
+      for (int j = 0; j < B; j++) {
+        const int size = r.Boundary(j + 1) - r.Boundary(j);
+        if (size < 2) {return std::snprintf(buf, len, "The input point size (which is %d) cannot be smaller than 2", size);}
+      }
+      return std::snprintf(buf, len, "%s", "");
+    }
+    case ORC_RING_ZERO_NORM_PAIR:    // math.cpp:41
+      return std::snprintf(buf, len, "All input values are zero. Angle cannot be calculated");
+    default:
+      return std::snprintf(buf, len, "%s", "");
+  }
 }
 
 void orc_label_to_color(uint8_t label, uint8_t rgb[3])   // color_points.cpp:39-68

@@ -103,6 +103,13 @@ void orc_label_out_of_range(uint8_t *labels, int n, const float *x, const float 
                             double min_range, double max_range);                      /* out_of_range.hpp:36-48 */
 void orc_label_parallel_beam(uint8_t *labels, int n, const float *x, const float *y,
                              double range_ratio_threshold);                           /* parallel_beam.hpp:36-51 */
+/* range_message.hpp:37-83: kind 0 LargerThanOrEqualTo, 1 SmallerThanOrEqualTo, 2 LargerThan, 3 SmallerThan; returns the length */
+int orc_range_message(int kind, const char *value_name, const char *range_name, long long value, long long range, char *buf, size_t len);
+void orc_irange(int size, int *out);                                                  /* iterator.cpp:33-36 */
+/* MappedPoints (mapped_points.hpp:40-72) over a cloud given by its y values: at(i) of Slice(begin, end) of the view; 1 = out of range */
+int orc_mapped_points_at(const double *cloud_y, int n_cloud, const int *indices, int n_indices, int begin, int end, int i, double *out, int *size);
+/* what() of the std::invalid_argument a ring is abandoned with (status = ORC_RING_*), for a ring of n points; returns the length */
+int orc_ring_message(int status, int n, const orc_params *p, char *buf, size_t len);
 void orc_label_to_color(uint8_t label, uint8_t rgb[3]);                               /* color_points.cpp:39-68 */
 
 /* ---- whole scan: the body of FeatureExtraction::Callback, feature_extraction.cpp:114-157 ----

@@ -127,3 +127,46 @@ def test_product_does_not_touch_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "oracle" not in text.lower().replace("no cpu", ""), os.path.join(dirpath, f)
+
+
+def test_reference_message_texts(lib):
+    """RangeMessage* (range_message.hpp:37-83, vectors of test_range_message.cpp:35-61) and the exception texts of
+    abandoned rings (convolution.cpp:40-41 pinned by test_convolution.cpp:61-70, index_range.cpp:36-38,
+    neighbor.hpp:72-73, math.cpp:41) as the library reports them: host-side string functions, no device."""
+    import json
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_unit_vectors.json")))
+    kinds = {"LargerThanOrEqualTo": 0, "SmallerThanOrEqualTo": 1, "LargerThan": 2, "SmallerThan": 3}
+    buf = C.create_string_buffer(256)
+    for c in vec["range_message"]["cases"]:
+        n = lib.lfx_range_message(kinds[c["kind"]], c["value_name"].encode(), c["range_name"].encode(), c["value"], c["range"], buf, 256)
+        assert buf.value.decode() == c["expect"] and n == len(c["expect"])
+    assert lib.lfx_range_message(7, b"i", b"max", 1, 2, buf, 256) == -1
+    t = vec["throw_texts"]
+    p = LB.Params()
+    lib.lfx_default_params(C.byref(p))
+
+    def msg(status, n):
+        lib.lfx_ring_message(status, n, C.byref(p), buf, 256)
+        return buf.value.decode()
+
+    assert msg(2, 9) == t["too_few_for_convolution"].format(n=9, m=11)
+    assert msg(3, 14) == t["too_few_for_blocks"].format(d=4, b=6)
+    assert msg(4, 17) == t["block_too_small"].format(n=1)
+    assert msg(5, 400) == t["zero_norm_pair"]
+    assert msg(0, 400) == "" and msg(1, 3) == "" and msg(7, 5000) == ""
+    p.padding = 1
+    conv = [c for c in vec["convolution1d"]["cases"] if c.get("throws")][0]
+    assert msg(2, len(conv["input"])) == conv["message"]
+    # the library and the oracle agree on every cause over a sweep of ring lengths
+    from oracle import binding as OB
+    ob = C.create_string_buffer(256)
+    for P, Bn in ((5, 6), (2, 6), (3, 17)):
+        p.padding, p.n_blocks = P, Bn
+        op = OB.Params(P, 2.0, 0.3, 0.02, 0.05, 0.05, 0.1, 100.0, Bn)
+        for n in range(0, 80):
+            for status in (2, 3, 4, 5):
+                if status == 4 and n - 2 * P < Bn:
+                    continue
+                lib.lfx_ring_message(status, n, C.byref(p), buf, 256)
+                OB.lib().orc_ring_message(status, n, C.byref(op), ob, 256)
+                assert buf.value == ob.value

@@ -781,8 +781,9 @@ def test_refvec_curvature_convolution(fx, refvec):
         assert w[p:3 * p + 1].tolist() == c["expect"][::-1]
     for c in refvec["convolution1d"]["cases"]:
         if c.get("throws"):
-            with pytest.raises(LB.LfxError):
+            with pytest.raises(LB.LfxError) as e:
                 fx.convolution1d(c["input"], c["weight"])
+            assert c["message"] in str(e.value)          # the throw text pinned by test_convolution.cpp:61-70
         else:
             assert fx.convolution1d(c["input"], c["weight"]).tolist() == c["expect"]
 

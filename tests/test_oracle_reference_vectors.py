@@ -291,3 +291,59 @@ def test_ref_pieces_bit_exact():
                 assert rc1 == rc2
                 if rc1 == 0:
                     assert b1.tolist() == b2.tolist()
+
+
+# ------------------------------------------------------------------ helpers and error texts
+KINDS = {"LargerThanOrEqualTo": 0, "SmallerThanOrEqualTo": 1, "LargerThan": 2, "SmallerThan": 3}
+
+
+def _text(fn, *args):
+    buf = C.create_string_buffer(256)
+    n = fn(*args, buf, 256)
+    assert 0 <= n < 256
+    return buf.value.decode()
+
+
+def test_range_message(refvec):
+    for c in refvec["range_message"]["cases"]:
+        got = _text(L.orc_range_message, KINDS[c["kind"]], c["value_name"].encode(), c["range_name"].encode(), c["value"], c["range"])
+        assert got == c["expect"]
+
+
+def test_irange(refvec):
+    for c in refvec["irange"]["cases"]:
+        out = np.full(c["size"], -1, np.int32)
+        L.orc_irange(c["size"], B.ptr(out, PI))
+        assert out.tolist() == c["expect"]
+
+
+def test_mapped_points(refvec):
+    m = refvec["mapped_points"]
+    y, idx = d(m["cloud_y"]), np.ascontiguousarray(m["indices"], dtype=np.int32)
+
+    def view(begin, end):
+        out, size, vals = C.c_double(0), C.c_int(0), []
+        k = 0
+        while L.orc_mapped_points_at(B.ptr(y, PD), len(y), B.ptr(idx, PI), len(idx), begin, end, k, C.byref(out), C.byref(size)) == 0:
+            vals.append(out.value)
+            k += 1
+        return size.value, vals
+
+    assert view(0, len(idx)) == (m["expect_size"], m["expect_y"])
+    s = m["slice"]
+    assert view(s["begin"], s["end"]) == (s["expect_size"], s["expect_y"])
+
+
+def test_throw_texts_of_abandoned_rings(refvec):
+    """The text of the exception a ring is abandoned with, for the ring's own numbers; the convolution text is the
+    one test_convolution.cpp:61-70 pins."""
+    t = refvec["throw_texts"]
+    p = B.default_params()                                   # P = 5, B = 6
+    assert _text(L.orc_ring_message, 2, 9, C.byref(p)) == t["too_few_for_convolution"].format(n=9, m=11)
+    assert _text(L.orc_ring_message, 3, 14, C.byref(p)) == t["too_few_for_blocks"].format(d=4, b=6)
+    assert _text(L.orc_ring_message, 4, 17, C.byref(p)) == t["block_too_small"].format(n=1)
+    assert _text(L.orc_ring_message, 5, 400, C.byref(p)) == t["zero_norm_pair"]
+    assert _text(L.orc_ring_message, 1, 3, C.byref(p)) == ""
+    p3 = B.Params(1, 2.0, 0.3, 0.02, 0.05, 0.05, 0.1, 100.0, 6)
+    conv = [c for c in refvec["convolution1d"]["cases"] if c.get("throws")][0]
+    assert _text(L.orc_ring_message, 2, len(conv["input"]), C.byref(p3)) == conv["message"]
