@@ -138,6 +138,7 @@ struct lfx_ctx
   // LFX_DEBUG_FUSED=0/1 pins it.
   bool fused_possible = false;
   int fused_env = -1;
+  int short_tail_env = -1;               // LFX_DEBUG_SHORT_TAIL=0/1 pins the two-launch tail of the bucketing route (tests)
   bool bucket_all = false;               // the stream is not organised: bucketing route for every scan
   uint32_t retry_in = 0;
   uint32_t redo_cap_env = 0;             // LFX_DEBUG_REDO_CAP: rings the second unit pass is launched for (tests)
@@ -326,6 +327,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   //      bucketing for every scan.  What earlier batches reported arrives in pinned memory unasked.
   bool fused = c->fused_possible && canon && chunks != 0;
   uint32_t fb_grid = batch;                            // list entries the bucketing kernels are launched for
+  bool short_tail = false;                             // bucketing route = bucketing + the workgroup-per-ring kernel only
   if (fused) {
     const uint32_t was_fused = c->h_counters[lfx::kCntFusedRan], fell = c->h_counters[lfx::kCntFallback],
       of = c->h_counters[lfx::kCntBatch];
@@ -345,6 +347,10 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     if (fused) {
       const uint32_t guess = (was_fused ? 2u * fell : 0u) + 8u;
       fb_grid = guess < batch ? guess : batch;
+      // a stream that has not been falling back: its odd scan out (if one turns up) is redone by the workgroup-per-ring
+      // kernel straight from the bucketed arrays -- two near-empty launches per batch instead of five
+      short_tail = was_fused && of && fell == 0 && c->pre_order_env < 0 && c->redo_cap_env == 0;
+      if (c->short_tail_env >= 0) {short_tail = c->short_tail_env != 0;}
     }
   }
   hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
@@ -399,7 +405,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   // the near-empty launches of the bucketing route are kept small while the organised-scan kernel takes the stream
   const uint32_t list_grid = fused ? (c->slow_grid < 4u * fb_grid ? c->slow_grid : 4u * fb_grid) : c->slow_grid;
-  if (c->fast_path) {
+  if (c->fast_path && !short_tail) {
     if (c->pre_order_env >= 0) {
       c->pre_order = c->pre_order_env != 0;
     } else if (c->h_counters && c->h_rings_seen) {
@@ -467,10 +473,10 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     Timed t(c, 6, st);
     const dim3 grid = c->fast_path ? dim3(list_grid) : dim3(c->max_rings, batch);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
-      c->dev, c->cap, c->stage_flags, c->fast_path ? 1u : 0u, pts, c->layout, c->scan_begin.p,
+      c->dev, c->cap, c->stage_flags, short_tail ? 2u : (c->fast_path ? 1u : 0u), pts, c->layout, c->scan_begin.p,
       c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
-      c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p, c->ring_flags.p, slow_count,
-      c->slow_list.p, c->max_rings);
+      c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p, c->ring_flags.p,
+      short_tail ? fb_count : slow_count, short_tail ? c->fb_list.p : c->slow_list.p, c->max_rings);
   }
   {
     Timed t(c, 7, st);
@@ -769,6 +775,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
   if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->fused_env = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->short_tail_env = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
   if (const char * dbg = std::getenv("LFX_DEBUG_REDO_CAP")) {c->redo_cap_env = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->pre_order_env = std::atoi(dbg) != 0 ? 1 : 0;}

@@ -2260,10 +2260,17 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int T = blockDim.x, tid = threadIdx.x;
-  const uint32_t n_items = use_list ? *slow_count : 1u;
+  // use_list: 0 = every ring of the batch, grid (max_rings, batch); 1 = the rings on the slow list; 2 = every ring of
+  // the SCANS listed (slow_count / slow_list are the fall-back list then): the whole bucketing route's tail in one
+  // launch, used while the organised-scan kernel takes the stream and no scan has been falling back
+  const uint32_t n_items = use_list == 2u ? *slow_count * max_rings : (use_list ? *slow_count : 1u);
   for (uint32_t item = use_list ? blockIdx.x : 0u; item < n_items; item += use_list ? gridDim.x : 1u) {
     uint32_t slot, s;
-    if (use_list) {
+    if (use_list == 2u) {
+      s = slow_list[item / max_rings];
+      slot = item % max_rings;
+      if (ring_count[s * kRings + slot] == 0u) {continue;}
+    } else if (use_list) {
       const uint32_t e = slow_list[item];
       s = e / kRings;
       slot = e % kRings;

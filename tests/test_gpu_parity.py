@@ -134,7 +134,7 @@ def _with_env(env, make):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("force", ["1", "0", None])
+@pytest.mark.parametrize("force", ["1", "0", None, "short-tail"])
 def test_organised_scan_kernel_and_its_fall_back(force):
     """A context that knows the sensor's ring count reads a driver's column-major scan directly (organised-scan
     kernel: no bucketing pass); every scan that is not of that form -- ragged, rotated, reversed, shuffled, ring ids
@@ -159,7 +159,9 @@ def test_organised_scan_kernel_and_its_fall_back(force):
     want = {k: OB.extract(c, canonical_ties=False) for k, c in clouds.items()}
     want["zero_norm_pair"] = OB.extract(pair, canonical_ties=True)      # the two (0, 0) points tie under the angle predicate
     assert want["zero_norm_pair"]["ring_status"].tolist().count(0) == R - 1
-    env = {} if force is None else {"LFX_DEBUG_FUSED": force}
+    # "short-tail": the form the bucketing route takes while no scan has been falling back (bucketing, then the
+    # workgroup-per-ring kernel over every ring of the scans that did), pinned for every batch
+    env = {} if force is None else ({"LFX_DEBUG_FUSED": "1", "LFX_DEBUG_SHORT_TAIL": "1"} if force == "short-tail" else {"LFX_DEBUG_FUSED": force})
     f = _with_env(env, lambda: FeatureExtraction(device=0, max_points_per_scan=R * 2 * Ccols, max_batch=6,
                                                  max_points_per_ring=2 * Ccols, max_rings=R))
     for name, c in clouds.items():
