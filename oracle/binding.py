@@ -77,6 +77,7 @@ def lib():
         L.orc_argsort.restype = None
         L.orc_index_range.argtypes = [_i, _i, _i, _pi]
         L.orc_padded_index_range.argtypes = [_i, _i, _i, _pi]
+        L.orc_voxel_downsample.argtypes = [_pf, _i, _f, _pf, _pi]
         L.orc_range_message.argtypes = [_i, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_size_t]
         L.orc_irange.argtypes = [_i, _pi]
         L.orc_irange.restype = None

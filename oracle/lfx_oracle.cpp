@@ -633,6 +633,54 @@ int orc_ring_message(int status, int n, const orc_params * p, char * buf, size_t
   }
 }
 
+// pcl::VoxelGrid<PointXYZ>::applyFilter (PCL 1.12.1, filters/impl/voxel_grid.hpp), see lfx_oracle.h: PARITY UNPINNED
+int orc_voxel_downsample(const float * points, int n, float leaf, float * out, int * n_out)
+{
+  *n_out = 0;
+  if (n <= 0) {return 0;}
+  float mn[3] = {points[0], points[1], points[2]}, mx[3] = {points[0], points[1], points[2]};
+  for (int i = 1; i < n; i++) {                                  // getMinMax3D
+    for (int a = 0; a < 3; a++) {
+      mn[a] = std::min(mn[a], points[4 * i + a]);
+      mx[a] = std::max(mx[a], points[4 * i + a]);
+    }
+  }
+  const float inv = 1.0f / leaf;                                 // inverse_leaf_size_ = Ones / leaf_size_
+  const long long dx = static_cast<long long>((mx[0] - mn[0]) * inv) + 1, dy = static_cast<long long>((mx[1] - mn[1]) * inv) + 1,
+    dz = static_cast<long long>((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > 2147483647LL) {return 1;}                    // "Leaf size is too small for the input dataset"
+  int min_b[3], div_b[3];
+  for (int a = 0; a < 3; a++) {
+    min_b[a] = static_cast<int>(std::floor(mn[a] * inv));
+    div_b[a] = static_cast<int>(std::floor(mx[a] * inv)) - min_b[a] + 1;
+  }
+  const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+  std::vector<std::pair<unsigned, int>> cells(n);
+  for (int i = 0; i < n; i++) {
+    const int i0 = static_cast<int>(std::floor(points[4 * i] * inv) - static_cast<float>(min_b[0]));
+    const int i1 = static_cast<int>(std::floor(points[4 * i + 1] * inv) - static_cast<float>(min_b[1]));
+    const int i2 = static_cast<int>(std::floor(points[4 * i + 2] * inv) - static_cast<float>(min_b[2]));
+    cells[i] = {static_cast<unsigned>(i0 + i1 * mul1 + i2 * mul2), i};
+  }
+  std::sort(cells.begin(), cells.end());                          // (cell, input index): canonical order inside a cell
+  int m = 0;
+  for (int a = 0; a < n; ) {
+    int b = a;
+    float sx = 0.f, sy = 0.f, sz = 0.f;                           // AccumulatorXYZ: Eigen::Vector3f sum
+    while (b < n && cells[b].first == cells[a].first) {
+      const float * p = points + 4 * cells[b].second;
+      sx += p[0]; sy += p[1]; sz += p[2];
+      b++;
+    }
+    const float cnt = static_cast<float>(b - a);
+    out[4 * m] = sx / cnt; out[4 * m + 1] = sy / cnt; out[4 * m + 2] = sz / cnt; out[4 * m + 3] = 1.0f;
+    m++;
+    a = b;
+  }
+  *n_out = m;
+  return 0;
+}
+
 void orc_label_to_color(uint8_t label, uint8_t rgb[3])   // color_points.cpp:39-68
 {
   static const uint8_t table[8][3] = {

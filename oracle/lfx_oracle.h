@@ -110,6 +110,15 @@ void orc_irange(int size, int *out);                                            
 int orc_mapped_points_at(const double *cloud_y, int n_cloud, const int *indices, int n_indices, int begin, int end, int i, double *out, int *size);
 /* what() of the std::invalid_argument a ring is abandoned with (status = ORC_RING_*), for a ring of n points; returns the length */
 int orc_ring_message(int status, int n, const orc_params *p, char *buf, size_t len);
+/* Voxel-grid Downsample (lib/include/lidar_feature_library/downsample.hpp:37-51 = pcl::VoxelGrid<T> with one leaf size,
+ * applied to the surface scan at localization/include/lidar_feature_localization/surface.hpp:111).  PARITY UNPINNED: the
+ * arithmetic is PCL's (third party, not under /root/reference, not in this image; ROS 2 Humble ships PCL 1.12.1); this
+ * restates the published algorithm of filters/include/pcl/filters/impl/voxel_grid.hpp (applyFilter): float bounds,
+ * inverse leaf size as float, cell index = floor(x * inv) - min cell, cells in ascending linear index, centroid =
+ * float sum / count.  PCL leaves the order of the float sum inside a cell to an unstable sort; here (and in the HIP
+ * path) it is ascending input index.  points / out: records of 4 floats (x, y, z, 1).  Returns 0, or 1 where PCL gives
+ * up (leaf too small for the cloud's extent: index would overflow int). */
+int orc_voxel_downsample(const float *points, int n, float leaf, float *out /* capacity n */, int *n_out);
 void orc_label_to_color(uint8_t label, uint8_t rgb[3]);                               /* color_points.cpp:39-68 */
 
 /* ---- whole scan: the body of FeatureExtraction::Callback, feature_extraction.cpp:114-157 ----
