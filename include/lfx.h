@@ -289,6 +289,22 @@ int lfx_gather(lfx_ctx *ctx, lfx_comm *comm, int dst, const float *d_edge, const
                const uint32_t *d_offsets, uint32_t batch, uint32_t floats_per_point, float *d_edge_all,
                float *d_surface_all, uint32_t *d_offsets_all, size_t capacity_points, uint64_t *counts_out, void *stream);
 
+/* --- voxel-grid Downsample ------------------------------------------------------------------------- */
+/* Downsample<T>(cloud, leaf) of lib/include/lidar_feature_library/downsample.hpp:37-51 (pcl::VoxelGrid with one leaf
+ * size), which the localizer applies to scan_surface before it builds residuals (localization/.../surface.hpp:111),
+ * for a batch of clouds that are already on the device.  Cloud s = d_count[s * count_stride] records of 4 floats
+ * (x, y, z, -) from record d_begin[s] of d_points; its downsampled cloud (x, y, z, 1: pcl::PointXYZ) is written from
+ * record d_begin[s] of d_out, cells in ascending cell index, d_out_count[s] records; d_status[s] = 1 where PCL gives
+ * the cloud back unfiltered because the leaf is too small for its extent (nothing is written then).  PARITY UNPINNED:
+ * VoxelGrid's arithmetic is PCL's, a third-party library that is neither under the reference tree nor in this image;
+ * implemented from its published algorithm (PCL 1.12.1), points of a cell summed in input order.  Asynchronous. */
+int lfx_voxel_downsample(lfx_ctx *ctx, const float *d_points, const uint32_t *d_begin, const uint32_t *d_count,
+                         uint32_t count_stride, uint32_t n_clouds, size_t total_points, float leaf, float *d_out,
+                         uint32_t *d_out_count, uint32_t *d_status, void *stream);
+/* The same for the surface clouds of the last device batch (scan s: the scan's n_surface points): d_out laid out like
+ * lfx_device_view::surface_points, d_out_count / d_status [batch]. */
+int lfx_downsample_surface(lfx_ctx *ctx, float leaf, float *d_out, uint32_t *d_out_count, uint32_t *d_status, void *stream);
+
 /* --- per-stage entry points (device-backed mirrors of the reference's free functions) ----- */
 /* One ring given as angle-sorted x[n], y[n] host arrays; every stage runs the same device
  * routines the fused ring kernel runs.  Optional inputs may be NULL.

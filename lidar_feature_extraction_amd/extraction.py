@@ -158,6 +158,20 @@ class FeatureExtraction:
         out[...] = cloud
         return out
 
+    def voxel_downsample(self, d_points, d_begin, d_count, count_stride, n_clouds, total_points, leaf, d_out, d_out_count,
+                         d_status, stream=0):
+        """lfx_voxel_downsample: Downsample (pcl::VoxelGrid, downsample.hpp:37-51) of device clouds; all pointers are device addresses."""
+        B.check(self._ctx, self._L.lfx_voxel_downsample(
+            self._ctx, C.c_void_p(int(d_points)), C.c_void_p(int(d_begin)), C.c_void_p(int(d_count)), int(count_stride),
+            int(n_clouds), int(total_points), float(leaf), C.c_void_p(int(d_out)), C.c_void_p(int(d_out_count)),
+            C.c_void_p(int(d_status)), C.c_void_p(int(stream))))
+
+    def downsample_surface(self, leaf, d_out, d_out_count, d_status, stream=0):
+        """lfx_downsample_surface: the surface clouds of the last device batch, as the localizer downsamples them (surface.hpp:111)."""
+        B.check(self._ctx, self._L.lfx_downsample_surface(
+            self._ctx, float(leaf), C.c_void_p(int(d_out)), C.c_void_p(int(d_out_count)), C.c_void_p(int(d_status)),
+            C.c_void_p(int(stream))))
+
     def batch_status(self, stream=0):
         """lfx_batch_status: raises LfxError if a scan of the last device batch carries an error bit."""
         bad = C.c_uint32(0)

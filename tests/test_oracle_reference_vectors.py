@@ -347,3 +347,40 @@ def test_throw_texts_of_abandoned_rings(refvec):
     p3 = B.Params(1, 2.0, 0.3, 0.02, 0.05, 0.05, 0.1, 100.0, 6)
     conv = [c for c in refvec["convolution1d"]["cases"] if c.get("throws")][0]
     assert _text(L.orc_ring_message, 2, len(conv["input"]), C.byref(p3)) == conv["message"]
+
+
+# ------------------------------------------------------------------ voxel-grid Downsample (parity unpinned)
+def test_voxel_downsample_known_answers():
+    """Downsample = pcl::VoxelGrid with one leaf size (downsample.hpp:37-51).  PCL is not in the image and the
+    reference holds no test of it: these are hand-computed cases of the published algorithm (cells of `leaf` metres
+    anchored at multiples of the leaf, one centroid per occupied cell, cells in ascending x-fastest index order)."""
+    pts = np.array([[0.1, 0.1, 0.1, 1], [0.3, 0.5, 0.9, 1],          # cell (0, 0, 0)
+                    [1.5, 0.2, 0.2, 1],                               # cell (1, 0, 0)
+                    [0.2, 1.2, 0.1, 1], [0.4, 1.4, 0.3, 1], [0.6, 1.9, 0.5, 1],   # cell (0, 1, 0)
+                    [-0.5, 0.5, 0.5, 1],                              # cell (-1, 0, 0): the grid's origin moves to it
+                    [0.5, 0.5, 2.5, 1]], np.float32)                  # cell (0, 0, 2)
+    out = np.zeros_like(pts)
+    n_out = C.c_int(0)
+    assert L.orc_voxel_downsample(B.ptr(pts, PF), len(pts), 1.0, B.ptr(out, PF), C.byref(n_out)) == 0
+    f = np.float32
+    want = [[-0.5, 0.5, 0.5, 1], [(f(0.1) + f(0.3)) / f(2), (f(0.1) + f(0.5)) / f(2), (f(0.1) + f(0.9)) / f(2), 1], [1.5, 0.2, 0.2, 1],
+            [(f(0.2) + f(0.4) + f(0.6)) / f(3), (f(1.2) + f(1.4) + f(1.9)) / f(3), (f(0.1) + f(0.3) + f(0.5)) / f(3), 1],
+            [0.5, 0.5, 2.5, 1]]
+    assert n_out.value == 5
+    assert out[:5].tolist() == np.array(want, np.float32).tolist()
+    # a leaf far too small for the extent: PCL warns and gives the cloud back; here: status 1
+    far = np.array([[0, 0, 0, 1], [4000, 4000, 4000, 1]], np.float32)
+    assert L.orc_voxel_downsample(B.ptr(far, PF), 2, 0.001, B.ptr(out, PF), C.byref(n_out)) == 1
+    # properties on a random cloud: every point lies in the cell of exactly one centroid, counts add up
+    rng = np.random.default_rng(3)
+    cloud = np.ones((5000, 4), np.float32)
+    cloud[:, :3] = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
+    out = np.zeros_like(cloud)
+    assert L.orc_voxel_downsample(B.ptr(cloud, PF), len(cloud), 2.0, B.ptr(out, PF), C.byref(n_out)) == 0
+    cells = np.floor(cloud[:, :3] * np.float32(0.5)).astype(np.int64)
+    uniq = np.unique(cells, axis=0)
+    assert n_out.value == len(uniq)
+    got_cells = np.floor(out[:n_out.value, :3] * np.float32(0.5)).astype(np.int64)
+    assert len(np.unique(got_cells, axis=0)) == n_out.value
+    order = np.lexsort((uniq[:, 0], uniq[:, 1], uniq[:, 2]))             # x fastest, then y, then z
+    assert np.array_equal(got_cells, uniq[order])
