@@ -12,7 +12,9 @@ constexpr int R = 64, C = 1800, B = 6, SPAN = 320;   // six blocks of ~300 colum
 __device__ inline void consume(float4 v, uint32_t w, float & acc) {acc += v.x + v.y + v.z + (float)(w & 0xFFFFu);}
 
 // G rings per workgroup (G = 4, 8, 16, 64): lane = (column piece, ring of the group); 256 threads.
-template<int G>
+// XCD: 0 = consecutive workgroups take adjacent ring groups (they land on different XCDs: blocks are dealt round-robin
+// over the 8 XCDs); 1 = the workgroups that share an XCD (ids b, b + 8, ...) take adjacent ring groups
+template<int G, int XCD = 0>
 __global__ __launch_bounds__(256) void read_groups(const uint8_t * __restrict__ pts, float * __restrict__ out)
 {
   constexpr int groups = R / G;
@@ -20,7 +22,13 @@ __global__ __launch_bounds__(256) void read_groups(const uint8_t * __restrict__ 
   constexpr int span = SPAN * 4 / G;                        // columns per workgroup so that bytes per workgroup stay equal
   constexpr int units = (C + span - 1) / span;              // workgroups along the columns
   const uint32_t s = blockIdx.y;
-  const uint32_t g = blockIdx.x % groups, j = blockIdx.x / groups;
+  uint32_t bx = blockIdx.x;
+  if (XCD) {
+    // ids of one XCD: x = 8 q + r (r fixed).  Per XCD the sequence q = 0, 1, 2 ... should walk g fastest.
+    const uint32_t nb = gridDim.x, r = bx % 8u, q = bx / 8u, per = nb / 8u;      // nb is a multiple of 8 here
+    bx = r * per + q;                                                           // XCD r owns the contiguous range [r * per, (r + 1) * per)
+  }
+  const uint32_t g = bx % groups, j = bx / groups;
   if (j >= units) {return;}
   const uint32_t t = threadIdx.x, sub = t % G, cq = t / G;
   const uint8_t * base = pts + (size_t)s * R * C * 32;
@@ -96,6 +104,7 @@ int main(int argc, char ** argv)
   const double gb = bytes / 1e9;
   time("linear (grid 8192)", [&] {hipLaunchKernelGGL(read_linear, dim3(8192), dim3(256), 0, 0, pts, out, n);}, gb);
   time("4 rings per workgroup", [&] {hipLaunchKernelGGL(read_groups<4>, dim3(16 * 6, scans), dim3(256), 0, 0, pts, out);}, gb * 320 * 6 / 1800);
+  time("4 rings per workgroup, XCD-local", [&] {hipLaunchKernelGGL((read_groups<4, 1>), dim3(16 * 6, scans), dim3(256), 0, 0, pts, out);}, gb * 320 * 6 / 1800);
   time("8 rings per workgroup", [&] {hipLaunchKernelGGL(read_groups<8>, dim3(8 * 12, scans), dim3(256), 0, 0, pts, out);}, gb * 160 * 12 / 1800);
   time("16 rings per workgroup", [&] {hipLaunchKernelGGL(read_groups<16>, dim3(4 * 23, scans), dim3(256), 0, 0, pts, out);}, gb * 80 * 23 / 1800);
   time("64 rings per workgroup", [&] {hipLaunchKernelGGL(read_groups<64>, dim3(1 * 90, scans), dim3(256), 0, 0, pts, out);}, gb * 20 * 90 / 1800);
