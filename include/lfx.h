@@ -305,6 +305,30 @@ int lfx_voxel_downsample(lfx_ctx *ctx, const float *d_points, const uint32_t *d_
  * lfx_device_view::surface_points, d_out_count / d_status [batch]. */
 int lfx_downsample_surface(lfx_ctx *ctx, float leaf, float *d_out, uint32_t *d_out_count, uint32_t *d_status, void *stream);
 
+/* --- scan-to-map residual build (first slice) --------------------------------------------------------- */
+/* What the reference's localizer does first with scan_edge / scan_surface, on clouds that are already on the device:
+ *   LFX_RESIDUAL_EDGE     Edge::Make (localization/include/lidar_feature_localization/edge.hpp:86-124): per point the k
+ *                         nearest points of the edge map, their mean and principal direction, residual[3] =
+ *                         (p - p1) x (p - p2) and the 3 x 7 row [Hat(p2 - p1) DRpDq(q, p0), Hat(p2 - p1)];
+ *   LFX_RESIDUAL_SURFACE  Surface::MakeFromDownsampled (surface.hpp:116-139; downsample first: lfx_downsample_surface):
+ *                         the plane X w = -1 through the k nearest points of the surface map, residual[1] = signed
+ *                         point-plane distance and the 1 x 7 row [u^T DRpDq(q, p), u^T], u = w / |w|.
+ * d_map: n_map records of 4 floats (x, y, z, -); pose: point_to_map as [R | t], row-major 3 x 4 doubles (host); clouds as
+ * in lfx_voxel_downsample; outputs addressed like the points (record d_begin[s] + i): d_residual 3 (edge) or 1 (surface)
+ * doubles per point, d_jacobian 21 or 7 doubles per point, row-major.  n_neighbors <= 16 (the localizer uses 15).
+ * Exact nearest-neighbour search (the reference's nanoflann KD-tree is exact too).  PARITY UNPINNED: Eigen's and
+ * nanoflann's arithmetic is not available here; tolerance-level agreement with the CPU restatement, edge rows up to
+ * the sign of the principal direction.  Asynchronous. */
+#define LFX_RESIDUAL_EDGE 0
+#define LFX_RESIDUAL_SURFACE 1
+int lfx_scan_to_map_residuals(lfx_ctx *ctx, int kind, const float *d_map, uint32_t n_map, const double pose[12],
+                              uint32_t n_neighbors, const float *d_points, const uint32_t *d_begin,
+                              const uint32_t *d_count, uint32_t count_stride, uint32_t n_clouds,
+                              uint32_t max_points_per_cloud, double *d_residual, double *d_jacobian, void *stream);
+/* The same for the edge clouds of the last device batch (outputs laid out like lfx_device_view::edge_points). */
+int lfx_edge_residuals(lfx_ctx *ctx, const float *d_map, uint32_t n_map, const double pose[12], uint32_t n_neighbors,
+                       double *d_residual, double *d_jacobian, void *stream);
+
 /* --- per-stage entry points (device-backed mirrors of the reference's free functions) ----- */
 /* One ring given as angle-sorted x[n], y[n] host arrays; every stage runs the same device
  * routines the fused ring kernel runs.  Optional inputs may be NULL.

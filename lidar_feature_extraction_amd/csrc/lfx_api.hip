@@ -1328,6 +1328,79 @@ int lfx_downsample_surface(lfx_ctx * c, float leaf, float * d_out, uint32_t * d_
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------- scan-to-map residuals
+extern "C" {
+
+int lfx_scan_to_map_residuals(
+  lfx_ctx * c, int kind, const float * d_map, uint32_t n_map, const double pose[12], uint32_t n_neighbors,
+  const float * d_points, const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride, uint32_t n_clouds,
+  uint32_t max_points_per_cloud, double * d_residual, double * d_jacobian, void * stream)
+{
+  if (!c || !d_map || !pose || !d_points || !d_begin || !d_count || !d_residual || !d_jacobian || n_clouds == 0 || count_stride == 0 ||
+    (kind != LFX_RESIDUAL_EDGE && kind != LFX_RESIDUAL_SURFACE))
+  {
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  if (n_neighbors == 0 || n_neighbors > (uint32_t)lfx::kNearestMax || n_map < n_neighbors || (kind == LFX_RESIDUAL_SURFACE && n_neighbors < 3)) {
+    return fail(c, LFX_ERR_INVALID_ARGUMENT, "n_neighbors must be in [1, 16] (>= 3 for planes) and the map must hold that many points");
+  }
+  if (max_points_per_cloud == 0) {return LFX_OK;}
+  LFX_HIP(c, hipSetDevice(c->device));
+  lfx::MapPose P;
+  for (int i = 0; i < 12; i++) {P.m[i] = pose[i];}
+  {
+    // Eigen::Quaterniond(Matrix3d): the branch on the trace, then on the largest diagonal entry
+    auto M = [&](int r, int col) {return pose[4 * r + col];};
+    double q[3], w, t = M(0, 0) + M(1, 1) + M(2, 2);
+    if (t > 0.) {
+      t = std::sqrt(t + 1.0);
+      w = 0.5 * t;
+      t = 0.5 / t;
+      q[0] = (M(2, 1) - M(1, 2)) * t; q[1] = (M(0, 2) - M(2, 0)) * t; q[2] = (M(1, 0) - M(0, 1)) * t;
+    } else {
+      int i = 0;
+      if (M(1, 1) > M(0, 0)) {i = 1;}
+      if (M(2, 2) > M(i, i)) {i = 2;}
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+      q[i] = 0.5 * t;
+      t = 0.5 / t;
+      w = (M(k, j) - M(j, k)) * t;
+      q[j] = (M(j, i) + M(i, j)) * t;
+      q[k] = (M(k, i) + M(i, k)) * t;
+    }
+    P.qw = w; P.qx = q[0]; P.qy = q[1]; P.qz = q[2];
+  }
+  const dim3 grid((max_points_per_cloud + 127u) / 128u, n_clouds);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kind == LFX_RESIDUAL_EDGE) {
+    hipLaunchKernelGGL(lfx::scan_to_map_kernel<false>, grid, dim3(128), 0, st, reinterpret_cast<const float4 *>(d_map), n_map, P,
+      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian);
+  } else {
+    hipLaunchKernelGGL(lfx::scan_to_map_kernel<true>, grid, dim3(128), 0, st, reinterpret_cast<const float4 *>(d_map), n_map, P,
+      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian);
+  }
+  LFX_HIP(c, hipGetLastError());
+  return LFX_OK;
+}
+
+int lfx_edge_residuals(
+  lfx_ctx * c, const float * d_map, uint32_t n_map, const double pose[12], uint32_t n_neighbors, double * d_residual,
+  double * d_jacobian, void * stream)
+{
+  if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
+  uint32_t longest = 0;
+  for (uint32_t s = 0; s < c->last_batch; s++) {
+    const uint32_t n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
+    longest = n > longest ? n : longest;                 // a scan has no more edge points than points
+  }
+  return lfx_scan_to_map_residuals(c, LFX_RESIDUAL_EDGE, d_map, n_map, pose, n_neighbors, reinterpret_cast<const float *>(c->edge_pts.p),
+           c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, c->last_batch, longest, d_residual, d_jacobian, stream);
+}
+
+}  // extern "C"
+
 // ---------------------------------------------------------------------------- stage entry points
 int lfx_stage_ring(
   lfx_ctx * c, const lfx_params * params, uint32_t flags, uint32_t n, const float * x, const float * y,

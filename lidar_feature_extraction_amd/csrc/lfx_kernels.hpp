@@ -2861,6 +2861,219 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Scan-to-map residual build (first slice): what the reference's localizer does with the two clouds this
+// path emits -- for every edge point the line through its k nearest edge-map points (mean + principal direction of their
+// covariance), residual (p - p1) x (p - p2) and its 3 x 7 Jacobian row (localization: edge.hpp:86-124, src/edge.cpp:38-84);
+// for every (downsampled) surface point the plane through its k nearest surface-map points (least squares X w = -1),
+// residual = signed point-plane distance and its 1 x 7 row (surface.hpp:40-139, math.hpp:36-40); quaternion derivative
+// rotationlib/src/jacobian/quaternion.cpp:35-52.  One thread per scan point; the map streams through LDS in tiles and
+// every thread keeps its 16 nearest candidates (exact search, squared L2 in f64, ties by the lower map index).
+// PARITY UNPINNED beyond the vectors of localization/test/test_edge.cpp / test_math.cpp: Eigen's and nanoflann's own
+// arithmetic (reduction orders, computeDirect, householderQr, order of equidistant neighbours) is not available here;
+// results agree with the CPU restatement to ~1e-9 relative, the edge rows up to the sign of the principal direction
+// (residual and Jacobian flip together, J^T r does not).
+constexpr int kNearestMax = 16;          // the localizer uses N_NEIGHBORS = 15 (localizer.hpp:46)
+struct MapPose
+{
+  double m[12];                           // point_to_map as [R | t], row-major 3 x 4
+  double qw, qx, qy, qz;                  // Eigen::Quaterniond(R), computed by the host
+};
+
+struct D3 { double x, y, z; };
+__device__ inline D3 d3_sub(D3 a, D3 b) {return {a.x - b.x, a.y - b.y, a.z - b.z};}
+__device__ inline D3 d3_cross(D3 a, D3 b) {return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};}
+__device__ inline double d3_dot(D3 a, D3 b) {return a.x * b.x + a.y * b.y + a.z * b.z;}
+
+// unit eigenvector of the largest eigenvalue of a symmetric 3 x 3 matrix, closed form (trigonometric roots of the
+// characteristic polynomial of the shifted, scaled matrix; the kernel of (A - lambda I) from the larger of two cross
+// products of its columns).  (0, 0, 1) where the spectrum is isotropic.
+__device__ inline D3 principal_direction(const double (&c)[6] /* xx xy xz yy yz zz */)
+{
+  const double shift = (c[0] + c[3] + c[5]) / 3.;
+  double a00 = c[0] - shift, a11 = c[3] - shift, a22 = c[5] - shift, a01 = c[1], a02 = c[2], a12 = c[4];
+  double scale = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fmax(fabs(a01), fmax(fabs(a02), fabs(a12)))));
+  if (!(scale > 0.)) {return {0., 0., 1.};}
+  const double inv = 1. / scale;
+  a00 *= inv; a11 *= inv; a22 *= inv; a01 *= inv; a02 *= inv; a12 *= inv;
+  // roots of x^3 - c1' x - c0 (trace is zero after the shift)
+  const double c0 = a00 * a11 * a22 + 2. * a01 * a02 * a12 - a00 * a12 * a12 - a11 * a02 * a02 - a22 * a01 * a01;
+  const double c1 = a00 * a11 - a01 * a01 + a00 * a22 - a02 * a02 + a11 * a22 - a12 * a12;
+  double a3 = -c1 / 3.;
+  a3 = a3 > 0. ? a3 : 0.;
+  const double half_b = 0.5 * c0;
+  double qd = a3 * a3 * a3 - half_b * half_b;
+  qd = qd > 0. ? qd : 0.;
+  const double rho = sqrt(a3), theta = atan2(sqrt(qd), half_b) / 3.;
+  const double lambda = 2. * rho * cos(theta);                       // the largest root
+  const double lo = -rho * (cos(theta) + 1.7320508075688772 * sin(theta));
+  if (!(lambda - lo > 1e-14)) {return {0., 0., 1.};}
+  const double m00 = a00 - lambda, m11 = a11 - lambda, m22 = a22 - lambda;
+  // columns of (A - lambda I); the one with the largest diagonal entry in magnitude is the representative
+  const D3 col0{m00, a01, a02}, col1{a01, m11, a12}, col2{a02, a12, m22};
+  const double d0 = fabs(m00), d1 = fabs(m11), d2 = fabs(m22);
+  D3 rep = col0, o1 = col1, o2 = col2;
+  if (d1 > d0 && d1 >= d2) {rep = col1; o1 = col2; o2 = col0;} else if (d2 > d0 && d2 > d1) {rep = col2; o1 = col0; o2 = col1;}
+  const D3 x1 = d3_cross(rep, o1), x2 = d3_cross(rep, o2);
+  const double n1 = d3_dot(x1, x1), n2 = d3_dot(x2, x2);
+  const D3 v = n1 > n2 ? x1 : x2;
+  const double nn = n1 > n2 ? n1 : n2;
+  if (!(nn > 0.)) {return {0., 0., 1.};}
+  const double s = 1. / sqrt(nn);
+  return {v.x * s, v.y * s, v.z * s};
+}
+
+// rotationlib::DRpDq: 3 x 4, row-major
+__device__ inline void drp_dq(const MapPose & P, D3 p, double (&d)[12])
+{
+  const D3 v{P.qx, P.qy, P.qz};
+  const D3 vxp = d3_cross(v, p);
+  const double vp = d3_dot(v, p), w = P.qw;
+  const double c0[3] = {w * p.x + vxp.x, w * p.y + vxp.y, w * p.z + vxp.z};
+  const double K[9] = {0., -p.z, p.y, p.z, 0., -p.x, -p.y, p.x, 0.};
+  const double vv[3] = {v.x, v.y, v.z}, pp[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    d[4 * r] = 2. * c0[r];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {d[4 * r + 1 + c] = 2. * ((r == c ? vp : 0.) + vv[r] * pp[c] - pp[r] * vv[c] - w * K[3 * r + c]);}
+  }
+}
+
+template<bool SURFACE>
+__global__ __launch_bounds__(128) void scan_to_map_kernel(
+  const float4 * __restrict__ map, uint32_t n_map, MapPose P, uint32_t k, const float4 * __restrict__ pts,
+  const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
+  double * __restrict__ residual, double * __restrict__ jacobian)
+{
+  constexpr int KM = kNearestMax, T = 128;
+  const uint32_t s = blockIdx.y, tid = threadIdx.x;
+  const uint32_t b = begin[s], n = count[(size_t)s * count_stride];
+  const uint32_t i = blockIdx.x * T + tid;
+  if (blockIdx.x * T >= n) {return;}                   // the whole workgroup is beyond this cloud
+  const bool valid = i < n;
+  const float4 pf = pts[b + (valid ? i : 0u)];
+  const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
+  const D3 q{P.m[0] * p0.x + P.m[1] * p0.y + P.m[2] * p0.z + P.m[3], P.m[4] * p0.x + P.m[5] * p0.y + P.m[6] * p0.z + P.m[7],
+    P.m[8] * p0.x + P.m[9] * p0.y + P.m[10] * p0.z + P.m[11]};
+  double dist[KM];
+  uint32_t idx[KM];
+#pragma unroll
+  for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
+  __shared__ float4 tile[T];
+  for (uint32_t t0 = 0; t0 < n_map; t0 += T) {
+    __syncthreads();
+    tile[tid] = map[t0 + tid < n_map ? t0 + tid : n_map - 1u];
+    __syncthreads();
+    const uint32_t lim = n_map - t0 < (uint32_t)T ? n_map - t0 : (uint32_t)T;
+    for (uint32_t e = 0; e < lim; e++) {
+      const float4 mpt = tile[e];
+      const double dx = (double)mpt.x - q.x, dy = (double)mpt.y - q.y, dz = (double)mpt.z - q.z;
+      const double d = dx * dx + dy * dy + dz * dz;
+      if (d < dist[KM - 1]) {                          // (ascending map index, strict <: equidistant points keep index order)
+        bool placed = false;
+#pragma unroll
+        for (int j = KM - 1; j > 0; j--) {
+          if (!placed) {
+            if (d < dist[j - 1]) {dist[j] = dist[j - 1]; idx[j] = idx[j - 1];} else {dist[j] = d; idx[j] = t0 + e; placed = true;}
+          }
+        }
+        if (!placed) {dist[0] = d; idx[0] = t0 + e;}
+      }
+    }
+  }
+  if (!valid) {return;}
+  const uint32_t kk = k < (uint32_t)KM ? k : (uint32_t)KM;
+  double d[12];
+  drp_dq(P, p0, d);
+  if (!SURFACE) {
+    // mean and covariance of the k neighbours (edge.cpp:38-49), in order of distance
+    double mx = 0., my = 0., mz = 0.;
+#pragma unroll
+    for (int j = 0; j < KM; j++) {
+      if ((uint32_t)j < kk) {const float4 m4 = map[idx[j]]; mx += (double)m4.x; my += (double)m4.y; mz += (double)m4.z;}
+    }
+    const double nk = (double)kk;
+    mx /= nk; my /= nk; mz /= nk;
+    double c[6] = {0., 0., 0., 0., 0., 0.};
+#pragma unroll
+    for (int j = 0; j < KM; j++) {
+      if ((uint32_t)j < kk) {
+        const float4 m4 = map[idx[j]];
+        const double ex = (double)m4.x - mx, ey = (double)m4.y - my, ez = (double)m4.z - mz;
+        c[0] += ex * ex; c[1] += ex * ey; c[2] += ex * ez; c[3] += ey * ey; c[4] += ey * ez; c[5] += ez * ez;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {c[a] /= nk;}
+    const D3 u = principal_direction(c);
+    const D3 p1{mx - u.x, my - u.y, mz - u.z}, p2{mx + u.x, my + u.y, mz + u.z};
+    const D3 e = d3_sub(p2, p1);
+    const double K[9] = {0., -e.z, e.y, e.z, 0., -e.x, -e.y, e.x, 0.};       // Hat(p2 - p1)
+    double * J = jacobian + 21 * (size_t)(b + i);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) {J[7 * r + cc] = K[3 * r] * d[cc] + K[3 * r + 1] * d[4 + cc] + K[3 * r + 2] * d[8 + cc];}
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) {J[7 * r + 4 + cc] = K[3 * r + cc];}
+    }
+    const D3 rr = d3_cross(d3_sub(q, p1), d3_sub(q, p2));                  // MakeEdgeResidual
+    double * R = residual + 3 * (size_t)(b + i);
+    R[0] = rr.x; R[1] = rr.y; R[2] = rr.z;
+  } else {
+    // plane coefficients: least squares X w = -1 by Householder QR (surface.hpp:78-83, math.hpp:36-40)
+    double X[KM][3], g[KM];
+#pragma unroll
+    for (int j = 0; j < KM; j++) {
+      X[j][0] = 0.; X[j][1] = 0.; X[j][2] = 0.; g[j] = 0.;
+      if ((uint32_t)j < kk) {const float4 m4 = map[idx[j]]; X[j][0] = (double)m4.x; X[j][1] = (double)m4.y; X[j][2] = (double)m4.z; g[j] = -1.0;}
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double norm = 0.;
+#pragma unroll
+      for (int r = 0; r < KM; r++) {if (r >= c) {norm += X[r][c] * X[r][c];}}       // rows >= kk hold zeros
+      norm = sqrt(norm);
+      const double alpha = X[c][c] > 0. ? -norm : norm;
+      double v[KM];
+      double vv = 0.;
+#pragma unroll
+      for (int r = 0; r < KM; r++) {v[r] = r >= c ? X[r][c] : 0.; if (r == c) {v[r] -= alpha;} vv += v[r] * v[r];}
+      if (vv > 0.) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          if (cc >= c) {
+            double sdot = 0.;
+#pragma unroll
+            for (int r = 0; r < KM; r++) {sdot += v[r] * X[r][cc];}
+            sdot = 2. * sdot / vv;
+#pragma unroll
+            for (int r = 0; r < KM; r++) {X[r][cc] -= sdot * v[r];}
+          }
+        }
+        double sdot = 0.;
+#pragma unroll
+        for (int r = 0; r < KM; r++) {sdot += v[r] * g[r];}
+        sdot = 2. * sdot / vv;
+#pragma unroll
+        for (int r = 0; r < KM; r++) {g[r] -= sdot * v[r];}
+      }
+    }
+    double w[3];
+    w[2] = g[2] / X[2][2];
+    w[1] = (g[1] - X[1][2] * w[2]) / X[1][1];
+    w[0] = (g[0] - X[0][1] * w[1] - X[0][2] * w[2]) / X[0][0];
+    const double norm = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double u[3] = {w[0] / norm, w[1] / norm, w[2] / norm};
+    double * J = jacobian + 7 * (size_t)(b + i);
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
+    J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
+    residual[b + i] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-stage kernel: one ring handed over as sorted x, y (lfx_stage_ring).
 __global__ __launch_bounds__(512) void ring_stage_kernel(
   Params prm, uint32_t cap, uint32_t flags, int N, const float * __restrict__ x, const float * __restrict__ y,

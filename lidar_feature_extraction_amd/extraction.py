@@ -172,6 +172,23 @@ class FeatureExtraction:
             self._ctx, float(leaf), C.c_void_p(int(d_out)), C.c_void_p(int(d_out_count)), C.c_void_p(int(d_status)),
             C.c_void_p(int(stream))))
 
+    def scan_to_map_residuals(self, kind, d_map, n_map, pose, n_neighbors, d_points, d_begin, d_count, count_stride, n_clouds,
+                              max_points_per_cloud, d_residual, d_jacobian, stream=0):
+        """lfx_scan_to_map_residuals: kind 0 = edge rows (edge.hpp:86-124), 1 = surface rows (surface.hpp:116-139);
+        pose: 3 x 4 [R | t] (point_to_map); device addresses otherwise."""
+        pm = np.ascontiguousarray(pose, np.float64).reshape(12)
+        B.check(self._ctx, self._L.lfx_scan_to_map_residuals(
+            self._ctx, int(kind), C.c_void_p(int(d_map)), int(n_map), pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
+            C.c_void_p(int(d_points)), C.c_void_p(int(d_begin)), C.c_void_p(int(d_count)), int(count_stride), int(n_clouds),
+            int(max_points_per_cloud), C.c_void_p(int(d_residual)), C.c_void_p(int(d_jacobian)), C.c_void_p(int(stream))))
+
+    def edge_residuals(self, d_map, n_map, pose, n_neighbors, d_residual, d_jacobian, stream=0):
+        """lfx_edge_residuals: the edge clouds of the last device batch against an edge map."""
+        pm = np.ascontiguousarray(pose, np.float64).reshape(12)
+        B.check(self._ctx, self._L.lfx_edge_residuals(
+            self._ctx, C.c_void_p(int(d_map)), int(n_map), pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
+            C.c_void_p(int(d_residual)), C.c_void_p(int(d_jacobian)), C.c_void_p(int(stream))))
+
     def batch_status(self, stream=0):
         """lfx_batch_status: raises LfxError if a scan of the last device batch carries an error bit."""
         bad = C.c_uint32(0)

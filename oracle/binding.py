@@ -38,8 +38,8 @@ def launch_params():
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "lfx_oracle.cpp")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("lfx_oracle.cpp", "lfx_oracle_loc.cpp", "lfx_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + ["all"])
     return _LIB
 
@@ -77,6 +77,21 @@ def lib():
         L.orc_argsort.restype = None
         L.orc_index_range.argtypes = [_i, _i, _i, _pi]
         L.orc_padded_index_range.argtypes = [_i, _i, _i, _pi]
+        L.orc_loc_triplet_cross.argtypes = [_pd, _pd, _pd, _pd]
+        L.orc_loc_triplet_cross.restype = None
+        L.orc_loc_mean_cov.argtypes = [_pd, _i, _pd, _pd]
+        L.orc_loc_mean_cov.restype = None
+        L.orc_loc_principal.argtypes = [_pd, _pd, _pd]
+        L.orc_loc_principal.restype = None
+        L.orc_loc_principal_is_reliable.argtypes = [_pd]
+        L.orc_loc_solve_linear.argtypes = [_pd, _i, _i, _pd, _pd]
+        L.orc_loc_solve_linear.restype = None
+        L.orc_loc_quaternion.argtypes = [_pd, _pd]
+        L.orc_loc_quaternion.restype = None
+        L.orc_loc_edge_residuals.argtypes = [_pf, _i, _pd, _i, _pf, _i, _pd, _pd]
+        L.orc_loc_edge_residuals.restype = None
+        L.orc_loc_surface_residuals.argtypes = [_pf, _i, _pd, _i, _pf, _i, _pd, _pd]
+        L.orc_loc_surface_residuals.restype = None
         L.orc_voxel_downsample.argtypes = [_pf, _i, _f, _pf, _pi]
         L.orc_range_message.argtypes = [_i, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_size_t]
         L.orc_irange.argtypes = [_i, _pi]

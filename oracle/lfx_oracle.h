@@ -119,6 +119,18 @@ int orc_ring_message(int status, int n, const orc_params *p, char *buf, size_t l
  * path) it is ascending input index.  points / out: records of 4 floats (x, y, z, 1).  Returns 0, or 1 where PCL gives
  * up (leaf too small for the cloud's extent: index would overflow int). */
 int orc_voxel_downsample(const float *points, int n, float leaf, float *out /* capacity n */, int *n_out);
+/* --- localization: the scan-to-map residual build that consumes the two clouds; lfx_oracle_loc.cpp.
+ * PARITY UNPINNED beyond the vectors of localization/test/test_edge.cpp, test_math.cpp (Eigen + nanoflann underneath). */
+void orc_loc_triplet_cross(const double *p0, const double *p1, const double *p2, double *out);          /* edge.cpp:51-57 */
+void orc_loc_mean_cov(const double *X /* [n][3] */, int n, double *mean /* 3 */, double *cov /* 9 */);   /* edge.cpp:38-49 */
+void orc_loc_principal(const double *cov, double *eigenvalues /* ascending */, double *eigenvectors /* columns, row-major */); /* edge.cpp:59-64 */
+int orc_loc_principal_is_reliable(const double *eigenvalues);                                           /* edge.cpp:92-96 */
+void orc_loc_solve_linear(const double *A, int rows, int cols, const double *b, double *x);             /* math.hpp:36-40 */
+void orc_loc_quaternion(const double *R /* row-major */, double *wxyz);                                 /* Eigen::Quaterniond(R) */
+void orc_loc_edge_residuals(const float *map, int n_map, const double *pose /* [R|t] 3x4 */, int k, const float *points,
+                            int n, double *residual /* [n][3] */, double *jacobian /* [n][3][7] */);     /* edge.hpp:86-124 */
+void orc_loc_surface_residuals(const float *map, int n_map, const double *pose, int k, const float *points, int n,
+                               double *residual /* [n] */, double *jacobian /* [n][7] */);              /* surface.hpp:116-139 */
 void orc_label_to_color(uint8_t label, uint8_t rgb[3]);                               /* color_points.cpp:39-68 */
 
 /* ---- whole scan: the body of FeatureExtraction::Callback, feature_extraction.cpp:114-157 ----

@@ -1,0 +1,137 @@
+"""Pins the oracle of the consumer's first step (oracle/lfx_oracle_loc.cpp: the scan-to-map residual build of the
+reference's localization package) against the vectors of localization/test/test_edge.cpp and
+test_math.cpp (restated in tests/golden/reference_unit_vectors.json) and against numpy's own eigen-decomposition and
+least squares.  Beyond those vectors parity is unpinned (Eigen and nanoflann are not in the image).  CPU only."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import binding as B
+
+L = B.lib()
+PD, PF = C.POINTER(C.c_double), C.POINTER(C.c_float)
+
+
+def d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def test_triplet_cross(refvec):
+    for c in refvec["loc_triplet_cross"]["cases"]:
+        out = np.zeros(3)
+        L.orc_loc_triplet_cross(B.ptr(d(c["p0"]), PD), B.ptr(d(c["p1"]), PD), B.ptr(d(c["p2"]), PD), B.ptr(out, PD))
+        assert out.tolist() == c["expect"]
+
+
+def test_center_and_covariance(refvec):
+    X = d(refvec["loc_center"]["X"])
+    mean, cov = np.zeros(3), np.zeros(9)
+    L.orc_loc_mean_cov(B.ptr(X, PD), len(X), B.ptr(mean, PD), B.ptr(cov, PD))
+    assert mean.tolist() == refvec["loc_center"]["expect"]
+    X = d(refvec["loc_mean_cov"]["X"])
+    L.orc_loc_mean_cov(B.ptr(X, PD), len(X), B.ptr(mean, PD), B.ptr(cov, PD))
+    assert (cov.reshape(3, 3) * 4).tolist() == refvec["loc_mean_cov"]["expect_cov_times_4"]      # EXPECT_EQ(norm, 0)
+
+
+def test_principal_components(refvec):
+    rng = np.random.default_rng(1)
+    ev, V = np.zeros(3), np.zeros(9)
+    for _ in range(200):
+        A = rng.uniform(-1, 1, (3, 3))
+        Cm = d(A @ A.T)
+        L.orc_loc_principal(B.ptr(Cm, PD), B.ptr(ev, PD), B.ptr(V, PD))
+        Vm = V.reshape(3, 3)
+        assert ev[0] <= ev[1] <= ev[2]                                                   # test_edge.cpp:67-68
+        assert np.linalg.norm(Cm - Vm @ np.diag(ev) @ np.linalg.inv(Vm)) <= 1e-4          # :73
+        assert np.linalg.norm(Cm @ Vm[:, 2] - ev[2] * Vm[:, 2]) <= 1e-4                   # :77
+        w, U = np.linalg.eigh(Cm)
+        assert np.allclose(ev, w, rtol=1e-12, atol=1e-14)
+        assert abs(abs(Vm[:, 2] @ U[:, 2]) - 1.0) < 1e-9
+    line = refvec["loc_principal_line"]
+    X = d(line["X"])
+    mean, cov = np.zeros(3), np.zeros(9)
+    L.orc_loc_mean_cov(B.ptr(X, PD), len(X), B.ptr(mean, PD), B.ptr(cov, PD))
+    L.orc_loc_principal(B.ptr(cov, PD), B.ptr(ev, PD), B.ptr(V, PD))
+    u = V.reshape(3, 3)[:, 2]
+    assert min(np.linalg.norm(u - line["expect_direction"]), np.linalg.norm(u + line["expect_direction"])) <= line["tolerance"]
+    assert abs(ev[0]) <= 1e-8 and abs(ev[1]) <= 1e-8 and ev[2] > 0
+    for c in refvec["loc_principal_is_reliable"]["cases"]:
+        assert bool(L.orc_loc_principal_is_reliable(B.ptr(d(c["ev"]), PD))) == c["expect"]
+
+
+def test_solve_linear(refvec):
+    for c in refvec["loc_solve_linear"]["cases"]:
+        A, b = d(c["A"]), d(c["b"])
+        x = np.zeros(A.shape[1])
+        L.orc_loc_solve_linear(B.ptr(A, PD), A.shape[0], A.shape[1], B.ptr(b, PD), B.ptr(x, PD))
+        assert np.linalg.norm(x - c["expect"]) <= refvec["loc_solve_linear"]["tolerance"]
+    rng = np.random.default_rng(2)
+    for _ in range(100):
+        A, b = d(rng.standard_normal((15, 3))), d(rng.standard_normal(15))
+        x = np.zeros(3)
+        L.orc_loc_solve_linear(B.ptr(A, PD), 15, 3, B.ptr(b, PD), B.ptr(x, PD))
+        assert np.allclose(x, np.linalg.lstsq(A, b, rcond=None)[0], rtol=1e-10, atol=1e-12)
+
+
+def _pose(rng):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return q, np.ascontiguousarray(np.hstack([R, rng.uniform(-2, 2, (3, 1))]))
+
+
+def test_quaternion_of_a_rotation():
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        q, pose = _pose(rng)
+        out = np.zeros(4)
+        R = np.ascontiguousarray(pose[:, :3])
+        L.orc_loc_quaternion(B.ptr(R, PD), B.ptr(out, PD))
+        assert min(np.linalg.norm(out - q), np.linalg.norm(out + q)) < 1e-12
+
+
+def test_edge_jacobian_approximates_the_residual(refvec):
+    """test_edge.cpp:144-192 (ApproximateError): r(theta + d) ~ r(theta) + J M d; here by central differences on the
+    quaternion and the translation, which is what the 3 x 7 row [K DRpDq, K] differentiates."""
+    rng = np.random.default_rng(4)
+    line = np.zeros((40, 4), np.float32)
+    line[:, 0] = np.linspace(0, 4, 40)
+    line[:, 1:3] = rng.normal(0, 0.01, (40, 2))
+    pts = np.array([[2, 1, 0, 1], [1.0, -0.5, 0.3, 1]], np.float32)
+    q, pose = _pose(rng)
+    res, jac = np.zeros((2, 3)), np.zeros((2, 3, 7))
+    L.orc_loc_edge_residuals(B.ptr(line, PF), len(line), B.ptr(pose, PD), 5, B.ptr(pts, PF), 2, B.ptr(res, PD), B.ptr(jac, PD))
+    eps = 1e-6
+    for a in range(3):                                          # translation columns 4..6
+        dp = pose.copy()
+        dp[a, 3] += eps
+        r1 = np.zeros((2, 3))
+        j1 = np.zeros((2, 3, 7))
+        L.orc_loc_edge_residuals(B.ptr(line, PF), len(line), B.ptr(dp, PD), 5, B.ptr(pts, PF), 2, B.ptr(r1, PD), B.ptr(j1, PD))
+        assert np.allclose((r1 - res) / eps, jac[:, :, 4 + a], atol=1e-4)
+    assert np.all(np.isfinite(jac)) and np.linalg.norm(res) > 0
+
+
+def test_residuals_of_points_on_the_map_vanish():
+    """A scan point that lies on the map's line / plane has a zero residual (the geometry of edge.cpp:76-84 and
+    surface.hpp:40-44), whatever the pose that puts it there."""
+    rng = np.random.default_rng(5)
+    q, pose = _pose(rng)
+    R, t = pose[:, :3], pose[:, 3]
+    line = np.zeros((60, 4), np.float32)
+    line[:, 0] = np.linspace(-3, 3, 60)
+    plane = np.zeros((400, 4), np.float32)
+    gx, gy = np.meshgrid(np.linspace(-2, 2, 20), np.linspace(-2, 2, 20))
+    plane[:, 0], plane[:, 1], plane[:, 2] = gx.ravel(), gy.ravel(), 1.5
+    on_line = np.array([[0.33, 0, 0], [-1.21, 0, 0]])
+    on_plane = np.array([[0.4, -0.3, 1.5], [1.1, 0.9, 1.5]])
+    for world, cloud, fn, shape in ((on_line, line, L.orc_loc_edge_residuals, (2, 3)), (on_plane, plane, L.orc_loc_surface_residuals, (2,))):
+        local = np.ones((2, 4), np.float32)
+        local[:, :3] = ((world - t) @ R).astype(np.float32)       # R^T (p - t)
+        res = np.zeros(shape)
+        jac = np.zeros((2, 21 if len(shape) == 2 else 7))
+        fn(B.ptr(cloud, PF), len(cloud), B.ptr(pose, PD), 5, B.ptr(local, PF), 2, B.ptr(res, PD), B.ptr(jac, PD))
+        assert np.all(np.abs(res) < 1e-5)
