@@ -237,6 +237,22 @@ def test_organised_scan_kernel_zero_point_filter_and_colored_scan():
     f.close()
 
 
+def test_contexts_of_different_ring_capacity_side_by_side():
+    """Two lidars of different width in one process: the dynamic-LDS limits of the workgroup-per-ring kernels are per
+    function, not per context, so a later, smaller context must not lower them for an earlier, larger one."""
+    big = make_scan(2, 3900, seed=1501, shuffle=True)            # rings of 3900 points: sorted and labelled by the workgroup-per-ring kernels
+    small = make_scan(16, 300, seed=1502, shuffle=True)
+    f_big = FeatureExtraction(device=0, max_points_per_scan=len(big), max_batch=1)                          # ring capacity 4096
+    f_small = FeatureExtraction(device=0, max_points_per_scan=len(small), max_batch=1, max_points_per_ring=320, max_rings=16)
+    want_big, want_small = OB.extract(big, canonical_ties=False), OB.extract(small, canonical_ties=False)
+    for rep in range(2):
+        assert_scan_equal(f_small.ExtractFeatures(small), want_small, "small context, rep %d" % rep)
+        assert_scan_equal(f_big.ExtractFeatures(big), want_big, "large context after the small one, rep %d" % rep)
+    f_small.close()
+    assert_scan_equal(f_big.ExtractFeatures(big), want_big, "large context after the small one was destroyed")
+    f_big.close()
+
+
 def _cloud(ring, x, y, z=None):
     c = np.zeros(len(ring), POINT_DTYPE)
     c["ring"], c["x"], c["y"] = ring, x, y
