@@ -773,7 +773,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
   c->single_pass = std::getenv("LFX_DEBUG_TWO_PASS") == nullptr;
   // the organised-scan kernel needs to know the sensor's ring count (max_rings given) and reads PointXYZIR records
-  c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->layout.step == 32 && c->layout.ox == 0 &&
+  c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
   if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->fused_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->short_tail_env = std::atoi(dbg) != 0 ? 1 : 0;}
