@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--cols", type=int, default=1800)
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic scans per GPU (tiled to --batch)")
+    ap.add_argument("--start-col", type=int, default=0, help="first column of every scan (a driver that does not cut its scans at -pi: every ring arrives rotated)")
+    ap.add_argument("--reverse", action="store_true", help="clockwise sensor: every ring arrives in descending angle order")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
@@ -78,7 +80,8 @@ def main():
 
     # ---- synthetic stream: scan i -> rank i mod world; seeds 1234 + scan id
     n_unique = max(1, min(a.unique, a.batch))
-    clouds = [make_scan(a.rings, a.cols, seed=1234 + (j * world + rank), vfov_deg=22.5 if a.rings >= 128 else 15.0) for j in range(n_unique)]
+    clouds = [make_scan(a.rings, a.cols, seed=1234 + (j * world + rank), vfov_deg=22.5 if a.rings >= 128 else 15.0,
+                        start_col=a.start_col, reverse=a.reverse) for j in range(n_unique)]
     n_pts = len(clouds[0])
     tiled = [clouds[j % n_unique] for j in range(a.batch)]
     host = concat(tiled).view(np.uint8)
@@ -288,6 +291,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "rings": a.rings, "cols": a.cols,
                        "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": "code defaults",
+                       "input_order": ("rings in angle order" if not (a.start_col or a.reverse) else
+                                       "rings %s%s" % ("reversed " if a.reverse else "", "rotated by %d columns" % a.start_col if a.start_col else "")),
                        "streams": 1 if use_gather else n_streams,
                        "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "")},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "parity_spot_check": parity,

@@ -215,6 +215,9 @@ int lfx_device_results(const lfx_ctx *ctx, lfx_device_view *view);
  * reads the last batch's scan_info and returns LFX_ERR_RING_ID / LFX_ERR_HIP if any scan carries an error bit
  * (the clouds of such a scan are not to be used), else LFX_OK.  first_bad (may be NULL): index of the first such scan. */
 int lfx_batch_status(lfx_ctx *ctx, void *stream, uint32_t *first_bad);
+/* Which route each scan of the last batch took (diagnostics; waits for `stream`): routes[s] = 1 read in place by the
+ * organised-scan kernel, 2 the same through per-ring transforms (rings rotated / reversed in the stream), 0 bucketed. */
+int lfx_scan_routes(lfx_ctx *ctx, void *stream, uint8_t *routes /* [batch] */);
 
 /* Pinned host memory for the caller's point buffers: lfx_extract reads a buffer allocated here by DMA (3.7 MB in
  * ~70 us for a 64 x 1800 scan); any other host pointer is first copied, chunk by chunk, through the context's own
@@ -367,7 +370,7 @@ int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_p
                               float *out);
 
 /* --- measurement ------------------------------------------------------------------------- */
-#define LFX_N_KERNELS 10  /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact, ring_unit_org (organised scans: loads the records itself) */
+#define LFX_N_KERNELS 11  /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact, ring_unit_org (organised scans: loads the records itself), ring_cut (transforms of rotated / reversed rings) */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);
 /* Record the events around every n-th batch only (default 1).  The event pairs between the kernels of a batch
  * cost ~7 % of the device-resident throughput at 64x1800x256; sampled, the durations stay live and the cost goes. */

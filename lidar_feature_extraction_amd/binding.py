@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LFX_LIB_PATH") or os.path.join(_HERE, "_lib", "liblfx.so")   # override: A/B builds only
 
-LFX_N_KERNELS = 10
+LFX_N_KERNELS = 11
 MAX_RINGS = 256
 
 STAGE_LABEL, STAGE_OCCLUSION, STAGE_OUT_OF_RANGE, STAGE_PARALLEL_BEAM = 1, 2, 4, 8
@@ -74,7 +74,7 @@ class DeviceView(C.Structure):
 EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
     "lfx_status_string", "lfx_ring_message", "lfx_range_message", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
-    "lfx_device_results", "lfx_batch_status", "lfx_host_alloc", "lfx_host_free", "lfx_comm_unique_id", "lfx_comm_create",
+    "lfx_device_results", "lfx_batch_status", "lfx_scan_routes", "lfx_host_alloc", "lfx_host_free", "lfx_comm_unique_id", "lfx_comm_create",
     "lfx_comm_destroy", "lfx_gather_counts", "lfx_gather_payload", "lfx_gather", "lfx_voxel_downsample", "lfx_downsample_surface",
     "lfx_scan_to_map_residuals", "lfx_edge_residuals",
     "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
@@ -119,6 +119,7 @@ def load():
     L.lfx_extract_batch_device.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     L.lfx_device_results.argtypes = [vp, C.POINTER(DeviceView)]
     L.lfx_batch_status.argtypes = [vp, vp, C.POINTER(u32)]
+    L.lfx_scan_routes.argtypes = [vp, vp, vp]
     L.lfx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.lfx_host_free.argtypes = [vp, vp]
     L.lfx_host_free.restype = None

@@ -27,7 +27,7 @@ std::string g_create_error;
 const char * kKernelNames[LFX_N_KERNELS] = {
   "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_unit_kernel",
   "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel", "ring_totals_kernel",
-  "feature_compact_kernel", "ring_unit_org_kernel"};
+  "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -138,6 +138,12 @@ struct lfx_ctx
   // LFX_DEBUG_FUSED=0/1 pins it.
   bool fused_possible = false;
   int fused_env = -1;
+  // Rings that arrive rotated / reversed (a driver that does not cut its scans at -pi, a clockwise sensor): while the
+  // organised-scan kernel keeps giving scans up for their angle order alone, ring_cut_kernel finds every ring's
+  // transform first and the kernel applies it in its loads (LFX_DEBUG_XFORM=0/1 pins it).
+  int xform_env = -1;
+  bool use_xform = false;
+  bool last_used_xform = false;          // the last batch's organised-scan kernel ran with the transforms
   int short_tail_env = -1;               // LFX_DEBUG_SHORT_TAIL=0/1 pins the two-launch tail of the bucketing route (tests)
   bool bucket_all = false;               // the stream is not organised: bucketing route for every scan
   uint32_t retry_in = 0;
@@ -148,7 +154,7 @@ struct lfx_ctx
 
   // device scratch
   DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
-    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list,
+    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list, xform,
     sidx, rec_idx, edge_idx,
     surf_idx, d_sidx;
   DevBuf<uint16_t> chunk_hist;
@@ -332,11 +338,21 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   if (fused) {
     const uint32_t was_fused = c->h_counters[lfx::kCntFusedRan], fell = c->h_counters[lfx::kCntFallback],
       of = c->h_counters[lfx::kCntBatch];
+    const uint32_t order_fell = c->h_counters[lfx::kCntOrderFell], cut_ran = c->h_counters[lfx::kCntCutRan],
+      turned = c->h_counters[lfx::kCntTurned];
+    if (was_fused && of) {
+      // most of what fell back did so for the angle order of its rings alone: find the rings' transforms first from now
+      // on; back to plain loads once (almost) no ring needs one any more
+      if (!cut_ran && 4u * order_fell > of && 2u * order_fell > fell) {c->use_xform = true;}
+      if (cut_ran && 50u * turned < of * c->max_rings) {c->use_xform = false;}
+    }
+    if (c->xform_env >= 0) {c->use_xform = c->xform_env != 0;}
     if (c->fused_env >= 0) {
       fused = c->fused_env != 0;
     } else {
       if (was_fused && of) {
-        const bool mostly_not = 4u * fell > of;
+        // (a report from before the transforms were switched on says nothing about the route with them)
+        const bool mostly_not = 4u * fell > of && !(c->use_xform && !cut_ran);
         if (mostly_not && !c->bucket_all) {c->retry_in = 16;}
         c->bucket_all = mostly_not;
       }
@@ -347,7 +363,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     }
     if (fused) {
       const uint32_t guess = (was_fused ? 2u * fell : 0u) + 8u;
-      fb_grid = guess < batch ? guess : batch;
+      fb_grid = guess < batch && !c->bucket_all ? guess : batch;      // (a retry on a stream that has been falling back: expect all of it)
       // a stream that has not been falling back: its odd scan out (if one turns up) is redone by the workgroup-per-ring
       // kernel straight from the bucketed arrays -- two near-empty launches per batch instead of five
       short_tail = was_fused && of && fell == 0 && c->pre_order_env < 0 && c->redo_cap_env == 0;
@@ -357,23 +373,31 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
     c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
     c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
-    fused ? 0u : 1u);
+    fused ? 0u : 1u, c->xform.p);
   if (chunks == 0) {return LFX_OK;}
+  c->last_used_xform = fused && c->use_xform;
   if (fused) {
+    const bool xf = c->use_xform;
+    if (xf) {
+      Timed t(c, 10, st);
+      hipLaunchKernelGGL(lfx::ring_cut_kernel, dim3(batch), dim3(lfx::kCutThreads), 0, st,
+        pts, c->scan_begin.p, c->max_rings, c->cap, c->xform.p, counters);
+    }
     Timed t(c, 9, st);
     const uint32_t groups = (c->max_rings + 3u) / 4u;
-    auto kern = &lfx::ring_unit_org_kernel<6, false>;
-    if (c->unit_chunks == 5) {kern = &lfx::ring_unit_org_kernel<5, false>;}
-    if (c->unit_chunks == 4) {kern = &lfx::ring_unit_org_kernel<4, false>;}
-    if (c->unit_chunks == 3) {kern = &lfx::ring_unit_org_kernel<3, false>;}
+    void (*kern)(lfx::Params, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t *,
+      const lfx::UnitTables *, const uint32_t *) = nullptr;
+#define LFX_PICK_ORG(DEFV, XFV) \
+    (c->unit_chunks == 5 ? &lfx::ring_unit_org_kernel<5, DEFV, XFV> : c->unit_chunks == 4 ? &lfx::ring_unit_org_kernel<4, DEFV, XFV> : \
+     c->unit_chunks == 3 ? &lfx::ring_unit_org_kernel<3, DEFV, XFV> : &lfx::ring_unit_org_kernel<6, DEFV, XFV>)
     if (c->default_thresholds) {
-      kern = &lfx::ring_unit_org_kernel<6, true>;
-      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_org_kernel<5, true>;}
-      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_org_kernel<4, true>;}
-      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_org_kernel<3, true>;}
+      kern = xf ? LFX_PICK_ORG(true, true) : LFX_PICK_ORG(true, false);
+    } else {
+      kern = xf ? LFX_PICK_ORG(false, true) : LFX_PICK_ORG(false, false);
     }
+#undef LFX_PICK_ORG
     hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-      c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p);
+      c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p);
   }
   // ---- the bucketing route, over the scans on the fall-back list
   if (c->single_pass) {
@@ -423,17 +447,13 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 3, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
-      auto kern = &lfx::ring_unit_kernel<false, 6, false>;
-      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<false, 5, false>;}
-      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<false, 4, false>;}
-      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3, false>;}
-      if (c->default_thresholds) {
-        // the reference's code defaults: the variant with the thresholds as literals
-        kern = &lfx::ring_unit_kernel<false, 6, true>;
-        if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<false, 5, true>;}
-        if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<false, 4, true>;}
-        if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<false, 3, true>;}
-      }
+      // the looping form only where the list's length is a guess (behind the organised-scan kernel)
+#define LFX_PICK_UNIT(DEFV, LOOPV) \
+      (c->unit_chunks == 5 ? &lfx::ring_unit_kernel<false, 5, DEFV, LOOPV> : c->unit_chunks == 4 ? &lfx::ring_unit_kernel<false, 4, DEFV, LOOPV> : \
+       c->unit_chunks == 3 ? &lfx::ring_unit_kernel<false, 3, DEFV, LOOPV> : &lfx::ring_unit_kernel<false, 6, DEFV, LOOPV>)
+      auto kern = c->default_thresholds ? (fused ? LFX_PICK_UNIT(true, true) : LFX_PICK_UNIT(true, false)) :
+        (fused ? LFX_PICK_UNIT(false, true) : LFX_PICK_UNIT(false, false));
+#undef LFX_PICK_UNIT
       hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, fb_grid),
         dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
@@ -455,7 +475,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(list_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
         c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 0u, counters + lfx::kCntPreFixed, redo_cap,
-        fb_count, c->fb_list.p, fb_grid);
+        fb_count, c->fb_list.p, 0xFFFFFFFFu /* the first unit pass covers the whole list (it loops where it has to) */);
     }
     {
       Timed t(c, 5, st);
@@ -535,7 +555,7 @@ int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t 
       LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, (size_t)n * 8, st));
       hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings), dim3(256), 0, st,
         s, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p, c->d_curv.p,
-        c->d_sidx.p, n, c->scan_info.p);
+        c->d_sidx.p, n, c->scan_info.p, c->xform.p);
       LFX_HIP(c, hipGetLastError());
       if (want_lab) {LFX_HIP(c, hipMemcpyAsync(H + o_lb + b, c->d_label.p, n, hipMemcpyDeviceToHost, st));}
       if (want_curv) {LFX_HIP(c, hipMemcpyAsync(H + o_cv + (size_t)b * 8, c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));}
@@ -777,6 +797,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
   if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->fused_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->short_tail_env = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_XFORM")) {c->xform_env = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
   if (const char * dbg = std::getenv("LFX_DEBUG_REDO_CAP")) {c->redo_cap_env = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->pre_order_env = std::atoi(dbg) != 0 ? 1 : 0;}
@@ -802,7 +823,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
   ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
   ok(c->ring_flags.alloc(tables + lfx::kCounters)); ok(c->slow_list.alloc(tables)); ok(c->defer_list.alloc(tables));
-  ok(c->fb_list.alloc(nb));
+  ok(c->fb_list.alloc(nb)); ok(c->xform.alloc(tables));
   ok(c->redo_list.alloc(tables));
   ok(c->unit_ne.alloc(tables * lfx::kUnitMaxBlocks)); ok(c->unit_ns.alloc(tables * lfx::kUnitMaxBlocks));
   ok(c->unit_span.alloc(tables * lfx::kUnitMaxBlocks));
@@ -856,7 +877,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
-  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
@@ -913,6 +934,24 @@ int lfx_batch_status(lfx_ctx * c, void * stream, uint32_t * first_bad)
              fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)") :
              fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
     }
+  }
+  return LFX_OK;
+}
+
+int lfx_scan_routes(lfx_ctx * c, void * stream, uint8_t * routes)
+{
+  if (!c || !routes) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!c->h_status) {
+    LFX_HIP(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_status), (size_t)c->max_batch * 16, hipHostMallocDefault));
+  }
+  LFX_HIP(c, hipMemcpyAsync(c->h_status, c->scan_info.p, (size_t)c->last_batch * 16, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipStreamSynchronize(st));
+  for (uint32_t s = 0; s < c->last_batch; s++) {
+    const uint32_t e = c->h_status[s * 4 + lfx::kInfoError];
+    routes[s] = lfx::scan_is_organised(e) ? (c->last_used_xform ? 2 : 1) : 0;
   }
   return LFX_OK;
 }
@@ -974,7 +1013,7 @@ int lfx_pack_colored(lfx_ctx * c, float * d_colored_out, uint32_t * d_offsets_ou
   hipLaunchKernelGGL(lfx::colored_pack_kernel, dim3(c->max_rings, batch), dim3(256), 0, st,
     c->ring_count.p, c->ring_status.p, d_offsets_out, c->sxy.p, c->sidx.p, c->label_s.p,
     static_cast<const uint8_t *>(c->last_points), c->layout, c->scan_begin.p, c->max_rings, c->cap,
-    reinterpret_cast<float4 *>(d_colored_out), capacity, c->scan_info.p);
+    reinterpret_cast<float4 *>(d_colored_out), capacity, c->scan_info.p, c->xform.p);
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
 }

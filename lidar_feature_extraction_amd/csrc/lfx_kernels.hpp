@@ -94,11 +94,23 @@ enum { kInfoRings = 0, kInfoError = 1, kInfoEdge = 2, kInfoSurface = 3 };
 // bits of scan_info[s][kInfoError]: errors, and the route the scan took.  kScanFused: the organised-scan kernel took
 // the scan (ring r's position k IS input point k * rings + r: nothing was staged, sxy / sz / sidx hold nothing for
 // it); kScanFellBack: that kernel (or the host) handed the scan to the bucketing route, whose staged arrays are valid.
-enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u };
+enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u, kScanOrderFell = 0x400u };
 __host__ __device__ inline bool scan_is_organised(uint32_t err) {return (err & (kScanFused | kScanFellBack)) == kScanFused;}
 // counters[8] behind ring_flags: rings deferred by the first unit pass, repaired after it, sent to the workgroup-per-ring
 // kernel, repaired before it; scans on the fall-back list; whether the organised-scan kernel ran; scans in the batch
-enum { kCntDefer = 0, kCntRedo = 1, kCntSlow = 2, kCntPreFixed = 3, kCntFallback = 4, kCntFusedRan = 5, kCntBatch = 6, kCounters = 8 };
+// ... scans the organised-scan kernel gave up on because a ring was not in angle order (the rest of the pattern held);
+// rings ring_cut_kernel found rotated / reversed; whether it ran
+enum { kCntDefer = 0, kCntRedo = 1, kCntSlow = 2, kCntPreFixed = 3, kCntFallback = 4, kCntFusedRan = 5, kCntBatch = 6,
+       kCntOrderFell = 7, kCntTurned = 8, kCntCutRan = 9, kCounters = 12 };
+// Ring transform of an organised scan (ring_cut_kernel): position k of the ring is column (start + k) mod C, or
+// (start - k) mod C for a clockwise sensor; 0 = the ring arrives in angle order.
+constexpr uint32_t kXformReversed = 0x80000000u;
+__host__ __device__ inline uint32_t ring_column(uint32_t xf, uint32_t k, uint32_t C)
+{
+  const uint32_t start = xf & ~kXformReversed;
+  if (xf & kXformReversed) {return k <= start ? start - k : start + C - k;}
+  return start + k < C ? start + k : start + k - C;
+}
 
 enum RingStatus : uint8_t
 {
@@ -118,13 +130,14 @@ __global__ __launch_bounds__(256) void batch_reset_kernel(
   uint32_t * __restrict__ scan_info, uint32_t n_info, uint32_t * __restrict__ ring_count, uint32_t n_count,
   uint32_t * __restrict__ chunk_flags, uint32_t n_flags, uint32_t * __restrict__ ring_flags, uint32_t n_rflags,
   uint32_t * __restrict__ counters /* [kCounters] */, uint32_t * __restrict__ fb_list, uint32_t batch,
-  uint32_t all_fall_back /* 1: every scan takes the bucketing route (the organised-scan kernel is not launched) */)
+  uint32_t all_fall_back /* 1: every scan takes the bucketing route (the organised-scan kernel is not launched) */,
+  uint32_t * __restrict__ xform /* [batch][256] ring transforms: identity unless ring_cut_kernel runs */)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t k = i; k < n_info; k += stride) {scan_info[k] = 0;}
   for (uint32_t k = i; k < n_count; k += stride) {ring_count[k] = 0;}
   for (uint32_t k = i; k < n_flags; k += stride) {chunk_flags[k] = 0;}
-  for (uint32_t k = i; k < n_rflags; k += stride) {ring_flags[k] = 0;}
+  for (uint32_t k = i; k < n_rflags; k += stride) {ring_flags[k] = 0; xform[k] = 0;}
   if (all_fall_back) {
     for (uint32_t k = i; k < batch; k += stride) {fb_list[k] = k;}
   }
@@ -1358,11 +1371,13 @@ struct UnitTables
 
 // A scan the organised-scan kernel cannot take (ring pattern, point count, angle order, a skip condition, a unit that
 // does not fit a wave) is flagged once and appended to the fall-back list: the bucketing route then redoes it whole.
-__device__ inline void scan_falls_back(const UnitTables * __restrict__ tab, uint32_t s)
+__device__ inline void scan_falls_back(const UnitTables * __restrict__ tab, uint32_t s, bool order_only = false)
 {
-  if ((atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kScanFellBack) & kScanFellBack) == 0u) {
-    tab->fb_list[atomicAdd(tab->fb_count, 1u)] = s;
-  }
+  const uint32_t bits = kScanFellBack | (order_only ? (uint32_t)kScanOrderFell : 0u);
+  const uint32_t old = atomicOr(tab->scan_info + s * 4 + kInfoError, bits);
+  if ((old & kScanFellBack) == 0u) {tab->fb_list[atomicAdd(tab->fb_count, 1u)] = s;}
+  // (counted for the host's choice of route: a stream whose rings are rotated / reversed gets ring_cut_kernel)
+  if (order_only && (old & kScanOrderFell) == 0u) {atomicAdd(tab->fb_count + (kCntOrderFell - kCntFallback), 1u);}
 }
 
 // ORG: the organised-scan form.  A driver's scan arrives column-major -- all rings of one firing, then the next
@@ -1380,6 +1395,7 @@ struct OrgScan
   const uint32_t * __restrict__ scan_begin;
   uint32_t * __restrict__ ring_count_out;
   uint32_t R, r0, wave, drop_zero;
+  const uint32_t * __restrict__ xform;    // [batch][256] ring transforms (XF instantiations only)
 };
 
 #ifndef LFX_ORG_FULL
@@ -1396,7 +1412,7 @@ struct OrgScan
 // 43 % of its life (profiles/r02_org1/sq_counters.json).  Measured: the interleaved chunks need 42 more scalar and 24
 // more vector registers than the wave has (spilled), 1700 vs 1440 us per 1024 scans.  Kept because it is what exposed
 // the aliasing hazard described at put_word().
-template<int PT, int CH, bool DEF, bool ORG, bool FULL>
+template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF = false>
 __device__ __forceinline__ void unit_body(
   const Params & prm, UnitLds<CH> * __restrict__ slabs, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
@@ -1438,7 +1454,7 @@ __device__ __forceinline__ void unit_body(
 #define LFX_DEFER(reason) \
   do { \
     if (ORG) { \
-      if (lane == 0) {scan_falls_back(tab, s);} \
+      if (lane == 0) {scan_falls_back(tab, s, (reason) == kDeferOrder);} \
     } else if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
       defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
     } \
@@ -1491,12 +1507,16 @@ __device__ __forceinline__ void unit_body(
     float4 rec[CH];
     uint32_t rw[CH];
     const uint8_t * const base = og.pts + (size_t)scan_first * 32u;
+    // XF: the rings of the stream arrive rotated (scan not cut at -pi) or reversed (clockwise sensor): position i of a
+    // ring is column ring_column(xf, i, N), xf found per ring by ring_cut_kernel; the order check below still decides
+    const uint32_t xf = XF ? og.xform[s * kRings + rload] : 0u;
 #pragma unroll
     for (int m = 0; m < CH; m++) {
       const int q = 64 * m + 16 * (int)og.wave + (int)cq;
       int i = g0 + q;
       i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
-      const uint8_t * p = base + ((uint32_t)i * og.R + rload) * 32u;        // a scan is < 2^27 points (host check)
+      const uint32_t col = XF ? ring_column(xf, (uint32_t)i, (uint32_t)N) : (uint32_t)i;
+      const uint8_t * p = base + (col * og.R + rload) * 32u;                // a scan is < 2^27 points (host check)
       rec[m] = *reinterpret_cast<const float4 *>(p);
       rw[m] = *reinterpret_cast<const uint32_t *>(p + 20);
     }
@@ -1934,7 +1954,8 @@ __device__ __forceinline__ void unit_body(
         const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
         const size_t at = l == kEdge ? off + o0 + pe + be : off + o1 - 1 - (ps + bs);
         rec_pts[at] = rec;
-        rec_idx[at] = ORG ? (uint32_t)i * og.R + slot : src[k];      // ORG: position i of ring `slot` is point i * R + slot
+        // ORG: position i of ring `slot` is point column * R + slot
+        rec_idx[at] = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
       }
       pe += __popcll(fe);
       ps += __popcll(fs);
@@ -1965,7 +1986,7 @@ __device__ __forceinline__ void unit_body(
 // kernel is not in use), grid = (units of a scan / 4, list entries or fewer); rings it cannot take go on
 // `defer_list` with the reason.  SECOND = true: second pass over the rings ring_order_kernel
 // repaired (redo_list, grid-stride); what still cannot be taken goes on the slow list.
-template<bool SECOND, int CH, bool DEF>
+template<bool SECOND, int CH, bool DEF, bool LOOP = false>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
@@ -1980,7 +2001,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   UnitLds<CH> * U = &lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
-  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u};
+  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr};
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
@@ -2003,20 +2024,25 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
     const uint32_t slot = u / B;
     if (slot >= max_rings) {return;}
     const int j = (int)(u % B);
-    // (redo_count / redo_list double as the fall-back list here.)  One list entry per blockIdx.y and no loop -- a loop
-    // around unit_body costs it 60 spilled scalar registers; entries beyond the grid (the host's guess from earlier
-    // batches was too low) are handed to the workgroup-per-ring kernel by ring_order_kernel: slower, same result.
-    if (blockIdx.y >= *redo_count) {return;}
-    const uint32_t s = redo_list[blockIdx.y];
-    if (DEF || prm.P == 5) {
-      unit_body<5, CH, DEF, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
-        defer_list, false, none);
-    } else if (prm.P == 2) {
-      unit_body<2, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
-        defer_list, false, none);
-    } else {
-      unit_body<0, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
-        defer_list, false, none);
+    // (redo_count / redo_list double as the fall-back list here.)  LOOP = false: one list entry per blockIdx.y, the grid
+    // covers the list (every scan of the batch is bucketed).  LOOP = true: the list is what the organised-scan kernel
+    // gave up on, of a length the host can only guess, so a workgroup walks entries blockIdx.y, + gridDim.y, ...; the loop
+    // around unit_body costs 60 spilled scalar registers, which is why the other form exists.
+    const uint32_t n_list = *redo_count;
+    for (uint32_t it = blockIdx.y; it < n_list; it += LOOP ? gridDim.y : n_list) {
+      const uint32_t s = redo_list[it];
+      if (DEF || prm.P == 5) {
+        unit_body<5, CH, DEF, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+          defer_list, false, none);
+      } else if (prm.P == 2) {
+        unit_body<2, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+          defer_list, false, none);
+      } else {
+        unit_body<0, CH, false, false, false>(prm, U, ring_cap, max_rings, dbg_flags, s, slot, j, ring_count, sxy, sz, sidx, tab, defer_count,
+          defer_list, false, none);
+      }
+      if (!LOOP) {break;}
+      LFX_WAVE_SYNC();                       // the wave's slab is reused by the next entry
     }
   }
 }
@@ -2024,11 +2050,11 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
 // The organised-scan kernel (unit_body<ORG>): workgroup = block j of the four adjacent rings 4g .. 4g+3 of scan
 // blockIdx.y, one ring per wave.  blockIdx.x = j * groups + g: workgroups dispatched together take neighbouring ring
 // groups of the same block, i.e. neighbouring 128-byte lines of the same columns -- whole DRAM pages between them.
-template<int CH, bool DEF>
+template<int CH, bool DEF, bool XF>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab)
+  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform)
 {
   __shared__ UnitLds<CH> lds[kUnitWaves];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2036,17 +2062,122 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   const uint32_t g = blockIdx.x % groups;
   const int j = (int)(blockIdx.x / groups);
   const uint32_t s = blockIdx.y;
-  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero};
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform};
   const uint32_t slot = 4u * g + wave;
   if (DEF || prm.P == 5) {
-    unit_body<5, CH, DEF, true, LFX_ORG_FULL>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+    unit_body<5, CH, DEF, true, LFX_ORG_FULL, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
       nullptr, false, og);
   } else if (prm.P == 2) {
-    unit_body<2, CH, false, true, false>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+    unit_body<2, CH, false, true, false, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
       nullptr, false, og);
   } else {
-    unit_body<0, CH, false, true, false>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+    unit_body<0, CH, false, true, false, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
       nullptr, false, og);
+  }
+}
+
+// The ring transforms of an organised stream whose rings do not arrive in angle order: a driver that starts its scans
+// at another azimuth delivers every ring as a ROTATION of its sorted order, a clockwise sensor as its REVERSE (or
+// both).  One wave per ring: direction by majority over 64 sampled adjacent pairs, then the column of the ring's
+// smallest angle by a 64-ary search for the wrap (two rounds of loads for rings of up to 4096 points) with the exact
+// predicate (ring.hpp:54-99).  Nothing is moved: ring_unit_org_kernel<XF> applies the transform in its loads and still
+// verifies every adjacent pair, so a ring that is not a rotation / reversal of its sorted order falls back as before.
+constexpr int kCutThreads = 256, kCutWindow = 32;
+__global__ __launch_bounds__(kCutThreads) void ring_cut_kernel(
+  const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t max_rings, uint32_t ring_cap,
+  uint32_t * __restrict__ xform, uint32_t * __restrict__ counters)
+{
+  // One workgroup per scan.  Ring 0 gets the full search (one wave); the rings of one scan start within a few columns
+  // of each other (per-laser azimuth offsets), so for the others the 32 columns around ring 0's wrap are read for ALL
+  // rings at once -- whole columns, i.e. contiguous records -- and a ring whose wrap is not cleanly inside that window
+  // gets the full search too.
+  const uint32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (s == 0u && tid == 0u) {counters[kCntCutRan] = 1u;}                            // this batch's report was made with the transforms on
+  const uint32_t first = scan_begin[s], n = scan_begin[s + 1] - first;
+  const uint32_t C = n / max_rings;
+  if (C * max_rings != n || C < 64u || C > ring_cap) {return;}                      // not this kernel's kind of scan: identity stays
+  __shared__ uint32_t lead, n_hard;
+  __shared__ uint32_t mask[kRings];
+  __shared__ float2 first_xy[kRings];
+  __shared__ uint16_t hard[kRings];
+  auto xy = [&](uint32_t ring, uint32_t c) {
+      return *reinterpret_cast<const float2 *>(pts + ((size_t)first + (size_t)c * max_rings + ring) * 32u);
+    };
+  // "column c lies beyond the wrap": forward rings -- its angle is below a[0]'s; reversed -- above it
+  auto beyond = [&](bool rev, float2 a0, float2 v) {
+      return rev ? polar_less(a0.x, a0.y, v.x, v.y) : polar_less(v.x, v.y, a0.x, a0.y);
+    };
+  // first column >= 1 beyond the wrap (C: none) -> transform
+  auto to_xform = [&](bool rev, uint32_t hi) {
+      return rev ? (kXformReversed | (hi - 1u)) : (hi < C ? hi : 0u);
+    };
+  auto full_search = [&](uint32_t ring) {                                            // by one wave
+      // direction: adjacent pairs at 8 spread columns; all but (at most) one of them do not straddle the wrap
+      bool up = false, down = false;
+      if (lane < 8u) {
+        const uint32_t cs = (lane * (C - 1u)) >> 3;                                    // in [0, C - 2]
+        const float2 a = xy(ring, cs), b = xy(ring, cs + 1u);
+        up = polar_less(a.x, a.y, b.x, b.y);
+        down = polar_less(b.x, b.y, a.x, a.y);
+      }
+      const bool rev = __popcll(__ballot(down)) > __popcll(__ballot(up));
+      const float2 a0 = xy(ring, 0u);
+      uint32_t lo = 0u, hi = C;                                                       // P(lo) false, P(hi) true (C: sentinel)
+      while (hi - lo > 1u) {
+        const uint32_t step = (hi - lo + 63u) >> 6;
+        const uint32_t c = lo + (lane + 1u) * step;
+        bool by = true;
+        if (c < hi) {by = beyond(rev, a0, xy(ring, c));}
+        const uint64_t m = __ballot(by);                                              // lanes with c >= hi vote true: m != 0
+        const uint32_t f = (uint32_t)__ffsll((long long)m) - 1u;
+        const uint32_t nhi = lo + (f + 1u) * step;
+        lo = lo + f * step;
+        hi = nhi < hi ? nhi : hi;
+      }
+      return to_xform(rev, hi);
+    };
+  if (tid < kRings) {mask[tid] = 0u;}
+  if (tid == 0u) {n_hard = 0u;}
+  if (wave == 0u) {
+    const uint32_t xf0 = full_search(0u);
+    if (lane == 0u) {lead = xf0;}
+  }
+  for (uint32_t r = tid; r < max_rings; r += kCutThreads) {first_xy[r] = xy(r, 0u);}   // column 0: contiguous records
+  __syncthreads();
+  const uint32_t xf0 = lead;
+  const bool rev0 = (xf0 & kXformReversed) != 0u;
+  const uint32_t start0 = xf0 & ~kXformReversed;
+  const uint32_t hi0 = rev0 ? start0 + 1u : (start0 == 0u ? C : start0);            // ring 0's first column beyond the wrap
+  for (uint32_t e = tid; e < (uint32_t)kCutWindow * max_rings; e += kCutThreads) {
+    const uint32_t w = e / max_rings, r = e % max_rings;
+    const int c = (int)hi0 - kCutWindow / 2 + (int)w;
+    bool by = c >= (int)C;                                                           // c <= 0: before the wrap by definition
+    if (c >= 1 && c < (int)C) {by = beyond(rev0, first_xy[r], xy(r, (uint32_t)c));}
+    if (by) {atomicOr(&mask[r], 1u << w);}
+  }
+  __syncthreads();
+  for (uint32_t r = tid; r < max_rings; r += kCutThreads) {
+    const uint32_t m = mask[r];
+    const uint32_t f = m ? (uint32_t)__ffs((int)m) - 1u : 32u;
+    if (r == 0u) {
+      xform[s * kRings] = xf0;
+      if (xf0 != 0u) {atomicAdd(counters + kCntTurned, 1u);}
+    } else if (f >= 1u && f < 32u && m == (0xFFFFFFFFu << f)) {                      // one clean false -> true step inside the window
+      const uint32_t xf = to_xform(rev0, (uint32_t)((int)hi0 - kCutWindow / 2 + (int)f));
+      xform[s * kRings + r] = xf;
+      if (xf != 0u) {atomicAdd(counters + kCntTurned, 1u);}
+    } else {
+      hard[atomicAdd(&n_hard, 1u)] = (uint16_t)r;
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = wave; k < n_hard; k += kCutThreads / 64) {
+    const uint32_t r = hard[k];
+    const uint32_t xf = full_search(r);
+    if (lane == 0u) {
+      xform[s * kRings + r] = xf;
+      if (xf != 0u) {atomicAdd(counters + kCntTurned, 1u);}
+    }
   }
 }
 
@@ -2498,7 +2629,7 @@ __global__ __launch_bounds__(256) void densify_kernel(
   uint32_t s, uint32_t max_rings, uint32_t cap, const uint32_t * __restrict__ ring_count,
   const uint8_t * __restrict__ label_s, const double * __restrict__ curv_s, const uint32_t * __restrict__ sidx,
   uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx, uint32_t n_points,
-  const uint32_t * __restrict__ scan_info)
+  const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ xform)
 {
   const uint32_t ring = blockIdx.x, tid = threadIdx.x;
   const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]);     // position i of the ring is point i * rings + ring
@@ -2516,7 +2647,7 @@ __global__ __launch_bounds__(256) void densify_kernel(
   const uint32_t Nfull = ring_count[s * kRings + ring];
   for (uint32_t i = tid; i < Nfull; i += blockDim.x) {
     const bool stored = i < N;
-    const uint32_t orig = stored ? (org ? i * max_rings + ring : sidx[off + i]) : 0xFFFFFFFFu;
+    const uint32_t orig = stored ? (org ? ring_column(xform[s * kRings + ring], i, Nfull) * max_rings + ring : sidx[off + i]) : 0xFFFFFFFFu;
     d_sidx[dense + i] = orig;
     if (orig < n_points) {
       d_label[orig] = label_s[off + i];
@@ -2663,7 +2794,7 @@ __global__ __launch_bounds__(256) void colored_pack_kernel(
   const uint32_t * __restrict__ offsets, const float2 * __restrict__ sxy, const uint32_t * __restrict__ sidx,
   const uint8_t * __restrict__ label_s, const uint8_t * __restrict__ pts, Layout L,
   const uint32_t * __restrict__ scan_begin, uint32_t max_rings, uint32_t cap, float4 * __restrict__ out,
-  uint32_t capacity, const uint32_t * __restrict__ scan_info)
+  uint32_t capacity, const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ xform)
 {
   const uint32_t s = blockIdx.y, ring = blockIdx.x, tid = threadIdx.x;
   if (ring_status[s * kRings + ring] != kOk) {return;}
@@ -2680,7 +2811,7 @@ __global__ __launch_bounds__(256) void colored_pack_kernel(
   const uint32_t table[8] = {0xFFFFFFFFu, 0xFFFF0000u, 0xFFFF3F00u, 0xFFFF0000u, 0xFFFF3F00u, 0xFF7F7F7Fu, 0xFFFF00FFu, 0xFF00FF00u};
   for (uint32_t i = tid; i < n; i += blockDim.x) {
     if (at + i >= capacity) {break;}
-    const uint32_t orig = org ? i * max_rings + ring : sidx[off + i];
+    const uint32_t orig = org ? ring_column(xform[s * kRings + ring], i, n) * max_rings + ring : sidx[off + i];
     const uint8_t * rec = pts + ((size_t)scan_begin[s] + orig) * L.step;
     const float2 xy = org ? make_float2(load_f32(rec + L.ox, L.be), load_f32(rec + L.oy, L.be)) : sxy[off + i];
     // z from the input record (the staged z of a ring the workgroup-per-ring kernel sorted itself is not re-ordered)

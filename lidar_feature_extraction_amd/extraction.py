@@ -189,6 +189,12 @@ class FeatureExtraction:
             self._ctx, C.c_void_p(int(d_map)), int(n_map), pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
             C.c_void_p(int(d_residual)), C.c_void_p(int(d_jacobian)), C.c_void_p(int(stream))))
 
+    def scan_routes(self, n_scans, stream=0):
+        """lfx_scan_routes: per scan of the last batch 1 = read in place, 2 = in place through ring transforms, 0 = bucketed."""
+        out = np.zeros(n_scans, np.uint8)
+        B.check(self._ctx, self._L.lfx_scan_routes(self._ctx, C.c_void_p(int(stream)), C.c_void_p(out.ctypes.data)))
+        return out
+
     def batch_status(self, stream=0):
         """lfx_batch_status: raises LfxError if a scan of the last device batch carries an error bit."""
         bad = C.c_uint32(0)

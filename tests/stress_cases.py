@@ -42,10 +42,18 @@ def draw(rng):
 
 
 def run_case(case, rng):
+    import os
     rings, cols, hp, order, kw, seed, sigma, exact_cap = draw(rng)
     clouds = [make_scan(rings, cols, seed=seed + i, sigma=sigma, **kw) for i in range(2)]
-    f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=2,
-                          max_points_per_ring=cols if exact_cap else 0, max_rings=rings if exact_cap else 0)
+    # a third of the contexts that know the sensor look for rotated / reversed rings from the first batch on
+    pin = bool(rng.integers(0, 3) == 0)
+    if pin:
+        os.environ["LFX_DEBUG_XFORM"] = "1"
+    try:
+        f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=2,
+                              max_points_per_ring=cols if exact_cap else 0, max_rings=rings if exact_cap else 0)
+    finally:
+        os.environ.pop("LFX_DEBUG_XFORM", None)
     op = OB.Params(hp.padding, hp.neighbor_degree_threshold, hp.distance_diff_threshold, hp.parallel_beam_min_range_ratio,
                    hp.edge_threshold, hp.surface_threshold, hp.min_range, hp.max_range, hp.n_blocks)
     want = []

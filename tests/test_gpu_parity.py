@@ -134,7 +134,7 @@ def _with_env(env, make):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("force", ["1", "0", None, "short-tail"])
+@pytest.mark.parametrize("force", ["1", "0", None, "short-tail", "transforms"])
 def test_organised_scan_kernel_and_its_fall_back(force):
     """A context that knows the sensor's ring count reads a driver's column-major scan directly (organised-scan
     kernel: no bucketing pass); every scan that is not of that form -- ragged, rotated, reversed, shuffled, ring ids
@@ -161,14 +161,57 @@ def test_organised_scan_kernel_and_its_fall_back(force):
     assert want["zero_norm_pair"]["ring_status"].tolist().count(0) == R - 1
     # "short-tail": the form the bucketing route takes while no scan has been falling back (bucketing, then the
     # workgroup-per-ring kernel over every ring of the scans that did), pinned for every batch
-    env = {} if force is None else ({"LFX_DEBUG_FUSED": "1", "LFX_DEBUG_SHORT_TAIL": "1"} if force == "short-tail" else {"LFX_DEBUG_FUSED": force})
+    # "transforms": every ring's rotation / reversal is found first (ring_cut_kernel) and applied in the kernel's loads
+    env = {} if force is None else ({"LFX_DEBUG_FUSED": "1", "LFX_DEBUG_SHORT_TAIL": "1"} if force == "short-tail" else
+                                    {"LFX_DEBUG_FUSED": "1", "LFX_DEBUG_XFORM": "1"} if force == "transforms" else {"LFX_DEBUG_FUSED": force})
     f = _with_env(env, lambda: FeatureExtraction(device=0, max_points_per_scan=R * 2 * Ccols, max_batch=6,
                                                  max_points_per_ring=2 * Ccols, max_rings=R))
     for name, c in clouds.items():
         for rep in range(3):
             got = f.extract_batch([c, clouds["sorted"], c, clouds["sorted"], clouds["sorted"]])
+            routes = f.scan_routes(5)
+            if force == "transforms":
+                # rotated / reversed rings stay on the organised route; what is not R x C in ring order does not
+                turned = name in ("rotated", "reversed", "reversed_rotated")
+                assert routes.tolist() == ([2, 2, 2, 2, 2] if turned or name in ("sorted",) else [0, 2, 0, 2, 2]), (name, routes)
+            if force == "0":
+                assert not routes.any()
             for i, key in enumerate([name, "sorted", name, "sorted", "sorted"]):
                 assert_scan_equal(got[i], want[key], "%s[%d]/fused %s/rep %d%s" % (key, i, force, rep, "[ties]" if want[key]["angle_ties"] else ""))
+    f.close()
+
+
+@pytest.mark.parametrize("kind", ["rotated", "reversed", "reversed_rotated"])
+def test_stream_of_turned_rings_stays_on_the_organised_route(kind):
+    """A driver that starts its scans at another azimuth (every ring a rotation of its angle order), a clockwise sensor
+    (reversed), or both: the first batch falls back for its angle order, the library then finds the rings' transforms
+    ahead of the kernel (ring_cut_kernel) and the stream is read in place again; when the stream arrives in order
+    again the transforms are dropped.  Rings of one scan start at different columns (per-laser azimuth offsets)."""
+    R, Ccols, nb = 16, 900, 4
+    kw = INPUT_ORDER_KW[kind]
+    turned = [make_scan(R, Ccols, seed=1600 + i, **kw) for i in range(nb)]
+    # per-ring offsets: rotate the records of some rings by another column or two inside the column-major layout
+    for c in turned:
+        grid = c.reshape(Ccols, R)
+        for r, shift in ((3, 1), (7, 2), (12, 5)):
+            grid[:, r] = np.roll(grid[:, r], shift)
+    plain = [make_scan(R, Ccols, seed=1700 + i) for i in range(nb)]
+    want_t = [OB.extract(c, canonical_ties=False) for c in turned]
+    want_p = [OB.extract(c, canonical_ties=False) for c in plain]
+    f = FeatureExtraction(device=0, max_points_per_scan=R * Ccols, max_batch=nb, max_points_per_ring=Ccols, max_rings=R)
+    seen = []
+    for rep in range(4):
+        got = f.extract_batch(turned)
+        seen.append(f.scan_routes(nb).tolist())
+        for i in range(nb):
+            assert_scan_equal(got[i], want_t[i], "%s scan %d, rep %d" % (kind, i, rep))
+    assert seen[0] == [0] * nb and seen[-1] == [2] * nb, seen
+    for rep in range(4):
+        got = f.extract_batch(plain)
+        seen.append(f.scan_routes(nb).tolist())
+        for i in range(nb):
+            assert_scan_equal(got[i], want_p[i], "in order again, scan %d, rep %d" % (i, rep))
+    assert seen[-1] == [1] * nb, seen
     f.close()
 
 
