@@ -332,6 +332,53 @@ int lfx_scan_to_map_residuals(lfx_ctx *ctx, int kind, const float *d_map, uint32
 int lfx_edge_residuals(lfx_ctx *ctx, const float *d_map, uint32_t n_map, const double pose[12], uint32_t n_neighbors,
                        double *d_residual, double *d_jacobian, void *stream);
 
+/* --- the optimizer around those rows (second slice) ---------------------------------------------------- */
+/* Optimizer<LOAMOptimizationProblem, EdgeSurfaceScan>::Run (localization/include/lidar_feature_localization/
+ * optimizer.hpp:79-123, as Localizer::Update calls it, localizer.hpp:76) for a batch of scans against one pair of maps,
+ * every scan from its own initial pose, all iterations on the device: per iteration Problem::Make (the two row builds
+ * above, edge rows first: loam_optimization_problem.hpp:62-84), ComputeErrors, NormalizeErrorScale (Scale = 1.4826 *
+ * median absolute deviation, robust.cpp:36-50), ComputeWeights (HuberDerivative, k = 1.345), WeightedUpdate (sums of
+ * J^T J, w J^T J, w J^T r; IsDegenerate(D, 0.1) -> no step; -(M^T A M).llt().solve(M^T b), optimizer.cpp:40-71),
+ * q <- q * AngleAxisToQuaternion(dx[0:3]), t <- t + dx[3:6], and the stopping tests in the reference's order (error
+ * larger than before, scale larger than before, |dq.vec| and |dt| < 1e-3, max_iter).  A scan that has stopped costs no
+ * further work.  The surface clouds are the ones AFTER Downsample (surface.hpp:111; lfx_downsample_surface, leaf 1.0).
+ * initial_poses: [n_clouds][12] host doubles ([R | t] row-major); results: [n_clouds], host.  Synchronous on `stream`.
+ * PARITY UNPINNED (Eigen / nanoflann / PCL arithmetic underneath; see lfx_scan_to_map_residuals): results agree with the
+ * CPU restatement to tolerance, and the restatement passes the reference's own optimizer tests. */
+#define LFX_ALIGN_CONVERGED 0      /* "Optimization successfully converged"           success */
+#define LFX_ALIGN_LARGER_ERROR 1   /* "The error is larger than previous iteration"   success */
+#define LFX_ALIGN_LARGER_SCALE 2   /* "The scale is larger than previous iteration"   success */
+#define LFX_ALIGN_MAX_ITERATION 3  /* "The iteration reached the maximum value"       failure */
+#define LFX_ALIGN_EMPTY_INPUT 4    /* "The input data is empty"                       failure */
+#define LFX_ALIGN_SUCCESS(code) ((code) <= LFX_ALIGN_LARGER_SCALE)
+typedef struct lfx_align_result {   /* OptimizationResult, optimization_result.hpp:35-43 */
+  double pose[12];                  /* [R | t] row-major 3 x 4 */
+  double error;                     /* sum of squared residuals at the last Problem::Make */
+  double error_scale;
+  int32_t iteration;
+  int32_t code;                     /* LFX_ALIGN_*; text: lfx_align_message */
+} lfx_align_result;
+const char *lfx_align_message(int code);
+int lfx_scan_to_map_align(lfx_ctx *ctx, const float *d_edge_map, uint32_t n_edge_map, const float *d_surface_map,
+                          uint32_t n_surface_map, uint32_t n_neighbors, int max_iter,
+                          const float *d_edge_points, const uint32_t *d_edge_begin, const uint32_t *d_edge_count,
+                          uint32_t edge_count_stride, uint32_t max_edge_points_per_cloud, size_t total_edge_points,
+                          const float *d_surface_points, const uint32_t *d_surface_begin, const uint32_t *d_surface_count,
+                          uint32_t surface_count_stride, uint32_t max_surface_points_per_cloud, size_t total_surface_points,
+                          uint32_t n_clouds, const double *initial_poses, lfx_align_result *results, void *stream);
+/* The same loop on AlignmentProblem (localization/src/alignment.cpp:33-78: rows [DRpDq(q, x), I], residual pose * x - y),
+ * the problem the reference's optimizer tests run (localization/test/test_optimizer.cpp).  d_source / d_target: records
+ * of 3 doubles on the device, cloud s = d_count[s] records from record d_begin[s]. */
+int lfx_align_point_pairs(lfx_ctx *ctx, const double *d_source, const double *d_target, const uint32_t *d_begin,
+                          const uint32_t *d_count, uint32_t max_points_per_cloud, size_t total_points, uint32_t n_clouds,
+                          int max_iter, const double *initial_poses, lfx_align_result *results, void *stream);
+/* Localizer::Update (localizer.hpp:71-80) for every scan of the last device batch: Downsample(scan_surface, surface_leaf)
+ * (the reference uses 1.0), then lfx_scan_to_map_align on scan_edge and the downsampled cloud; nothing leaves the device
+ * but the results. */
+int lfx_localize_batch(lfx_ctx *ctx, const float *d_edge_map, uint32_t n_edge_map, const float *d_surface_map,
+                       uint32_t n_surface_map, uint32_t n_neighbors, int max_iter, float surface_leaf,
+                       const double *initial_poses, lfx_align_result *results, void *stream);
+
 /* --- per-stage entry points (device-backed mirrors of the reference's free functions) ----- */
 /* One ring given as angle-sorted x[n], y[n] host arrays; every stage runs the same device
  * routines the fused ring kernel runs.  Optional inputs may be NULL.

@@ -166,6 +166,8 @@ struct lfx_ctx
   DevBuf<float4> edge_pts, surf_pts, rec_pts;
   DevBuf<lfx::UnitTables> unit_tab;      // the unit kernel's output pointers (one element)
   DevBuf<uint32_t> vox_scratch;          // lfx_voxel_downsample: sort keys / values, allocated on first use
+  DevBuf<double> align_scratch;          // lfx_scan_to_map_align: states, rows, errors; allocated on first use
+  DevBuf<float> align_surface;           // lfx_localize_batch: the downsampled surface clouds (+ counts, status)
 
   hipStream_t stream = nullptr;          // used by the synchronous host entry points
   std::vector<uint32_t> h_scan_begin;    // of the last batch
@@ -883,7 +885,7 @@ void lfx_destroy(lfx_ctx * c)
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
-  c->h_in.release(); c->h_out.release(); c->vox_scratch.release();
+  c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release();
   if (c->h_status) {(void)hipHostFree(c->h_status); c->h_status = nullptr;}
   if (c->stream) {(void)hipStreamDestroy(c->stream);}
   delete c;
@@ -1414,10 +1416,12 @@ int lfx_scan_to_map_residuals(
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (kind == LFX_RESIDUAL_EDGE) {
     hipLaunchKernelGGL(lfx::scan_to_map_kernel<false>, grid, dim3(128), 0, st, reinterpret_cast<const float4 *>(d_map), n_map, P,
-      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian);
+      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian,
+      static_cast<const lfx::AlignState *>(nullptr));
   } else {
     hipLaunchKernelGGL(lfx::scan_to_map_kernel<true>, grid, dim3(128), 0, st, reinterpret_cast<const float4 *>(d_map), n_map, P,
-      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian);
+      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian,
+      static_cast<const lfx::AlignState *>(nullptr));
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -1436,6 +1440,178 @@ int lfx_edge_residuals(
   }
   return lfx_scan_to_map_residuals(c, LFX_RESIDUAL_EDGE, d_map, n_map, pose, n_neighbors, reinterpret_cast<const float *>(c->edge_pts.p),
            c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, c->last_batch, longest, d_residual, d_jacobian, stream);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------- the optimizer around the rows
+namespace
+{
+struct AlignProblem                     // what Problem::Make reads, per kind
+{
+  // rows of dimension 3: the edge clouds, or the point pairs
+  const float * edge_map = nullptr; uint32_t n_edge_map = 0;
+  const float * edge_points = nullptr; const double * X = nullptr, * Y = nullptr;
+  const uint32_t * begin3 = nullptr, * count3 = nullptr; uint32_t stride3 = 1, longest3 = 0; size_t total3 = 0;
+  // rows of dimension 1: the downsampled surface clouds
+  const float * surface_map = nullptr; uint32_t n_surface_map = 0;
+  const float * surface_points = nullptr;
+  const uint32_t * begin1 = nullptr, * count1 = nullptr; uint32_t stride1 = 1, longest1 = 0; size_t total1 = 0;
+  uint32_t n_neighbors = 0;
+};
+
+int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_iter, const double * initial_poses,
+  lfx_align_result * results, hipStream_t st)
+{
+  static_assert(sizeof(lfx::AlignState) % 8 == 0, "AlignState is an array of doubles' worth");
+  const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds, pose_d = 12 * (size_t)n_clouds;
+  const size_t rows = pr.total3 + pr.total1;
+  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + 2 * rows + 8;
+  if (c->align_scratch.n < need) {
+    c->align_scratch.release();
+    if (c->align_scratch.alloc(need) != hipSuccess) {
+      c->align_scratch.n = 0;
+      return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the rows of the scan-to-map alignment");
+    }
+  }
+  double * w = c->align_scratch.p;
+  lfx::AlignState * states = reinterpret_cast<lfx::AlignState *>(w); w += state_d;
+  double * d_initial = w; w += pose_d;
+  double * r3 = w; w += 3 * pr.total3;
+  double * J3 = w; w += 21 * pr.total3;
+  double * r1 = w; w += pr.total1;
+  double * J1 = w; w += 7 * pr.total1;
+  double * err = w; w += rows;
+  double * dev = w;
+  LFX_HIP(c, hipMemcpyAsync(d_initial, initial_poses, pose_d * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lfx::align_begin_kernel, dim3((n_clouds + 63u) / 64u), dim3(64), 0, st, states, d_initial, n_clouds);
+  const lfx::MapPose none{};
+  for (int iter = 0; iter < max_iter; iter++) {
+    if (pr.X) {
+      if (pr.longest3) {
+        hipLaunchKernelGGL(lfx::pair_rows_kernel, dim3((pr.longest3 + 127u) / 128u, n_clouds), dim3(128), 0, st, pr.X, pr.Y,
+          pr.begin3, pr.count3, r3, J3, states);
+      }
+    } else {
+      if (pr.longest3) {
+        hipLaunchKernelGGL(lfx::scan_to_map_kernel<false>, dim3((pr.longest3 + 127u) / 128u, n_clouds), dim3(128), 0, st,
+          reinterpret_cast<const float4 *>(pr.edge_map), pr.n_edge_map, none, pr.n_neighbors,
+          reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3, states);
+      }
+      if (pr.longest1) {
+        hipLaunchKernelGGL(lfx::scan_to_map_kernel<true>, dim3((pr.longest1 + 127u) / 128u, n_clouds), dim3(128), 0, st,
+          reinterpret_cast<const float4 *>(pr.surface_map), pr.n_surface_map, none, pr.n_neighbors,
+          reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1, r1, J1, states);
+      }
+    }
+    hipLaunchKernelGGL(lfx::align_step_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, max_iter,
+      r3, J3, pr.begin3, pr.count3, pr.stride3, r1, J1, pr.begin1, pr.count1, pr.stride1, err, dev);
+  }
+  LFX_HIP(c, hipGetLastError());
+  std::vector<lfx::AlignState> h(n_clouds);
+  LFX_HIP(c, hipMemcpyAsync(h.data(), states, sizeof(lfx::AlignState) * n_clouds, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipStreamSynchronize(st));
+  for (uint32_t s = 0; s < n_clouds; s++) {
+    for (int i = 0; i < 12; i++) {results[s].pose[i] = h[s].pose.m[i];}
+    results[s].error = h[s].error; results[s].error_scale = h[s].scale;
+    results[s].iteration = h[s].iteration; results[s].code = h[s].code;
+  }
+  return LFX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char * lfx_align_message(int code)
+{
+  switch (code) {                         // the texts of optimization_result.hpp:43-79
+    case LFX_ALIGN_CONVERGED: return "Optimization successfully converged";
+    case LFX_ALIGN_LARGER_ERROR: return "The error is larger than previous iteration";
+    case LFX_ALIGN_LARGER_SCALE: return "The scale is larger than previous iteration";
+    case LFX_ALIGN_MAX_ITERATION: return "The iteration reached the maximum value";
+    case LFX_ALIGN_EMPTY_INPUT: return "The input data is empty";
+    default: return "unknown";
+  }
+}
+
+int lfx_scan_to_map_align(
+  lfx_ctx * c, const float * d_edge_map, uint32_t n_edge_map, const float * d_surface_map, uint32_t n_surface_map,
+  uint32_t n_neighbors, int max_iter,
+  const float * d_edge_points, const uint32_t * d_edge_begin, const uint32_t * d_edge_count, uint32_t edge_count_stride,
+  uint32_t max_edge_points_per_cloud, size_t total_edge_points,
+  const float * d_surface_points, const uint32_t * d_surface_begin, const uint32_t * d_surface_count,
+  uint32_t surface_count_stride, uint32_t max_surface_points_per_cloud, size_t total_surface_points,
+  uint32_t n_clouds, const double * initial_poses, lfx_align_result * results, void * stream)
+{
+  if (!c || !d_edge_map || !d_surface_map || !d_edge_points || !d_edge_begin || !d_edge_count || !d_surface_points ||
+    !d_surface_begin || !d_surface_count || !initial_poses || !results || n_clouds == 0 || edge_count_stride == 0 ||
+    surface_count_stride == 0)
+  {
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  if (max_iter < 1) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "max_iter must be >= 1");}
+  if (n_neighbors < 3 || n_neighbors > (uint32_t)lfx::kNearestMax || n_edge_map < n_neighbors || n_surface_map < n_neighbors) {
+    return fail(c, LFX_ERR_INVALID_ARGUMENT, "n_neighbors must be in [3, 16] and both maps must hold that many points");
+  }
+  LFX_HIP(c, hipSetDevice(c->device));
+  AlignProblem pr;
+  pr.edge_map = d_edge_map; pr.n_edge_map = n_edge_map; pr.edge_points = d_edge_points;
+  pr.begin3 = d_edge_begin; pr.count3 = d_edge_count; pr.stride3 = edge_count_stride; pr.longest3 = max_edge_points_per_cloud;
+  pr.total3 = total_edge_points;
+  pr.surface_map = d_surface_map; pr.n_surface_map = n_surface_map; pr.surface_points = d_surface_points;
+  pr.begin1 = d_surface_begin; pr.count1 = d_surface_count; pr.stride1 = surface_count_stride;
+  pr.longest1 = max_surface_points_per_cloud; pr.total1 = total_surface_points;
+  pr.n_neighbors = n_neighbors;
+  return run_align(c, pr, n_clouds, max_iter, initial_poses, results, static_cast<hipStream_t>(stream));
+}
+
+int lfx_align_point_pairs(
+  lfx_ctx * c, const double * d_source, const double * d_target, const uint32_t * d_begin, const uint32_t * d_count,
+  uint32_t max_points_per_cloud, size_t total_points, uint32_t n_clouds, int max_iter, const double * initial_poses,
+  lfx_align_result * results, void * stream)
+{
+  if (!c || !d_source || !d_target || !d_begin || !d_count || !initial_poses || !results || n_clouds == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (max_iter < 1) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "max_iter must be >= 1");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  AlignProblem pr;
+  pr.X = d_source; pr.Y = d_target; pr.begin3 = d_begin; pr.count3 = d_count; pr.stride3 = 1; pr.longest3 = max_points_per_cloud;
+  pr.total3 = total_points;
+  return run_align(c, pr, n_clouds, max_iter, initial_poses, results, static_cast<hipStream_t>(stream));
+}
+
+int lfx_localize_batch(
+  lfx_ctx * c, const float * d_edge_map, uint32_t n_edge_map, const float * d_surface_map, uint32_t n_surface_map,
+  uint32_t n_neighbors, int max_iter, float surface_leaf, const double * initial_poses, lfx_align_result * results, void * stream)
+{
+  if (!c || !initial_poses || !results) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  const uint32_t batch = c->last_batch;
+  const size_t total = c->h_scan_begin[batch];
+  const size_t need = 4 * total + 2 * (size_t)batch;
+  if (c->align_surface.n < need) {
+    c->align_surface.release();
+    if (c->align_surface.alloc(need) != hipSuccess) {
+      c->align_surface.n = 0;
+      return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the downsampled surface clouds");
+    }
+  }
+  float * down = c->align_surface.p;
+  uint32_t * down_count = reinterpret_cast<uint32_t *>(down + 4 * total), * down_status = down_count + batch;
+  const int rc = lfx_downsample_surface(c, surface_leaf, down, down_count, down_status, stream);
+  if (rc != LFX_OK) {return rc;}
+  // where PCL gives the cloud back unfiltered (leaf too small for its extent) the rows are built from all surface points
+  hipLaunchKernelGGL(lfx::downsample_passthrough_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream),
+    reinterpret_cast<const float4 *>(c->surf_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoSurface, 4u,
+    reinterpret_cast<float4 *>(down), down_count, down_status);
+  uint32_t longest = 0;
+  for (uint32_t s = 0; s < batch; s++) {
+    const uint32_t n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
+    longest = n > longest ? n : longest;                 // a scan has no more edge / surface points than points
+  }
+  return lfx_scan_to_map_align(c, d_edge_map, n_edge_map, d_surface_map, n_surface_map, n_neighbors, max_iter,
+           reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest, total,
+           down, c->scan_begin.p, down_count, 1, longest, total, batch, initial_poses, results, stream);
 }
 
 }  // extern "C"

@@ -3010,6 +3010,16 @@ struct MapPose
   double qw, qx, qy, qz;                  // Eigen::Quaterniond(R), computed by the host
 };
 
+// state of Optimizer::Run (optimizer.hpp:79-123) for one scan, kept on the device between the kernels of an iteration
+struct AlignState
+{
+  MapPose pose;                           // MakePose(q, t) and Quaterniond(pose.rotation()), what Problem::Make is given
+  double q[4], t[3];                      // the optimizer's q (w x y z) and t
+  double prev_error, prev_scale;
+  double error, scale;                    // OptimizationResult
+  int32_t iteration, code, done, pad;
+};
+
 struct D3 { double x, y, z; };
 __device__ inline D3 d3_sub(D3 a, D3 b) {return {a.x - b.x, a.y - b.y, a.z - b.z};}
 __device__ inline D3 d3_cross(D3 a, D3 b) {return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};}
@@ -3074,10 +3084,14 @@ template<bool SURFACE>
 __global__ __launch_bounds__(128) void scan_to_map_kernel(
   const float4 * __restrict__ map, uint32_t n_map, MapPose P, uint32_t k, const float4 * __restrict__ pts,
   const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
-  double * __restrict__ residual, double * __restrict__ jacobian)
+  double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align)
 {
   constexpr int KM = kNearestMax, T = 128;
   const uint32_t s = blockIdx.y, tid = threadIdx.x;
+  if (align) {                                         // inside lfx_scan_to_map_align: this scan's current pose
+    if (align[s].done) {return;}
+    P = align[s].pose;
+  }
   const uint32_t b = begin[s], n = count[(size_t)s * count_stride];
   const uint32_t i = blockIdx.x * T + tid;
   if (blockIdx.x * T >= n) {return;}                   // the whole workgroup is beyond this cloud
@@ -3201,6 +3215,390 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
     for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
     J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
     residual[b + i] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+  }
+}
+
+// lfx_localize_batch: where voxel_downsample_kernel gave a cloud back unfiltered (status 1, nothing written), Downsample
+// returns the input cloud (downsample.hpp:37-51 -> pcl::VoxelGrid::applyFilter), so the rows are built from all its points.
+__global__ void downsample_passthrough_kernel(
+  const float4 * __restrict__ pts, const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
+  float4 * __restrict__ out, uint32_t * __restrict__ out_count, const uint32_t * __restrict__ status)
+{
+  const uint32_t s = blockIdx.x;
+  if (status[s] == 0u) {return;}
+  const uint32_t n = count[(size_t)s * count_stride], b = begin[s];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float4 p = pts[b + i];
+    out[b + i] = make_float4(p.x, p.y, p.z, 1.f);
+  }
+  if (threadIdx.x == 0) {out_count[s] = n;}
+}
+
+// ------------------------------------------------------------------------------------------
+// The optimizer around the rows: Optimizer::Run (localization/include/lidar_feature_localization/optimizer.hpp:79-123)
+// as kernels, so that the iterations of a batch of scans run without a round trip to the host: align_begin_kernel, then
+// per iteration the two row builds above and align_step_kernel (errors, robust scale, weights, the sums of
+// WeightedUpdate, the 6 x 6 solve, the pose update and the three stopping tests); a finished scan's kernels return at
+// once.  PARITY UNPINNED (Eigen's arithmetic; sums are taken in a fixed tree order here, not row by row).
+constexpr int kAlignThreads = 256;
+enum AlignCode : int32_t {kAlignConverged = 0, kAlignLargerError = 1, kAlignLargerScale = 2, kAlignMaxIteration = 3, kAlignEmpty = 4};
+
+// Eigen::Quaterniond(Matrix3d): the branch on the trace, then on the largest diagonal entry
+__device__ inline void quaternion_of_rotation(const double (&m)[12], double & w, double (&v)[3])
+{
+  double t = m[0] + m[5] + m[10];
+  if (t > 0.) {
+    t = sqrt(t + 1.0);
+    w = 0.5 * t;
+    t = 0.5 / t;
+    v[0] = (m[9] - m[6]) * t; v[1] = (m[2] - m[8]) * t; v[2] = (m[4] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[5] > m[0]) {i = 1;}
+    if (m[10] > m[5 * i]) {i = 2;}
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[5 * i] - m[5 * j] - m[5 * k] + 1.0);
+    v[i] = 0.5 * t;
+    t = 0.5 / t;
+    w = (m[4 * k + j] - m[4 * j + k]) * t;
+    v[j] = (m[4 * j + i] + m[4 * i + j]) * t;
+    v[k] = (m[4 * k + i] + m[4 * i + k]) * t;
+  }
+}
+
+// MakePose (posevec.cpp:47-55: q.toRotationMatrix(), q as it is) followed by what every Problem::Make starts with
+__device__ inline void refresh_pose(AlignState & a)
+{
+  const double w = a.q[0], x = a.q[1], y = a.q[2], z = a.q[3];
+  const double tx = 2. * x, ty = 2. * y, tz = 2. * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  double (&m)[12] = a.pose.m;
+  m[0] = 1. - (tyy + tzz); m[1] = txy - twz; m[2] = txz + twy; m[3] = a.t[0];
+  m[4] = txy + twz; m[5] = 1. - (txx + tzz); m[6] = tyz - twx; m[7] = a.t[1];
+  m[8] = txz - twy; m[9] = tyz + twx; m[10] = 1. - (txx + tyy); m[11] = a.t[2];
+  double qw, v[3];
+  quaternion_of_rotation(m, qw, v);
+  a.pose.qw = qw; a.pose.qx = v[0]; a.pose.qy = v[1]; a.pose.qz = v[2];
+}
+
+__global__ void align_begin_kernel(AlignState * __restrict__ states, const double * __restrict__ initial /* [n][12] */, uint32_t n)
+{
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) {return;}
+  AlignState a;
+  double m[12];
+  for (int i = 0; i < 12; i++) {m[i] = initial[12 * (size_t)s + i];}
+  double w, v[3];
+  quaternion_of_rotation(m, w, v);                     // Eigen::Quaterniond q(initial_pose.linear())
+  a.q[0] = w; a.q[1] = v[0]; a.q[2] = v[1]; a.q[3] = v[2];
+  a.t[0] = m[3]; a.t[1] = m[7]; a.t[2] = m[11];
+  a.prev_error = 1.7976931348623157e308; a.prev_scale = 1.7976931348623157e308;   // std::numeric_limits<double>::max()
+  a.error = 0.; a.scale = 0.; a.iteration = 0; a.code = kAlignMaxIteration; a.done = 0; a.pad = 0;
+  refresh_pose(a);
+  states[s] = a;
+}
+
+// AlignmentProblem::Make (alignment.cpp:33-78), the problem the reference's optimizer tests run: rows [DRpDq(q, x), I],
+// residual pose * x - y.  X, Y: [n][3] doubles of cloud s from record begin[s].
+__global__ __launch_bounds__(128) void pair_rows_kernel(
+  const double * __restrict__ X, const double * __restrict__ Y, const uint32_t * __restrict__ begin,
+  const uint32_t * __restrict__ count, double * __restrict__ residual, double * __restrict__ jacobian,
+  const AlignState * __restrict__ align)
+{
+  const uint32_t s = blockIdx.y;
+  if (align[s].done) {return;}
+  const uint32_t i = blockIdx.x * 128u + threadIdx.x;
+  if (i >= count[s]) {return;}
+  const MapPose P = align[s].pose;
+  const size_t at = (size_t)begin[s] + i;
+  const D3 x{X[3 * at], X[3 * at + 1], X[3 * at + 2]};
+  double d[12];
+  drp_dq(P, x, d);
+  double * J = jacobian + 21 * at;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {J[7 * r + c] = d[4 * r + c];}
+#pragma unroll
+    for (int c = 0; c < 3; c++) {J[7 * r + 4 + c] = r == c ? 1. : 0.;}
+  }
+  residual[3 * at] = P.m[0] * x.x + P.m[1] * x.y + P.m[2] * x.z + P.m[3] - Y[3 * at];
+  residual[3 * at + 1] = P.m[4] * x.x + P.m[5] * x.y + P.m[6] * x.z + P.m[7] - Y[3 * at + 1];
+  residual[3 * at + 2] = P.m[8] * x.x + P.m[9] * x.y + P.m[10] * x.z + P.m[11] - Y[3 * at + 2];
+}
+
+// k-th smallest (0-based) of the n non-negative doubles v[0..n): most-significant-byte-first radix selection over their bit
+// patterns (non-negative doubles order like their bits), a 256-bin histogram in LDS per byte.  Every thread of the
+// workgroup calls it and gets the value.  sh: 258 words of LDS.
+__device__ inline double workgroup_select(const double * __restrict__ v, uint32_t n, uint32_t k, uint32_t * sh)
+{
+  const int tid = threadIdx.x, T = blockDim.x;
+  uint64_t prefix = 0, mask = 0;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int b = tid; b < 256; b += T) {sh[b] = 0u;}
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += T) {
+      const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
+      if ((key & mask) == prefix) {atomicAdd(&sh[(uint32_t)(key >> shift) & 255u], 1u);}
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t cum = 0, b = 0;
+      for (; b < 255u; b++) {
+        if (cum + sh[b] > k) {break;}
+        cum += sh[b];
+      }
+      sh[256] = b; sh[257] = k - cum;
+    }
+    __syncthreads();
+    prefix |= (uint64_t)sh[256] << shift;
+    mask |= 0xFFull << shift;
+    k = sh[257];
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)prefix);
+}
+
+// Median (lib/src/stats.cpp:34-55) of non-negative values
+__device__ inline double workgroup_median(const double * __restrict__ v, uint32_t n, uint32_t * sh)
+{
+  if (n & 1u) {return workgroup_select(v, n, (n - 1u) / 2u, sh);}
+  const double e0 = workgroup_select(v, n, n / 2u, sh);
+  const double e1 = workgroup_select(v, n, n / 2u - 1u, sh);
+  return (e0 + e1) / 2.;
+}
+
+// IsDegenerate (degenerate.cpp:32-37) of a symmetric 7 x 7 matrix: cyclic Jacobi rotations, then |eigenvalue| < threshold
+__device__ inline bool is_degenerate7(const double * Din, double threshold)
+{
+  constexpr int n = 7;
+  double A[n * n];
+  for (int i = 0; i < n * n; i++) {A[i] = Din[i];}
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0., diag = 0.;
+    for (int i = 0; i < n; i++) {
+      diag += A[i * n + i] * A[i * n + i];
+      for (int j = i + 1; j < n; j++) {off += A[i * n + j] * A[i * n + j];}
+    }
+    if (off <= 1e-30 * diag || off == 0.) {break;}
+    for (int p = 0; p < n; p++) {
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        if (apq == 0.) {continue;}
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2. * apq);
+        const double t = (theta >= 0. ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+        const double c = 1. / sqrt(t * t + 1.), sn = t * c;
+        for (int k = 0; k < n; k++) {
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - sn * akq;
+          A[k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - sn * aqk;
+          A[q * n + k] = sn * apk + c * aqk;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {if (fabs(A[i * n + i]) < threshold) {return true;}}
+  return false;
+}
+
+// CalcUpdate without the sums (optimizer.cpp:60-97): MakeM, the degenerate test on D, -(M^T A M).llt().solve(M^T b),
+// AngleAxisToQuaternion.  D, A: 7 x 7 row-major; dq (w x y z), dt out.
+__device__ inline void solve_update(const double (&q)[4], const double * D, const double * A, const double * b, double (&dq)[4], double (&dt)[3])
+{
+  double dx[6] = {0., 0., 0., 0., 0., 0.};
+  if (!is_degenerate7(D, 0.1)) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double L[16] = {w, -x, -y, -z, x, w, -z, y, y, z, w, -x, z, -y, x, w};   // rotationlib LeftMultiplicationMatrix
+    double M[42];
+    for (int i = 0; i < 42; i++) {M[i] = 0.;}
+    for (int r = 0; r < 4; r++) {for (int c = 0; c < 3; c++) {M[6 * r + c] = 0.5 * L[4 * r + 1 + c];}}
+    for (int a = 0; a < 3; a++) {M[6 * (4 + a) + 3 + a] = 1.;}
+    double AM[42], H[36], g[6];
+    for (int r = 0; r < 7; r++) {
+      for (int c = 0; c < 6; c++) {
+        double s = 0.;
+        for (int k = 0; k < 7; k++) {s += A[7 * r + k] * M[6 * k + c];}
+        AM[6 * r + c] = s;
+      }
+    }
+    for (int r = 0; r < 6; r++) {
+      for (int c = 0; c < 6; c++) {
+        double s = 0.;
+        for (int k = 0; k < 7; k++) {s += M[6 * k + r] * AM[6 * k + c];}
+        H[6 * r + c] = s;
+      }
+      double s = 0.;
+      for (int k = 0; k < 7; k++) {s += M[6 * k + r] * b[k];}
+      g[r] = s;
+    }
+    double Lc[36];
+    for (int i = 0; i < 36; i++) {Lc[i] = 0.;}
+    for (int j = 0; j < 6; j++) {
+      double s = H[6 * j + j];
+      for (int k = 0; k < j; k++) {s -= Lc[6 * j + k] * Lc[6 * j + k];}
+      Lc[6 * j + j] = sqrt(s);
+      for (int i = j + 1; i < 6; i++) {
+        double v = H[6 * i + j];
+        for (int k = 0; k < j; k++) {v -= Lc[6 * i + k] * Lc[6 * j + k];}
+        Lc[6 * i + j] = v / Lc[6 * j + j];
+      }
+    }
+    double yv[6], xv[6];
+    for (int i = 0; i < 6; i++) {
+      double v = g[i];
+      for (int k = 0; k < i; k++) {v -= Lc[6 * i + k] * yv[k];}
+      yv[i] = v / Lc[6 * i + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+      double v = yv[i];
+      for (int k = i + 1; k < 6; k++) {v -= Lc[6 * k + i] * xv[k];}
+      xv[i] = v / Lc[6 * i + i];
+    }
+    for (int a = 0; a < 6; a++) {dx[a] = -xv[a];}
+  }
+  const double k = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);            // AngleAxisToQuaternion, posevec.cpp:32-45
+  if (k < 1e-8) {
+    dq[0] = 1.; dq[1] = 0.; dq[2] = 0.; dq[3] = 0.;
+  } else {
+    const double sn = sin(k / 2.);
+    dq[0] = cos(k / 2.);
+    for (int a = 0; a < 3; a++) {dq[1 + a] = (dx[a] / k) * sn;}
+  }
+  for (int a = 0; a < 3; a++) {dt[a] = dx[3 + a];}
+}
+
+// One iteration of Optimizer::Run after Problem::Make, one workgroup per scan.  Rows of scan s: n3 = count3[s * stride3]
+// residuals of dimension 3 (r3 / J3 from record begin3[s]: the edge rows, or the point pairs), then n1 = count1[...]
+// of dimension 1 (the surface rows; count1 may be null).  errors / deviations: scratch, one double per row, rows of scan
+// s from begin3[s] + begin1[s].
+__global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
+  AlignState * __restrict__ states, int iter, int max_iter,
+  const double * __restrict__ r3, const double * __restrict__ J3, const uint32_t * __restrict__ begin3,
+  const uint32_t * __restrict__ count3, uint32_t stride3,
+  const double * __restrict__ r1, const double * __restrict__ J1, const uint32_t * __restrict__ begin1,
+  const uint32_t * __restrict__ count1, uint32_t stride1, double * __restrict__ errors, double * __restrict__ deviations)
+{
+  constexpr int T = kAlignThreads, NS = 64;                 // 28 (D) + 28 (A) upper triangles + 7 (b) + 1 (error)
+  const uint32_t s = blockIdx.x;
+  const int tid = threadIdx.x;
+  AlignState & st = states[s];
+  if (st.done) {return;}
+  __shared__ uint32_t sh[258];
+  __shared__ double part[T / 64][NS];
+  __shared__ double total[NS];
+  const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u, n = n3 + n1;
+  if (n == 0u) {                                            // EmptyInput (optimization_result.hpp:46-50)
+    if (tid == 0) {st.iteration = iter; st.error = 0.; st.scale = 0.; st.code = kAlignEmpty; st.done = 1;}
+    return;
+  }
+  const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
+  double * err = errors + (size_t)b3 + b1;
+  double * dev = deviations + (size_t)b3 + b1;
+  // ComputeErrors (optimizer.cpp:99-107)
+  for (uint32_t i = tid; i < n; i += T) {
+    double e;
+    if (i < n3) {
+      const double * r = r3 + 3 * ((size_t)b3 + i);
+      e = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    } else {
+      const double r = r1[(size_t)b1 + (i - n3)];
+      e = r * r;
+    }
+    err[i] = e;
+  }
+  __syncthreads();
+  // Scale (robust.cpp:36-50): b * median(|e - median(e)|)
+  const double median = workgroup_median(err, n, sh);
+  for (uint32_t i = tid; i < n; i += T) {dev[i] = fabs(err[i] - median);}
+  __syncthreads();
+  const double scale = 1.482602218505602 * workgroup_median(dev, n, sh);
+  // ComputeWeights (optimizer.cpp:120-127) and the sums of WeightedUpdate (optimizer.cpp:40-64)
+  double acc[NS];
+#pragma unroll
+  for (int a = 0; a < NS; a++) {acc[a] = 0.;}
+  for (uint32_t i = tid; i < n; i += T) {
+    const double e = err[i];
+    const double en = e / (scale + 1e-16);
+    const double w = en < 1.345 * 1.345 ? 1. : 1.345 / sqrt(en);          // HuberDerivative, robust.cpp:61-68
+    acc[63] += e;
+    const int dim = i < n3 ? 3 : 1;
+    const double * J = i < n3 ? J3 + 21 * ((size_t)b3 + i) : J1 + 7 * ((size_t)b1 + (i - n3));
+    const double * r = i < n3 ? r3 + 3 * ((size_t)b3 + i) : r1 + ((size_t)b1 + (i - n3));
+    for (int k = 0; k < dim; k++) {
+      double row[7];
+#pragma unroll
+      for (int a = 0; a < 7; a++) {row[a] = J[7 * k + a];}
+      const double rk = r[k];
+      int at = 0;
+#pragma unroll
+      for (int a = 0; a < 7; a++) {
+#pragma unroll
+        for (int c = a; c < 7; c++) {
+          const double jj = row[a] * row[c];
+          acc[at] += jj;
+          acc[28 + at] += w * jj;
+          at++;
+        }
+        acc[56 + a] += w * (row[a] * rk);
+      }
+    }
+  }
+  // fixed-order tree: lanes of a wave, then the waves
+#pragma unroll
+  for (int a = 0; a < NS; a++) {
+    double v = acc[a];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {v += __shfl_xor(v, off, 64);}
+    if ((tid & 63) == 0) {part[tid >> 6][a] = v;}
+  }
+  __syncthreads();
+  if (tid < NS) {
+    double v = 0.;
+    for (int wv = 0; wv < T / 64; wv++) {v += part[wv][tid];}
+    total[tid] = v;
+  }
+  __syncthreads();
+  if (tid != 0) {return;}
+  const double error = total[63];
+  if (error > st.prev_error) {                               // LargerErrorThanPrevious
+    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerError; st.done = 1;
+    return;
+  }
+  st.prev_error = error;
+  if (scale > st.prev_scale) {                               // LargerScaleThanPrevious
+    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerScale; st.done = 1;
+    return;
+  }
+  st.prev_scale = scale;
+  double D[49], A[49], b[7];
+  {
+    int at = 0;
+    for (int a = 0; a < 7; a++) {
+      for (int c = a; c < 7; c++) {
+        D[7 * a + c] = total[at]; D[7 * c + a] = total[at];
+        A[7 * a + c] = total[28 + at]; A[7 * c + a] = total[28 + at];
+        at++;
+      }
+      b[a] = total[56 + a];
+    }
+  }
+  double q[4] = {st.q[0], st.q[1], st.q[2], st.q[3]}, dq[4], dt[3];
+  solve_update(q, D, A, b, dq, dt);
+  st.q[0] = q[0] * dq[0] - q[1] * dq[1] - q[2] * dq[2] - q[3] * dq[3];          // q = q * dq
+  st.q[1] = q[0] * dq[1] + q[1] * dq[0] + q[2] * dq[3] - q[3] * dq[2];
+  st.q[2] = q[0] * dq[2] + q[2] * dq[0] + q[3] * dq[1] - q[1] * dq[3];
+  st.q[3] = q[0] * dq[3] + q[3] * dq[0] + q[1] * dq[2] - q[2] * dq[1];
+  st.t[0] += dt[0]; st.t[1] += dt[1]; st.t[2] += dt[2];
+  refresh_pose(st);
+  const double nq = sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]), nt = sqrt(dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2]);
+  if (nq < 1e-3 && nt < 1e-3) {                              // CheckConvergence (optimizer.cpp:35-38)
+    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignConverged; st.done = 1;
+  } else if (iter == max_iter - 1) {                         // ReachedMaximumIteration
+    st.iteration = max_iter; st.error = error; st.scale = scale; st.code = kAlignMaxIteration; st.done = 1;
   }
 }
 

@@ -189,6 +189,50 @@ class FeatureExtraction:
             self._ctx, C.c_void_p(int(d_map)), int(n_map), pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
             C.c_void_p(int(d_residual)), C.c_void_p(int(d_jacobian)), C.c_void_p(int(stream))))
 
+    def _align_results(self, res):
+        out = []
+        for r in res:
+            out.append(dict(pose=np.array(r.pose[:], np.float64).reshape(3, 4), error=r.error, error_scale=r.error_scale,
+                            iteration=r.iteration, code=r.code, success=r.code <= 2,
+                            message=self._L.lfx_align_message(r.code).decode()))
+        return out
+
+    def scan_to_map_align(self, d_edge_map, n_edge_map, d_surface_map, n_surface_map, n_neighbors, max_iter, d_edge_points,
+                          d_edge_begin, d_edge_count, edge_count_stride, max_edge, total_edge, d_surface_points, d_surface_begin,
+                          d_surface_count, surface_count_stride, max_surface, total_surface, initial_poses, stream=0):
+        """lfx_scan_to_map_align: Optimizer<LOAMOptimizationProblem>::Run (optimizer.hpp:79-123) per scan; initial_poses
+        [n][3][4]; returns one dict per scan (pose, error, error_scale, iteration, code, success, message)."""
+        poses = np.ascontiguousarray(initial_poses, np.float64).reshape(-1, 12)
+        res = (B.AlignResult * len(poses))()
+        v = lambda a: C.c_void_p(int(a))   # noqa: E731
+        B.check(self._ctx, self._L.lfx_scan_to_map_align(
+            self._ctx, v(d_edge_map), int(n_edge_map), v(d_surface_map), int(n_surface_map), int(n_neighbors), int(max_iter),
+            v(d_edge_points), v(d_edge_begin), v(d_edge_count), int(edge_count_stride), int(max_edge), int(total_edge),
+            v(d_surface_points), v(d_surface_begin), v(d_surface_count), int(surface_count_stride), int(max_surface),
+            int(total_surface), len(poses), poses.ctypes.data_as(C.POINTER(C.c_double)), res, v(stream)))
+        return self._align_results(res)
+
+    def align_point_pairs(self, d_source, d_target, d_begin, d_count, max_points, total_points, max_iter, initial_poses, stream=0):
+        """lfx_align_point_pairs: the same optimizer on AlignmentProblem (alignment.cpp:33-78)."""
+        poses = np.ascontiguousarray(initial_poses, np.float64).reshape(-1, 12)
+        res = (B.AlignResult * len(poses))()
+        v = lambda a: C.c_void_p(int(a))   # noqa: E731
+        B.check(self._ctx, self._L.lfx_align_point_pairs(
+            self._ctx, v(d_source), v(d_target), v(d_begin), v(d_count), int(max_points), int(total_points), len(poses),
+            int(max_iter), poses.ctypes.data_as(C.POINTER(C.c_double)), res, v(stream)))
+        return self._align_results(res)
+
+    def localize_batch(self, d_edge_map, n_edge_map, d_surface_map, n_surface_map, initial_poses, n_neighbors=15, max_iter=20,
+                       surface_leaf=1.0, stream=0):
+        """lfx_localize_batch: Localizer::Update (localizer.hpp:71-80) for every scan of the last device batch."""
+        poses = np.ascontiguousarray(initial_poses, np.float64).reshape(-1, 12)
+        res = (B.AlignResult * len(poses))()
+        B.check(self._ctx, self._L.lfx_localize_batch(
+            self._ctx, C.c_void_p(int(d_edge_map)), int(n_edge_map), C.c_void_p(int(d_surface_map)), int(n_surface_map),
+            int(n_neighbors), int(max_iter), float(surface_leaf), poses.ctypes.data_as(C.POINTER(C.c_double)), res,
+            C.c_void_p(int(stream))))
+        return self._align_results(res)
+
     def scan_routes(self, n_scans, stream=0):
         """lfx_scan_routes: per scan of the last batch 1 = read in place, 2 = in place through ring transforms, 0 = bucketed."""
         out = np.zeros(n_scans, np.uint8)

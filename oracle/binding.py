@@ -92,6 +92,20 @@ def lib():
         L.orc_loc_edge_residuals.restype = None
         L.orc_loc_surface_residuals.argtypes = [_pf, _i, _pd, _i, _pf, _i, _pd, _pd]
         L.orc_loc_surface_residuals.restype = None
+        for name in ("orc_loc_median", "orc_loc_mad", "orc_loc_scale"):
+            getattr(L, name).argtypes = [_pd, _i]
+            getattr(L, name).restype = _d
+        for name in ("orc_loc_huber", "orc_loc_huber_derivative"):
+            getattr(L, name).argtypes = [_d, _d]
+            getattr(L, name).restype = _d
+        L.orc_loc_is_degenerate.argtypes = [_pd, _i, _d]
+        for name in ("orc_loc_angle_axis_to_quaternion", "orc_loc_rotation_matrix", "orc_loc_make_m"):
+            getattr(L, name).argtypes = [_pd, _pd]
+            getattr(L, name).restype = None
+        L.orc_loc_pairs_update.argtypes = [_pd, _pd, _i, _pd, _pd, _pd]
+        L.orc_loc_pairs_update.restype = None
+        L.orc_loc_optimize_pairs.argtypes = [_pd, _pd, _i, _pd, _i, _pd, _pd, _pd, _pi, _pi]
+        L.orc_loc_optimize_scan.argtypes = [_pf, _i, _pf, _i, _i, _pf, _i, _pf, _i, _pd, _i, _pd, _pd, _pd, _pi, _pi]
         L.orc_voxel_downsample.argtypes = [_pf, _i, _f, _pf, _pi]
         L.orc_range_message.argtypes = [_i, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_size_t]
         L.orc_irange.argtypes = [_i, _pi]

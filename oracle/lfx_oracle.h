@@ -131,6 +131,25 @@ void orc_loc_edge_residuals(const float *map, int n_map, const double *pose /* [
                             int n, double *residual /* [n][3] */, double *jacobian /* [n][3][7] */);     /* edge.hpp:86-124 */
 void orc_loc_surface_residuals(const float *map, int n_map, const double *pose, int k, const float *points, int n,
                                double *residual /* [n] */, double *jacobian /* [n][7] */);              /* surface.hpp:116-139 */
+/* the optimizer around those rows (optimizer.hpp:70-127, src/optimizer.cpp, robust.cpp, degenerate.cpp, posevec.cpp,
+ * lib/src/stats.cpp, alignment.cpp); pinned by test_robust.cpp, test_degenerate.cpp, test_posevec.cpp, test_optimizer.cpp.
+ * code: 0 converged, 1 error larger than before, 2 scale larger than before (success), 3 maximum iteration, 4 empty input. */
+double orc_loc_median(const double *v, int n);                                                          /* stats.cpp:34-55 */
+double orc_loc_mad(const double *v, int n);                                                             /* robust.cpp:36-40 */
+double orc_loc_scale(const double *v, int n);                                                           /* robust.cpp:42-50 */
+double orc_loc_huber(double e, double k);                                                               /* robust.cpp:52-59 */
+double orc_loc_huber_derivative(double e, double k);                                                    /* robust.cpp:61-68 */
+int orc_loc_is_degenerate(const double *C /* [n][n] */, int n, double threshold);                       /* degenerate.cpp:32-37 */
+void orc_loc_angle_axis_to_quaternion(const double *theta, double *wxyz);                               /* posevec.cpp:32-45 */
+void orc_loc_rotation_matrix(const double *wxyz, double *R /* row-major */);                            /* Eigen toRotationMatrix */
+void orc_loc_make_m(const double *wxyz, double *M /* [7][6] */);                                        /* optimizer.cpp:73-84 */
+void orc_loc_pairs_update(const double *X, const double *Y, int n, const double *pose, double *dq /* wxyz */, double *dt);
+int orc_loc_optimize_pairs(const double *X /* [n][3] */, const double *Y, int n, const double *initial_pose, int max_iter,
+                           double *pose_out, double *error_out, double *scale_out, int *iteration_out, int *code_out);
+int orc_loc_optimize_scan(const float *edge_map, int n_edge_map, const float *surface_map, int n_surface_map, int k,
+                          const float *edge_points, int n_edge, const float *surface_points, int n_surface,
+                          const double *initial_pose, int max_iter, double *pose_out, double *error_out, double *scale_out,
+                          int *iteration_out, int *code_out);
 void orc_label_to_color(uint8_t label, uint8_t rgb[3]);                               /* color_points.cpp:39-68 */
 
 /* ---- whole scan: the body of FeatureExtraction::Callback, feature_extraction.cpp:114-157 ----

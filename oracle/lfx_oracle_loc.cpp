@@ -7,7 +7,13 @@
 // (NearestKSearch), math.hpp:36-40 (SolveLinear), rotationlib/src/jacobian/quaternion.cpp:35-52 (DRpDq),
 // rotationlib/src/hat.cpp:35-43 (Hat), lib/src/algorithm.cpp:33-50 (SortThreeValues).
 //
-// PARITY UNPINNED beyond the vectors of localization/test/test_edge.cpp and test_math.cpp: the arithmetic underneath is
+// ... and of the optimizer around it (optimizer.hpp:70-127 Optimizer::Run, src/optimizer.cpp:35-127 CheckConvergence,
+// WeightedUpdate, MakeM, CalcUpdate, ComputeErrors, NormalizeErrorScale, ComputeWeights; src/robust.cpp:36-71;
+// src/degenerate.cpp:32-37; src/posevec.cpp:32-55; lib/src/stats.cpp:34-67 Median; src/alignment.cpp:33-78 the
+// point-pair problem the reference's optimizer tests run; rotationlib/src/quaternion.cpp:45-60).
+//
+// PARITY UNPINNED beyond the vectors of localization/test/test_edge.cpp, test_math.cpp, test_robust.cpp,
+// test_degenerate.cpp, test_posevec.cpp and test_optimizer.cpp: the arithmetic underneath is
 // third party and absent from this image -- Eigen (sums of colwise().mean(), D^T D, SelfAdjointEigenSolver::
 // computeDirect, householderQr, Quaternion(Matrix3)) and nanoflann 1.x (un-vendored submodule: exact L2 k-nearest
 // search, order of equidistant neighbours unspecified).  This file uses plain sequential double arithmetic, a Jacobi
@@ -17,6 +23,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <limits>
 #include <utility>
 #include <vector>
 
@@ -175,6 +183,253 @@ void SolveLinear(std::vector<double> A, int rows, int cols, std::vector<double> 
     x[c] = s / A[c * cols + c];
   }
 }
+
+// ---- the optimizer (optimizer.hpp / src/optimizer.cpp) ---------------------------------------------------------------
+double MedianOf(std::vector<double> v)                                  // lib/src/stats.cpp:34-55
+{
+  const size_t size = v.size();
+  if (size % 2 == 1) {
+    const size_t n = (size - 1) / 2;
+    std::nth_element(v.begin(), v.begin() + n, v.end());
+    return v[n];
+  }
+  const size_t n = size / 2;
+  std::nth_element(v.begin(), v.begin() + n, v.end());
+  const double e0 = v[n];
+  std::nth_element(v.begin(), v.begin() + n - 1, v.end());
+  const double e1 = v[n - 1];
+  return (e0 + e1) / 2.;
+}
+
+double Mad(const std::vector<double> & v)                               // robust.cpp:36-40
+{
+  const double median = MedianOf(v);
+  std::vector<double> dev(v.size());
+  for (size_t i = 0; i < v.size(); i++) {dev[i] = std::fabs(v[i] - median);}
+  return MedianOf(dev);
+}
+
+double ScaleOf(const std::vector<double> & v) {return 1.482602218505602 * Mad(v);}   // robust.cpp:42-50
+
+double HuberOf(double e, double k) {return e < k * k ? e : 2 * k * std::sqrt(e) - k * k;}       // robust.cpp:52-59
+double HuberDerivativeOf(double e, double k) {return e < k * k ? 1. : k / std::sqrt(e);}       // robust.cpp:61-68
+
+// eigenvalues of a symmetric n x n matrix (row-major) by cyclic Jacobi rotations, ascending
+void JacobiEigenvalues(std::vector<double> A, int n, std::vector<double> & ev)
+{
+  for (int sweep = 0; sweep < 100; sweep++) {
+    double off = 0., diag = 0.;
+    for (int i = 0; i < n; i++) {
+      diag += A[i * n + i] * A[i * n + i];
+      for (int j = i + 1; j < n; j++) {off += A[i * n + j] * A[i * n + j];}
+    }
+    if (off <= 1e-30 * diag || off == 0.) {break;}
+    for (int p = 0; p < n; p++) {
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        if (apq == 0.) {continue;}
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2. * apq);
+        const double t = (theta >= 0. ? 1. : -1.) / (std::fabs(theta) + std::sqrt(theta * theta + 1.));
+        const double c = 1. / std::sqrt(t * t + 1.), s = t * c;
+        for (int k = 0; k < n; k++) {                                   // A <- A G
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq;
+          A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {                                   // A <- G^T A
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk;
+          A[q * n + k] = s * apk + c * aqk;
+        }
+      }
+    }
+  }
+  ev.resize(n);
+  for (int i = 0; i < n; i++) {ev[i] = A[i * n + i];}
+  std::sort(ev.begin(), ev.end());
+}
+
+bool IsDegenerateOf(const std::vector<double> & C, int n, double threshold)      // degenerate.cpp:32-37
+{
+  std::vector<double> ev;
+  JacobiEigenvalues(C, n, ev);
+  for (double e : ev) {if (std::fabs(e) < threshold) {return true;}}
+  return false;
+}
+
+void RotationOfQuaternion(const double q[4] /* w x y z */, double R[9])    // Eigen QuaternionBase::toRotationMatrix
+{
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2. * x, ty = 2. * y, tz = 2. * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1. - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1. - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1. - (txx + tyy);
+}
+
+void PoseOf(const double q[4], const double t[3], double pose[12])         // posevec.cpp:47-55 MakePose
+{
+  double R[9];
+  RotationOfQuaternion(q, R);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) {pose[4 * r + c] = R[3 * r + c];}
+    pose[4 * r + 3] = t[r];
+  }
+}
+
+void AngleAxisToQuaternionOf(const double theta[3], double q[4])           // posevec.cpp:32-45
+{
+  const double k = std::sqrt(theta[0] * theta[0] + theta[1] * theta[1] + theta[2] * theta[2]);
+  if (k < 1e-8) {q[0] = 1.; q[1] = q[2] = q[3] = 0.; return;}
+  const double s = std::sin(k / 2.);
+  q[0] = std::cos(k / 2.);
+  for (int a = 0; a < 3; a++) {q[1 + a] = (theta[a] / k) * s;}
+}
+
+void MakeMOf(const double q[4], double M[42])                              // optimizer.cpp:73-84, 7 x 6 row-major
+{
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double L[16] = {w, -x, -y, -z, x, w, -z, y, y, z, w, -x, z, -y, x, w};   // rotationlib quaternion.cpp:45-60
+  for (int i = 0; i < 42; i++) {M[i] = 0.;}
+  for (int r = 0; r < 4; r++) {for (int c = 0; c < 3; c++) {M[6 * r + c] = 0.5 * L[4 * r + 1 + c];}}
+  for (int a = 0; a < 3; a++) {M[6 * (4 + a) + 3 + a] = 1.;}
+}
+
+// rows: residuals of dimension 3 (r3 [n3][3], J3 [n3][3][7]) followed by residuals of dimension 1 (r1 [n1], J1 [n1][7])
+struct RowSet
+{
+  std::vector<double> J3, r3, J1, r1;
+  size_t size() const {return r3.size() / 3 + r1.size();}
+};
+
+// WeightedUpdate (optimizer.cpp:40-71); weights in row order
+bool WeightedUpdateOf(const double M[42], const std::vector<double> & weights, const RowSet & rows, double dx[6])
+{
+  std::vector<double> D(49, 0.), A(49, 0.);
+  double b[7] = {0., 0., 0., 0., 0., 0., 0.};
+  const size_t n3 = rows.r3.size() / 3;
+  for (size_t i = 0; i < rows.size(); i++) {
+    const int dim = i < n3 ? 3 : 1;
+    const double * J = i < n3 ? &rows.J3[21 * i] : &rows.J1[7 * (i - n3)];
+    const double * r = i < n3 ? &rows.r3[3 * i] : &rows.r1[i - n3];
+    double JtJ[49], Jtr[7];
+    for (int a = 0; a < 7; a++) {
+      for (int c = 0; c < 7; c++) {
+        double s = 0.;
+        for (int k = 0; k < dim; k++) {s += J[7 * k + a] * J[7 * k + c];}
+        JtJ[7 * a + c] = s;
+      }
+      double s = 0.;
+      for (int k = 0; k < dim; k++) {s += J[7 * k + a] * r[k];}
+      Jtr[a] = s;
+    }
+    for (int a = 0; a < 49; a++) {D[a] += JtJ[a]; A[a] += weights[i] * JtJ[a];}
+    for (int a = 0; a < 7; a++) {b[a] += weights[i] * Jtr[a];}
+  }
+  for (int a = 0; a < 6; a++) {dx[a] = 0.;}
+  if (IsDegenerateOf(D, 7, 0.1)) {return false;}
+  double AM[42], H[36], g[6];
+  for (int r = 0; r < 7; r++) {
+    for (int c = 0; c < 6; c++) {
+      double s = 0.;
+      for (int k = 0; k < 7; k++) {s += A[7 * r + k] * M[6 * k + c];}
+      AM[6 * r + c] = s;
+    }
+  }
+  for (int r = 0; r < 6; r++) {
+    for (int c = 0; c < 6; c++) {
+      double s = 0.;
+      for (int k = 0; k < 7; k++) {s += M[6 * k + r] * AM[6 * k + c];}
+      H[6 * r + c] = s;
+    }
+    double s = 0.;
+    for (int k = 0; k < 7; k++) {s += M[6 * k + r] * b[k];}
+    g[r] = s;
+  }
+  // llt().solve: H = L L^T
+  double Lc[36] = {0.};
+  for (int j = 0; j < 6; j++) {
+    double s = H[6 * j + j];
+    for (int k = 0; k < j; k++) {s -= Lc[6 * j + k] * Lc[6 * j + k];}
+    Lc[6 * j + j] = std::sqrt(s);
+    for (int i = j + 1; i < 6; i++) {
+      double v = H[6 * i + j];
+      for (int k = 0; k < j; k++) {v -= Lc[6 * i + k] * Lc[6 * j + k];}
+      Lc[6 * i + j] = v / Lc[6 * j + j];
+    }
+  }
+  double y[6], x[6];
+  for (int i = 0; i < 6; i++) {
+    double v = g[i];
+    for (int k = 0; k < i; k++) {v -= Lc[6 * i + k] * y[k];}
+    y[i] = v / Lc[6 * i + i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double v = y[i];
+    for (int k = i + 1; k < 6; k++) {v -= Lc[6 * k + i] * x[k];}
+    x[i] = v / Lc[6 * i + i];
+  }
+  for (int a = 0; a < 6; a++) {dx[a] = -x[a];}
+  return true;
+}
+
+// Optimizer::Run (optimizer.hpp:79-123).  make(pose, rows) is ProblemType::Make.  result: pose[12], error, error_scale,
+// iteration, code (0 converged, 1 larger error, 2 larger scale, 3 maximum iteration, 4 empty input); returns success.
+int RunOptimizer(const std::function<void(const double *, RowSet &)> & make, const double * initial_pose, int max_iter,
+  double * pose_out, double * error_out, double * scale_out, int * iteration_out, int * code_out)
+{
+  const double R0[9] = {initial_pose[0], initial_pose[1], initial_pose[2], initial_pose[4], initial_pose[5], initial_pose[6],
+    initial_pose[8], initial_pose[9], initial_pose[10]};
+  double q[4], t[3] = {initial_pose[3], initial_pose[7], initial_pose[11]};
+  QuaternionFromRotation(R0, q[0], q + 1);
+  double prev_scale = std::numeric_limits<double>::max(), prev_error = std::numeric_limits<double>::max();
+  auto finish = [&](int iteration, double error, double scale, int code) {
+      PoseOf(q, t, pose_out);
+      *error_out = error; *scale_out = scale; *iteration_out = iteration; *code_out = code;
+      return code <= 2 ? 1 : 0;
+    };
+  RowSet rows;
+  for (int iter = 0; iter < max_iter; iter++) {
+    double pose[12];
+    PoseOf(q, t, pose);
+    make(pose, rows);
+    if (rows.size() == 0) {return finish(iter, 0., 0., 4);}
+    const size_t n3 = rows.r3.size() / 3;
+    std::vector<double> errors(rows.size());
+    for (size_t i = 0; i < rows.size(); i++) {
+      if (i < n3) {
+        const double * r = &rows.r3[3 * i];
+        errors[i] = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      } else {
+        errors[i] = rows.r1[i - n3] * rows.r1[i - n3];
+      }
+    }
+    const double scale = ScaleOf(errors);
+    double error = 0.;
+    for (double e : errors) {error += e;}
+    if (error > prev_error) {return finish(iter, error, scale, 1);}
+    prev_error = error;
+    if (scale > prev_scale) {return finish(iter, error, scale, 2);}
+    prev_scale = scale;
+    std::vector<double> weights(errors.size());
+    for (size_t i = 0; i < errors.size(); i++) {weights[i] = HuberDerivativeOf(errors[i] / (scale + 1e-16), 1.345);}
+    double M[42], dx[6], dq[4];
+    MakeMOf(q, M);
+    WeightedUpdateOf(M, weights, rows, dx);
+    AngleAxisToQuaternionOf(dx, dq);
+    const double qn[4] = {                                               // q * dq (Eigen quaternion product)
+      q[0] * dq[0] - q[1] * dq[1] - q[2] * dq[2] - q[3] * dq[3],
+      q[0] * dq[1] + q[1] * dq[0] + q[2] * dq[3] - q[3] * dq[2],
+      q[0] * dq[2] + q[2] * dq[0] + q[3] * dq[1] - q[1] * dq[3],
+      q[0] * dq[3] + q[3] * dq[0] + q[1] * dq[2] - q[2] * dq[1]};
+    for (int a = 0; a < 4; a++) {q[a] = qn[a];}
+    for (int a = 0; a < 3; a++) {t[a] += dx[3 + a];}
+    const double nq = std::sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+    const double nt = std::sqrt(dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
+    if (nq < 1e-3 && nt < 1e-3) {return finish(iter, error, scale, 0);}   // CheckConvergence, optimizer.cpp:35-38
+  }
+  return finish(max_iter, prev_error, prev_scale, 3);
+}
 }  // namespace
 
 extern "C" {
@@ -272,6 +527,88 @@ void orc_loc_surface_residuals(const float * map, int n_map, const double * pose
     for (int c = 0; c < 3; c++) {J[4 + c] = u[c];}
     residual[i] = (wv[0] * on_map.x + wv[1] * on_map.y + wv[2] * on_map.z + 1.0) / norm;   // SignedPointPlaneDistance
   }
+}
+
+double orc_loc_median(const double * v, int n) {return MedianOf(std::vector<double>(v, v + n));}
+double orc_loc_mad(const double * v, int n) {return Mad(std::vector<double>(v, v + n));}
+double orc_loc_scale(const double * v, int n) {return ScaleOf(std::vector<double>(v, v + n));}
+double orc_loc_huber(double e, double k) {return HuberOf(e, k);}
+double orc_loc_huber_derivative(double e, double k) {return HuberDerivativeOf(e, k);}
+int orc_loc_is_degenerate(const double * C, int n, double threshold) {return IsDegenerateOf(std::vector<double>(C, C + n * n), n, threshold);}
+void orc_loc_angle_axis_to_quaternion(const double * theta, double * wxyz) {AngleAxisToQuaternionOf(theta, wxyz);}
+void orc_loc_rotation_matrix(const double * wxyz, double * R) {RotationOfQuaternion(wxyz, R);}
+void orc_loc_make_m(const double * wxyz, double * M) {MakeMOf(wxyz, M);}
+
+// one CalcUpdate (optimizer.cpp:86-97) of the point-pair problem: dq [4] (w x y z), dt [3]
+void orc_loc_pairs_update(const double * X, const double * Y, int n, const double * pose, double * dq, double * dt);
+
+// AlignmentProblem (alignment.cpp:33-78) under Optimizer::Run: X, Y [n][3]
+int orc_loc_optimize_pairs(const double * X, const double * Y, int n, const double * initial_pose, int max_iter,
+  double * pose_out, double * error_out, double * scale_out, int * iteration_out, int * code_out)
+{
+  auto make = [&](const double * pose, RowSet & rows) {
+      const double R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+      double w, v[3];
+      QuaternionFromRotation(R, w, v);
+      rows.J3.assign(21 * (size_t)n, 0.); rows.r3.resize(3 * (size_t)n); rows.J1.clear(); rows.r1.clear();
+      for (int i = 0; i < n; i++) {
+        const V3 x{X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+        double d[12];
+        DRpDq(w, v, x, d);
+        for (int r = 0; r < 3; r++) {
+          for (int c = 0; c < 4; c++) {rows.J3[21 * i + 7 * r + c] = d[4 * r + c];}
+          rows.J3[21 * i + 7 * r + 4 + r] = 1.;
+        }
+        const V3 p = Transform(pose, x);
+        rows.r3[3 * i] = p.x - Y[3 * i]; rows.r3[3 * i + 1] = p.y - Y[3 * i + 1]; rows.r3[3 * i + 2] = p.z - Y[3 * i + 2];
+      }
+    };
+  return RunOptimizer(make, initial_pose, max_iter, pose_out, error_out, scale_out, iteration_out, code_out);
+}
+
+// LOAMOptimizationProblem::Make (loam_optimization_problem.hpp:62-84) under Optimizer::Run (localizer.hpp:76); the surface
+// cloud is the one AFTER Downsample (surface.hpp:111), edge rows first
+int orc_loc_optimize_scan(const float * edge_map, int n_edge_map, const float * surface_map, int n_surface_map, int k,
+  const float * edge_points, int n_edge, const float * surface_points, int n_surface, const double * initial_pose, int max_iter,
+  double * pose_out, double * error_out, double * scale_out, int * iteration_out, int * code_out)
+{
+  auto make = [&](const double * pose, RowSet & rows) {
+      rows.J3.resize(21 * (size_t)n_edge); rows.r3.resize(3 * (size_t)n_edge);
+      rows.J1.resize(7 * (size_t)n_surface); rows.r1.resize((size_t)n_surface);
+      orc_loc_edge_residuals(edge_map, n_edge_map, pose, k, edge_points, n_edge, rows.r3.data(), rows.J3.data());
+      orc_loc_surface_residuals(surface_map, n_surface_map, pose, k, surface_points, n_surface, rows.r1.data(), rows.J1.data());
+    };
+  return RunOptimizer(make, initial_pose, max_iter, pose_out, error_out, scale_out, iteration_out, code_out);
+}
+
+void orc_loc_pairs_update(const double * X, const double * Y, int n, const double * pose, double * dq, double * dt)
+{
+  const double R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+  double q[4];
+  QuaternionFromRotation(R, q[0], q + 1);
+  RowSet rows;
+  rows.J3.assign(21 * (size_t)n, 0.); rows.r3.resize(3 * (size_t)n);
+  std::vector<double> errors(n);
+  for (int i = 0; i < n; i++) {
+    const V3 x{X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+    double d[12];
+    DRpDq(q[0], q + 1, x, d);
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 4; c++) {rows.J3[21 * i + 7 * r + c] = d[4 * r + c];}
+      rows.J3[21 * i + 7 * r + 4 + r] = 1.;
+    }
+    const V3 p = Transform(pose, x);
+    rows.r3[3 * i] = p.x - Y[3 * i]; rows.r3[3 * i + 1] = p.y - Y[3 * i + 1]; rows.r3[3 * i + 2] = p.z - Y[3 * i + 2];
+    errors[i] = rows.r3[3 * i] * rows.r3[3 * i] + rows.r3[3 * i + 1] * rows.r3[3 * i + 1] + rows.r3[3 * i + 2] * rows.r3[3 * i + 2];
+  }
+  const double scale = ScaleOf(errors);
+  std::vector<double> weights(n);
+  for (int i = 0; i < n; i++) {weights[i] = HuberDerivativeOf(errors[i] / (scale + 1e-16), 1.345);}
+  double M[42], dx[6];
+  MakeMOf(q, M);
+  WeightedUpdateOf(M, weights, rows, dx);
+  AngleAxisToQuaternionOf(dx, dq);
+  for (int a = 0; a < 3; a++) {dt[a] = dx[3 + a];}
 }
 
 }  // extern "C"

@@ -135,3 +135,125 @@ def test_residuals_of_points_on_the_map_vanish():
         jac = np.zeros((2, 21 if len(shape) == 2 else 7))
         fn(B.ptr(cloud, PF), len(cloud), B.ptr(pose, PD), 5, B.ptr(local, PF), 2, B.ptr(res, PD), B.ptr(jac, PD))
         assert np.all(np.abs(res) < 1e-5)
+
+
+# ---- the optimizer around the rows (optimizer.hpp / src/optimizer.cpp, robust.cpp, degenerate.cpp, posevec.cpp) ----------
+PI = C.POINTER(C.c_int)
+
+
+def test_median_absolute_deviation_and_scale(refvec):
+    for c in refvec["loc_mad"]["cases"]:
+        v = d(c["v"])
+        assert L.orc_loc_mad(B.ptr(v, PD), len(v)) == c["expect"]                        # EXPECT_EQ
+        assert L.orc_loc_median(B.ptr(v, PD), len(v)) == float(np.median(v))
+    s = refvec["loc_scale_normal"]
+    e = np.random.default_rng(5).normal(s["mean"], s["stddev"], s["n"])
+    nf = float(s["n"])
+    assert abs(np.sqrt((nf - 1) / nf) * s["stddev"] - L.orc_loc_scale(B.ptr(e, PD), len(e))) <= s["tolerance"]
+
+
+def test_huber_and_its_derivative(refvec):
+    k = refvec["loc_huber"]["k"]
+    for c in refvec["loc_huber"]["cases"]:
+        assert L.orc_loc_huber(c["r"] * c["r"], k) == c["expect"]
+    hd = refvec["loc_huber_derivative"]
+    for c in hd["cases"]:
+        num = (L.orc_loc_huber(c["e"] + c["h"], hd["k"]) - L.orc_loc_huber(c["e"], hd["k"])) / c["h"]
+        assert abs(num - L.orc_loc_huber_derivative(c["e"], hd["k"])) < hd["tolerance"]
+
+
+def test_is_degenerate(refvec):
+    g = refvec["loc_is_degenerate"]
+    Cm = d(g["C"])
+    for c in g["cases"]:
+        assert bool(L.orc_loc_is_degenerate(B.ptr(Cm, PD), 3, c["threshold"])) == c["expect"]
+    rng = np.random.default_rng(2)
+    for n in (3, 6, 7):
+        for _ in range(50):
+            A = rng.normal(size=(n, n))
+            S = d(A + A.T)
+            w = np.linalg.eigvalsh(S)
+            thr = float(rng.uniform(0.05, 1.0))
+            if np.min(np.abs(np.abs(w) - thr)) < 1e-9:
+                continue
+            assert bool(L.orc_loc_is_degenerate(B.ptr(S, PD), n, thr)) == bool((np.abs(w) < thr).any())
+
+
+def _rotation(q):
+    R = np.zeros(9)
+    L.orc_loc_rotation_matrix(B.ptr(d(q), PD), B.ptr(R, PD))
+    return R.reshape(3, 3)
+
+
+def test_angle_axis_and_make_m(refvec):
+    g = refvec["loc_angle_axis"]
+    q = np.zeros(4)
+    L.orc_loc_angle_axis_to_quaternion(B.ptr(d(g["cases"][0]["theta"]), PD), B.ptr(q, PD))
+    assert np.linalg.norm(q) == 1.0 and q[0] == 1.0
+    theta = d(g["cases"][1]["theta"])
+    L.orc_loc_angle_axis_to_quaternion(B.ptr(theta, PD), B.ptr(q, PD))
+    k = np.linalg.norm(theta)
+    u = theta / k
+    K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
+    E = np.eye(3) + np.sin(k) * K + (1 - np.cos(k)) * K @ K                              # AngleAxisd(k, u).toRotationMatrix()
+    assert abs(np.linalg.norm(q) - 1.0) <= g["tolerance"] and np.linalg.norm(_rotation(q) - E) <= g["tolerance"]
+    for c in refvec["loc_make_m"]["cases"]:
+        M = np.zeros(42)
+        L.orc_loc_make_m(B.ptr(d(c["q_wxyz"]), PD), B.ptr(M, PD))
+        assert np.linalg.norm(M.reshape(7, 6) - d(c["expect"])) <= refvec["loc_make_m"]["tolerance"]
+
+
+def _pose_of(q_unnormalised, t):
+    q = d(q_unnormalised) / np.linalg.norm(q_unnormalised)
+    return d(np.hstack([_rotation(q), d(t).reshape(3, 1)]).reshape(-1))
+
+
+def run_pairs(X, Y, pose, max_iter):
+    out, err, scale, it, code = np.zeros(12), C.c_double(), C.c_double(), C.c_int(), C.c_int()
+    ok = L.orc_loc_optimize_pairs(B.ptr(d(X), PD), B.ptr(d(Y), PD), len(X), B.ptr(d(pose), PD), max_iter, B.ptr(out, PD),
+                                  C.byref(err), C.byref(scale), C.byref(it), C.byref(code))
+    return dict(pose=out.reshape(3, 4), error=err.value, scale=scale.value, iteration=it.value, code=code.value, success=bool(ok))
+
+
+def test_optimizer_on_the_alignment_problem(refvec):
+    """localization/test/test_optimizer.cpp:53-242 on the restated Optimizer::Run + AlignmentProblem."""
+    g = refvec["loc_alignment"]
+    true = _pose_of(g["q_true_wxyz_unnormalised"], g["t_true"]).reshape(3, 4)
+    X = d(g["X"])
+    Y = d(X @ true[:, :3].T + true[:, 3])
+    # one CalcUpdate lowers the error (:73-96)
+    one = g["one_update"]
+    pose0 = _pose_of(one["q_wxyz_unnormalised"], one["t"])
+    dq, dt = np.zeros(4), np.zeros(3)
+    L.orc_loc_pairs_update(B.ptr(X, PD), B.ptr(Y, PD), len(X), B.ptr(pose0, PD), B.ptr(dq, PD), B.ptr(dt, PD))
+    q0 = d(one["q_wxyz_unnormalised"]) / np.linalg.norm(one["q_wxyz_unnormalised"])
+    w0, v0, w1, v1 = q0[0], q0[1:], dq[0], dq[1:]
+    q1 = np.concatenate([[w0 * w1 - v0 @ v1], w0 * v1 + w1 * v0 + np.cross(v0, v1)])
+    R0, R1 = pose0.reshape(3, 4)[:, :3], _rotation(q1)
+    e0 = np.sum((X @ R0.T + d(one["t"]) - Y) ** 2)
+    e1 = np.sum((X @ R1.T + d(one["t"]) + dt - Y) ** 2)
+    assert e1 < e0
+    b = g["bounds"]
+    for run in g["runs"]:
+        r = run_pairs(X, Y, _pose_of(run["q_wxyz_unnormalised"], run["t"]), g["max_iter"])
+        assert r["success"] == b["success"], run["name"]
+        if "iteration_eq" in run:
+            assert r["iteration"] == run["iteration_eq"]
+        else:
+            assert r["iteration"] < run["iteration_lt"], (run["name"], r["iteration"])
+        assert r["error"] < b["error_lt"] and r["scale"] < b["error_scale_lt"]
+        assert np.linalg.norm(true[:, :3] - r["pose"][:, :3]) <= b["rotation_norm_le"]
+        assert np.linalg.norm(true[:, 3] - r["pose"][:, 3]) <= b["translation_norm_le"]
+    ident = d(np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(-1))
+    r = run_pairs(np.zeros((0, 3)), np.zeros((0, 3)), ident, 10)                           # ShouldReturnFalseForEmptyData
+    e = g["empty"]
+    assert (r["iteration"], r["success"], r["error"], r["scale"]) == (e["iteration"], e["success"], e["error"], e["error_scale"])
+    nc = g["no_convergence"]                                                              # ShouldReturnFalseWhenNoConvergence
+    rng = np.random.default_rng(3)
+    r = run_pairs(rng.normal(*nc["x"], (nc["n"], 3)), rng.normal(*nc["y"], (nc["n"], 3)), ident, nc["max_iter"])
+    assert r["iteration"] == nc["iteration"] and r["success"] == nc["success"]
+    assert r["error"] > nc["error_gt"] and r["scale"] > nc["error_scale_gt"]
+    # WeightedUpdate returns zero when D is degenerate (:313-328): one point pair leaves the rotation about it free
+    dq, dt = np.zeros(4), np.zeros(3)
+    L.orc_loc_pairs_update(B.ptr(d([[0, 0, 0]]), PD), B.ptr(d([[1, 1, 1]]), PD), 1, B.ptr(ident, PD), B.ptr(dq, PD), B.ptr(dt, PD))
+    assert dq.tolist() == [1, 0, 0, 0] and dt.tolist() == [0, 0, 0]
