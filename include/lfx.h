@@ -308,6 +308,25 @@ int lfx_voxel_downsample(lfx_ctx *ctx, const float *d_points, const uint32_t *d_
  * lfx_device_view::surface_points, d_out_count / d_status [batch]. */
 int lfx_downsample_surface(lfx_ctx *ctx, float leaf, float *d_out, uint32_t *d_out_count, uint32_t *d_status, void *stream);
 
+/* --- the map a scan is matched against ---------------------------------------------------------------- */
+/* KDTreeEigen (localization/include/lidar_feature_localization/kdtree.hpp:50-63, src/kdtree.cpp:37-68; MakeKDTree :66-71):
+ * built once per map, answers exact k-nearest queries.  lfx_map_create copies n_points records of 4 floats (x, y, z, -)
+ * from the device into an index of its own: a uniform grid of cubic cells of cell_size (map units; grown if the map's
+ * extent would need more than 2^25 cells), the points sorted by cell -- or, with cell_size 0, no grid: every query reads
+ * the whole map (small maps; the check of the grid).  Both answer alike: neighbours by ascending squared distance,
+ * equal distances by the lower index in the map as given (nanoflann leaves that order open).  Points must be finite.
+ * Synchronous on `stream`.  A map belongs to the device of the context that made it and outlives nothing: destroy it
+ * before the context's device is reset. */
+typedef struct lfx_map lfx_map;
+int lfx_map_create(lfx_ctx *ctx, const float *d_points, uint32_t n_points, float cell_size, lfx_map **out, void *stream);
+void lfx_map_destroy(lfx_map *map);
+int lfx_map_info(const lfx_map *map, uint32_t *n_points, float *cell_size /* 0: no grid */, int32_t dims[3]);
+/* KDTreeEigen::NearestKSearch (src/kdtree.cpp:44-68) for n_queries queries of 3 doubles on the device: per query the k
+ * nearest points of the map -- d_neighbours [n][k][3] doubles (GetRows of the map), d_squared_distances [n][k],
+ * d_indices [n][k] into the map as given; any of the three may be NULL.  k <= 16.  Asynchronous. */
+int lfx_map_nearest(lfx_ctx *ctx, const lfx_map *map, const double *d_queries, uint32_t n_queries, uint32_t k,
+                    double *d_neighbours, double *d_squared_distances, uint32_t *d_indices, void *stream);
+
 /* --- scan-to-map residual build (first slice) --------------------------------------------------------- */
 /* What the reference's localizer does first with scan_edge / scan_surface, on clouds that are already on the device:
  *   LFX_RESIDUAL_EDGE     Edge::Make (localization/include/lidar_feature_localization/edge.hpp:86-124): per point the k
@@ -316,25 +335,26 @@ int lfx_downsample_surface(lfx_ctx *ctx, float leaf, float *d_out, uint32_t *d_o
  *   LFX_RESIDUAL_SURFACE  Surface::MakeFromDownsampled (surface.hpp:116-139; downsample first: lfx_downsample_surface):
  *                         the plane X w = -1 through the k nearest points of the surface map, residual[1] = signed
  *                         point-plane distance and the 1 x 7 row [u^T DRpDq(q, p), u^T], u = w / |w|.
- * d_map: n_map records of 4 floats (x, y, z, -); pose: point_to_map as [R | t], row-major 3 x 4 doubles (host); clouds as
- * in lfx_voxel_downsample; outputs addressed like the points (record d_begin[s] + i): d_residual 3 (edge) or 1 (surface)
- * doubles per point, d_jacobian 21 or 7 doubles per point, row-major.  n_neighbors <= 16 (the localizer uses 15).
- * Exact nearest-neighbour search (the reference's nanoflann KD-tree is exact too).  PARITY UNPINNED: Eigen's and
- * nanoflann's arithmetic is not available here; tolerance-level agreement with the CPU restatement, edge rows up to
- * the sign of the principal direction.  Asynchronous. */
+ * pose: point_to_map as [R | t], row-major 3 x 4 doubles (host); clouds as in lfx_voxel_downsample; outputs addressed
+ * like the points (record d_begin[s] + i): d_residual 3 (edge) or 1 (surface) doubles per point, d_jacobian 21 or 7
+ * doubles per point, row-major.  n_neighbors <= 16 (the localizer uses 15).  Exact nearest-neighbour search (the
+ * reference's nanoflann KD-tree is exact too).  PARITY UNPINNED: Eigen's and nanoflann's arithmetic is not available
+ * here; tolerance-level agreement with the CPU restatement, edge rows up to the sign of the principal direction (see
+ * DESIGN.md).  Asynchronous. */
 #define LFX_RESIDUAL_EDGE 0
 #define LFX_RESIDUAL_SURFACE 1
-int lfx_scan_to_map_residuals(lfx_ctx *ctx, int kind, const float *d_map, uint32_t n_map, const double pose[12],
-                              uint32_t n_neighbors, const float *d_points, const uint32_t *d_begin,
-                              const uint32_t *d_count, uint32_t count_stride, uint32_t n_clouds,
-                              uint32_t max_points_per_cloud, double *d_residual, double *d_jacobian, void *stream);
+int lfx_scan_to_map_residuals(lfx_ctx *ctx, int kind, const lfx_map *map, const double pose[12], uint32_t n_neighbors,
+                              const float *d_points, const uint32_t *d_begin, const uint32_t *d_count,
+                              uint32_t count_stride, uint32_t n_clouds, uint32_t max_points_per_cloud,
+                              double *d_residual, double *d_jacobian, void *stream);
 /* The same for the edge clouds of the last device batch (outputs laid out like lfx_device_view::edge_points). */
-int lfx_edge_residuals(lfx_ctx *ctx, const float *d_map, uint32_t n_map, const double pose[12], uint32_t n_neighbors,
+int lfx_edge_residuals(lfx_ctx *ctx, const lfx_map *map, const double pose[12], uint32_t n_neighbors,
                        double *d_residual, double *d_jacobian, void *stream);
 
 /* --- the optimizer around those rows (second slice) ---------------------------------------------------- */
 /* Optimizer<LOAMOptimizationProblem, EdgeSurfaceScan>::Run (localization/include/lidar_feature_localization/
- * optimizer.hpp:79-123, as Localizer::Update calls it, localizer.hpp:76) for a batch of scans against one pair of maps,
+ * optimizer.hpp:79-123, as Localizer::Update calls it, localizer.hpp:76) for a batch of scans against one pair of maps
+ * (lfx_map_create: the reference builds its two KD-trees in the problem's constructor, loam_optimization_problem.hpp:54-60),
  * every scan from its own initial pose, all iterations on the device: per iteration Problem::Make (the two row builds
  * above, edge rows first: loam_optimization_problem.hpp:62-84), ComputeErrors, NormalizeErrorScale (Scale = 1.4826 *
  * median absolute deviation, robust.cpp:36-50), ComputeWeights (HuberDerivative, k = 1.345), WeightedUpdate (sums of
@@ -359,8 +379,7 @@ typedef struct lfx_align_result {   /* OptimizationResult, optimization_result.h
   int32_t code;                     /* LFX_ALIGN_*; text: lfx_align_message */
 } lfx_align_result;
 const char *lfx_align_message(int code);
-int lfx_scan_to_map_align(lfx_ctx *ctx, const float *d_edge_map, uint32_t n_edge_map, const float *d_surface_map,
-                          uint32_t n_surface_map, uint32_t n_neighbors, int max_iter,
+int lfx_scan_to_map_align(lfx_ctx *ctx, const lfx_map *edge_map, const lfx_map *surface_map, uint32_t n_neighbors, int max_iter,
                           const float *d_edge_points, const uint32_t *d_edge_begin, const uint32_t *d_edge_count,
                           uint32_t edge_count_stride, uint32_t max_edge_points_per_cloud, size_t total_edge_points,
                           const float *d_surface_points, const uint32_t *d_surface_begin, const uint32_t *d_surface_count,
@@ -375,8 +394,8 @@ int lfx_align_point_pairs(lfx_ctx *ctx, const double *d_source, const double *d_
 /* Localizer::Update (localizer.hpp:71-80) for every scan of the last device batch: Downsample(scan_surface, surface_leaf)
  * (the reference uses 1.0), then lfx_scan_to_map_align on scan_edge and the downsampled cloud; nothing leaves the device
  * but the results. */
-int lfx_localize_batch(lfx_ctx *ctx, const float *d_edge_map, uint32_t n_edge_map, const float *d_surface_map,
-                       uint32_t n_surface_map, uint32_t n_neighbors, int max_iter, float surface_leaf,
+int lfx_localize_batch(lfx_ctx *ctx, const lfx_map *edge_map, const lfx_map *surface_map, uint32_t n_neighbors, int max_iter,
+                       float surface_leaf,
                        const double *initial_poses, lfx_align_result *results, void *stream);
 
 /* --- per-stage entry points (device-backed mirrors of the reference's free functions) ----- */

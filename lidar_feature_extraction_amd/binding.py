@@ -82,6 +82,7 @@ EXPORTS = [
     "lfx_status_string", "lfx_ring_message", "lfx_range_message", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
     "lfx_device_results", "lfx_batch_status", "lfx_scan_routes", "lfx_host_alloc", "lfx_host_free", "lfx_comm_unique_id", "lfx_comm_create",
     "lfx_comm_destroy", "lfx_gather_counts", "lfx_gather_payload", "lfx_gather", "lfx_voxel_downsample", "lfx_downsample_surface",
+    "lfx_map_create", "lfx_map_destroy", "lfx_map_info", "lfx_map_nearest",
     "lfx_scan_to_map_residuals", "lfx_edge_residuals", "lfx_align_message", "lfx_scan_to_map_align", "lfx_align_point_pairs",
     "lfx_localize_batch",
     "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
@@ -137,15 +138,20 @@ def load():
     L.lfx_gather_counts.argtypes = [vp, vp, vp, u32, vp]
     L.lfx_gather_payload.argtypes = [vp, vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]
     L.lfx_voxel_downsample.argtypes = [vp, vp, vp, vp, u32, u32, C.c_size_t, C.c_float, vp, vp, vp, vp]
-    L.lfx_scan_to_map_residuals.argtypes = [vp, i32, vp, u32, C.POINTER(C.c_double), u32, vp, vp, vp, u32, u32, u32, vp, vp, vp]
-    L.lfx_edge_residuals.argtypes = [vp, vp, u32, C.POINTER(C.c_double), u32, vp, vp, vp]
+    L.lfx_map_create.argtypes = [vp, vp, u32, C.c_float, C.POINTER(vp), vp]
+    L.lfx_map_destroy.argtypes = [vp]
+    L.lfx_map_destroy.restype = None
+    L.lfx_map_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(i32)]
+    L.lfx_map_nearest.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, vp]
+    L.lfx_scan_to_map_residuals.argtypes = [vp, i32, vp, C.POINTER(C.c_double), u32, vp, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.lfx_edge_residuals.argtypes = [vp, vp, C.POINTER(C.c_double), u32, vp, vp, vp]
     L.lfx_align_message.argtypes = [i32]
     L.lfx_align_message.restype = C.c_char_p
     pd, pres = C.POINTER(C.c_double), C.POINTER(AlignResult)
-    L.lfx_scan_to_map_align.argtypes = [vp, vp, u32, vp, u32, u32, i32, vp, vp, vp, u32, u32, C.c_size_t, vp, vp, vp, u32, u32,
+    L.lfx_scan_to_map_align.argtypes = [vp, vp, vp, u32, i32, vp, vp, vp, u32, u32, C.c_size_t, vp, vp, vp, u32, u32,
                                         C.c_size_t, u32, pd, pres, vp]
     L.lfx_align_point_pairs.argtypes = [vp, vp, vp, vp, vp, u32, C.c_size_t, u32, i32, pd, pres, vp]
-    L.lfx_localize_batch.argtypes = [vp, vp, u32, vp, u32, u32, i32, C.c_float, pd, pres, vp]
+    L.lfx_localize_batch.argtypes = [vp, vp, vp, u32, i32, C.c_float, pd, pres, vp]
     L.lfx_downsample_surface.argtypes = [vp, C.c_float, vp, vp, vp, vp]
     L.lfx_gather.argtypes = [vp, vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]
     L.lfx_layout_from_fields.argtypes = [C.POINTER(PointField), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Layout)]

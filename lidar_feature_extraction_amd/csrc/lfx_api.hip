@@ -1369,22 +1369,184 @@ int lfx_downsample_surface(lfx_ctx * c, float leaf, float * d_out, uint32_t * d_
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------- the map (KDTreeEigen's place)
+struct lfx_map
+{
+  int device = 0;
+  DevBuf<float4> pts;                    // the map's own copy of the points (sorted by cell when there is a grid)
+  DevBuf<uint32_t> start;                // first point of every cell, + 1
+  lfx::MapIndex index{};
+  float cell = 0.f;
+};
+
+namespace
+{
+void launch_rows(bool surface, const lfx::MapIndex & mi, const lfx::MapPose & P, uint32_t k, const float * d_points,
+  const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride, uint32_t n_clouds, uint32_t longest, double * d_residual,
+  double * d_jacobian, const lfx::AlignState * states, hipStream_t st)
+{
+  const dim3 grid((longest + 127u) / 128u, n_clouds);
+  const float4 * pts = reinterpret_cast<const float4 *>(d_points);
+#define LFX_ROWS(S, G) hipLaunchKernelGGL((lfx::scan_to_map_kernel<S, G>), grid, dim3(128), 0, st, mi, P, k, pts, d_begin, d_count, \
+    count_stride, d_residual, d_jacobian, states)
+  if (mi.start) {
+    if (surface) {LFX_ROWS(true, true);} else {LFX_ROWS(false, true);}
+  } else {
+    if (surface) {LFX_ROWS(true, false);} else {LFX_ROWS(false, false);}
+  }
+#undef LFX_ROWS
+}
+}  // namespace
+
+extern "C" {
+
+int lfx_map_create(lfx_ctx * c, const float * d_points, uint32_t n_points, float cell_size, lfx_map ** out, void * stream)
+{
+  if (!c || !d_points || !out || n_points == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (!(cell_size >= 0.f) || !std::isfinite(cell_size)) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "cell_size must be >= 0 (0: no grid)");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  lfx_map * m = new (std::nothrow) lfx_map();
+  if (!m) {return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the map");}
+  m->device = c->device;
+  auto give_up = [&](int code, const char * why) {lfx_map_destroy(m); return fail(c, code, why);};
+  if (m->pts.alloc(n_points) != hipSuccess) {m->pts.p = nullptr; return give_up(LFX_ERR_OUT_OF_MEMORY, "cannot allocate the map's points");}
+  lfx::MapIndex & mi = m->index;
+  mi.pts = m->pts.p; mi.start = nullptr; mi.n = n_points;
+  mi.ox = mi.oy = mi.oz = 0.; mi.h = 0.; mi.inv_h = 0.; mi.nx = mi.ny = mi.nz = 1;
+  const float4 * src = reinterpret_cast<const float4 *>(d_points);
+  if (cell_size == 0.f) {
+    hipError_t e = hipMemcpyAsync(m->pts.p, src, sizeof(float4) * (size_t)n_points, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) {e = hipStreamSynchronize(st);}
+    if (e != hipSuccess) {return give_up(LFX_ERR_HIP, hipGetErrorString(e));}
+    *out = m;
+    return LFX_OK;
+  }
+  // bounds of the map
+  uint32_t * d_bounds = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&d_bounds), 6 * sizeof(uint32_t)) != hipSuccess) {return give_up(LFX_ERR_OUT_OF_MEMORY, "cannot allocate the map's bounds");}
+  const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  uint32_t got[6];
+  hipError_t e = hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    const uint32_t blocks = std::min<uint32_t>((n_points + 255u) / 256u, 2048u);
+    hipLaunchKernelGGL(lfx::map_bounds_kernel, dim3(blocks), dim3(256), 0, st, src, n_points, d_bounds);
+    e = hipMemcpyAsync(got, d_bounds, sizeof(got), hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) {e = hipStreamSynchronize(st);}
+  (void)hipFree(d_bounds);
+  if (e != hipSuccess) {return give_up(LFX_ERR_HIP, hipGetErrorString(e));}
+  auto back = [](uint32_t u) {
+      const uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+      float f;
+      std::memcpy(&f, &b, 4);
+      return (double)f;
+    };
+  const double lo[3] = {back(got[0]), back(got[1]), back(got[2])}, hi[3] = {back(got[3]), back(got[4]), back(got[5])};
+  for (int a = 0; a < 3; a++) {
+    if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) {return give_up(LFX_ERR_INVALID_ARGUMENT, "the map holds a point that is not finite");}
+  }
+  // the grid: cubic cells of the asked size, grown until the grid has at most 2^25 cells
+  double h = (double)cell_size;
+  const double limit = 33554432.;
+  int dims[3];
+  for (;;) {
+    double cells = 1.;
+    for (int a = 0; a < 3; a++) {
+      const double na = std::floor((hi[a] - lo[a]) / h) + 1.;
+      dims[a] = na > 2147483647. ? 2147483647 : (int)na;
+      cells *= na;
+    }
+    if (cells <= limit) {break;}
+    h *= std::max(1.05, std::cbrt(cells / limit));
+  }
+  mi.ox = lo[0]; mi.oy = lo[1]; mi.oz = lo[2]; mi.h = h; mi.inv_h = 1. / h; mi.nx = dims[0]; mi.ny = dims[1]; mi.nz = dims[2];
+  m->cell = (float)h;
+  const size_t cells = (size_t)dims[0] * dims[1] * dims[2];
+  const uint32_t n_blocks = (uint32_t)((cells + lfx::kScanItems - 1) / lfx::kScanItems);
+  DevBuf<uint32_t> cell_count, partial;
+  if (m->start.alloc(cells + 1) != hipSuccess) {m->start.p = nullptr; return give_up(LFX_ERR_OUT_OF_MEMORY, "cannot allocate the map's cells");}
+  if (cell_count.alloc(cells) != hipSuccess || partial.alloc(n_blocks + 1) != hipSuccess) {
+    cell_count.release(); partial.release();
+    return give_up(LFX_ERR_OUT_OF_MEMORY, "cannot allocate the map's cells");
+  }
+  e = hipMemsetAsync(cell_count.p, 0, cells * sizeof(uint32_t), st);
+  if (e == hipSuccess) {
+    const dim3 per_point((n_points + 255u) / 256u);
+    hipLaunchKernelGGL(lfx::map_count_kernel, per_point, dim3(256), 0, st, mi, src, cell_count.p);
+    hipLaunchKernelGGL(lfx::cell_block_sum_kernel, dim3(n_blocks), dim3(lfx::kScanThreads), 0, st, cell_count.p, cells, partial.p);
+    hipLaunchKernelGGL(lfx::cell_partial_scan_kernel, dim3(1), dim3(lfx::kScanThreads), 0, st, partial.p, n_blocks);
+    hipLaunchKernelGGL(lfx::cell_start_kernel, dim3(n_blocks), dim3(lfx::kScanThreads), 0, st, cell_count.p, cells, partial.p, m->start.p, n_points);
+    hipLaunchKernelGGL(lfx::map_scatter_kernel, per_point, dim3(256), 0, st, mi, src, cell_count.p, m->start.p, m->pts.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {e = hipStreamSynchronize(st);}
+  cell_count.release(); partial.release();
+  if (e != hipSuccess) {return give_up(LFX_ERR_HIP, hipGetErrorString(e));}
+  mi.start = m->start.p;
+  *out = m;
+  return LFX_OK;
+}
+
+void lfx_map_destroy(lfx_map * m)
+{
+  if (!m) {return;}
+  (void)hipSetDevice(m->device);
+  m->pts.release(); m->start.release();
+  delete m;
+}
+
+int lfx_map_info(const lfx_map * m, uint32_t * n_points, float * cell_size, int32_t dims[3])
+{
+  if (!m) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (n_points) {*n_points = m->index.n;}
+  if (cell_size) {*cell_size = m->index.start ? m->cell : 0.f;}
+  if (dims) {dims[0] = m->index.nx; dims[1] = m->index.ny; dims[2] = m->index.nz;}
+  return LFX_OK;
+}
+
+int lfx_map_nearest(
+  lfx_ctx * c, const lfx_map * m, const double * d_queries, uint32_t n_queries, uint32_t k, double * d_neighbours,
+  double * d_squared_distances, uint32_t * d_indices, void * stream)
+{
+  if (!c || !m || !d_queries) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (k == 0 || k > (uint32_t)lfx::kNearestMax || m->index.n < k) {
+    return fail(c, LFX_ERR_INVALID_ARGUMENT, "k must be in [1, 16] and the map must hold that many points");
+  }
+  if (m->device != c->device) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "the map lives on another device");}
+  if (n_queries == 0) {return LFX_OK;}
+  LFX_HIP(c, hipSetDevice(c->device));
+  const dim3 grid((n_queries + 127u) / 128u);
+  if (m->index.start) {
+    hipLaunchKernelGGL(lfx::map_nearest_kernel<true>, grid, dim3(128), 0, static_cast<hipStream_t>(stream), m->index, d_queries,
+      n_queries, k, d_neighbours, d_squared_distances, d_indices);
+  } else {
+    hipLaunchKernelGGL(lfx::map_nearest_kernel<false>, grid, dim3(128), 0, static_cast<hipStream_t>(stream), m->index, d_queries,
+      n_queries, k, d_neighbours, d_squared_distances, d_indices);
+  }
+  LFX_HIP(c, hipGetLastError());
+  return LFX_OK;
+}
+
+}  // extern "C"
+
 // ---------------------------------------------------------------------------- scan-to-map residuals
 extern "C" {
 
 int lfx_scan_to_map_residuals(
-  lfx_ctx * c, int kind, const float * d_map, uint32_t n_map, const double pose[12], uint32_t n_neighbors,
+  lfx_ctx * c, int kind, const lfx_map * map, const double pose[12], uint32_t n_neighbors,
   const float * d_points, const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride, uint32_t n_clouds,
   uint32_t max_points_per_cloud, double * d_residual, double * d_jacobian, void * stream)
 {
-  if (!c || !d_map || !pose || !d_points || !d_begin || !d_count || !d_residual || !d_jacobian || n_clouds == 0 || count_stride == 0 ||
+  if (!c || !map || !pose || !d_points || !d_begin || !d_count || !d_residual || !d_jacobian || n_clouds == 0 || count_stride == 0 ||
     (kind != LFX_RESIDUAL_EDGE && kind != LFX_RESIDUAL_SURFACE))
   {
     return LFX_ERR_INVALID_ARGUMENT;
   }
-  if (n_neighbors == 0 || n_neighbors > (uint32_t)lfx::kNearestMax || n_map < n_neighbors || (kind == LFX_RESIDUAL_SURFACE && n_neighbors < 3)) {
+  if (n_neighbors == 0 || n_neighbors > (uint32_t)lfx::kNearestMax || map->index.n < n_neighbors || (kind == LFX_RESIDUAL_SURFACE && n_neighbors < 3)) {
     return fail(c, LFX_ERR_INVALID_ARGUMENT, "n_neighbors must be in [1, 16] (>= 3 for planes) and the map must hold that many points");
   }
+  if (map->device != c->device) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "the map lives on another device");}
   if (max_points_per_cloud == 0) {return LFX_OK;}
   LFX_HIP(c, hipSetDevice(c->device));
   lfx::MapPose P;
@@ -1412,24 +1574,15 @@ int lfx_scan_to_map_residuals(
     }
     P.qw = w; P.qx = q[0]; P.qy = q[1]; P.qz = q[2];
   }
-  const dim3 grid((max_points_per_cloud + 127u) / 128u, n_clouds);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (kind == LFX_RESIDUAL_EDGE) {
-    hipLaunchKernelGGL(lfx::scan_to_map_kernel<false>, grid, dim3(128), 0, st, reinterpret_cast<const float4 *>(d_map), n_map, P,
-      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian,
-      static_cast<const lfx::AlignState *>(nullptr));
-  } else {
-    hipLaunchKernelGGL(lfx::scan_to_map_kernel<true>, grid, dim3(128), 0, st, reinterpret_cast<const float4 *>(d_map), n_map, P,
-      n_neighbors, reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, d_residual, d_jacobian,
-      static_cast<const lfx::AlignState *>(nullptr));
-  }
+  launch_rows(kind == LFX_RESIDUAL_SURFACE, map->index, P, n_neighbors, d_points, d_begin, d_count, count_stride, n_clouds,
+    max_points_per_cloud, d_residual, d_jacobian, nullptr, static_cast<hipStream_t>(stream));
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
 }
 
 int lfx_edge_residuals(
-  lfx_ctx * c, const float * d_map, uint32_t n_map, const double pose[12], uint32_t n_neighbors, double * d_residual,
-  double * d_jacobian, void * stream)
+  lfx_ctx * c, const lfx_map * map, const double pose[12], uint32_t n_neighbors, double * d_residual, double * d_jacobian,
+  void * stream)
 {
   if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
   if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
@@ -1438,7 +1591,7 @@ int lfx_edge_residuals(
     const uint32_t n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
     longest = n > longest ? n : longest;                 // a scan has no more edge points than points
   }
-  return lfx_scan_to_map_residuals(c, LFX_RESIDUAL_EDGE, d_map, n_map, pose, n_neighbors, reinterpret_cast<const float *>(c->edge_pts.p),
+  return lfx_scan_to_map_residuals(c, LFX_RESIDUAL_EDGE, map, pose, n_neighbors, reinterpret_cast<const float *>(c->edge_pts.p),
            c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, c->last_batch, longest, d_residual, d_jacobian, stream);
 }
 
@@ -1450,11 +1603,11 @@ namespace
 struct AlignProblem                     // what Problem::Make reads, per kind
 {
   // rows of dimension 3: the edge clouds, or the point pairs
-  const float * edge_map = nullptr; uint32_t n_edge_map = 0;
+  const lfx_map * edge_map = nullptr;
   const float * edge_points = nullptr; const double * X = nullptr, * Y = nullptr;
   const uint32_t * begin3 = nullptr, * count3 = nullptr; uint32_t stride3 = 1, longest3 = 0; size_t total3 = 0;
   // rows of dimension 1: the downsampled surface clouds
-  const float * surface_map = nullptr; uint32_t n_surface_map = 0;
+  const lfx_map * surface_map = nullptr;
   const float * surface_points = nullptr;
   const uint32_t * begin1 = nullptr, * count1 = nullptr; uint32_t stride1 = 1, longest1 = 0; size_t total1 = 0;
   uint32_t n_neighbors = 0;
@@ -1494,14 +1647,12 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
       }
     } else {
       if (pr.longest3) {
-        hipLaunchKernelGGL(lfx::scan_to_map_kernel<false>, dim3((pr.longest3 + 127u) / 128u, n_clouds), dim3(128), 0, st,
-          reinterpret_cast<const float4 *>(pr.edge_map), pr.n_edge_map, none, pr.n_neighbors,
-          reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3, states);
+        launch_rows(false, pr.edge_map->index, none, pr.n_neighbors, pr.edge_points, pr.begin3, pr.count3, pr.stride3, n_clouds,
+          pr.longest3, r3, J3, states, st);
       }
       if (pr.longest1) {
-        hipLaunchKernelGGL(lfx::scan_to_map_kernel<true>, dim3((pr.longest1 + 127u) / 128u, n_clouds), dim3(128), 0, st,
-          reinterpret_cast<const float4 *>(pr.surface_map), pr.n_surface_map, none, pr.n_neighbors,
-          reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1, r1, J1, states);
+        launch_rows(true, pr.surface_map->index, none, pr.n_neighbors, pr.surface_points, pr.begin1, pr.count1, pr.stride1, n_clouds,
+          pr.longest1, r1, J1, states, st);
       }
     }
     hipLaunchKernelGGL(lfx::align_step_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, max_iter,
@@ -1535,30 +1686,30 @@ const char * lfx_align_message(int code)
 }
 
 int lfx_scan_to_map_align(
-  lfx_ctx * c, const float * d_edge_map, uint32_t n_edge_map, const float * d_surface_map, uint32_t n_surface_map,
-  uint32_t n_neighbors, int max_iter,
+  lfx_ctx * c, const lfx_map * edge_map, const lfx_map * surface_map, uint32_t n_neighbors, int max_iter,
   const float * d_edge_points, const uint32_t * d_edge_begin, const uint32_t * d_edge_count, uint32_t edge_count_stride,
   uint32_t max_edge_points_per_cloud, size_t total_edge_points,
   const float * d_surface_points, const uint32_t * d_surface_begin, const uint32_t * d_surface_count,
   uint32_t surface_count_stride, uint32_t max_surface_points_per_cloud, size_t total_surface_points,
   uint32_t n_clouds, const double * initial_poses, lfx_align_result * results, void * stream)
 {
-  if (!c || !d_edge_map || !d_surface_map || !d_edge_points || !d_edge_begin || !d_edge_count || !d_surface_points ||
+  if (!c || !edge_map || !surface_map || !d_edge_points || !d_edge_begin || !d_edge_count || !d_surface_points ||
     !d_surface_begin || !d_surface_count || !initial_poses || !results || n_clouds == 0 || edge_count_stride == 0 ||
     surface_count_stride == 0)
   {
     return LFX_ERR_INVALID_ARGUMENT;
   }
   if (max_iter < 1) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "max_iter must be >= 1");}
-  if (n_neighbors < 3 || n_neighbors > (uint32_t)lfx::kNearestMax || n_edge_map < n_neighbors || n_surface_map < n_neighbors) {
+  if (n_neighbors < 3 || n_neighbors > (uint32_t)lfx::kNearestMax || edge_map->index.n < n_neighbors || surface_map->index.n < n_neighbors) {
     return fail(c, LFX_ERR_INVALID_ARGUMENT, "n_neighbors must be in [3, 16] and both maps must hold that many points");
   }
+  if (edge_map->device != c->device || surface_map->device != c->device) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "a map lives on another device");}
   LFX_HIP(c, hipSetDevice(c->device));
   AlignProblem pr;
-  pr.edge_map = d_edge_map; pr.n_edge_map = n_edge_map; pr.edge_points = d_edge_points;
+  pr.edge_map = edge_map; pr.edge_points = d_edge_points;
   pr.begin3 = d_edge_begin; pr.count3 = d_edge_count; pr.stride3 = edge_count_stride; pr.longest3 = max_edge_points_per_cloud;
   pr.total3 = total_edge_points;
-  pr.surface_map = d_surface_map; pr.n_surface_map = n_surface_map; pr.surface_points = d_surface_points;
+  pr.surface_map = surface_map; pr.surface_points = d_surface_points;
   pr.begin1 = d_surface_begin; pr.count1 = d_surface_count; pr.stride1 = surface_count_stride;
   pr.longest1 = max_surface_points_per_cloud; pr.total1 = total_surface_points;
   pr.n_neighbors = n_neighbors;
@@ -1580,8 +1731,7 @@ int lfx_align_point_pairs(
 }
 
 int lfx_localize_batch(
-  lfx_ctx * c, const float * d_edge_map, uint32_t n_edge_map, const float * d_surface_map, uint32_t n_surface_map,
-  uint32_t n_neighbors, int max_iter, float surface_leaf, const double * initial_poses, lfx_align_result * results, void * stream)
+  lfx_ctx * c, const lfx_map * edge_map, const lfx_map * surface_map, uint32_t n_neighbors, int max_iter, float surface_leaf, const double * initial_poses, lfx_align_result * results, void * stream)
 {
   if (!c || !initial_poses || !results) {return LFX_ERR_INVALID_ARGUMENT;}
   if (c->last_batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no batch has been extracted yet");}
@@ -1609,7 +1759,7 @@ int lfx_localize_batch(
     const uint32_t n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
     longest = n > longest ? n : longest;                 // a scan has no more edge / surface points than points
   }
-  return lfx_scan_to_map_align(c, d_edge_map, n_edge_map, d_surface_map, n_surface_map, n_neighbors, max_iter,
+  return lfx_scan_to_map_align(c, edge_map, surface_map, n_neighbors, max_iter,
            reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest, total,
            down, c->scan_begin.p, down_count, 1, longest, total, batch, initial_poses, results, stream);
 }

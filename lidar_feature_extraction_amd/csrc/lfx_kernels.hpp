@@ -3080,9 +3080,114 @@ __device__ inline void drp_dq(const MapPose & P, D3 p, double (&d)[12])
   }
 }
 
-template<bool SURFACE>
+// The map a scan is matched against: the reference's KDTreeEigen (localization/include/lidar_feature_localization/
+// kdtree.hpp:50-63: built once per map, exact k-nearest queries).  Here a uniform grid of cubic cells: the points sorted
+// by cell (x fastest), start[] = the first point of every cell, so that the cells of one grid row between two x are one
+// contiguous run of points.  start == nullptr: no grid, every query reads the whole map (small maps, and the check of
+// the grid).  Both give the same neighbours in the same order: ascending distance, equal distances by the lower index
+// of the point in the map as it was given.
+struct MapIndex
+{
+  const float4 * pts;                     // grid: sorted by cell, w = the point's original index (bits); else as given
+  const uint32_t * start;                 // [nx * ny * nz + 1] or nullptr
+  double ox, oy, oz, h, inv_h;            // cell (ix, iy, iz) = floor((p - o) * inv_h), clamped into the grid
+  int nx, ny, nz;
+  uint32_t n;
+};
+
+__device__ inline int cell_coordinate(double p, double o, double inv_h)
+{
+  double u = floor((p - o) * inv_h);
+  u = u < -268435456. ? -268435456. : (u > 268435456. ? 268435456. : u);
+  return (int)u;
+}
+
+// candidate (d, at) into the ascending list; GRID: equal distances ordered by the original index kept in pts[].w
+template<bool GRID>
+__device__ inline void nearest_insert(double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax], double d, uint32_t at, uint32_t orig,
+  const float4 * __restrict__ pts)
+{
+  constexpr int KM = kNearestMax;
+  auto before = [&](int j) {                            // does the candidate come before entry j?
+      if (d < dist[j]) {return true;}
+      if (!GRID || d != dist[j]) {return false;}
+      return orig < __float_as_uint(pts[idx[j]].w);
+    };
+  if (!before(KM - 1)) {return;}
+  bool placed = false;
+#pragma unroll
+  for (int j = KM - 1; j > 0; j--) {
+    if (!placed) {
+      if (before(j - 1)) {dist[j] = dist[j - 1]; idx[j] = idx[j - 1];} else {dist[j] = d; idx[j] = at; placed = true;}
+    }
+  }
+  if (!placed) {dist[0] = d; idx[0] = at;}
+}
+
+// every thread of the workgroup (T threads) calls this; the map passes through LDS in tiles
+template<int T>
+__device__ inline void nearest_whole_map(const MapIndex & mi, D3 q, double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax], float4 * tile)
+{
+  const uint32_t tid = threadIdx.x, n_map = mi.n;
+  for (uint32_t t0 = 0; t0 < n_map; t0 += T) {
+    __syncthreads();
+    tile[tid] = mi.pts[t0 + tid < n_map ? t0 + tid : n_map - 1u];
+    __syncthreads();
+    const uint32_t lim = n_map - t0 < (uint32_t)T ? n_map - t0 : (uint32_t)T;
+    for (uint32_t e = 0; e < lim; e++) {
+      const float4 mpt = tile[e];
+      const double dx = (double)mpt.x - q.x, dy = (double)mpt.y - q.y, dz = (double)mpt.z - q.z;
+      nearest_insert<false>(dist, idx, dx * dx + dy * dy + dz * dz, t0 + e, 0u, nullptr);   // ascending index, strict <
+    }
+  }
+}
+
+// one thread, one query: the cube of cells within rho of the query's cell, rho grown until the kk-th distance is inside
+// the cube's inscribed sphere (no unseen point can be nearer) or the cube holds the whole grid
+__device__ inline void nearest_in_grid(const MapIndex & mi, D3 q, uint32_t kk, double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax])
+{
+  constexpr int KM = kNearestMax;
+  const double ux = (q.x - mi.ox) * mi.inv_h, uy = (q.y - mi.oy) * mi.inv_h, uz = (q.z - mi.oz) * mi.inv_h;
+  const int cx = cell_coordinate(q.x, mi.ox, mi.inv_h), cy = cell_coordinate(q.y, mi.oy, mi.inv_h), cz = cell_coordinate(q.z, mi.oz, mi.inv_h);
+  auto outside = [](int c, int n) {return c < 0 ? -c : (c > n - 1 ? c - (n - 1) : 0);};
+  int rho = max(max(outside(cx, mi.nx), outside(cy, mi.ny)), max(outside(cz, mi.nz), 1));
+  for (;;) {
+#pragma unroll
+    for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
+    const int xlo = max(cx - rho, 0), xhi = min(cx + rho, mi.nx - 1), ylo = max(cy - rho, 0), yhi = min(cy + rho, mi.ny - 1);
+    const int zlo = max(cz - rho, 0), zhi = min(cz + rho, mi.nz - 1);
+    if (xlo <= xhi) {
+      for (int z = zlo; z <= zhi; z++) {
+        for (int y = ylo; y <= yhi; y++) {
+          const size_t row = ((size_t)z * mi.ny + y) * mi.nx;
+          const uint32_t a = mi.start[row + xlo], b = mi.start[row + xhi + 1];
+          for (uint32_t at = a; at < b; at++) {
+            const float4 mpt = mi.pts[at];
+            const double dx = (double)mpt.x - q.x, dy = (double)mpt.y - q.y, dz = (double)mpt.z - q.z;
+            nearest_insert<true>(dist, idx, dx * dx + dy * dy + dz * dz, at, __float_as_uint(mpt.w), mi.pts);
+          }
+        }
+      }
+    }
+    const bool whole = cx - rho <= 0 && cx + rho >= mi.nx - 1 && cy - rho <= 0 && cy + rho >= mi.ny - 1 && cz - rho <= 0 && cz + rho >= mi.nz - 1;
+    if (whole) {return;}
+    // a point in a cell outside the cube differs from the query by at least g cells along some axis (1e-7 cells: rounding
+    // of the cell coordinates of points on a face)
+    const double r = (double)rho;
+    const double g = fmin(fmin(fmin(ux - ((double)cx - r), ((double)cx + r + 1.) - ux), fmin(uy - ((double)cy - r), ((double)cy + r + 1.) - uy)),
+        fmin(uz - ((double)cz - r), ((double)cz + r + 1.) - uz)) - 1e-7;
+    double kth = INFINITY;
+#pragma unroll
+    for (int j = 0; j < KM; j++) {if ((uint32_t)j == kk - 1u) {kth = dist[j];}}
+    const double reach = g * mi.h;
+    if (g > 0. && kth <= reach * reach) {return;}
+    rho = rho < 2 ? rho + 1 : 2 * rho;
+  }
+}
+
+template<bool SURFACE, bool GRID>
 __global__ __launch_bounds__(128) void scan_to_map_kernel(
-  const float4 * __restrict__ map, uint32_t n_map, MapPose P, uint32_t k, const float4 * __restrict__ pts,
+  MapIndex mi, MapPose P, uint32_t k, const float4 * __restrict__ pts,
   const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
   double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align)
 {
@@ -3092,6 +3197,7 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
     if (align[s].done) {return;}
     P = align[s].pose;
   }
+  const float4 * __restrict__ map = mi.pts;
   const uint32_t b = begin[s], n = count[(size_t)s * count_stride];
   const uint32_t i = blockIdx.x * T + tid;
   if (blockIdx.x * T >= n) {return;}                   // the whole workgroup is beyond this cloud
@@ -3100,34 +3206,19 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
   const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
   const D3 q{P.m[0] * p0.x + P.m[1] * p0.y + P.m[2] * p0.z + P.m[3], P.m[4] * p0.x + P.m[5] * p0.y + P.m[6] * p0.z + P.m[7],
     P.m[8] * p0.x + P.m[9] * p0.y + P.m[10] * p0.z + P.m[11]};
+  const uint32_t kk = k < (uint32_t)KM ? k : (uint32_t)KM;
   double dist[KM];
   uint32_t idx[KM];
+  if (GRID) {
+    if (!valid) {return;}
+    nearest_in_grid(mi, q, kk, dist, idx);
+  } else {
 #pragma unroll
-  for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
-  __shared__ float4 tile[T];
-  for (uint32_t t0 = 0; t0 < n_map; t0 += T) {
-    __syncthreads();
-    tile[tid] = map[t0 + tid < n_map ? t0 + tid : n_map - 1u];
-    __syncthreads();
-    const uint32_t lim = n_map - t0 < (uint32_t)T ? n_map - t0 : (uint32_t)T;
-    for (uint32_t e = 0; e < lim; e++) {
-      const float4 mpt = tile[e];
-      const double dx = (double)mpt.x - q.x, dy = (double)mpt.y - q.y, dz = (double)mpt.z - q.z;
-      const double d = dx * dx + dy * dy + dz * dz;
-      if (d < dist[KM - 1]) {                          // (ascending map index, strict <: equidistant points keep index order)
-        bool placed = false;
-#pragma unroll
-        for (int j = KM - 1; j > 0; j--) {
-          if (!placed) {
-            if (d < dist[j - 1]) {dist[j] = dist[j - 1]; idx[j] = idx[j - 1];} else {dist[j] = d; idx[j] = t0 + e; placed = true;}
-          }
-        }
-        if (!placed) {dist[0] = d; idx[0] = t0 + e;}
-      }
-    }
+    for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
+    __shared__ float4 tile[T];
+    nearest_whole_map<T>(mi, q, dist, idx, tile);
   }
   if (!valid) {return;}
-  const uint32_t kk = k < (uint32_t)KM ? k : (uint32_t)KM;
   double d[12];
   drp_dq(P, p0, d);
   if (!SURFACE) {
@@ -3215,6 +3306,169 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
     for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
     J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
     residual[b + i] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Building a MapIndex (lfx_map_create): bounds, points per cell, the cells' first points by an exclusive scan, then the
+// points into their cells.  The order of the points inside a cell is whatever the atomics give; nothing depends on it
+// (nearest_insert orders equal distances by the original index).
+__device__ inline uint32_t float_order(float f)         // unsigned ints that order like the floats
+{
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void map_bounds_kernel(const float4 * __restrict__ pts, uint32_t n, uint32_t * __restrict__ bounds /* min xyz, max xyz */)
+{
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    const uint32_t v[3] = {float_order(p.x), float_order(p.y), float_order(p.z)};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {lo[a] = min(lo[a], v[a]); hi[a] = max(hi[a], v[a]);}
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], off, 64));
+      hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {atomicMin(&bounds[a], lo[a]); atomicMax(&bounds[3 + a], hi[a]);}
+  }
+}
+
+__device__ inline size_t map_cell_of(const MapIndex & mi, float4 p)
+{
+  const int ix = min(max(cell_coordinate((double)p.x, mi.ox, mi.inv_h), 0), mi.nx - 1);
+  const int iy = min(max(cell_coordinate((double)p.y, mi.oy, mi.inv_h), 0), mi.ny - 1);
+  const int iz = min(max(cell_coordinate((double)p.z, mi.oz, mi.inv_h), 0), mi.nz - 1);
+  return ((size_t)iz * mi.ny + iy) * mi.nx + ix;
+}
+
+__global__ __launch_bounds__(256) void map_count_kernel(MapIndex mi, const float4 * __restrict__ pts, uint32_t * __restrict__ cell_count)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < mi.n) {atomicAdd(&cell_count[map_cell_of(mi, pts[i])], 1u);}
+}
+
+constexpr int kScanThreads = 1024, kScanItems = 4 * kScanThreads;
+// exclusive scan of one value per thread over the workgroup; sh: kScanThreads words; returns the thread's offset, total in `total`
+__device__ inline uint32_t workgroup_exclusive_scan(uint32_t v, uint32_t * sh, uint32_t & total)
+{
+  const int tid = threadIdx.x;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+    if ((tid & 63) >= off) {incl += o;}
+  }
+  if ((tid & 63) == 63) {sh[tid >> 6] = incl;}
+  __syncthreads();
+  if (tid < 64) {
+    const uint32_t w = tid < kScanThreads / 64 ? sh[tid] : 0u;
+    uint32_t wi = w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)wi, off, 64);
+      if (tid >= off) {wi += o;}
+    }
+    if (tid < kScanThreads / 64) {sh[64 + tid] = wi - w;}
+    if (tid == kScanThreads / 64 - 1) {sh[128] = wi;}
+  }
+  __syncthreads();
+  total = sh[128];
+  const uint32_t r = sh[64 + (tid >> 6)] + incl - v;
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(kScanThreads) void cell_block_sum_kernel(const uint32_t * __restrict__ cell_count, size_t cells, uint32_t * __restrict__ partial)
+{
+  __shared__ uint32_t sh[kScanThreads];
+  const size_t base = (size_t)blockIdx.x * kScanItems + 4 * (size_t)threadIdx.x;
+  uint32_t v = 0;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {if (base + a < cells) {v += cell_count[base + a];}}
+  uint32_t total;
+  (void)workgroup_exclusive_scan(v, sh, total);
+  if (threadIdx.x == 0) {partial[blockIdx.x] = total;}
+}
+
+__global__ __launch_bounds__(kScanThreads) void cell_partial_scan_kernel(uint32_t * __restrict__ partial, uint32_t n_blocks)
+{
+  __shared__ uint32_t sh[kScanThreads];
+  const uint32_t per = (n_blocks + kScanThreads - 1) / kScanThreads;
+  const uint32_t a = threadIdx.x * per, b = min(a + per, n_blocks);
+  uint32_t v = 0;
+  for (uint32_t i = a; i < b; i++) {v += partial[i];}
+  uint32_t total;
+  uint32_t run = workgroup_exclusive_scan(v, sh, total);
+  for (uint32_t i = a; i < b; i++) {const uint32_t c = partial[i]; partial[i] = run; run += c;}
+}
+
+__global__ __launch_bounds__(kScanThreads) void cell_start_kernel(
+  const uint32_t * __restrict__ cell_count, size_t cells, const uint32_t * __restrict__ partial, uint32_t * __restrict__ start, uint32_t n_points)
+{
+  __shared__ uint32_t sh[kScanThreads];
+  const size_t base = (size_t)blockIdx.x * kScanItems + 4 * (size_t)threadIdx.x;
+  uint32_t c[4];
+  uint32_t v = 0;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {c[a] = base + a < cells ? cell_count[base + a] : 0u; v += c[a];}
+  uint32_t total;
+  uint32_t run = partial[blockIdx.x] + workgroup_exclusive_scan(v, sh, total);
+#pragma unroll
+  for (int a = 0; a < 4; a++) {if (base + a < cells) {start[base + a] = run;} run += c[a];}
+  if (blockIdx.x == 0 && threadIdx.x == 0) {start[cells] = n_points;}
+}
+
+__global__ __launch_bounds__(256) void map_scatter_kernel(
+  MapIndex mi, const float4 * __restrict__ pts, uint32_t * __restrict__ cell_count, const uint32_t * __restrict__ start, float4 * __restrict__ sorted)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mi.n) {return;}
+  const float4 p = pts[i];
+  const size_t cell = map_cell_of(mi, p);
+  const uint32_t slot = atomicSub(&cell_count[cell], 1u) - 1u;
+  sorted[start[cell] + slot] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
+}
+
+// KDTreeEigen::NearestKSearch (localization/src/kdtree.cpp:44-68) for a batch of queries: per query the k nearest points
+// of the map, ascending; neighbours [n][k][3] doubles (GetRows of the map), squared distances [n][k], indices [n][k]
+// into the map as it was given.
+template<bool GRID>
+__global__ __launch_bounds__(128) void map_nearest_kernel(
+  MapIndex mi, const double * __restrict__ queries, uint32_t n, uint32_t k, double * __restrict__ neighbours,
+  double * __restrict__ squared_distances, uint32_t * __restrict__ indices)
+{
+  constexpr int KM = kNearestMax, T = 128;
+  const uint32_t i = blockIdx.x * T + threadIdx.x;
+  const bool valid = i < n;
+  const size_t at = valid ? i : 0u;
+  const D3 q{queries[3 * at], queries[3 * at + 1], queries[3 * at + 2]};
+  const uint32_t kk = k < (uint32_t)KM ? k : (uint32_t)KM;
+  double dist[KM];
+  uint32_t idx[KM];
+  if (GRID) {
+    if (!valid) {return;}
+    nearest_in_grid(mi, q, kk, dist, idx);
+  } else {
+#pragma unroll
+    for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
+    __shared__ float4 tile[T];
+    nearest_whole_map<T>(mi, q, dist, idx, tile);
+    if (!valid) {return;}
+  }
+#pragma unroll
+  for (int j = 0; j < KM; j++) {
+    if ((uint32_t)j < kk) {
+      const float4 m4 = mi.pts[idx[j]];
+      const size_t o = (size_t)i * kk + j;
+      if (neighbours) {neighbours[3 * o] = (double)m4.x; neighbours[3 * o + 1] = (double)m4.y; neighbours[3 * o + 2] = (double)m4.z;}
+      if (squared_distances) {squared_distances[o] = dist[j];}
+      if (indices) {indices[o] = GRID ? __float_as_uint(m4.w) : idx[j];}
+    }
   }
 }
 

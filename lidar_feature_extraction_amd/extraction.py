@@ -172,21 +172,25 @@ class FeatureExtraction:
             self._ctx, float(leaf), C.c_void_p(int(d_out)), C.c_void_p(int(d_out_count)), C.c_void_p(int(d_status)),
             C.c_void_p(int(stream))))
 
-    def scan_to_map_residuals(self, kind, d_map, n_map, pose, n_neighbors, d_points, d_begin, d_count, count_stride, n_clouds,
+    def make_map(self, d_points, n_points, cell_size=1.0, stream=0):
+        """lfx_map_create: the map a scan is matched against (KDTreeEigen, kdtree.hpp:50-71); cell_size 0 = no grid."""
+        return ScanMap(self, d_points, n_points, cell_size, stream)
+
+    def scan_to_map_residuals(self, kind, scan_map, pose, n_neighbors, d_points, d_begin, d_count, count_stride, n_clouds,
                               max_points_per_cloud, d_residual, d_jacobian, stream=0):
         """lfx_scan_to_map_residuals: kind 0 = edge rows (edge.hpp:86-124), 1 = surface rows (surface.hpp:116-139);
         pose: 3 x 4 [R | t] (point_to_map); device addresses otherwise."""
         pm = np.ascontiguousarray(pose, np.float64).reshape(12)
         B.check(self._ctx, self._L.lfx_scan_to_map_residuals(
-            self._ctx, int(kind), C.c_void_p(int(d_map)), int(n_map), pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
+            self._ctx, int(kind), scan_map.handle, pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
             C.c_void_p(int(d_points)), C.c_void_p(int(d_begin)), C.c_void_p(int(d_count)), int(count_stride), int(n_clouds),
             int(max_points_per_cloud), C.c_void_p(int(d_residual)), C.c_void_p(int(d_jacobian)), C.c_void_p(int(stream))))
 
-    def edge_residuals(self, d_map, n_map, pose, n_neighbors, d_residual, d_jacobian, stream=0):
+    def edge_residuals(self, scan_map, pose, n_neighbors, d_residual, d_jacobian, stream=0):
         """lfx_edge_residuals: the edge clouds of the last device batch against an edge map."""
         pm = np.ascontiguousarray(pose, np.float64).reshape(12)
         B.check(self._ctx, self._L.lfx_edge_residuals(
-            self._ctx, C.c_void_p(int(d_map)), int(n_map), pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
+            self._ctx, scan_map.handle, pm.ctypes.data_as(C.POINTER(C.c_double)), int(n_neighbors),
             C.c_void_p(int(d_residual)), C.c_void_p(int(d_jacobian)), C.c_void_p(int(stream))))
 
     def _align_results(self, res):
@@ -197,7 +201,7 @@ class FeatureExtraction:
                             message=self._L.lfx_align_message(r.code).decode()))
         return out
 
-    def scan_to_map_align(self, d_edge_map, n_edge_map, d_surface_map, n_surface_map, n_neighbors, max_iter, d_edge_points,
+    def scan_to_map_align(self, edge_map, surface_map, n_neighbors, max_iter, d_edge_points,
                           d_edge_begin, d_edge_count, edge_count_stride, max_edge, total_edge, d_surface_points, d_surface_begin,
                           d_surface_count, surface_count_stride, max_surface, total_surface, initial_poses, stream=0):
         """lfx_scan_to_map_align: Optimizer<LOAMOptimizationProblem>::Run (optimizer.hpp:79-123) per scan; initial_poses
@@ -206,7 +210,7 @@ class FeatureExtraction:
         res = (B.AlignResult * len(poses))()
         v = lambda a: C.c_void_p(int(a))   # noqa: E731
         B.check(self._ctx, self._L.lfx_scan_to_map_align(
-            self._ctx, v(d_edge_map), int(n_edge_map), v(d_surface_map), int(n_surface_map), int(n_neighbors), int(max_iter),
+            self._ctx, edge_map.handle, surface_map.handle, int(n_neighbors), int(max_iter),
             v(d_edge_points), v(d_edge_begin), v(d_edge_count), int(edge_count_stride), int(max_edge), int(total_edge),
             v(d_surface_points), v(d_surface_begin), v(d_surface_count), int(surface_count_stride), int(max_surface),
             int(total_surface), len(poses), poses.ctypes.data_as(C.POINTER(C.c_double)), res, v(stream)))
@@ -222,14 +226,12 @@ class FeatureExtraction:
             int(max_iter), poses.ctypes.data_as(C.POINTER(C.c_double)), res, v(stream)))
         return self._align_results(res)
 
-    def localize_batch(self, d_edge_map, n_edge_map, d_surface_map, n_surface_map, initial_poses, n_neighbors=15, max_iter=20,
-                       surface_leaf=1.0, stream=0):
+    def localize_batch(self, edge_map, surface_map, initial_poses, n_neighbors=15, max_iter=20, surface_leaf=1.0, stream=0):
         """lfx_localize_batch: Localizer::Update (localizer.hpp:71-80) for every scan of the last device batch."""
         poses = np.ascontiguousarray(initial_poses, np.float64).reshape(-1, 12)
         res = (B.AlignResult * len(poses))()
         B.check(self._ctx, self._L.lfx_localize_batch(
-            self._ctx, C.c_void_p(int(d_edge_map)), int(n_edge_map), C.c_void_p(int(d_surface_map)), int(n_surface_map),
-            int(n_neighbors), int(max_iter), float(surface_leaf), poses.ctypes.data_as(C.POINTER(C.c_double)), res,
+            self._ctx, edge_map.handle, surface_map.handle, int(n_neighbors), int(max_iter), float(surface_leaf), poses.ctypes.data_as(C.POINTER(C.c_double)), res,
             C.c_void_p(int(stream))))
         return self._align_results(res)
 
@@ -370,3 +372,37 @@ def layout_from_fields(fields, point_step, is_bigendian=False):
         raise B.LfxError(rc, {-7: "the cloud has no ring field", -8: "x / y / z must be FLOAT32 and ring an integer field inside point_step"}.get(rc, "invalid field list"))
     return out
 
+
+
+class ScanMap:
+    """lfx_map: the index a scan is matched against -- the place of the reference's KDTreeEigen (kdtree.hpp:50-71)."""
+
+    def __init__(self, fx, d_points, n_points, cell_size=1.0, stream=0):
+        self._fx = fx
+        self._L = fx._L
+        h = C.c_void_p()
+        B.check(fx._ctx, self._L.lfx_map_create(fx._ctx, C.c_void_p(int(d_points)), int(n_points), float(cell_size), C.byref(h),
+                                                C.c_void_p(int(stream))))
+        self.handle = h
+
+    def info(self):
+        n, cell, dims = C.c_uint32(), C.c_float(), (C.c_int32 * 3)()
+        self._L.lfx_map_info(self.handle, C.byref(n), C.byref(cell), dims)
+        return dict(n_points=n.value, cell_size=cell.value, dims=tuple(dims))
+
+    def nearest(self, d_queries, n_queries, k, d_neighbours=0, d_squared_distances=0, d_indices=0, stream=0):
+        """lfx_map_nearest: KDTreeEigen::NearestKSearch (src/kdtree.cpp:44-68) for a batch of queries on the device."""
+        B.check(self._fx._ctx, self._L.lfx_map_nearest(
+            self._fx._ctx, self.handle, C.c_void_p(int(d_queries)), int(n_queries), int(k), C.c_void_p(int(d_neighbours)),
+            C.c_void_p(int(d_squared_distances)), C.c_void_p(int(d_indices)), C.c_void_p(int(stream))))
+
+    def close(self):
+        if self.handle:
+            self._L.lfx_map_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -134,6 +134,8 @@ void orc_loc_surface_residuals(const float *map, int n_map, const double *pose, 
 /* the optimizer around those rows (optimizer.hpp:70-127, src/optimizer.cpp, robust.cpp, degenerate.cpp, posevec.cpp,
  * lib/src/stats.cpp, alignment.cpp); pinned by test_robust.cpp, test_degenerate.cpp, test_posevec.cpp, test_optimizer.cpp.
  * code: 0 converged, 1 error larger than before, 2 scale larger than before (success), 3 maximum iteration, 4 empty input. */
+void orc_loc_nearest(const float *map, int n_map, const double *query, int k, double *neighbours /* [k][3] */,
+                     double *squared_distances, int *indices);                                           /* kdtree.cpp:44-68 */
 double orc_loc_median(const double *v, int n);                                                          /* stats.cpp:34-55 */
 double orc_loc_mad(const double *v, int n);                                                             /* robust.cpp:36-40 */
 double orc_loc_scale(const double *v, int n);                                                           /* robust.cpp:42-50 */

@@ -529,6 +529,20 @@ void orc_loc_surface_residuals(const float * map, int n_map, const double * pose
   }
 }
 
+// KDTreeEigen::NearestKSearch (src/kdtree.cpp:44-68): neighbours [k][3], squared distances [k], indices [k]
+void orc_loc_nearest(const float * map, int n_map, const double * query, int k, double * neighbours, double * squared_distances, int * indices)
+{
+  std::vector<int> idx;
+  const V3 q{query[0], query[1], query[2]};
+  Nearest(map, n_map, q, k, idx);
+  for (int j = 0; j < k; j++) {
+    const double dx = (double)map[4 * idx[j]] - q.x, dy = (double)map[4 * idx[j] + 1] - q.y, dz = (double)map[4 * idx[j] + 2] - q.z;
+    for (int a = 0; a < 3; a++) {neighbours[3 * j + a] = (double)map[4 * idx[j] + a];}
+    squared_distances[j] = dx * dx + dy * dy + dz * dz;
+    indices[j] = idx[j];
+  }
+}
+
 double orc_loc_median(const double * v, int n) {return MedianOf(std::vector<double>(v, v + n));}
 double orc_loc_mad(const double * v, int n) {return Mad(std::vector<double>(v, v + n));}
 double orc_loc_scale(const double * v, int n) {return ScaleOf(std::vector<double>(v, v + n));}

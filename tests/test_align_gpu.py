@@ -186,7 +186,14 @@ def test_localize_batch_against_the_oracle():
     d_emap, d_smap = torch.from_numpy(edge_map).to(dev), torch.from_numpy(surf_map).to(dev)
     poses = np.stack([_pose(rng.normal(0, 0.004, 3), rng.normal(0, 0.03, 3)) for _ in range(batch)])
     poses[0] = _pose([0, 0, 0], [0, 0, 0])
-    got = fx.localize_batch(d_emap.data_ptr(), len(edge_map), d_smap.data_ptr(), len(surf_map), poses, k, max_iter, 1.0, stream)
+    emap, smap = fx.make_map(d_emap.data_ptr(), len(edge_map), 1.0, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), 2.0, stream)
+    got = fx.localize_batch(emap, smap, poses, k, max_iter, 1.0, stream)
+    # the same with maps that have no grid (every query reads the whole map): the same neighbours, so the same bits
+    emap0, smap0 = fx.make_map(d_emap.data_ptr(), len(edge_map), 0.0, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), 0.0, stream)
+    got0 = fx.localize_batch(emap0, smap0, poses, k, max_iter, 1.0, stream)
+    for a, b in zip(got, got0):
+        assert a["pose"].tobytes() == b["pose"].tobytes() and (a["code"], a["iteration"], a["error"], a["error_scale"]) == (
+            b["code"], b["iteration"], b["error"], b["error_scale"])
     moved = 0
     for s in range(batch):
         down = _downsample(want[s]["surface_points"], 1.0)
@@ -231,8 +238,10 @@ def test_scan_to_map_align_on_caller_clouds_and_its_arguments():
     d_s, d_sb, d_sn, sn = lay(surfs)
     d_emap, d_smap = torch.from_numpy(edge_map).to(dev), torch.from_numpy(surf_map).to(dev)
     poses = np.stack([_pose(rng.normal(0, 0.003, 3), rng.normal(0, 0.02, 3)) for _ in range(3)])
+    emap, smap = fx.make_map(d_emap.data_ptr(), len(edge_map), 0.7), fx.make_map(d_smap.data_ptr(), len(surf_map), 1.5)
+    tiny = fx.make_map(d_emap.data_ptr(), 5, 1.0)
     for max_iter in (20, 2):
-        got = fx.scan_to_map_align(d_emap.data_ptr(), len(edge_map), d_smap.data_ptr(), len(surf_map), k, max_iter, d_e.data_ptr(),
+        got = fx.scan_to_map_align(emap, smap, k, max_iter, d_e.data_ptr(),
                                    d_eb.data_ptr(), d_en.data_ptr(), 1, int(en.max()), int(en.sum()), d_s.data_ptr(), d_sb.data_ptr(),
                                    d_sn.data_ptr(), 1, int(sn.max()), int(sn.sum()), poses, 0)
         for s in range(3):
@@ -242,9 +251,9 @@ def test_scan_to_map_align_on_caller_clouds_and_its_arguments():
             else:
                 _same_result(got[s], w, "scan %d, max_iter %d" % (s, max_iter), pose_tol=1e-6, rel=1e-5)
     with pytest.raises(LfxError):
-        fx.scan_to_map_align(d_emap.data_ptr(), len(edge_map), d_smap.data_ptr(), len(surf_map), k, 0, d_e.data_ptr(), d_eb.data_ptr(),
+        fx.scan_to_map_align(emap, smap, k, 0, d_e.data_ptr(), d_eb.data_ptr(),
                              d_en.data_ptr(), 1, 1, 1, d_s.data_ptr(), d_sb.data_ptr(), d_sn.data_ptr(), 1, 1, 1, poses, 0)
     with pytest.raises(LfxError):
-        fx.scan_to_map_align(d_emap.data_ptr(), 5, d_smap.data_ptr(), len(surf_map), k, 5, d_e.data_ptr(), d_eb.data_ptr(),
+        fx.scan_to_map_align(tiny, smap, k, 5, d_e.data_ptr(), d_eb.data_ptr(),
                              d_en.data_ptr(), 1, 1, 1, d_s.data_ptr(), d_sb.data_ptr(), d_sn.data_ptr(), 1, 1, 1, poses, 0)
     fx.close()

@@ -257,3 +257,15 @@ def test_optimizer_on_the_alignment_problem(refvec):
     dq, dt = np.zeros(4), np.zeros(3)
     L.orc_loc_pairs_update(B.ptr(d([[0, 0, 0]]), PD), B.ptr(d([[1, 1, 1]]), PD), 1, B.ptr(ident, PD), B.ptr(dq, PD), B.ptr(dt, PD))
     assert dq.tolist() == [1, 0, 0, 0] and dt.tolist() == [0, 0, 0]
+
+
+def test_nearest_k_search(refvec):
+    """localization/test/test_kdtree.cpp:37-77 on the restated exact search."""
+    g = refvec["loc_kdtree"]
+    pts = np.zeros((len(g["points"]), 4), np.float32)
+    pts[:, :3] = g["points"]
+    for c in g["cases"]:
+        k = c["k"]
+        X, dist, idx = np.zeros((k, 3)), np.zeros(k), np.zeros(k, np.int32)
+        L.orc_loc_nearest(B.ptr(pts, PF), len(pts), B.ptr(d(g["query"]), PD), k, B.ptr(X, PD), B.ptr(dist, PD), B.ptr(idx, PI))
+        assert X.tolist() == c["X"] and dist.tolist() == c["squared_distances"]

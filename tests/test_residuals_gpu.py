@@ -55,7 +55,8 @@ def test_edge_and_surface_rows_of_an_extracted_batch():
     # ---- edge rows, straight from the batch's edge clouds
     d_res = torch.zeros((total, 3), dtype=torch.float64, device=dev)
     d_jac = torch.zeros((total, 21), dtype=torch.float64, device=dev)
-    fx.edge_residuals(d_emap.data_ptr(), len(edge_map), pose, k, d_res.data_ptr(), d_jac.data_ptr(), stream)
+    emap, smap = fx.make_map(d_emap.data_ptr(), len(edge_map), 1.0, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), 0.0, stream)
+    fx.edge_residuals(emap, pose, k, d_res.data_ptr(), d_jac.data_ptr(), stream)
     # ---- surface rows: downsample (surface.hpp:111), then the planes
     d_down = torch.zeros((total, 4), dtype=torch.float32, device=dev)
     d_dn = torch.zeros(batch, dtype=torch.int32, device=dev)
@@ -64,7 +65,7 @@ def test_edge_and_surface_rows_of_an_extracted_batch():
     d_sres = torch.zeros(total, dtype=torch.float64, device=dev)
     d_sjac = torch.zeros((total, 7), dtype=torch.float64, device=dev)
     view = fx.device_view()
-    fx.scan_to_map_residuals(1, d_smap.data_ptr(), len(surf_map), pose, k, d_down.data_ptr(), view.scan_begin, d_dn.data_ptr(), 1,
+    fx.scan_to_map_residuals(1, smap, pose, k, d_down.data_ptr(), view.scan_begin, d_dn.data_ptr(), 1,
                              batch, rings * cols, d_sres.data_ptr(), d_sjac.data_ptr(), stream)
     torch.cuda.synchronize()
     res, jac = d_res.cpu().numpy(), d_jac.cpu().numpy()
@@ -112,11 +113,12 @@ def test_reference_vectors_through_the_device():
     pts = np.array([[2, 1, 0, 1], [0.5, 0, 0, 1]], np.float32)       # p0 of :177, and a point on the line
     pose = np.hstack([np.eye(3), np.array([[3.0], [2.0], [1.0]])])   # theta0 = 0, t0 = (3, 2, 1), :167-168
     d_map, d_pts = torch.from_numpy(line).to(dev), torch.from_numpy(pts).to(dev)
+    line_map = fx.make_map(d_map.data_ptr(), 5, 0.5)
     d_b = torch.zeros(1, dtype=torch.int32, device=dev)
     d_n = torch.tensor([2], dtype=torch.int32, device=dev)
     d_res = torch.zeros((2, 3), dtype=torch.float64, device=dev)
     d_jac = torch.zeros((2, 21), dtype=torch.float64, device=dev)
-    fx.scan_to_map_residuals(0, d_map.data_ptr(), 5, pose, 5, d_pts.data_ptr(), d_b.data_ptr(), d_n.data_ptr(), 1, 1, 2,
+    fx.scan_to_map_residuals(0, line_map, pose, 5, d_pts.data_ptr(), d_b.data_ptr(), d_n.data_ptr(), 1, 1, 2,
                              d_res.data_ptr(), d_jac.data_ptr(), 0)
     torch.cuda.synchronize()
     res, jac = d_res.cpu().numpy(), d_jac.cpu().numpy().reshape(2, 3, 7)
@@ -129,7 +131,7 @@ def test_reference_vectors_through_the_device():
     assert min(np.abs(jac[0][:, 4:] - K).max(), np.abs(jac[0][:, 4:] + K).max()) < 1e-12
     # identity pose: the second point lies on the line
     pose0 = np.hstack([np.eye(3), np.zeros((3, 1))])
-    fx.scan_to_map_residuals(0, d_map.data_ptr(), 5, pose0, 5, d_pts.data_ptr(), d_b.data_ptr(), d_n.data_ptr(), 1, 1, 2,
+    fx.scan_to_map_residuals(0, line_map, pose0, 5, d_pts.data_ptr(), d_b.data_ptr(), d_n.data_ptr(), 1, 1, 2,
                              d_res.data_ptr(), d_jac.data_ptr(), 0)
     torch.cuda.synchronize()
     assert np.abs(d_res.cpu().numpy()[1]).max() < 1e-12
