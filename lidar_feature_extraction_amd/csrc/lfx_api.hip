@@ -1385,14 +1385,15 @@ void launch_rows(bool surface, const lfx::MapIndex & mi, const lfx::MapPose & P,
   const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride, uint32_t n_clouds, uint32_t longest, double * d_residual,
   double * d_jacobian, const lfx::AlignState * states, hipStream_t st)
 {
-  const dim3 grid((longest + 127u) / 128u, n_clouds);
+  const bool wave = mi.start != nullptr;              // a grid: one query per wave; no grid: one per thread, the map through LDS
+  const dim3 grid(wave ? longest : (longest + 127u) / 128u, n_clouds), block(wave ? 64 : 128);
   const float4 * pts = reinterpret_cast<const float4 *>(d_points);
-#define LFX_ROWS(S, G) hipLaunchKernelGGL((lfx::scan_to_map_kernel<S, G>), grid, dim3(128), 0, st, mi, P, k, pts, d_begin, d_count, \
+#define LFX_ROWS(S, M) hipLaunchKernelGGL((lfx::scan_to_map_kernel<S, M>), grid, block, 0, st, mi, P, k, pts, d_begin, d_count, \
     count_stride, d_residual, d_jacobian, states)
-  if (mi.start) {
-    if (surface) {LFX_ROWS(true, true);} else {LFX_ROWS(false, true);}
+  if (wave) {
+    if (surface) {LFX_ROWS(true, lfx::kSearchGridWave);} else {LFX_ROWS(false, lfx::kSearchGridWave);}
   } else {
-    if (surface) {LFX_ROWS(true, false);} else {LFX_ROWS(false, false);}
+    if (surface) {LFX_ROWS(true, lfx::kSearchWholeMap);} else {LFX_ROWS(false, lfx::kSearchWholeMap);}
   }
 #undef LFX_ROWS
 }
@@ -1516,13 +1517,13 @@ int lfx_map_nearest(
   if (m->device != c->device) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "the map lives on another device");}
   if (n_queries == 0) {return LFX_OK;}
   LFX_HIP(c, hipSetDevice(c->device));
-  const dim3 grid((n_queries + 127u) / 128u);
+  hipStream_t st = static_cast<hipStream_t>(stream);
   if (m->index.start) {
-    hipLaunchKernelGGL(lfx::map_nearest_kernel<true>, grid, dim3(128), 0, static_cast<hipStream_t>(stream), m->index, d_queries,
+    hipLaunchKernelGGL(lfx::map_nearest_kernel<lfx::kSearchGridWave>, dim3(n_queries), dim3(64), 0, st, m->index, d_queries,
       n_queries, k, d_neighbours, d_squared_distances, d_indices);
   } else {
-    hipLaunchKernelGGL(lfx::map_nearest_kernel<false>, grid, dim3(128), 0, static_cast<hipStream_t>(stream), m->index, d_queries,
-      n_queries, k, d_neighbours, d_squared_distances, d_indices);
+    hipLaunchKernelGGL(lfx::map_nearest_kernel<lfx::kSearchWholeMap>, dim3((n_queries + 127u) / 128u), dim3(128), 0, st, m->index,
+      d_queries, n_queries, k, d_neighbours, d_squared_distances, d_indices);
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -1754,14 +1755,21 @@ int lfx_localize_batch(
   hipLaunchKernelGGL(lfx::downsample_passthrough_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream),
     reinterpret_cast<const float4 *>(c->surf_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoSurface, 4u,
     reinterpret_cast<float4 *>(down), down_count, down_status);
-  uint32_t longest = 0;
+  // the longest edge cloud and the longest downsampled surface cloud size the launches (and choose between one query per
+  // thread and one per wave): two small copies, and the call is synchronous anyway
+  std::vector<uint32_t> info(4 * (size_t)batch), down_n(batch);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LFX_HIP(c, hipMemcpyAsync(info.data(), c->scan_info.p, sizeof(uint32_t) * 4 * batch, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipMemcpyAsync(down_n.data(), down_count, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipStreamSynchronize(st));
+  uint32_t longest_edge = 0, longest_surface = 0;
   for (uint32_t s = 0; s < batch; s++) {
-    const uint32_t n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
-    longest = n > longest ? n : longest;                 // a scan has no more edge / surface points than points
+    longest_edge = std::max(longest_edge, info[4 * s + lfx::kInfoEdge]);
+    longest_surface = std::max(longest_surface, down_n[s]);
   }
   return lfx_scan_to_map_align(c, edge_map, surface_map, n_neighbors, max_iter,
-           reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest, total,
-           down, c->scan_begin.p, down_count, 1, longest, total, batch, initial_poses, results, stream);
+           reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest_edge, total,
+           down, c->scan_begin.p, down_count, 1, longest_surface, total, batch, initial_poses, results, stream);
 }
 
 }  // extern "C"

@@ -3126,7 +3126,7 @@ __device__ inline void nearest_insert(double (&dist)[kNearestMax], uint32_t (&id
 
 // every thread of the workgroup (T threads) calls this; the map passes through LDS in tiles
 template<int T>
-__device__ inline void nearest_whole_map(const MapIndex & mi, D3 q, double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax], float4 * tile)
+__device__ __forceinline__ void nearest_whole_map(const MapIndex & mi, D3 q, double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax], float4 * tile)
 {
   const uint32_t tid = threadIdx.x, n_map = mi.n;
   for (uint32_t t0 = 0; t0 < n_map; t0 += T) {
@@ -3142,50 +3142,146 @@ __device__ inline void nearest_whole_map(const MapIndex & mi, D3 q, double (&dis
   }
 }
 
-// one thread, one query: the cube of cells within rho of the query's cell, rho grown until the kk-th distance is inside
-// the cube's inscribed sphere (no unseen point can be nearer) or the cube holds the whole grid
-__device__ inline void nearest_in_grid(const MapIndex & mi, D3 q, uint32_t kk, double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax])
+// the cube of cells within rho of the query's cell, clipped to the grid, and the test that ends the search
+struct GridCube
 {
-  constexpr int KM = kNearestMax;
-  const double ux = (q.x - mi.ox) * mi.inv_h, uy = (q.y - mi.oy) * mi.inv_h, uz = (q.z - mi.oz) * mi.inv_h;
-  const int cx = cell_coordinate(q.x, mi.ox, mi.inv_h), cy = cell_coordinate(q.y, mi.oy, mi.inv_h), cz = cell_coordinate(q.z, mi.oz, mi.inv_h);
-  auto outside = [](int c, int n) {return c < 0 ? -c : (c > n - 1 ? c - (n - 1) : 0);};
-  int rho = max(max(outside(cx, mi.nx), outside(cy, mi.ny)), max(outside(cz, mi.nz), 1));
-  for (;;) {
-#pragma unroll
-    for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
-    const int xlo = max(cx - rho, 0), xhi = min(cx + rho, mi.nx - 1), ylo = max(cy - rho, 0), yhi = min(cy + rho, mi.ny - 1);
-    const int zlo = max(cz - rho, 0), zhi = min(cz + rho, mi.nz - 1);
+  double ux, uy, uz;
+  int cx, cy, cz, rho;
+  int xlo, xhi, ylo, yhi, zlo, zhi;
+  __device__ __forceinline__ void begin(const MapIndex & mi, D3 q)
+  {
+    ux = (q.x - mi.ox) * mi.inv_h; uy = (q.y - mi.oy) * mi.inv_h; uz = (q.z - mi.oz) * mi.inv_h;
+    cx = cell_coordinate(q.x, mi.ox, mi.inv_h); cy = cell_coordinate(q.y, mi.oy, mi.inv_h); cz = cell_coordinate(q.z, mi.oz, mi.inv_h);
+    auto outside = [](int c, int n) {return c < 0 ? -c : (c > n - 1 ? c - (n - 1) : 0);};
+    rho = max(max(outside(cx, mi.nx), outside(cy, mi.ny)), max(outside(cz, mi.nz), 1));
+    clip(mi);
+  }
+  __device__ __forceinline__ void clip(const MapIndex & mi)
+  {
+    xlo = max(cx - rho, 0); xhi = min(cx + rho, mi.nx - 1); ylo = max(cy - rho, 0); yhi = min(cy + rho, mi.ny - 1);
+    zlo = max(cz - rho, 0); zhi = min(cz + rho, mi.nz - 1);
+  }
+  __device__ __forceinline__ void grow(const MapIndex & mi) {rho = rho < 2 ? rho + 1 : 2 * rho; clip(mi);}
+  __device__ __forceinline__ uint32_t candidates(const MapIndex & mi) const
+  {
+    uint32_t total = 0;
     if (xlo <= xhi) {
       for (int z = zlo; z <= zhi; z++) {
         for (int y = ylo; y <= yhi; y++) {
           const size_t row = ((size_t)z * mi.ny + y) * mi.nx;
-          const uint32_t a = mi.start[row + xlo], b = mi.start[row + xhi + 1];
-          for (uint32_t at = a; at < b; at++) {
-            const float4 mpt = mi.pts[at];
-            const double dx = (double)mpt.x - q.x, dy = (double)mpt.y - q.y, dz = (double)mpt.z - q.z;
-            nearest_insert<true>(dist, idx, dx * dx + dy * dy + dz * dz, at, __float_as_uint(mpt.w), mi.pts);
-          }
+          total += mi.start[row + xhi + 1] - mi.start[row + xlo];
         }
       }
     }
-    const bool whole = cx - rho <= 0 && cx + rho >= mi.nx - 1 && cy - rho <= 0 && cy + rho >= mi.ny - 1 && cz - rho <= 0 && cz + rho >= mi.nz - 1;
-    if (whole) {return;}
-    // a point in a cell outside the cube differs from the query by at least g cells along some axis (1e-7 cells: rounding
-    // of the cell coordinates of points on a face)
+    return total;
+  }
+  // all points seen, or the kk-th distance inside the cube's inscribed sphere (no unseen point can be nearer): a point in a
+  // cell outside the cube differs from the query by at least g cells along some axis (1e-7 cells: rounding of the cell
+  // coordinates of points on a face)
+  __device__ __forceinline__ bool done(const MapIndex & mi, double kth) const
+  {
+    if (cx - rho <= 0 && cx + rho >= mi.nx - 1 && cy - rho <= 0 && cy + rho >= mi.ny - 1 && cz - rho <= 0 && cz + rho >= mi.nz - 1) {return true;}
     const double r = (double)rho;
     const double g = fmin(fmin(fmin(ux - ((double)cx - r), ((double)cx + r + 1.) - ux), fmin(uy - ((double)cy - r), ((double)cy + r + 1.) - uy)),
         fmin(uz - ((double)cz - r), ((double)cz + r + 1.) - uz)) - 1e-7;
-    double kth = INFINITY;
-#pragma unroll
-    for (int j = 0; j < KM; j++) {if ((uint32_t)j == kk - 1u) {kth = dist[j];}}
     const double reach = g * mi.h;
-    if (g > 0. && kth <= reach * reach) {return;}
-    rho = rho < 2 ? rho + 1 : 2 * rho;
+    return g > 0. && kth <= reach * reach;
+  }
+};
+
+#ifndef LFX_GRID_UNROLL
+#define LFX_GRID_UNROLL 2
+#endif
+constexpr int kGridUnroll = LFX_GRID_UNROLL;      // runs of 64 points loaded at once
+
+__device__ __forceinline__ double wave_read(double v, int lane)
+{
+  const long long b = __double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// one wave, one query (the same q in every lane): rho grown until GridCube::done.  The 64 lanes take 64 consecutive points
+// of a run of cells at a time; the list of the KM nearest so far lives in lanes 0..KM-1 (distance, position, original
+// index), its last distance is the bar a point has to pass, and the few points that pass are inserted one at a time (a
+// shift along the lanes).  The query's own row of cells first: its points set a low bar early.  All 64 lanes must be
+// here; the list comes back in lanes 0..KM-1.
+// (Measured against one query per thread -- lists in registers with batched insertion, or heaps in LDS: a thread inserts
+// for a few points in a hundred, but some thread of 64 does at nearly every point, so the wave paid the insertion at every
+// point; this form was 2-4x faster from one scan to 64 and level at 256, and it is the only one kept.)
+__device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, uint32_t kk, double & ldist, uint32_t & lidx)
+{
+  constexpr int KM = kNearestMax;
+  const int lane = threadIdx.x & 63;
+  GridCube cube;
+  cube.begin(mi, q);
+  uint32_t lorig = 0u;
+  for (;;) {
+    ldist = INFINITY; lidx = 0u; lorig = 0xFFFFFFFFu;
+    // (the bar read back from the list, through an empty asm the compiler cannot see through, rather than set to the
+    // constant: hipcc 7.2 materialises a wave-uniform double constant with s_mov_b64 and a 64-bit literal, which gfx950
+    // truncates to its low word -- infinity became 0.0 here)
+    asm volatile("" : "+v"(ldist));
+    double bar = wave_read(ldist, KM - 1);
+    uint32_t bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+    auto row = [&](int z, int y) __attribute__((always_inline)) {
+        const size_t cell0 = ((size_t)z * mi.ny + y) * mi.nx;
+        const uint32_t a = mi.start[cell0 + cube.xlo], b = mi.start[cell0 + cube.xhi + 1];
+        for (uint32_t base = a; base < b; base += 64u * kGridUnroll) {
+          float4 mpts[kGridUnroll];
+#pragma unroll
+          for (int u = 0; u < kGridUnroll; u++) {
+            const uint32_t at = base + 64u * u + (uint32_t)lane;
+            mpts[u] = mi.pts[at < b ? at : b - 1u];
+          }
+#pragma unroll
+          for (int u = 0; u < kGridUnroll; u++) {
+            const uint32_t at = base + 64u * u + (uint32_t)lane;
+            if (base + 64u * u >= b) {continue;}                                      // (the same in every lane)
+            const bool live = at < b;
+            const float4 mpt = mpts[u];
+            const double dx = (double)mpt.x - q.x, dy = (double)mpt.y - q.y, dz = (double)mpt.z - q.z;
+            const double d = dx * dx + dy * dy + dz * dz;
+            const uint32_t orig = __float_as_uint(mpt.w);
+            uint64_t pass = __ballot(live && (d < bar || (d == bar && orig < bar_orig)));
+            while (pass) {
+              const int src = __ffsll((unsigned long long)pass) - 1;
+              pass &= pass - 1;
+              const double cd = wave_read(d, src);
+              const uint32_t cat = (uint32_t)__builtin_amdgcn_readlane((int)at, src), corig = (uint32_t)__builtin_amdgcn_readlane((int)orig, src);
+              if (!(cd < bar || (cd == bar && corig < bar_orig))) {continue;}         // the bar has moved since the ballot
+              const uint64_t later = __ballot(lane < KM && (cd < ldist || (cd == ldist && corig < lorig))) & 0xFFFFull;
+              const int place = __ffsll((unsigned long long)later) - 1;                 // the first entry the point comes before
+              const double up_d = __shfl_up(ldist, 1, 64);
+              const uint32_t up_i = (uint32_t)__shfl_up((int)lidx, 1, 64), up_o = (uint32_t)__shfl_up((int)lorig, 1, 64);
+              const bool shifts = lane > place, lands = lane == place;
+              ldist = shifts ? up_d : (lands ? cd : ldist);
+              lidx = shifts ? up_i : (lands ? cat : lidx);
+              lorig = shifts ? up_o : (lands ? corig : lorig);
+              bar = wave_read(ldist, KM - 1);
+              bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+            }
+          }
+        }
+      };
+    if (cube.xlo <= cube.xhi) {
+      const bool own = cube.cy >= cube.ylo && cube.cy <= cube.yhi && cube.cz >= cube.zlo && cube.cz <= cube.zhi;
+      if (own) {row(cube.cz, cube.cy);}
+      for (int z = cube.zlo; z <= cube.zhi; z++) {
+        for (int y = cube.ylo; y <= cube.yhi; y++) {
+          if (!(own && z == cube.cz && y == cube.cy)) {row(z, y);}
+        }
+      }
+    }
+    if (cube.done(mi, wave_read(ldist, (int)kk - 1))) {return;}
+    cube.grow(mi);
   }
 }
 
-template<bool SURFACE, bool GRID>
+// how a query finds its neighbours
+enum : int {kSearchWholeMap = 0, kSearchGridWave = 2};
+
+template<bool SURFACE, int SEARCH>
 __global__ __launch_bounds__(128) void scan_to_map_kernel(
   MapIndex mi, MapPose P, uint32_t k, const float4 * __restrict__ pts,
   const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
@@ -3199,8 +3295,9 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
   }
   const float4 * __restrict__ map = mi.pts;
   const uint32_t b = begin[s], n = count[(size_t)s * count_stride];
-  const uint32_t i = blockIdx.x * T + tid;
-  if (blockIdx.x * T >= n) {return;}                   // the whole workgroup is beyond this cloud
+  // kSearchGridWave: a workgroup is one wave and has one query, the same in every lane
+  const uint32_t i = SEARCH == kSearchGridWave ? blockIdx.x : blockIdx.x * T + tid;
+  if ((SEARCH == kSearchGridWave ? blockIdx.x : blockIdx.x * T) >= n) {return;}       // the whole workgroup is beyond this cloud
   const bool valid = i < n;
   const float4 pf = pts[b + (valid ? i : 0u)];
   const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
@@ -3209,9 +3306,17 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
   const uint32_t kk = k < (uint32_t)KM ? k : (uint32_t)KM;
   double dist[KM];
   uint32_t idx[KM];
-  if (GRID) {
-    if (!valid) {return;}
-    nearest_in_grid(mi, q, kk, dist, idx);
+  if (SEARCH == kSearchGridWave) {
+    __shared__ double list_d[KM];
+    __shared__ uint32_t list_i[KM];
+    double ld;
+    uint32_t li;
+    nearest_in_grid_wave(mi, q, kk, ld, li);
+    if (tid < (uint32_t)KM) {list_d[tid] = ld; list_i[tid] = li;}
+    __syncthreads();
+    if (tid != 0) {return;}                              // one lane does the rest
+#pragma unroll
+    for (int j = 0; j < KM; j++) {dist[j] = list_d[j]; idx[j] = list_i[j];}
   } else {
 #pragma unroll
     for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
@@ -3437,29 +3542,38 @@ __global__ __launch_bounds__(256) void map_scatter_kernel(
 // KDTreeEigen::NearestKSearch (localization/src/kdtree.cpp:44-68) for a batch of queries: per query the k nearest points
 // of the map, ascending; neighbours [n][k][3] doubles (GetRows of the map), squared distances [n][k], indices [n][k]
 // into the map as it was given.
-template<bool GRID>
+template<int SEARCH>
 __global__ __launch_bounds__(128) void map_nearest_kernel(
   MapIndex mi, const double * __restrict__ queries, uint32_t n, uint32_t k, double * __restrict__ neighbours,
   double * __restrict__ squared_distances, uint32_t * __restrict__ indices)
 {
   constexpr int KM = kNearestMax, T = 128;
-  const uint32_t i = blockIdx.x * T + threadIdx.x;
+  const uint32_t i = SEARCH == kSearchGridWave ? blockIdx.x : blockIdx.x * T + threadIdx.x;
   const bool valid = i < n;
   const size_t at = valid ? i : 0u;
   const D3 q{queries[3 * at], queries[3 * at + 1], queries[3 * at + 2]};
   const uint32_t kk = k < (uint32_t)KM ? k : (uint32_t)KM;
   double dist[KM];
   uint32_t idx[KM];
-  if (GRID) {
-    if (!valid) {return;}
-    nearest_in_grid(mi, q, kk, dist, idx);
+  constexpr bool GRID = SEARCH != kSearchWholeMap;
+  if (SEARCH == kSearchGridWave) {
+    __shared__ double list_d[KM];
+    __shared__ uint32_t list_i[KM];
+    double ld;
+    uint32_t li;
+    nearest_in_grid_wave(mi, q, kk, ld, li);
+    if (threadIdx.x < (uint32_t)KM) {list_d[threadIdx.x] = ld; list_i[threadIdx.x] = li;}
+    __syncthreads();
+    if (threadIdx.x != 0) {return;}
+#pragma unroll
+    for (int j = 0; j < KM; j++) {dist[j] = list_d[j]; idx[j] = list_i[j];}
   } else {
 #pragma unroll
     for (int j = 0; j < KM; j++) {dist[j] = INFINITY; idx[j] = 0u;}
     __shared__ float4 tile[T];
     nearest_whole_map<T>(mi, q, dist, idx, tile);
-    if (!valid) {return;}
   }
+  if (!valid) {return;}
 #pragma unroll
   for (int j = 0; j < KM; j++) {
     if ((uint32_t)j < kk) {
@@ -3583,27 +3697,33 @@ __global__ __launch_bounds__(128) void pair_rows_kernel(
 
 // k-th smallest (0-based) of the n non-negative doubles v[0..n): most-significant-byte-first radix selection over their bit
 // patterns (non-negative doubles order like their bits), a 256-bin histogram in LDS per byte.  Every thread of the
-// workgroup calls it and gets the value.  sh: 258 words of LDS.
+// workgroup (256 threads) calls it and gets the value.  sh: 264 words of LDS.
 __device__ inline double workgroup_select(const double * __restrict__ v, uint32_t n, uint32_t k, uint32_t * sh)
 {
-  const int tid = threadIdx.x, T = blockDim.x;
+  const int tid = threadIdx.x, T = blockDim.x;           // T == 256: one thread per bin
   uint64_t prefix = 0, mask = 0;
   for (int shift = 56; shift >= 0; shift -= 8) {
-    for (int b = tid; b < 256; b += T) {sh[b] = 0u;}
+    sh[tid] = 0u;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += T) {
       const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
       if ((key & mask) == prefix) {atomicAdd(&sh[(uint32_t)(key >> shift) & 255u], 1u);}
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t cum = 0, b = 0;
-      for (; b < 255u; b++) {
-        if (cum + sh[b] > k) {break;}
-        cum += sh[b];
-      }
-      sh[256] = b; sh[257] = k - cum;
+    // the bin that holds rank k: inclusive prefix sums of the 256 counts (lanes of a wave, then the four waves)
+    const uint32_t mine = sh[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+      if ((tid & 63) >= off) {incl += o;}
     }
+    if ((tid & 63) == 63) {sh[260 + (tid >> 6)] = incl;}
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < (tid >> 6); w++) {before += sh[260 + w];}
+    incl += before;
+    if (k < incl && k >= incl - mine) {sh[256] = (uint32_t)tid; sh[257] = k - (incl - mine);}     // exactly one thread
     __syncthreads();
     prefix |= (uint64_t)sh[256] << shift;
     mask |= 0xFFull << shift;
@@ -3741,7 +3861,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
   const int tid = threadIdx.x;
   AlignState & st = states[s];
   if (st.done) {return;}
-  __shared__ uint32_t sh[258];
+  __shared__ uint32_t sh[264];
   __shared__ double part[T / 64][NS];
   __shared__ double total[NS];
   const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u, n = n3 + n1;

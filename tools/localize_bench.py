@@ -1,0 +1,137 @@
+"""tools/localize_bench.py -- time of lfx_localize_batch (Localizer::Update for a batch of scans) on the
+GPU box, beside the CPU restatement (oracle, exhaustive neighbour search, one core) on a few scans.
+
+  python3 tools/localize_bench.py [--rings 64] [--cols 1800] [--batch 64] [--map-scans 40] [--cell 1.0] [--steps 5]
+
+The maps are the edge / surface features of `map-scans` other scans of the synthetic scene, each moved to a pose of its own
+along a track (so that the map is larger than one scan's surroundings, as a localizer's map is)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--cols", type=int, default=1800)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--map-scans", type=int, default=40)
+    ap.add_argument("--cell", type=float, default=1.0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--max-iter", type=int, default=20)
+    ap.add_argument("--cpu-scans", type=int, default=2)
+    ap.add_argument("--whole-map", action="store_true", help="also time maps without a grid")
+    a = ap.parse_args()
+    import torch
+    from lidar_feature_extraction_amd import FeatureExtraction, make_scan, concat
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1)
+    fx = FeatureExtraction(device=0, max_points_per_scan=a.rings * a.cols, max_batch=max(a.batch, 8), max_points_per_ring=a.cols,
+                           max_rings=a.rings)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def features(clouds):
+        d = torch.from_numpy(concat(clouds).view(np.uint8).copy()).to(dev)
+        fx.extract_batch_device(d.data_ptr(), [len(c) for c in clouds], stream)
+        total = sum(len(c) for c in clouds)
+        d_e = torch.zeros((total, 4), dtype=torch.float32, device=dev)
+        d_s = torch.zeros((total, 4), dtype=torch.float32, device=dev)
+        d_o = torch.zeros(2 * len(clouds) + 2, dtype=torch.int32, device=dev)
+        fx.pack_xyz(d_e.data_ptr(), d_s.data_ptr(), d_o.data_ptr(), total, stream)
+        torch.cuda.synchronize()
+        o = d_o.cpu().numpy()
+        n = len(clouds)
+        eo, so = o[:n + 1], o[n + 1:2 * n + 2]
+        e, s = d_e.cpu().numpy(), d_s.cpu().numpy()
+        return [e[eo[i]:eo[i + 1]] for i in range(n)], [s[so[i]:so[i + 1]] for i in range(n)]
+
+    # the maps: features of other scans, each shifted along a track
+    edge_parts, surf_parts = [], []
+    for at in range(0, a.map_scans, 8):
+        clouds = [make_scan(a.rings, a.cols, seed=9000 + at + i) for i in range(min(8, a.map_scans - at))]
+        e, s = features(clouds)
+        for i in range(len(clouds)):
+            shift = np.array([3.0 * (at + i), 0.5 * ((at + i) % 5), 0, 0], np.float32)
+            edge_parts.append(e[i] + shift)
+            surf_parts.append(s[i] + shift)
+    edge_map = np.ascontiguousarray(np.concatenate(edge_parts))
+    surf_map = np.ascontiguousarray(np.concatenate(surf_parts))
+    d_emap, d_smap = torch.from_numpy(edge_map).to(dev), torch.from_numpy(surf_map).to(dev)
+    t0 = time.perf_counter()
+    emap, smap = fx.make_map(d_emap.data_ptr(), len(edge_map), a.cell, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), a.cell, stream)
+    t_build = time.perf_counter() - t0
+    # the scans to localize: the first positions of the track, each from a perturbed pose
+    clouds = [make_scan(a.rings, a.cols, seed=9000 + (i % a.map_scans)) for i in range(a.batch)]
+    d = torch.from_numpy(concat(clouds).view(np.uint8).copy()).to(dev)
+    n_points = [len(c) for c in clouds]
+
+    def pose(i):
+        th = rng.normal(0, 0.004, 3)
+        k = np.linalg.norm(th)
+        u = th / k
+        K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
+        R = np.eye(3) + np.sin(k) * K + (1 - np.cos(k)) * K @ K
+        t = np.array([3.0 * (i % a.map_scans), 0.5 * ((i % a.map_scans) % 5), 0.0]) + rng.normal(0, 0.03, 3)
+        return np.hstack([R, t.reshape(3, 1)])
+    poses = np.stack([pose(i) for i in range(a.batch)])
+    out = {"rings": a.rings, "cols": a.cols, "batch": a.batch, "edge_map_points": len(edge_map), "surface_map_points": len(surf_map),
+           "cell": a.cell, "map_dims": [emap.info()["dims"], smap.info()["dims"]], "map_build_ms": round(1e3 * t_build, 2), "max_iter": a.max_iter}
+
+    def timed(em, sm, steps):
+        fx.extract_batch_device(d.data_ptr(), n_points, stream)
+        res = fx.localize_batch(em, sm, poses, 15, a.max_iter, 1.0, stream)          # warm-up
+        torch.cuda.synchronize()
+        t = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            res = fx.localize_batch(em, sm, poses, 15, a.max_iter, 1.0, stream)
+            t.append(time.perf_counter() - t0)
+        return res, float(np.median(t))
+    res, t_grid = timed(emap, smap, a.steps)
+    it = np.array([r["iteration"] for r in res])
+    out["localize_ms_per_batch"] = round(1e3 * t_grid, 3)
+    out["localize_ms_per_scan"] = round(1e3 * t_grid / a.batch, 4)
+    out["iterations_mean"] = float(it.mean())
+    out["codes"] = {str(c): int(sum(r["code"] == c for r in res)) for c in range(5)}
+    out["pose_error_after"] = float(np.median([np.abs(r["pose"][:, 3] - [3.0 * (i % a.map_scans), 0.5 * ((i % a.map_scans) % 5), 0]).max()
+                                               for i, r in enumerate(res)]))
+    if a.whole_map:
+        em0, sm0 = fx.make_map(d_emap.data_ptr(), len(edge_map), 0.0, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), 0.0, stream)
+        res0, t_whole = timed(em0, sm0, max(1, a.steps // 3))
+        out["whole_map_ms_per_scan"] = round(1e3 * t_whole / a.batch, 4)
+        out["whole_map_same_bits"] = all(x["pose"].tobytes() == y["pose"].tobytes() for x, y in zip(res, res0))
+    if a.cpu_scans:
+        from oracle import binding as OB
+        L = OB.lib()
+        PD, PF = C.POINTER(C.c_double), C.POINTER(C.c_float)
+        e, s = features(clouds[:a.cpu_scans])
+        t_cpu, same = [], []
+        for i in range(a.cpu_scans):
+            pts = np.ascontiguousarray(s[i], np.float32)
+            down, n_down = np.zeros_like(pts), C.c_int(0)
+            L.orc_voxel_downsample(OB.ptr(pts, PF), len(pts), C.c_float(1.0), OB.ptr(down, PF), C.byref(n_down))
+            down = np.ascontiguousarray(down[:n_down.value])
+            ee = np.ascontiguousarray(e[i], np.float32)
+            po, err, sc, itn, code = np.zeros(12), C.c_double(), C.c_double(), C.c_int(), C.c_int()
+            p0 = np.ascontiguousarray(poses[i])
+            t0 = time.perf_counter()
+            L.orc_loc_optimize_scan(OB.ptr(edge_map, PF), len(edge_map), OB.ptr(surf_map, PF), len(surf_map), 15, OB.ptr(ee, PF), len(ee),
+                                    OB.ptr(down, PF), len(down), OB.ptr(p0, PD), a.max_iter, OB.ptr(po, PD), C.byref(err), C.byref(sc),
+                                    C.byref(itn), C.byref(code))
+            t_cpu.append(time.perf_counter() - t0)
+            same.append(float(np.abs(po.reshape(3, 4) - res[i]["pose"]).max()))
+        out["cpu_oracle_ms_per_scan"] = round(1e3 * float(np.mean(t_cpu)), 1)
+        out["cpu_oracle_note"] = "exhaustive neighbour search, one core; not the reference's KD-tree"
+        out["max_pose_difference_to_oracle"] = max(same)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
