@@ -168,6 +168,7 @@ struct lfx_ctx
   DevBuf<uint32_t> vox_scratch;          // lfx_voxel_downsample: sort keys / values, allocated on first use
   DevBuf<double> align_scratch;          // lfx_scan_to_map_align: states, rows, errors; allocated on first use
   DevBuf<float> align_surface;           // lfx_localize_batch: the downsampled surface clouds (+ counts, status)
+  PinnedBuf h_align;                     // the alignment's small copies to and from the host (poses, counts, states)
 
   hipStream_t stream = nullptr;          // used by the synchronous host entry points
   std::vector<uint32_t> h_scan_begin;    // of the last batch
@@ -885,7 +886,7 @@ void lfx_destroy(lfx_ctx * c)
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
-  c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release();
+  c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release(); c->h_align.release();
   if (c->h_status) {(void)hipHostFree(c->h_status); c->h_status = nullptr;}
   if (c->stream) {(void)hipStreamDestroy(c->stream);}
   delete c;
@@ -1620,7 +1621,7 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   static_assert(sizeof(lfx::AlignState) % 8 == 0, "AlignState is an array of doubles' worth");
   const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds, pose_d = 12 * (size_t)n_clouds;
   const size_t rows = pr.total3 + pr.total1;
-  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + 2 * rows + 8;
+  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + rows + 9;
   if (c->align_scratch.n < need) {
     c->align_scratch.release();
     if (c->align_scratch.alloc(need) != hipSuccess) {
@@ -1636,9 +1637,13 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   double * r1 = w; w += pr.total1;
   double * J1 = w; w += 7 * pr.total1;
   double * err = w; w += rows;
-  double * dev = w;
-  LFX_HIP(c, hipMemcpyAsync(d_initial, initial_poses, pose_d * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(lfx::align_begin_kernel, dim3((n_clouds + 63u) / 64u), dim3(64), 0, st, states, d_initial, n_clouds);
+  uint32_t * d_active = reinterpret_cast<uint32_t *>(w);
+  // small copies through pinned memory: [poses | states | active]
+  const size_t h_states_at = pose_d * 8, h_active_at = h_states_at + sizeof(lfx::AlignState) * n_clouds;
+  LFX_HIP(c, c->h_align.reserve(h_active_at + 16 + 20 * (size_t)n_clouds));
+  std::memcpy(c->h_align.p, initial_poses, pose_d * 8);
+  LFX_HIP(c, hipMemcpyAsync(d_initial, c->h_align.p, pose_d * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lfx::align_begin_kernel, dim3((n_clouds + 63u) / 64u), dim3(64), 0, st, states, d_initial, n_clouds, d_active);
   const lfx::MapPose none{};
   for (int iter = 0; iter < max_iter; iter++) {
     if (pr.X) {
@@ -1657,11 +1662,18 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
       }
     }
     hipLaunchKernelGGL(lfx::align_step_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, max_iter,
-      r3, J3, pr.begin3, pr.count3, pr.stride3, r1, J1, pr.begin1, pr.count1, pr.stride1, err, dev);
+      r3, J3, pr.begin3, pr.count3, pr.stride3, r1, J1, pr.begin1, pr.count1, pr.stride1, err, d_active);
+    // the kernels of a finished scan return at once, but a launch is a launch: now and then ask whether any scan still iterates
+    if ((iter == 2 || iter == 4 || iter == 7 || iter == 11 || iter == 15) && iter + 1 < max_iter) {
+      uint32_t * active = reinterpret_cast<uint32_t *>(c->h_align.p + h_active_at);
+      LFX_HIP(c, hipMemcpyAsync(active, d_active, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      LFX_HIP(c, hipStreamSynchronize(st));
+      if (*active == 0) {break;}
+    }
   }
   LFX_HIP(c, hipGetLastError());
-  std::vector<lfx::AlignState> h(n_clouds);
-  LFX_HIP(c, hipMemcpyAsync(h.data(), states, sizeof(lfx::AlignState) * n_clouds, hipMemcpyDeviceToHost, st));
+  const lfx::AlignState * h = reinterpret_cast<const lfx::AlignState *>(c->h_align.p + h_states_at);
+  LFX_HIP(c, hipMemcpyAsync(c->h_align.p + h_states_at, states, sizeof(lfx::AlignState) * n_clouds, hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipStreamSynchronize(st));
   for (uint32_t s = 0; s < n_clouds; s++) {
     for (int i = 0; i < 12; i++) {results[s].pose[i] = h[s].pose.m[i];}
@@ -1757,10 +1769,11 @@ int lfx_localize_batch(
     reinterpret_cast<float4 *>(down), down_count, down_status);
   // the longest edge cloud and the longest downsampled surface cloud size the launches (and choose between one query per
   // thread and one per wave): two small copies, and the call is synchronous anyway
-  std::vector<uint32_t> info(4 * (size_t)batch), down_n(batch);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  LFX_HIP(c, hipMemcpyAsync(info.data(), c->scan_info.p, sizeof(uint32_t) * 4 * batch, hipMemcpyDeviceToHost, st));
-  LFX_HIP(c, hipMemcpyAsync(down_n.data(), down_count, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, c->h_align.reserve(20 * (size_t)batch));
+  uint32_t * info = reinterpret_cast<uint32_t *>(c->h_align.p), * down_n = info + 4 * (size_t)batch;
+  LFX_HIP(c, hipMemcpyAsync(info, c->scan_info.p, sizeof(uint32_t) * 4 * batch, hipMemcpyDeviceToHost, st));
+  LFX_HIP(c, hipMemcpyAsync(down_n, down_count, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipStreamSynchronize(st));
   uint32_t longest_edge = 0, longest_surface = 0;
   for (uint32_t s = 0; s < batch; s++) {

@@ -3608,7 +3608,7 @@ __global__ void downsample_passthrough_kernel(
 // per iteration the two row builds above and align_step_kernel (errors, robust scale, weights, the sums of
 // WeightedUpdate, the 6 x 6 solve, the pose update and the three stopping tests); a finished scan's kernels return at
 // once.  PARITY UNPINNED (Eigen's arithmetic; sums are taken in a fixed tree order here, not row by row).
-constexpr int kAlignThreads = 256;
+constexpr int kAlignThreads = 256, kAlignKeysLds = 6144;
 enum AlignCode : int32_t {kAlignConverged = 0, kAlignLargerError = 1, kAlignLargerScale = 2, kAlignMaxIteration = 3, kAlignEmpty = 4};
 
 // Eigen::Quaterniond(Matrix3d): the branch on the trace, then on the largest diagonal entry
@@ -3649,9 +3649,11 @@ __device__ inline void refresh_pose(AlignState & a)
   a.pose.qw = qw; a.pose.qx = v[0]; a.pose.qy = v[1]; a.pose.qz = v[2];
 }
 
-__global__ void align_begin_kernel(AlignState * __restrict__ states, const double * __restrict__ initial /* [n][12] */, uint32_t n)
+__global__ void align_begin_kernel(AlignState * __restrict__ states, const double * __restrict__ initial /* [n][12] */, uint32_t n,
+  uint32_t * __restrict__ active)
 {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) {*active = n;}                            // scans still iterating; the host looks at it now and then
   if (s >= n) {return;}
   AlignState a;
   double m[12];
@@ -3742,40 +3744,25 @@ __device__ inline double workgroup_median(const double * __restrict__ v, uint32_
   return (e0 + e1) / 2.;
 }
 
-// IsDegenerate (degenerate.cpp:32-37) of a symmetric 7 x 7 matrix: cyclic Jacobi rotations, then |eigenvalue| < threshold
+// IsDegenerate (degenerate.cpp:32-37: some |eigenvalue| < threshold) of D = sum of J^T J.  D is positive semi-definite, so
+// the test is "smallest eigenvalue < threshold", which is "D - threshold I is not positive definite": one Cholesky
+// factorisation that meets a pivot <= 0 (Sylvester's criterion), instead of an eigen-decomposition on one thread.
 __device__ inline bool is_degenerate7(const double * Din, double threshold)
 {
   constexpr int n = 7;
-  double A[n * n];
-  for (int i = 0; i < n * n; i++) {A[i] = Din[i];}
-  for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0., diag = 0.;
-    for (int i = 0; i < n; i++) {
-      diag += A[i * n + i] * A[i * n + i];
-      for (int j = i + 1; j < n; j++) {off += A[i * n + j] * A[i * n + j];}
-    }
-    if (off <= 1e-30 * diag || off == 0.) {break;}
-    for (int p = 0; p < n; p++) {
-      for (int q = p + 1; q < n; q++) {
-        const double apq = A[p * n + q];
-        if (apq == 0.) {continue;}
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2. * apq);
-        const double t = (theta >= 0. ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
-        const double c = 1. / sqrt(t * t + 1.), sn = t * c;
-        for (int k = 0; k < n; k++) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - sn * akq;
-          A[k * n + q] = sn * akp + c * akq;
-        }
-        for (int k = 0; k < n; k++) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - sn * aqk;
-          A[q * n + k] = sn * apk + c * aqk;
-        }
-      }
+  double L[n * n];
+  for (int j = 0; j < n; j++) {
+    double s = Din[j * n + j] - threshold;
+    for (int k = 0; k < j; k++) {s -= L[j * n + k] * L[j * n + k];}
+    if (!(s > 0.)) {return true;}
+    const double ljj = sqrt(s);
+    L[j * n + j] = ljj;
+    for (int i = j + 1; i < n; i++) {
+      double v = Din[i * n + j];
+      for (int k = 0; k < j; k++) {v -= L[i * n + k] * L[j * n + k];}
+      L[i * n + j] = v / ljj;
     }
   }
-  for (int i = 0; i < n; i++) {if (fabs(A[i * n + i]) < threshold) {return true;}}
   return false;
 }
 
@@ -3847,14 +3834,14 @@ __device__ inline void solve_update(const double (&q)[4], const double * D, cons
 
 // One iteration of Optimizer::Run after Problem::Make, one workgroup per scan.  Rows of scan s: n3 = count3[s * stride3]
 // residuals of dimension 3 (r3 / J3 from record begin3[s]: the edge rows, or the point pairs), then n1 = count1[...]
-// of dimension 1 (the surface rows; count1 may be null).  errors / deviations: scratch, one double per row, rows of scan
-// s from begin3[s] + begin1[s].
+// of dimension 1 (the surface rows; count1 may be null).  errors: scratch for scans with more than kAlignKeysLds rows, one
+// double per row, rows of scan s from begin3[s] + begin1[s].
 __global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
   AlignState * __restrict__ states, int iter, int max_iter,
   const double * __restrict__ r3, const double * __restrict__ J3, const uint32_t * __restrict__ begin3,
   const uint32_t * __restrict__ count3, uint32_t stride3,
   const double * __restrict__ r1, const double * __restrict__ J1, const uint32_t * __restrict__ begin1,
-  const uint32_t * __restrict__ count1, uint32_t stride1, double * __restrict__ errors, double * __restrict__ deviations)
+  const uint32_t * __restrict__ count1, uint32_t stride1, double * __restrict__ errors, uint32_t * __restrict__ active)
 {
   constexpr int T = kAlignThreads, NS = 64;                 // 28 (D) + 28 (A) upper triangles + 7 (b) + 1 (error)
   const uint32_t s = blockIdx.x;
@@ -3866,36 +3853,34 @@ __global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
   __shared__ double total[NS];
   const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u, n = n3 + n1;
   if (n == 0u) {                                            // EmptyInput (optimization_result.hpp:46-50)
-    if (tid == 0) {st.iteration = iter; st.error = 0.; st.scale = 0.; st.code = kAlignEmpty; st.done = 1;}
+    if (tid == 0) {st.iteration = iter; st.error = 0.; st.scale = 0.; st.code = kAlignEmpty; st.done = 1; atomicSub(active, 1u);}
     return;
   }
   const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
-  double * err = errors + (size_t)b3 + b1;
-  double * dev = deviations + (size_t)b3 + b1;
-  // ComputeErrors (optimizer.cpp:99-107)
-  for (uint32_t i = tid; i < n; i += T) {
-    double e;
-    if (i < n3) {
-      const double * r = r3 + 3 * ((size_t)b3 + i);
-      e = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-    } else {
+  // the values the two medians are taken of: in LDS when the scan's rows fit (the selection passes over them 16-32 times)
+  __shared__ double keys_lds[kAlignKeysLds];
+  double * key = n <= (uint32_t)kAlignKeysLds ? keys_lds : errors + (size_t)b3 + b1;
+  auto row_error = [&](uint32_t i) {                         // ComputeErrors (optimizer.cpp:99-107)
+      if (i < n3) {
+        const double * r = r3 + 3 * ((size_t)b3 + i);
+        return r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      }
       const double r = r1[(size_t)b1 + (i - n3)];
-      e = r * r;
-    }
-    err[i] = e;
-  }
+      return r * r;
+    };
+  for (uint32_t i = tid; i < n; i += T) {key[i] = row_error(i);}
   __syncthreads();
   // Scale (robust.cpp:36-50): b * median(|e - median(e)|)
-  const double median = workgroup_median(err, n, sh);
-  for (uint32_t i = tid; i < n; i += T) {dev[i] = fabs(err[i] - median);}
+  const double median = workgroup_median(key, n, sh);
+  for (uint32_t i = tid; i < n; i += T) {key[i] = fabs(key[i] - median);}
   __syncthreads();
-  const double scale = 1.482602218505602 * workgroup_median(dev, n, sh);
+  const double scale = 1.482602218505602 * workgroup_median(key, n, sh);
   // ComputeWeights (optimizer.cpp:120-127) and the sums of WeightedUpdate (optimizer.cpp:40-64)
   double acc[NS];
 #pragma unroll
   for (int a = 0; a < NS; a++) {acc[a] = 0.;}
   for (uint32_t i = tid; i < n; i += T) {
-    const double e = err[i];
+    const double e = row_error(i);
     const double en = e / (scale + 1e-16);
     const double w = en < 1.345 * 1.345 ? 1. : 1.345 / sqrt(en);          // HuberDerivative, robust.cpp:61-68
     acc[63] += e;
@@ -3939,12 +3924,12 @@ __global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
   if (tid != 0) {return;}
   const double error = total[63];
   if (error > st.prev_error) {                               // LargerErrorThanPrevious
-    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerError; st.done = 1;
+    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerError; st.done = 1; atomicSub(active, 1u);
     return;
   }
   st.prev_error = error;
   if (scale > st.prev_scale) {                               // LargerScaleThanPrevious
-    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerScale; st.done = 1;
+    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerScale; st.done = 1; atomicSub(active, 1u);
     return;
   }
   st.prev_scale = scale;
@@ -3970,9 +3955,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
   refresh_pose(st);
   const double nq = sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]), nt = sqrt(dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2]);
   if (nq < 1e-3 && nt < 1e-3) {                              // CheckConvergence (optimizer.cpp:35-38)
-    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignConverged; st.done = 1;
+    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignConverged; st.done = 1; atomicSub(active, 1u);
   } else if (iter == max_iter - 1) {                         // ReachedMaximumIteration
-    st.iteration = max_iter; st.error = error; st.scale = scale; st.code = kAlignMaxIteration; st.done = 1;
+    st.iteration = max_iter; st.error = error; st.scale = scale; st.code = kAlignMaxIteration; st.done = 1; atomicSub(active, 1u);
   }
 }
 
