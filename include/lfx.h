@@ -319,6 +319,8 @@ int lfx_downsample_surface(lfx_ctx *ctx, float leaf, float *d_out, uint32_t *d_o
  * before the context's device is reset. */
 typedef struct lfx_map lfx_map;
 int lfx_map_create(lfx_ctx *ctx, const float *d_points, uint32_t n_points, float cell_size, lfx_map **out, void *stream);
+/* The same from host memory (the points are staged through a temporary device buffer). */
+int lfx_map_create_host(lfx_ctx *ctx, const float *points, uint32_t n_points, float cell_size, lfx_map **out, void *stream);
 void lfx_map_destroy(lfx_map *map);
 int lfx_map_info(const lfx_map *map, uint32_t *n_points, float *cell_size /* 0: no grid */, int32_t dims[3]);
 /* KDTreeEigen::NearestKSearch (src/kdtree.cpp:44-68) for n_queries queries of 3 doubles on the device: per query the k
@@ -397,6 +399,13 @@ int lfx_align_point_pairs(lfx_ctx *ctx, const double *d_source, const double *d_
 int lfx_localize_batch(lfx_ctx *ctx, const lfx_map *edge_map, const lfx_map *surface_map, uint32_t n_neighbors, int max_iter,
                        float surface_leaf,
                        const double *initial_poses, lfx_align_result *results, void *stream);
+
+/* Localizer::Update for one scan whose two clouds are on the host -- the consumer in a process of its own, handed
+ * scan_edge / scan_surface as published (records of 4 floats: x, y, z, -; pcl::PointXYZ on the wire): upload, Downsample
+ * of the surface cloud, lfx_scan_to_map_align.  Synchronous. */
+int lfx_localize_host(lfx_ctx *ctx, const lfx_map *edge_map, const lfx_map *surface_map, uint32_t n_neighbors, int max_iter,
+                      float surface_leaf, const float *edge_points, uint32_t n_edge, const float *surface_points,
+                      uint32_t n_surface, const double initial_pose[12], lfx_align_result *result, void *stream);
 
 /* --- per-stage entry points (device-backed mirrors of the reference's free functions) ----- */
 /* One ring given as angle-sorted x[n], y[n] host arrays; every stage runs the same device

@@ -159,5 +159,70 @@ private:
   std::vector<void *> pinned_;
 };
 
+// The consumer of the two clouds: Localizer of the reference's localization package (localization/include/
+// lidar_feature_localization/localizer.hpp:48-95) -- maps built once (there: two KD-trees in the problem's constructor),
+// Init(pose), Update(scan) -> success, Get() -> pose.  Poses are [R | t], row-major 3 x 4.
+class Localizer
+{
+public:
+  // edge_map / surface_map: records of 4 floats (x, y, z, -) on the host; cell_size: the grid behind the nearest-neighbour
+  // search (lfx_map_create).  `fx` must outlive the localizer.
+  Localizer(
+    const FeatureExtraction & fx, const std::vector<float> & edge_map, const std::vector<float> & surface_map,
+    int max_iter = 20, float cell_size = 1.0f)
+  : ctx_(fx.handle()), max_iter_(max_iter)
+  {
+    int rc = lfx_map_create_host(ctx_, edge_map.data(), static_cast<std::uint32_t>(edge_map.size() / 4), cell_size, &edge_, nullptr);
+    if (rc == LFX_OK) {
+      rc = lfx_map_create_host(ctx_, surface_map.data(), static_cast<std::uint32_t>(surface_map.size() / 4), cell_size, &surface_, nullptr);
+    }
+    if (rc != LFX_OK) {
+      lfx_map_destroy(edge_);
+      throw Error(rc, lfx_last_error(ctx_));
+    }
+    const double identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int i = 0; i < 12; i++) {last_.pose[i] = identity[i];}
+  }
+  ~Localizer() {lfx_map_destroy(edge_); lfx_map_destroy(surface_);}
+  Localizer(const Localizer &) = delete;
+  Localizer & operator=(const Localizer &) = delete;
+
+  void Init(const double pose[12])
+  {
+    for (int i = 0; i < 12; i++) {last_.pose[i] = pose[i];}
+    initialized_ = true;
+  }
+  bool IsInitialized() const {return initialized_;}
+  const double * Get() const {return last_.pose;}
+  const lfx_align_result & Result() const {return last_;}      // OptimizationResult of the last Update
+
+  // Update with the scan the FeatureExtraction was last given (its clouds are still on the device: nothing is copied)
+  bool Update()
+  {
+    lfx_align_result r{};
+    const int rc = lfx_localize_batch(ctx_, edge_, surface_, kNeighbors, max_iter_, 1.0f, last_.pose, &r, nullptr);
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+    last_ = r;
+    return LFX_ALIGN_SUCCESS(r.code);
+  }
+  // Update with clouds received from elsewhere (scan_edge / scan_surface as published: 4 floats per point)
+  bool Update(const float * edge, std::uint32_t n_edge, const float * surface, std::uint32_t n_surface)
+  {
+    lfx_align_result r{};
+    const int rc = lfx_localize_host(ctx_, edge_, surface_, kNeighbors, max_iter_, 1.0f, edge, n_edge, surface, n_surface, last_.pose, &r, nullptr);
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+    last_ = r;
+    return LFX_ALIGN_SUCCESS(r.code);
+  }
+
+private:
+  static constexpr std::uint32_t kNeighbors = 15;               // N_NEIGHBORS, localizer.hpp:46
+  lfx_ctx * ctx_;
+  int max_iter_;
+  lfx_map * edge_ = nullptr, * surface_ = nullptr;
+  lfx_align_result last_{};
+  bool initialized_ = false;
+};
+
 }  // namespace lfx
 #endif  // LFX_HPP_

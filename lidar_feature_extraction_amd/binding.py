@@ -82,9 +82,9 @@ EXPORTS = [
     "lfx_status_string", "lfx_ring_message", "lfx_range_message", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
     "lfx_device_results", "lfx_batch_status", "lfx_scan_routes", "lfx_host_alloc", "lfx_host_free", "lfx_comm_unique_id", "lfx_comm_create",
     "lfx_comm_destroy", "lfx_gather_counts", "lfx_gather_payload", "lfx_gather", "lfx_voxel_downsample", "lfx_downsample_surface",
-    "lfx_map_create", "lfx_map_destroy", "lfx_map_info", "lfx_map_nearest",
+    "lfx_map_create", "lfx_map_create_host", "lfx_map_destroy", "lfx_map_info", "lfx_map_nearest",
     "lfx_scan_to_map_residuals", "lfx_edge_residuals", "lfx_align_message", "lfx_scan_to_map_align", "lfx_align_point_pairs",
-    "lfx_localize_batch",
+    "lfx_localize_batch", "lfx_localize_host",
     "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
 ]
@@ -139,6 +139,7 @@ def load():
     L.lfx_gather_payload.argtypes = [vp, vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]
     L.lfx_voxel_downsample.argtypes = [vp, vp, vp, vp, u32, u32, C.c_size_t, C.c_float, vp, vp, vp, vp]
     L.lfx_map_create.argtypes = [vp, vp, u32, C.c_float, C.POINTER(vp), vp]
+    L.lfx_map_create_host.argtypes = [vp, vp, u32, C.c_float, C.POINTER(vp), vp]
     L.lfx_map_destroy.argtypes = [vp]
     L.lfx_map_destroy.restype = None
     L.lfx_map_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(i32)]
@@ -152,6 +153,7 @@ def load():
                                         C.c_size_t, u32, pd, pres, vp]
     L.lfx_align_point_pairs.argtypes = [vp, vp, vp, vp, vp, u32, C.c_size_t, u32, i32, pd, pres, vp]
     L.lfx_localize_batch.argtypes = [vp, vp, vp, u32, i32, C.c_float, pd, pres, vp]
+    L.lfx_localize_host.argtypes = [vp, vp, vp, u32, i32, C.c_float, vp, u32, vp, u32, pd, pres, vp]
     L.lfx_downsample_surface.argtypes = [vp, C.c_float, vp, vp, vp, vp]
     L.lfx_gather.argtypes = [vp, vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]
     L.lfx_layout_from_fields.argtypes = [C.POINTER(PointField), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Layout)]

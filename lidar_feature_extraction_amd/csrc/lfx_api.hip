@@ -1498,6 +1498,20 @@ void lfx_map_destroy(lfx_map * m)
   delete m;
 }
 
+int lfx_map_create_host(lfx_ctx * c, const float * points, uint32_t n_points, float cell_size, lfx_map ** out, void * stream)
+{
+  if (!c || !points || !out || n_points == 0) {return LFX_ERR_INVALID_ARGUMENT;}
+  LFX_HIP(c, hipSetDevice(c->device));
+  DevBuf<float> staged;
+  if (staged.alloc(4 * (size_t)n_points) != hipSuccess) {return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot stage the map's points");}
+  hipError_t e = hipMemcpyAsync(staged.p, points, sizeof(float) * 4 * (size_t)n_points, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+  if (e == hipSuccess) {e = hipStreamSynchronize(static_cast<hipStream_t>(stream));}
+  if (e != hipSuccess) {staged.release(); return fail(c, LFX_ERR_HIP, hipGetErrorString(e));}
+  const int rc = lfx_map_create(c, staged.p, n_points, cell_size, out, stream);
+  staged.release();
+  return rc;
+}
+
 int lfx_map_info(const lfx_map * m, uint32_t * n_points, float * cell_size, int32_t dims[3])
 {
   if (!m) {return LFX_ERR_INVALID_ARGUMENT;}
@@ -1783,6 +1797,49 @@ int lfx_localize_batch(
   return lfx_scan_to_map_align(c, edge_map, surface_map, n_neighbors, max_iter,
            reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest_edge, total,
            down, c->scan_begin.p, down_count, 1, longest_surface, total, batch, initial_poses, results, stream);
+}
+
+int lfx_localize_host(
+  lfx_ctx * c, const lfx_map * edge_map, const lfx_map * surface_map, uint32_t n_neighbors, int max_iter, float surface_leaf,
+  const float * edge_points, uint32_t n_edge, const float * surface_points, uint32_t n_surface, const double initial_pose[12],
+  lfx_align_result * result, void * stream)
+{
+  if (!c || !edge_map || !surface_map || !initial_pose || !result || (n_edge && !edge_points) || (n_surface && !surface_points)) {
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  LFX_HIP(c, hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // [edge | surface | downsampled surface] records of 4 floats, then begin / count words
+  const size_t ne = n_edge, ns = n_surface, words = 8;
+  const size_t need = 4 * (ne + 2 * ns + 2) + words;
+  if (c->align_surface.n < need) {
+    c->align_surface.release();
+    if (c->align_surface.alloc(need) != hipSuccess) {
+      c->align_surface.n = 0;
+      return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the scan's clouds");
+    }
+  }
+  float * d_edge = c->align_surface.p, * d_surface = d_edge + 4 * (ne + 1), * d_down = d_surface + 4 * (ns + 1);
+  uint32_t * d_words = reinterpret_cast<uint32_t *>(d_down + 4 * ns);
+  // words: [0] begin (0), [1] n_edge, [2] n_surface, [3] downsampled count, [4] downsample status
+  LFX_HIP(c, c->h_align.reserve(sizeof(uint32_t) * words));
+  uint32_t * h_words = reinterpret_cast<uint32_t *>(c->h_align.p);
+  h_words[0] = 0; h_words[1] = n_edge; h_words[2] = n_surface; h_words[3] = 0; h_words[4] = 0;
+  LFX_HIP(c, hipMemcpyAsync(d_words, h_words, sizeof(uint32_t) * words, hipMemcpyHostToDevice, st));
+  if (n_edge) {LFX_HIP(c, hipMemcpyAsync(d_edge, edge_points, sizeof(float) * 4 * ne, hipMemcpyHostToDevice, st));}
+  uint32_t n_down = 0;
+  if (n_surface) {
+    LFX_HIP(c, hipMemcpyAsync(d_surface, surface_points, sizeof(float) * 4 * ns, hipMemcpyHostToDevice, st));
+    const int rc = lfx_voxel_downsample(c, d_surface, d_words, d_words + 2, 1, 1, ns, surface_leaf, d_down, d_words + 3, d_words + 4, stream);
+    if (rc != LFX_OK) {return rc;}
+    hipLaunchKernelGGL(lfx::downsample_passthrough_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float4 *>(d_surface),
+      d_words, d_words + 2, 1u, reinterpret_cast<float4 *>(d_down), d_words + 3, d_words + 4);
+    LFX_HIP(c, hipMemcpyAsync(h_words + 3, d_words + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    LFX_HIP(c, hipStreamSynchronize(st));
+    n_down = h_words[3];
+  }
+  return lfx_scan_to_map_align(c, edge_map, surface_map, n_neighbors, max_iter, d_edge, d_words, d_words + 1, 1, n_edge, ne,
+           d_down, d_words, d_words + 3, 1, n_down, ns, 1, initial_pose, result, stream);
 }
 
 }  // extern "C"

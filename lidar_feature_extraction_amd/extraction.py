@@ -176,6 +176,10 @@ class FeatureExtraction:
         """lfx_map_create: the map a scan is matched against (KDTreeEigen, kdtree.hpp:50-71); cell_size 0 = no grid."""
         return ScanMap(self, d_points, n_points, cell_size, stream)
 
+    def make_map_from_host(self, points, cell_size=1.0, stream=0):
+        """lfx_map_create_host: points [n][4] float32 on the host."""
+        return ScanMap(self, 0, 0, cell_size, stream, host_points=points)
+
     def scan_to_map_residuals(self, kind, scan_map, pose, n_neighbors, d_points, d_begin, d_count, count_stride, n_clouds,
                               max_points_per_cloud, d_residual, d_jacobian, stream=0):
         """lfx_scan_to_map_residuals: kind 0 = edge rows (edge.hpp:86-124), 1 = surface rows (surface.hpp:116-139);
@@ -234,6 +238,19 @@ class FeatureExtraction:
             self._ctx, edge_map.handle, surface_map.handle, int(n_neighbors), int(max_iter), float(surface_leaf), poses.ctypes.data_as(C.POINTER(C.c_double)), res,
             C.c_void_p(int(stream))))
         return self._align_results(res)
+
+    def localize_host(self, edge_map, surface_map, edge_points, surface_points, initial_pose, n_neighbors=15, max_iter=20,
+                      surface_leaf=1.0, stream=0):
+        """lfx_localize_host: Localizer::Update for one scan whose clouds ([n][4] float32) are on the host."""
+        e = np.ascontiguousarray(edge_points, np.float32).reshape(-1, 4)
+        sf = np.ascontiguousarray(surface_points, np.float32).reshape(-1, 4)
+        pose = np.ascontiguousarray(initial_pose, np.float64).reshape(12)
+        res = (B.AlignResult * 1)()
+        B.check(self._ctx, self._L.lfx_localize_host(
+            self._ctx, edge_map.handle, surface_map.handle, int(n_neighbors), int(max_iter), float(surface_leaf),
+            C.c_void_p(e.ctypes.data), len(e), C.c_void_p(sf.ctypes.data), len(sf), pose.ctypes.data_as(C.POINTER(C.c_double)), res,
+            C.c_void_p(int(stream))))
+        return self._align_results(res)[0]
 
     def scan_routes(self, n_scans, stream=0):
         """lfx_scan_routes: per scan of the last batch 1 = read in place, 2 = in place through ring transforms, 0 = bucketed."""
@@ -377,12 +394,17 @@ def layout_from_fields(fields, point_step, is_bigendian=False):
 class ScanMap:
     """lfx_map: the index a scan is matched against -- the place of the reference's KDTreeEigen (kdtree.hpp:50-71)."""
 
-    def __init__(self, fx, d_points, n_points, cell_size=1.0, stream=0):
+    def __init__(self, fx, d_points, n_points, cell_size=1.0, stream=0, host_points=None):
         self._fx = fx
         self._L = fx._L
         h = C.c_void_p()
-        B.check(fx._ctx, self._L.lfx_map_create(fx._ctx, C.c_void_p(int(d_points)), int(n_points), float(cell_size), C.byref(h),
-                                                C.c_void_p(int(stream))))
+        if host_points is not None:
+            pts = np.ascontiguousarray(host_points, np.float32).reshape(-1, 4)
+            B.check(fx._ctx, self._L.lfx_map_create_host(fx._ctx, C.c_void_p(pts.ctypes.data), len(pts), float(cell_size), C.byref(h),
+                                                         C.c_void_p(int(stream))))
+        else:
+            B.check(fx._ctx, self._L.lfx_map_create(fx._ctx, C.c_void_p(int(d_points)), int(n_points), float(cell_size), C.byref(h),
+                                                    C.c_void_p(int(stream))))
         self.handle = h
 
     def info(self):

@@ -80,3 +80,45 @@ def test_cpp_host_side_against_the_oracle(case, tmp_path):
         assert np.array_equal(g["ring"], cloud["ring"][idx])
     assert len(got["edge"]) > 0 and len(got["surface"]) > 0
     assert "scan_edge %d" % len(want["edge_index"]) in r.stdout
+
+
+LOCALIZE = os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "localize_scan")
+
+
+def test_localizer_example_builds_without_a_gpu():
+    if not os.path.exists(LOCALIZE):
+        import __graft_entry__
+        __graft_entry__.build()
+    assert os.access(LOCALIZE, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_cpp_localizer_against_the_oracle(tmp_path):
+    """lfx::Localizer (include/lfx.hpp; the reference's Localizer, localizer.hpp:48-95) in a C++ process of its own: Init,
+    Update on the extraction's device clouds, Update on host clouds; both poses against the oracle chain extract ->
+    Downsample -> Optimizer::Run (tolerance: parity unpinned, see tests/test_align_gpu.py)."""
+    import ctypes as C
+    from oracle import binding as OB
+    from tests.test_align_gpu import _oracle_scan, _downsample
+    rings, cols = 32, 1024
+    cloud = make_scan(rings, cols, seed=7700)
+    want = OB.extract(cloud, canonical_ties=False)
+    maps = [OB.extract(make_scan(rings, cols, seed=s), canonical_ties=False) for s in (7790, 7791)]
+    edge_map = np.ascontiguousarray(np.concatenate([m["edge_points"] for m in maps]), np.float32)
+    surf_map = np.ascontiguousarray(np.concatenate([m["surface_points"] for m in maps]), np.float32)
+    paths = [str(tmp_path / n) for n in ("edge_map.bin", "surface_map.bin", "scan.bin", "poses.bin")]
+    edge_map.tofile(paths[0]); surf_map.tofile(paths[1]); cloud.tofile(paths[2])
+    r = subprocess.run([LOCALIZE, paths[0], paths[1], paths[2], str(rings), str(cols), paths[3], "host"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw = open(paths[3], "rb").read()
+    rec = np.dtype([("pose", "<f8", 12), ("error", "<f8"), ("scale", "<f8"), ("iteration", "<i4"), ("code", "<i4")])
+    got = np.frombuffer(raw, rec)
+    assert len(got) == 2
+    initial = np.array([[1, 0, 0, 0.02], [0, 1, 0, -0.015], [0, 0, 1, 0.01]], np.float64)
+    w = _oracle_scan(edge_map, surf_map, 15, want["edge_points"], _downsample(want["surface_points"], 1.0), initial, 20)
+    for g in got:
+        assert abs(int(g["iteration"]) - w["iteration"]) <= 1 and (int(g["code"]) <= 2) == w["success"]
+        assert np.abs(g["pose"].reshape(3, 4) - w["pose"]).max() < (1e-6 if int(g["iteration"]) == w["iteration"] else 2e-3)
+    # the two ways in give the same clouds to the same optimizer
+    assert got[0]["pose"].tobytes() == got[1]["pose"].tobytes() and got[0]["iteration"] == got[1]["iteration"]
+    assert ("update succeeded" in r.stdout) == w["success"]
