@@ -279,6 +279,20 @@ def main():
                       "pageable_input": {"ms_per_scan_one_at_a_time": one_pg, "ms_per_scan_batches_of_16": many_pg},
                       "pageable_input_all_outputs": {"ms_per_scan_one_at_a_time": one_all, "ms_per_scan_batches_of_16": many_all}}
 
+    # ---- the consumer of the two clouds: Localizer::Update on the device, one scan and a batch
+    consumer = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.rings * a.cols <= 64 * 1800:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import localize_bench
+        one = localize_bench.run(rings=a.rings, cols=a.cols, batch=1, map_scans=16, steps=9, device=local_rank)
+        many = localize_bench.run(rings=a.rings, cols=a.cols, batch=32, map_scans=16, steps=3, device=local_rank)
+        consumer = {"localize_ms_one_scan": one["localize_ms_per_scan"], "localize_ms_per_scan_batches_of_32": many["localize_ms_per_scan"],
+                    "iterations_mean": many["iterations_mean"], "edge_map_points": one["edge_map_points"],
+                    "surface_map_points": one["surface_map_points"],
+                    "note": "lfx_localize_batch after extraction (Downsample + Optimizer::Run of the reference localizer, localizer.hpp:71-80; "
+                            "clouds never leave the device); maps = the features of 16 scans along a track, grid cells of 1 m; "
+                            "parity with Eigen / nanoflann / PCL arithmetic unpinned (DESIGN.md 7)"}
+
     if rank == 0:
         workload = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800): "vlp16-16x1800 (BASELINE.json configs[1])",
                     (16, 900): "plumbing-16x900 (BASELINE.json configs[0])",
@@ -295,7 +309,7 @@ def main():
                                        "rings %s%s" % ("reversed " if a.reverse else "", "rotated by %d columns" % a.start_col if a.start_col else "")),
                        "streams": 1 if use_gather else n_streams,
                        "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "parity_spot_check": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
         }
         print(json.dumps(out))
         sys.stdout.flush()

@@ -17,6 +17,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def run(rings=64, cols=1800, batch=64, map_scans=40, cell=1.0, steps=5, max_iter=20, cpu_scans=0, whole_map=False, device=0):
+    """The measurement as a function (bench.py reports it beside the extraction numbers)."""
+    return _measure(argparse.Namespace(rings=rings, cols=cols, batch=batch, map_scans=map_scans, cell=cell, steps=steps, max_iter=max_iter,
+                                       cpu_scans=cpu_scans, whole_map=whole_map, device=device))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rings", type=int, default=64)
@@ -29,11 +35,16 @@ def main():
     ap.add_argument("--cpu-scans", type=int, default=2)
     ap.add_argument("--whole-map", action="store_true", help="also time maps without a grid")
     a = ap.parse_args()
+    a.device = 0
+    print(json.dumps(_measure(a)))
+
+
+def _measure(a):
     import torch
     from lidar_feature_extraction_amd import FeatureExtraction, make_scan, concat
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", a.device)
     rng = np.random.default_rng(1)
-    fx = FeatureExtraction(device=0, max_points_per_scan=a.rings * a.cols, max_batch=max(a.batch, 8), max_points_per_ring=a.cols,
+    fx = FeatureExtraction(device=a.device, max_points_per_scan=a.rings * a.cols, max_batch=max(a.batch, 8), max_points_per_ring=a.cols,
                            max_rings=a.rings)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -130,7 +141,10 @@ def main():
         out["cpu_oracle_ms_per_scan"] = round(1e3 * float(np.mean(t_cpu)), 1)
         out["cpu_oracle_note"] = "exhaustive neighbour search, one core; not the reference's KD-tree"
         out["max_pose_difference_to_oracle"] = max(same)
-    print(json.dumps(out))
+    emap.close()
+    smap.close()
+    fx.close()
+    return out
 
 
 if __name__ == "__main__":
