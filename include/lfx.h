@@ -364,6 +364,8 @@ int lfx_edge_residuals(lfx_ctx *ctx, const lfx_map *map, const double pose[12], 
  * q <- q * AngleAxisToQuaternion(dx[0:3]), t <- t + dx[3:6], and the stopping tests in the reference's order (error
  * larger than before, scale larger than before, |dq.vec| and |dt| < 1e-3, max_iter).  A scan that has stopped costs no
  * further work.  The surface clouds are the ones AFTER Downsample (surface.hpp:111; lfx_downsample_surface, leaf 1.0).
+ * max_*_points_per_cloud must be at least the longest cloud's count (they size the launches; lfx_localize_batch reads the
+ * counts back itself), total_*_points the extent of the point arrays in records (rows are addressed like the points).
  * initial_poses: [n_clouds][12] host doubles ([R | t] row-major); results: [n_clouds], host.  Synchronous on `stream`.
  * PARITY UNPINNED (Eigen / nanoflann / PCL arithmetic underneath; see lfx_scan_to_map_residuals): results agree with the
  * CPU restatement to tolerance, and the restatement passes the reference's own optimizer tests. */

@@ -3193,12 +3193,31 @@ struct GridCube
 #define LFX_GRID_UNROLL 2
 #endif
 constexpr int kGridUnroll = LFX_GRID_UNROLL;      // runs of 64 points loaded at once
+#ifndef LFX_BULK_INSERT
+#define LFX_BULK_INSERT 10
+#endif
+constexpr int kBulkInsert = LFX_BULK_INSERT;      // this many points passing the bar at once are merged in, not inserted one by one
 
 __device__ __forceinline__ double wave_read(double v, int lane)
 {
   const long long b = __double_as_longlong(v);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// ascending bitonic sort of (d, orig) with `at` carried along, over the 64 lanes of the wave
+__device__ __forceinline__ void wave_sort_steps(double & d, uint32_t & orig, uint32_t & at, int lane, int k_first, int k_last)
+{
+  for (int k = k_first; k <= k_last; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const double od = __shfl_xor(d, j, 64);
+      const uint32_t oo = (uint32_t)__shfl_xor((int)orig, j, 64), oa = (uint32_t)__shfl_xor((int)at, j, 64);
+      const bool want_min = ((lane & j) == 0) == ((lane & k) == 0);      // the lower lane of a pair in an ascending run
+      const bool other_less = od < d || (od == d && oo < orig), self_less = d < od || (d == od && orig < oo);
+      const bool take = want_min ? other_less : self_less;
+      d = take ? od : d; orig = take ? oo : orig; at = take ? oa : at;
+    }
+  }
 }
 
 // one wave, one query (the same q in every lane): rho grown until GridCube::done.  The 64 lanes take 64 consecutive points
@@ -3244,6 +3263,25 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
             const double d = dx * dx + dy * dy + dz * dz;
             const uint32_t orig = __float_as_uint(mpt.w);
             uint64_t pass = __ballot(live && (d < bar || (d == bar && orig < bar_orig)));
+            if (__popcll(pass) >= kBulkInsert) {
+              // many at once (the first points of a query, before there is a bar worth the name): sort the 64 of them, merge
+              // their 16 smallest with the list -- the cost of about eight single insertions, whatever their number
+              const bool mine = ((pass >> lane) & 1ull) != 0ull;
+              double sd = mine ? d : INFINITY;
+              uint32_t so = mine ? orig : 0xFFFFFFFFu, sa = mine ? at : 0u;
+              wave_sort_steps(sd, so, sa, lane, 2, 64);
+              // lanes 0..15 now hold the 16 smallest, ascending; against the list, reversed: the smaller of each pair are the
+              // 16 smallest of the 32 and form a bitonic run, which four more steps put in order
+              const int from = 15 - (lane & 15);
+              const double rd = __shfl(sd, from, 64);
+              const uint32_t ro = (uint32_t)__shfl((int)so, from, 64), ra = (uint32_t)__shfl((int)sa, from, 64);
+              const bool cand_less = rd < ldist || (rd == ldist && ro < lorig);
+              if (lane < KM) {ldist = cand_less ? rd : ldist; lorig = cand_less ? ro : lorig; lidx = cand_less ? ra : lidx;}
+              wave_sort_steps(ldist, lorig, lidx, lane, 16, 16);             // (k = 16 within lanes 0..15: ascending)
+              bar = wave_read(ldist, KM - 1);
+              bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+              pass = 0;
+            }
             while (pass) {
               const int src = __ffsll((unsigned long long)pass) - 1;
               pass &= pass - 1;
