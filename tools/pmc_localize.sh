@@ -1,5 +1,6 @@
 #!/bin/bash
-# counters of the scan_to_map kernels for one iteration of the localization bench
+# tools/pmc_localize.sh [LIB] -- on the GPU box: SQ counters (rocprofv3 --pmc with --kernel-trace only) and durations of the
+# scan_to_map / align_step kernels for one iteration of tools/localize_bench.py; LIB: a library under _lib/ (A/B builds)
 export TMPDIR=/tmp
 OUT=gpurun_out/locpmc
 mkdir -p $OUT
