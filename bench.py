@@ -101,6 +101,7 @@ def main():
     step_no = [0]
 
     use_gather = (world > 1 and not a.no_gather) or a.force_gather
+    gather_error = None
     if use_gather:
         # two sets of packed-cloud buffers: while the clouds of step k-1 travel to rank 0 on a side
         # stream, step k extracts and packs into the other set (gather.py: CloudGather)
@@ -112,13 +113,36 @@ def main():
                  torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(2)]
         # RCCL through the library's own entry points (lfx_comm_*, lfx_gather_*); torch.distributed only carries the
         # 128-byte communicator id from rank 0 to the others
+        # If the communicator cannot be made on some rank (the RCCL library does not open, the id does not arrive), every
+        # rank drops the gather together and the line says so ("sharding"): a measurement of the sharded extraction without
+        # its exchange is worth more than none.
+        gather, gather_error = None, None
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8))
+        try:
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8))
+        except Exception as e:             # noqa: BLE001
+            gather_error = "rank 0: %s" % e
         if world > 1:
             dist.broadcast(idt, 0)
-        gather = CloudGather(fx, rank, world, bytes(idt.cpu().numpy().tobytes()), dst=0, device=dev,
-                             capacity_points=feat_cap * world, batch=a.batch)
+        if gather_error is None and not bool(idt.any().item()):
+            gather_error = "no communicator id from rank 0"
+        if gather_error is None:
+            try:
+                gather = CloudGather(fx, rank, world, bytes(idt.cpu().numpy().tobytes()), dst=0, device=dev,
+                                     capacity_points=feat_cap * world, batch=a.batch)
+            except Exception as e:         # noqa: BLE001
+                gather_error = "rank %d: %s" % (rank, e)
+        if world > 1:
+            failed = torch.tensor([0 if gather_error is None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+            if int(failed.item()) and gather_error is None:
+                gather_error = "another rank could not create its communicator"
+        if gather_error is not None:
+            print("bench.py: gather disabled: %s" % gather_error, file=sys.stderr)
+            if gather is not None:
+                gather.close()
+            use_gather = False
 
     def step():
         k = step_no[0] % n_streams
@@ -308,7 +332,8 @@ def main():
                        "input_order": ("rings in angle order" if not (a.start_col or a.reverse) else
                                        "rings %s%s" % ("reversed " if a.reverse else "", "rotated by %d columns" % a.start_col if a.start_col else "")),
                        "streams": 1 if use_gather else n_streams,
-                       "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "")},
+                       "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "") +
+                                   (" (gather unavailable: %s)" % gather_error if gather_error else "")},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
         }
         print(json.dumps(out))
