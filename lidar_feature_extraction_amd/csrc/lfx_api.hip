@@ -1837,6 +1837,8 @@ int lfx_localize_host(
     LFX_HIP(c, hipMemcpyAsync(h_words + 3, d_words + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     LFX_HIP(c, hipStreamSynchronize(st));
     n_down = h_words[3];
+  } else {
+    LFX_HIP(c, hipStreamSynchronize(st));             // the words have left the pinned block: the alignment stages through it too
   }
   return lfx_scan_to_map_align(c, edge_map, surface_map, n_neighbors, max_iter, d_edge, d_words, d_words + 1, 1, n_edge, ne,
            d_down, d_words, d_words + 3, 1, n_down, ns, 1, initial_pose, result, stream);

@@ -3788,6 +3788,11 @@ __device__ inline double workgroup_median(const double * __restrict__ v, uint32_
 __device__ inline bool is_degenerate7(const double * Din, double threshold)
 {
   constexpr int n = 7;
+  // a matrix with a NaN in it has no eigenvalue below the threshold (every comparison with NaN is false): not degenerate,
+  // and the NaN goes on into the solve, as it does in the reference
+  bool nan = false;
+  for (int i = 0; i < n * n; i++) {nan = nan || Din[i] != Din[i];}
+  if (nan) {return false;}
   double L[n * n];
   for (int j = 0; j < n; j++) {
     double s = Din[j * n + j] - threshold;

@@ -260,3 +260,55 @@ def test_scan_to_map_align_on_caller_clouds_and_its_arguments():
         fx.scan_to_map_align(tiny, smap, k, 5, d_e.data_ptr(), d_eb.data_ptr(),
                              d_en.data_ptr(), 1, 1, 1, d_s.data_ptr(), d_sb.data_ptr(), d_sn.data_ptr(), 1, 1, 1, poses, 0)
     fx.close()
+
+
+def test_large_problem_degenerate_map_and_host_clouds():
+    """(1) A scan with more rows than the step kernel keeps in LDS (its selection then runs over global memory);
+    (2) maps that leave the pose unconstrained -- one plane, no edges worth the name: WeightedUpdate returns zero
+    (IsDegenerate, optimizer.cpp:66-68), which CheckConvergence reads as converged at iteration 0 with the pose untouched;
+    (3) lfx_localize_host: clouds from the host, empty clouds included."""
+    from lidar_feature_extraction_amd import FeatureExtraction
+    rng = np.random.default_rng(51)
+    fx = FeatureExtraction(device=0, max_points_per_scan=1024, max_batch=1)
+    # (1)
+    n = 9000
+    X = rng.uniform(-30, 30, (n, 3))
+    true = _pose(rng.normal(0, 0.2, 3), rng.normal(0, 1, 3))
+    Y = X @ true[:, :3].T + true[:, 3] + rng.normal(0, 0.05, (n, 3))
+    Y[rng.choice(n, 900, replace=False)] += rng.normal(0, 4.0, (900, 3))
+    start = _pose(rng.normal(0, 0.1, 3), rng.normal(0, 0.5, 3))
+    got = _run_pairs(fx, [(X, Y, start), (X[:100], Y[:100], start)], 20)
+    _same_result(got[0], _oracle_pairs(X, Y, start, 20), "9000 pairs")
+    _same_result(got[1], _oracle_pairs(X[:100], Y[:100], start, 20), "100 pairs beside them")
+    # (2) a plane z = -2 as both maps; scan points a little above it
+    plane = np.zeros((4000, 4), np.float32)
+    plane[:, :2] = rng.uniform(-20, 20, (4000, 2))
+    plane[:, 2] = -2.0
+    scan_surface = np.zeros((300, 4), np.float32)
+    scan_surface[:, :2] = rng.uniform(-15, 15, (300, 2))
+    scan_surface[:, 2] = -1.95
+    emap, smap = fx.make_map_from_host(plane, 1.0), fx.make_map_from_host(plane, 1.0)
+    ident = _pose([0, 0, 0], [0, 0, 0])
+    none = np.zeros((0, 4), np.float32)
+    for leaf in (1000.0, 0.5):                              # a handful of rows, then hundreds: D = sum J^T J has rank 3 either way
+        r = fx.localize_host(emap, smap, none, scan_surface, ident, 15, 20, leaf)
+        w = _oracle_scan(plane, plane, 15, none, _downsample(scan_surface, leaf), ident, 20)
+        assert (r["code"], r["iteration"]) == (w["code"], w["iteration"]) == (0, 0), (leaf, r, w)
+        assert np.array_equal(r["pose"], ident) and r["success"]
+    emap.close()
+    smap.close()
+    # a plane THROUGH THE ORIGIN cannot be written as w . x = -1 (surface.hpp:78-83): the reference's rows are NaN there, no
+    # test passes any more, and the loop runs to max_iter with a NaN pose -- the library does the same
+    plane[:, 2] = 0.0
+    scan_surface[:, 2] = 0.05
+    emap, smap = fx.make_map_from_host(plane, 1.0), fx.make_map_from_host(plane, 1.0)
+    r = fx.localize_host(emap, smap, none, scan_surface, ident, 15, 7, 1000.0)
+    w = _oracle_scan(plane, plane, 15, none, _downsample(scan_surface, 1000.0), ident, 7)
+    assert (r["code"], r["iteration"], r["success"]) == (w["code"], w["iteration"], w["success"]) == (3, 7, False)
+    assert np.isnan(r["pose"]).all() and np.isnan(w["pose"]).all()
+    # (3) nothing at all: EmptyInput
+    r = fx.localize_host(emap, smap, none, none, ident)
+    assert (r["code"], r["iteration"], r["success"], r["error"]) == (4, 0, False, 0.0) and r["message"] == "The input data is empty"
+    emap.close()
+    smap.close()
+    fx.close()

@@ -134,3 +134,25 @@ def test_map_arguments():
         m.nearest(d_q.data_ptr(), 1, 17)
     m.close()
     fx.close()
+
+
+def test_many_queries_and_small_k():
+    """20 000 queries in one call (one wave each), k = 2 and 7, against scipy's exact KD-tree where distances are distinct."""
+    import torch
+    from scipy.spatial import cKDTree
+    from lidar_feature_extraction_amd import FeatureExtraction
+    rng = np.random.default_rng(9)
+    pts = np.zeros((30000, 4), np.float32)
+    pts[:, :3] = rng.normal(0, 8, (30000, 3)) * [1, 1, 0.2]
+    queries = rng.normal(0, 9, (20000, 3)) * [1, 1, 0.2]
+    fx = FeatureExtraction(device=0, max_points_per_scan=1024, max_batch=1)
+    d_pts = torch.from_numpy(pts).to("cuda:0")
+    m = fx.make_map(d_pts.data_ptr(), len(pts), 0.8)
+    tree = cKDTree(pts[:, :3].astype(np.float64))
+    for k in (2, 7):
+        X, dist, idx = _query(fx, m, queries, k)
+        wd, wi = tree.query(queries, k)
+        assert np.array_equal(idx.astype(np.int64), wi)
+        assert np.allclose(dist, wd * wd, rtol=1e-12, atol=0)
+    m.close()
+    fx.close()
