@@ -3095,6 +3095,7 @@ struct MapIndex
   uint32_t n;
 };
 
+// (a NaN coordinate converts to cell 0: a query that is not a number walks the grid from there and ends when its cube holds it)
 __device__ inline int cell_coordinate(double p, double o, double inv_h)
 {
   double u = floor((p - o) * inv_h);
@@ -3102,23 +3103,17 @@ __device__ inline int cell_coordinate(double p, double o, double inv_h)
   return (int)u;
 }
 
-// candidate (d, at) into the ascending list; GRID: equal distances ordered by the original index kept in pts[].w
-template<bool GRID>
-__device__ inline void nearest_insert(double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax], double d, uint32_t at, uint32_t orig,
-  const float4 * __restrict__ pts)
+// candidate (d, at) into the ascending list of the no-grid search; candidates arrive by ascending map index, so `<` alone
+// keeps equal distances in index order
+__device__ inline void nearest_insert(double (&dist)[kNearestMax], uint32_t (&idx)[kNearestMax], double d, uint32_t at)
 {
   constexpr int KM = kNearestMax;
-  auto before = [&](int j) {                            // does the candidate come before entry j?
-      if (d < dist[j]) {return true;}
-      if (!GRID || d != dist[j]) {return false;}
-      return orig < __float_as_uint(pts[idx[j]].w);
-    };
-  if (!before(KM - 1)) {return;}
+  if (!(d < dist[KM - 1])) {return;}
   bool placed = false;
 #pragma unroll
   for (int j = KM - 1; j > 0; j--) {
     if (!placed) {
-      if (before(j - 1)) {dist[j] = dist[j - 1]; idx[j] = idx[j - 1];} else {dist[j] = d; idx[j] = at; placed = true;}
+      if (d < dist[j - 1]) {dist[j] = dist[j - 1]; idx[j] = idx[j - 1];} else {dist[j] = d; idx[j] = at; placed = true;}
     }
   }
   if (!placed) {dist[0] = d; idx[0] = at;}
@@ -3137,7 +3132,7 @@ __device__ __forceinline__ void nearest_whole_map(const MapIndex & mi, D3 q, dou
     for (uint32_t e = 0; e < lim; e++) {
       const float4 mpt = tile[e];
       const double dx = (double)mpt.x - q.x, dy = (double)mpt.y - q.y, dz = (double)mpt.z - q.z;
-      nearest_insert<false>(dist, idx, dx * dx + dy * dy + dz * dz, t0 + e, 0u, nullptr);   // ascending index, strict <
+      nearest_insert(dist, idx, dx * dx + dy * dy + dz * dz, t0 + e);
     }
   }
 }
@@ -3455,7 +3450,7 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
 // ------------------------------------------------------------------------------------------
 // Building a MapIndex (lfx_map_create): bounds, points per cell, the cells' first points by an exclusive scan, then the
 // points into their cells.  The order of the points inside a cell is whatever the atomics give; nothing depends on it
-// (nearest_insert orders equal distances by the original index).
+// (the search orders equal distances by the original index, which travels in the w of every sorted point).
 __device__ inline uint32_t float_order(float f)         // unsigned ints that order like the floats
 {
   const uint32_t u = __float_as_uint(f);
