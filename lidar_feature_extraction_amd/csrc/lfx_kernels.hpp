@@ -3758,12 +3758,24 @@ __device__ inline double workgroup_select(const double * __restrict__ v, uint32_
     uint32_t before = 0;
     for (int w = 0; w < (tid >> 6); w++) {before += sh[260 + w];}
     incl += before;
-    if (k < incl && k >= incl - mine) {sh[256] = (uint32_t)tid; sh[257] = k - (incl - mine);}     // exactly one thread
+    if (k < incl && k >= incl - mine) {sh[256] = (uint32_t)tid; sh[257] = k - (incl - mine); sh[258] = mine;}   // exactly one thread
     __syncthreads();
     prefix |= (uint64_t)sh[256] << shift;
     mask |= 0xFFull << shift;
     k = sh[257];
+    const uint32_t left = sh[258];
     __syncthreads();
+    if (left == 1u && shift > 0) {
+      // one value carries this prefix: it is the answer, and the passes over its remaining bytes are one pass to fetch it
+      for (uint32_t i = tid; i < n; i += T) {
+        const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
+        if ((key & mask) == prefix) {sh[256] = (uint32_t)key; sh[257] = (uint32_t)(key >> 32);}
+      }
+      __syncthreads();
+      const uint64_t key = ((uint64_t)sh[257] << 32) | sh[256];
+      __syncthreads();
+      return __longlong_as_double((long long)key);
+    }
   }
   return __longlong_as_double((long long)prefix);
 }
