@@ -170,3 +170,23 @@ def test_reference_message_texts(lib):
                 lib.lfx_ring_message(status, n, C.byref(p), buf, 256)
                 OB.lib().orc_ring_message(status, n, C.byref(op), ob, 256)
                 assert buf.value == ob.value
+
+
+def test_alignment_texts_and_null_arguments(lib):
+    """The result texts of optimization_result.hpp:43-79 and the success rule (:46-79: empty input and maximum iteration
+    fail), without a device; entry points refuse null arguments before any device work."""
+    lib.lfx_align_message.restype = C.c_char_p
+    texts = {0: "Optimization successfully converged", 1: "The error is larger than previous iteration",
+             2: "The scale is larger than previous iteration", 3: "The iteration reached the maximum value",
+             4: "The input data is empty"}
+    for code, text in texts.items():
+        assert lib.lfx_align_message(code).decode() == text
+    assert lib.lfx_align_message(99) == b"unknown"
+    null = C.c_void_p(0)
+    assert lib.lfx_map_create(null, null, 10, C.c_float(1.0), null, null) == -1
+    assert lib.lfx_map_create_host(null, null, 10, C.c_float(1.0), null, null) == -1
+    assert lib.lfx_map_info(null, None, None, None) == -1
+    assert lib.lfx_map_nearest(null, null, null, 1, 1, null, null, null, null) == -1
+    assert lib.lfx_localize_batch(null, null, null, 15, 20, C.c_float(1.0), None, None, null) == -1
+    assert lib.lfx_localize_host(null, null, null, 15, 20, C.c_float(1.0), null, 0, null, 0, None, None, null) == -1
+    lib.lfx_map_destroy(null)                 # a no-op
