@@ -92,6 +92,8 @@ def lib():
         L.orc_loc_edge_residuals.restype = None
         L.orc_loc_surface_residuals.argtypes = [_pf, _i, _pd, _i, _pf, _i, _pd, _pd]
         L.orc_loc_surface_residuals.restype = None
+        L.orc_loc_drp_dq.argtypes = [_pd, _pd, _pd]
+        L.orc_loc_drp_dq.restype = None
         L.orc_loc_nearest.argtypes = [_pf, _i, _pd, _i, _pd, _pd, _pi]
         L.orc_loc_nearest.restype = None
         for name in ("orc_loc_median", "orc_loc_mad", "orc_loc_scale"):

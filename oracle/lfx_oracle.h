@@ -136,6 +136,7 @@ void orc_loc_surface_residuals(const float *map, int n_map, const double *pose, 
  * code: 0 converged, 1 error larger than before, 2 scale larger than before (success), 3 maximum iteration, 4 empty input. */
 void orc_loc_nearest(const float *map, int n_map, const double *query, int k, double *neighbours /* [k][3] */,
                      double *squared_distances, int *indices);                                           /* kdtree.cpp:44-68 */
+void orc_loc_drp_dq(const double *wxyz, const double *p, double *out /* 3 x 4 row-major */);          /* rotationlib jacobian/quaternion.cpp:35-52 */
 double orc_loc_median(const double *v, int n);                                                          /* stats.cpp:34-55 */
 double orc_loc_mad(const double *v, int n);                                                             /* robust.cpp:36-40 */
 double orc_loc_scale(const double *v, int n);                                                           /* robust.cpp:42-50 */

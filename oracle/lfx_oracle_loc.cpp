@@ -543,6 +543,11 @@ void orc_loc_nearest(const float * map, int n_map, const double * query, int k, 
   }
 }
 
+void orc_loc_drp_dq(const double * wxyz, const double * p, double * out /* 3 x 4 */)   // rotationlib jacobian/quaternion.cpp:35-52
+{
+  DRpDq(wxyz[0], wxyz + 1, V3{p[0], p[1], p[2]}, out);
+}
+
 double orc_loc_median(const double * v, int n) {return MedianOf(std::vector<double>(v, v + n));}
 double orc_loc_mad(const double * v, int n) {return Mad(std::vector<double>(v, v + n));}
 double orc_loc_scale(const double * v, int n) {return ScaleOf(std::vector<double>(v, v + n));}

@@ -269,3 +269,37 @@ def test_nearest_k_search(refvec):
         X, dist, idx = np.zeros((k, 3)), np.zeros(k), np.zeros(k, np.int32)
         L.orc_loc_nearest(B.ptr(pts, PF), len(pts), B.ptr(d(g["query"]), PD), k, B.ptr(X, PD), B.ptr(dist, PD), B.ptr(idx, PI))
         assert X.tolist() == c["X"] and dist.tolist() == c["squared_distances"]
+
+
+def _qmul(a, b):
+    w0, v0, w1, v1 = a[0], np.asarray(a[1:]), b[0], np.asarray(b[1:])
+    return np.concatenate([[w0 * w1 - v0 @ v1], w0 * v1 + w1 * v0 + np.cross(v0, v1)])
+
+
+def test_drp_dq_and_left_multiplication(refvec):
+    """rotationlib/test/test_jacobian_quaternion.cpp:67-82 (DRpDq against the quaternion-product form) and
+    test_quaternion.cpp:40-48 (LeftMultiplicationMatrix, the matrix inside MakeM) on the restatement."""
+    g = refvec["loc_drp_dq"]
+    q = d(g["q_wxyz_unnormalised"]) / np.linalg.norm(g["q_wxyz_unnormalised"])
+    p = d(g["p"])
+    J = np.zeros(12)
+    L.orc_loc_drp_dq(B.ptr(q, PD), B.ptr(p, PD), B.ptr(J, PD))
+
+    def Q(a):
+        w, x, y, z = a
+        return np.array([[w, -x, -y, -z], [x, w, -z, y], [y, z, w, -x], [z, -y, x, w]])
+
+    def P(a):
+        w, x, y, z = a
+        return np.array([[w, -x, -y, -z], [x, w, z, -y], [y, -z, w, x], [z, y, -x, w]])
+    u = np.concatenate([[0.0], p])
+    q_inv = np.concatenate([[q[0]], -q[1:]])                                   # unit quaternion
+    D = Q(_qmul(q, u)) @ np.diag([1.0, -1.0, -1.0, -1.0]) + P(_qmul(u, q_inv))
+    assert np.abs(D[1:] - J.reshape(3, 4)).max() <= 1e-14
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        q1, q2 = rng.uniform(-1, 1, 4), rng.uniform(-1, 1, 4)
+        M = np.zeros(42)
+        L.orc_loc_make_m(B.ptr(d(q1), PD), B.ptr(M, PD))
+        left_cols = 2.0 * M.reshape(7, 6)[:4, :3]                              # columns 1..3 of LeftMultiplicationMatrix(q1)
+        assert np.abs(left_cols @ q2[1:] + q1 * q2[0] - _qmul(q1, q2)).max() <= 1e-12
