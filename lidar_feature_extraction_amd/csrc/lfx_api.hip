@@ -1635,7 +1635,8 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   static_assert(sizeof(lfx::AlignState) % 8 == 0, "AlignState is an array of doubles' worth");
   const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds, pose_d = 12 * (size_t)n_clouds;
   const size_t rows = pr.total3 + pr.total1;
-  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + rows + 9;
+  const size_t partial_d = (size_t)n_clouds * lfx::kAlignSlices * 64;
+  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + (n_clouds + 1) / 2 + 9;
   if (c->align_scratch.n < need) {
     c->align_scratch.release();
     if (c->align_scratch.alloc(need) != hipSuccess) {
@@ -1650,8 +1651,11 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   double * J3 = w; w += 21 * pr.total3;
   double * r1 = w; w += pr.total1;
   double * J1 = w; w += 7 * pr.total1;
-  double * err = w; w += rows;
+  double * d_weights = w; w += rows;
+  double * d_partials = w; w += partial_d;
+  uint32_t * d_tickets = reinterpret_cast<uint32_t *>(w); w += (n_clouds + 1) / 2;
   uint32_t * d_active = reinterpret_cast<uint32_t *>(w);
+  LFX_HIP(c, hipMemsetAsync(d_tickets, 0, sizeof(uint32_t) * n_clouds, st));
   // small copies through pinned memory: [poses | states | active]
   const size_t h_states_at = pose_d * 8, h_active_at = h_states_at + sizeof(lfx::AlignState) * n_clouds;
   LFX_HIP(c, c->h_align.reserve(h_active_at + 16 + 20 * (size_t)n_clouds));
@@ -1666,17 +1670,33 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
           pr.begin3, pr.count3, r3, J3, states);
       }
     } else {
-      if (pr.longest3) {
-        launch_rows(false, pr.edge_map->index, none, pr.n_neighbors, pr.edge_points, pr.begin3, pr.count3, pr.stride3, n_clouds,
-          pr.longest3, r3, J3, states, st);
-      }
-      if (pr.longest1) {
-        launch_rows(true, pr.surface_map->index, none, pr.n_neighbors, pr.surface_points, pr.begin1, pr.count1, pr.stride1, n_clouds,
-          pr.longest1, r1, J1, states, st);
+      const bool both_grids = pr.edge_map->index.start && pr.surface_map->index.start;
+      // a few scans: edge and surface rows in one launch, side by side (the short surface part otherwise runs after the edge
+      // part on a mostly idle chip).  Many scans fill the chip anyway, and the one kernel's register count (the surface
+      // rows' QR) would halve the edge searches' occupancy: 64 scans took 13.4 ms that way against 8.4 ms.
+      const bool few = (uint64_t)n_clouds * ((uint64_t)pr.longest3 + pr.longest1) <= 32768u;
+      if (pr.longest3 && pr.longest1 && both_grids && few) {
+        const lfx::RowsOfKind e{pr.edge_map->index, reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3};
+        const lfx::RowsOfKind f{pr.surface_map->index, reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1,
+          r1, J1};
+        hipLaunchKernelGGL(lfx::scan_to_map_both_kernel<lfx::kSearchGridWave>, dim3(pr.longest3 + pr.longest1, n_clouds), dim3(64), 0, st,
+          e, f, pr.longest3, none, pr.n_neighbors, states);
+      } else {
+        if (pr.longest3) {
+          launch_rows(false, pr.edge_map->index, none, pr.n_neighbors, pr.edge_points, pr.begin3, pr.count3, pr.stride3, n_clouds,
+            pr.longest3, r3, J3, states, st);
+        }
+        if (pr.longest1) {
+          launch_rows(true, pr.surface_map->index, none, pr.n_neighbors, pr.surface_points, pr.begin1, pr.count1, pr.stride1, n_clouds,
+            pr.longest1, r1, J1, states, st);
+        }
       }
     }
-    hipLaunchKernelGGL(lfx::align_step_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, max_iter,
-      r3, J3, pr.begin3, pr.count3, pr.stride3, r1, J1, pr.begin1, pr.count1, pr.stride1, err, d_active);
+    hipLaunchKernelGGL(lfx::align_scale_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, r3, pr.begin3, pr.count3,
+      pr.stride3, r1, pr.begin1, pr.count1, pr.stride1, d_weights, d_active);
+    hipLaunchKernelGGL(lfx::align_update_kernel, dim3(lfx::kAlignSlices, n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter,
+      max_iter, r3, J3, pr.begin3, pr.count3, pr.stride3, r1, J1, pr.begin1, pr.count1, pr.stride1, d_weights, d_partials, d_tickets,
+      d_active);
     // the kernels of a finished scan return at once, but a launch is a launch: now and then ask whether any scan still iterates
     if ((iter == 2 || iter == 4 || iter == 7 || iter == 11 || iter == 15) && iter + 1 < max_iter) {
       uint32_t * active = reinterpret_cast<uint32_t *>(c->h_align.p + h_active_at);

@@ -3017,6 +3017,7 @@ struct AlignState
   double q[4], t[3];                      // the optimizer's q (w x y z) and t
   double prev_error, prev_scale;
   double error, scale;                    // OptimizationResult
+  double cur_error, cur_scale;            // this iteration's, from align_scale_kernel to align_update_kernel
   int32_t iteration, code, done, pad;
 };
 
@@ -3314,9 +3315,10 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
 // how a query finds its neighbours
 enum : int {kSearchWholeMap = 0, kSearchGridWave = 2};
 
+// the rows of one workgroup: `bx` = its index along x among the workgroups of its kind
 template<bool SURFACE, int SEARCH>
-__global__ __launch_bounds__(128) void scan_to_map_kernel(
-  MapIndex mi, MapPose P, uint32_t k, const float4 * __restrict__ pts,
+__device__ __forceinline__ void scan_to_map_rows(
+  uint32_t bx, const MapIndex & mi, MapPose P, uint32_t k, const float4 * __restrict__ pts,
   const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
   double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align)
 {
@@ -3329,8 +3331,8 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
   const float4 * __restrict__ map = mi.pts;
   const uint32_t b = begin[s], n = count[(size_t)s * count_stride];
   // kSearchGridWave: a workgroup is one wave and has one query, the same in every lane
-  const uint32_t i = SEARCH == kSearchGridWave ? blockIdx.x : blockIdx.x * T + tid;
-  if ((SEARCH == kSearchGridWave ? blockIdx.x : blockIdx.x * T) >= n) {return;}       // the whole workgroup is beyond this cloud
+  const uint32_t i = SEARCH == kSearchGridWave ? bx : bx * T + tid;
+  if ((SEARCH == kSearchGridWave ? bx : bx * T) >= n) {return;}                        // the whole workgroup is beyond this cloud
   const bool valid = i < n;
   const float4 pf = pts[b + (valid ? i : 0u)];
   const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
@@ -3444,6 +3446,39 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
     for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
     J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
     residual[b + i] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+  }
+}
+
+template<bool SURFACE, int SEARCH>
+__global__ __launch_bounds__(128) void scan_to_map_kernel(
+  MapIndex mi, MapPose P, uint32_t k, const float4 * __restrict__ pts,
+  const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
+  double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align)
+{
+  scan_to_map_rows<SURFACE, SEARCH>(blockIdx.x, mi, P, k, pts, begin, count, count_stride, residual, jacobian, align);
+}
+
+// Problem::Make of the localizer in one launch (loam_optimization_problem.hpp:62-84: edge rows and surface rows of the same
+// scans against their two maps): workgroups [0, x_edge) along x build edge rows, the rest surface rows, so that the short
+// surface part runs beside the edge part instead of after it.
+struct RowsOfKind
+{
+  MapIndex mi;
+  const float4 * pts;
+  const uint32_t * begin, * count;
+  uint32_t count_stride;
+  double * residual, * jacobian;
+};
+template<int SEARCH>
+__global__ __launch_bounds__(128) void scan_to_map_both_kernel(
+  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge, MapPose P, uint32_t k, const AlignState * __restrict__ align)
+{
+  if (blockIdx.x < x_edge) {
+    scan_to_map_rows<false, SEARCH>(blockIdx.x, edge.mi, P, k, edge.pts, edge.begin, edge.count, edge.count_stride, edge.residual,
+      edge.jacobian, align);
+  } else {
+    scan_to_map_rows<true, SEARCH>(blockIdx.x - x_edge, surface.mi, P, k, surface.pts, surface.begin, surface.count, surface.count_stride,
+      surface.residual, surface.jacobian, align);
   }
 }
 
@@ -3696,7 +3731,7 @@ __global__ void align_begin_kernel(AlignState * __restrict__ states, const doubl
   a.q[0] = w; a.q[1] = v[0]; a.q[2] = v[1]; a.q[3] = v[2];
   a.t[0] = m[3]; a.t[1] = m[7]; a.t[2] = m[11];
   a.prev_error = 1.7976931348623157e308; a.prev_scale = 1.7976931348623157e308;   // std::numeric_limits<double>::max()
-  a.error = 0.; a.scale = 0.; a.iteration = 0; a.code = kAlignMaxIteration; a.done = 0; a.pad = 0;
+  a.error = 0.; a.scale = 0.; a.cur_error = 0.; a.cur_scale = 0.; a.iteration = 0; a.code = kAlignMaxIteration; a.done = 0; a.pad = 0;
   refresh_pose(a);
   states[s] = a;
 }
@@ -3882,34 +3917,35 @@ __device__ inline void solve_update(const double (&q)[4], const double * D, cons
   for (int a = 0; a < 3; a++) {dt[a] = dx[3 + a];}
 }
 
-// One iteration of Optimizer::Run after Problem::Make, one workgroup per scan.  Rows of scan s: n3 = count3[s * stride3]
-// residuals of dimension 3 (r3 / J3 from record begin3[s]: the edge rows, or the point pairs), then n1 = count1[...]
-// of dimension 1 (the surface rows; count1 may be null).  errors: scratch for scans with more than kAlignKeysLds rows, one
-// double per row, rows of scan s from begin3[s] + begin1[s].
-__global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
-  AlignState * __restrict__ states, int iter, int max_iter,
-  const double * __restrict__ r3, const double * __restrict__ J3, const uint32_t * __restrict__ begin3,
-  const uint32_t * __restrict__ count3, uint32_t stride3,
-  const double * __restrict__ r1, const double * __restrict__ J1, const uint32_t * __restrict__ begin1,
-  const uint32_t * __restrict__ count1, uint32_t stride1, double * __restrict__ errors, uint32_t * __restrict__ active)
+// One iteration of Optimizer::Run after Problem::Make, in two kernels.  Rows of scan s: n3 = count3[s * stride3] residuals of
+// dimension 3 (r3 / J3 from record begin3[s]: the edge rows, or the point pairs), then n1 = count1[...] of dimension 1
+// (the surface rows; count1 may be null).  weights: one double per row, rows of scan s from begin3[s] + begin1[s] (also the
+// selection's keys when a scan has more than kAlignKeysLds rows).
+//
+// align_scale_kernel, one workgroup per scan: ComputeErrors, the error of the scan, Scale, ComputeWeights.
+__global__ __launch_bounds__(kAlignThreads) void align_scale_kernel(
+  AlignState * __restrict__ states, int iter,
+  const double * __restrict__ r3, const uint32_t * __restrict__ begin3, const uint32_t * __restrict__ count3, uint32_t stride3,
+  const double * __restrict__ r1, const uint32_t * __restrict__ begin1, const uint32_t * __restrict__ count1, uint32_t stride1,
+  double * __restrict__ weights, uint32_t * __restrict__ active)
 {
-  constexpr int T = kAlignThreads, NS = 64;                 // 28 (D) + 28 (A) upper triangles + 7 (b) + 1 (error)
+  constexpr int T = kAlignThreads;
   const uint32_t s = blockIdx.x;
   const int tid = threadIdx.x;
   AlignState & st = states[s];
   if (st.done) {return;}
   __shared__ uint32_t sh[264];
-  __shared__ double part[T / 64][NS];
-  __shared__ double total[NS];
+  __shared__ double part[T / 64];
   const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u, n = n3 + n1;
   if (n == 0u) {                                            // EmptyInput (optimization_result.hpp:46-50)
     if (tid == 0) {st.iteration = iter; st.error = 0.; st.scale = 0.; st.code = kAlignEmpty; st.done = 1; atomicSub(active, 1u);}
     return;
   }
   const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
+  double * w_out = weights + (size_t)b3 + b1;
   // the values the two medians are taken of: in LDS when the scan's rows fit (the selection passes over them 16-32 times)
   __shared__ double keys_lds[kAlignKeysLds];
-  double * key = n <= (uint32_t)kAlignKeysLds ? keys_lds : errors + (size_t)b3 + b1;
+  double * key = n <= (uint32_t)kAlignKeysLds ? keys_lds : w_out;
   auto row_error = [&](uint32_t i) {                         // ComputeErrors (optimizer.cpp:99-107)
       if (i < n3) {
         const double * r = r3 + 3 * ((size_t)b3 + i);
@@ -3918,45 +3954,96 @@ __global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
       const double r = r1[(size_t)b1 + (i - n3)];
       return r * r;
     };
-  for (uint32_t i = tid; i < n; i += T) {key[i] = row_error(i);}
+  double esum = 0.;
+  for (uint32_t i = tid; i < n; i += T) {const double e = row_error(i); key[i] = e; esum += e;}
   __syncthreads();
   // Scale (robust.cpp:36-50): b * median(|e - median(e)|)
   const double median = workgroup_median(key, n, sh);
   for (uint32_t i = tid; i < n; i += T) {key[i] = fabs(key[i] - median);}
   __syncthreads();
   const double scale = 1.482602218505602 * workgroup_median(key, n, sh);
-  // ComputeWeights (optimizer.cpp:120-127) and the sums of WeightedUpdate (optimizer.cpp:40-64)
+  // ComputeWeights (optimizer.cpp:120-127)
+  for (uint32_t i = tid; i < n; i += T) {
+    const double en = row_error(i) / (scale + 1e-16);
+    w_out[i] = en < 1.345 * 1.345 ? 1. : 1.345 / sqrt(en);                // HuberDerivative, robust.cpp:61-68
+  }
+  // the error of the scan (errors.sum()), fixed tree order
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {esum += __shfl_xor(esum, off, 64);}
+  if ((tid & 63) == 0) {part[tid >> 6] = esum;}
+  __syncthreads();
+  if (tid == 0) {
+    double e = 0.;
+    for (int wv = 0; wv < T / 64; wv++) {e += part[wv];}
+    st.cur_error = e; st.cur_scale = scale;
+  }
+}
+
+// align_update_kernel, kAlignSlices workgroups per scan: each sums the rows of its slice for WeightedUpdate (optimizer.cpp:
+// 40-64) -- one 1 x 7 row of a Jacobian with its residual at a time: the three rows of an edge residual lie one after the
+// other (J3 is [n3][3][7]), the surface rows follow; four rows per thread in flight, this loop is a chain of small loads
+// whose latency is its whole cost -- and leaves its 63 sums in `partials`; the workgroup that finishes last adds the slices
+// up in slice order and does the rest of the iteration on one thread: the stopping tests, CalcUpdate, the pose.
+constexpr int kAlignSlices = 8;
+__global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
+  AlignState * __restrict__ states, int iter, int max_iter,
+  const double * __restrict__ r3, const double * __restrict__ J3, const uint32_t * __restrict__ begin3,
+  const uint32_t * __restrict__ count3, uint32_t stride3,
+  const double * __restrict__ r1, const double * __restrict__ J1, const uint32_t * __restrict__ begin1,
+  const uint32_t * __restrict__ count1, uint32_t stride1, const double * __restrict__ weights, double * __restrict__ partials,
+  uint32_t * __restrict__ tickets, uint32_t * __restrict__ active)
+{
+  constexpr int T = kAlignThreads, NS = 64, G = kAlignSlices;   // 28 (D) + 28 (A) upper triangles + 7 (b) (+ 1 unused)
+  const uint32_t s = blockIdx.y, g = blockIdx.x;
+  const int tid = threadIdx.x;
+  AlignState & st = states[s];
+  if (st.done) {return;}
+  __shared__ double part[T / 64][NS];
+  __shared__ double total[NS];
+  __shared__ uint32_t last;
+  const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u;
+  const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
+  const double * key = weights + (size_t)b3 + b1;
   double acc[NS];
 #pragma unroll
   for (int a = 0; a < NS; a++) {acc[a] = 0.;}
-  for (uint32_t i = tid; i < n; i += T) {
-    const double e = row_error(i);
-    const double en = e / (scale + 1e-16);
-    const double w = en < 1.345 * 1.345 ? 1. : 1.345 / sqrt(en);          // HuberDerivative, robust.cpp:61-68
-    acc[63] += e;
-    const int dim = i < n3 ? 3 : 1;
-    const double * J = i < n3 ? J3 + 21 * ((size_t)b3 + i) : J1 + 7 * ((size_t)b1 + (i - n3));
-    const double * r = i < n3 ? r3 + 3 * ((size_t)b3 + i) : r1 + ((size_t)b1 + (i - n3));
-    for (int k = 0; k < dim; k++) {
-      double row[7];
+  {
+    const uint32_t m3 = 3u * n3, m_all = m3 + n1;
+    const double * Je = J3 + 21 * (size_t)b3, * re = r3 + 3 * (size_t)b3;
+    const double * Js = J1 + 7 * (size_t)b1, * rs = r1 + (size_t)b1;
+    constexpr int U = 4;
+    for (uint32_t base = g * T + tid; base < m_all; base += U * G * T) {
+      double row[U][7], rk[U], w[U];
 #pragma unroll
-      for (int a = 0; a < 7; a++) {row[a] = J[7 * k + a];}
-      const double rk = r[k];
-      int at = 0;
+      for (int u = 0; u < U; u++) {
+        const uint32_t m = base + u * G * T;
+        const bool live = m < m_all;
+        const uint32_t mm = live ? m : m_all - 1u;
+        const bool edge = mm < m3;
+        const double * J = edge ? Je + 7 * (size_t)mm : Js + 7 * (size_t)(mm - m3);
 #pragma unroll
-      for (int a = 0; a < 7; a++) {
+        for (int a = 0; a < 7; a++) {row[u][a] = live ? J[a] : 0.;}
+        rk[u] = live ? (edge ? re[mm] : rs[mm - m3]) : 0.;
+        w[u] = live ? key[edge ? mm / 3u : n3 + (mm - m3)] : 0.;
+      }
 #pragma unroll
-        for (int c = a; c < 7; c++) {
-          const double jj = row[a] * row[c];
-          acc[at] += jj;
-          acc[28 + at] += w * jj;
-          at++;
+      for (int u = 0; u < U; u++) {
+        int at = 0;
+#pragma unroll
+        for (int a = 0; a < 7; a++) {
+#pragma unroll
+          for (int c = a; c < 7; c++) {
+            const double jj = row[u][a] * row[u][c];
+            acc[at] += jj;
+            acc[28 + at] += w[u] * jj;
+            at++;
+          }
+          acc[56 + a] += w[u] * (row[u][a] * rk[u]);
         }
-        acc[56 + a] += w * (row[a] * rk);
       }
     }
   }
-  // fixed-order tree: lanes of a wave, then the waves
+  // fixed-order tree: lanes of a wave, the waves, then (by the last workgroup) the slices
 #pragma unroll
   for (int a = 0; a < NS; a++) {
     double v = acc[a];
@@ -3965,14 +4052,28 @@ __global__ __launch_bounds__(kAlignThreads) void align_step_kernel(
     if ((tid & 63) == 0) {part[tid >> 6][a] = v;}
   }
   __syncthreads();
+  double * mine = partials + ((size_t)s * G + g) * NS;
   if (tid < NS) {
     double v = 0.;
     for (int wv = 0; wv < T / 64; wv++) {v += part[wv][tid];}
+    mine[tid] = v;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {last = atomicAdd(&tickets[s], 1u) == (uint32_t)G - 1u ? 1u : 0u;}
+  __syncthreads();
+  if (last == 0u) {return;}
+  __threadfence();
+  if (tid < NS) {
+    const volatile double * all = partials + (size_t)s * G * NS;
+    double v = 0.;
+    for (int k = 0; k < G; k++) {v += all[(size_t)k * NS + tid];}
     total[tid] = v;
   }
   __syncthreads();
   if (tid != 0) {return;}
-  const double error = total[63];
+  tickets[s] = 0u;                                           // for the next iteration
+  const double error = st.cur_error, scale = st.cur_scale;
   if (error > st.prev_error) {                               // LargerErrorThanPrevious
     st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerError; st.done = 1; atomicSub(active, 1u);
     return;
