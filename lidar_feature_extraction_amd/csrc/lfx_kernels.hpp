@@ -3673,9 +3673,9 @@ __global__ void downsample_passthrough_kernel(
 // ------------------------------------------------------------------------------------------
 // The optimizer around the rows: Optimizer::Run (localization/include/lidar_feature_localization/optimizer.hpp:79-123)
 // as kernels, so that the iterations of a batch of scans run without a round trip to the host: align_begin_kernel, then
-// per iteration the two row builds above and align_step_kernel (errors, robust scale, weights, the sums of
-// WeightedUpdate, the 6 x 6 solve, the pose update and the three stopping tests); a finished scan's kernels return at
-// once.  PARITY UNPINNED (Eigen's arithmetic; sums are taken in a fixed tree order here, not row by row).
+// per iteration the two row builds above, align_scale_kernel (errors, robust scale, weights) and align_update_kernel (the
+// sums of WeightedUpdate, the 6 x 6 solve, the pose update and the three stopping tests); a finished scan's kernels return
+// at once.  PARITY UNPINNED (Eigen's arithmetic; sums are taken in a fixed tree order here, not row by row).
 constexpr int kAlignThreads = 256, kAlignKeysLds = 6144;
 enum AlignCode : int32_t {kAlignConverged = 0, kAlignLargerError = 1, kAlignLargerScale = 2, kAlignMaxIteration = 3, kAlignEmpty = 4};
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/pmc_localize.sh [LIB] -- on the GPU box: SQ counters (rocprofv3 --pmc with --kernel-trace only) and durations of the
-# scan_to_map / align_step kernels for one iteration of tools/localize_bench.py; LIB: a library under _lib/ (A/B builds)
+# scan_to_map / align_* kernels for one iteration of tools/localize_bench.py; LIB: a library under _lib/ (A/B builds)
 export TMPDIR=/tmp
 OUT=gpurun_out/locpmc
 mkdir -p $OUT
@@ -15,13 +15,13 @@ dur = collections.defaultdict(list)
 for f in glob.glob(out + "/p1/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "scan_to_map" not in k and "align_step" not in k: continue
+        if "scan_to_map" not in k and "align_" not in k: continue
         k = k[:60]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 for f in glob.glob(out + "/p1/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "scan_to_map" not in k and "align_step" not in k: continue
+        if "scan_to_map" not in k and "align_" not in k: continue
         dur[k[:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k in acc:
     print(k)
