@@ -291,7 +291,8 @@ def main():
         one, many = timed(fe, pinned, 32)
         one_pg, many_pg = timed(fe, clouds, 16)
         fe.close()
-        # every output (labels, curvature, sorted index: 13 more bytes per point over PCIe), pageable input
+        # every output (labels, curvature, sorted index: 13 more bytes per point over PCIe, and as many again copied by the
+        # Python binding out of the pinned block into arrays of the caller's own), pageable input
         fe = FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=16,
                                max_points_per_ring=cap, max_rings=a.rings)
         one_all, many_all = timed(fe, clouds, 16)

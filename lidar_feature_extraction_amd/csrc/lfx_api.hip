@@ -548,22 +548,27 @@ int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t 
     c->surf_pts.p, c->surf_idx.p, H + o_hdr, reinterpret_cast<float4 *>(H + o_ep), reinterpret_cast<float4 *>(H + o_sp),
     reinterpret_cast<uint32_t *>(H + o_ei), reinterpret_cast<uint32_t *>(H + o_si));
   LFX_HIP(c, hipGetLastError());
-  if (want_lab || want_curv || want_sidx) {
-    for (uint32_t k = 0; k < count; k++) {
-      const uint32_t s = first + k, b = c->h_scan_begin[s] - p0, n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
-      if (n == 0) {continue;}
-      // ring-major (fixed capacity per ring) -> the caller's point order (labels, curvature) and the dense list of
-      // angle-sorted indices, rings ascending; points that are in no ring (zero filter, over-long ring) stay Default / 0
-      LFX_HIP(c, hipMemsetAsync(c->d_label.p, 0, n, st));
-      LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, (size_t)n * 8, st));
-      hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings), dim3(256), 0, st,
-        s, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p, c->d_curv.p,
-        c->d_sidx.p, n, c->scan_info.p, c->xform.p);
-      LFX_HIP(c, hipGetLastError());
-      if (want_lab) {LFX_HIP(c, hipMemcpyAsync(H + o_lb + b, c->d_label.p, n, hipMemcpyDeviceToHost, st));}
-      if (want_curv) {LFX_HIP(c, hipMemcpyAsync(H + o_cv + (size_t)b * 8, c->d_curv.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));}
-      if (want_sidx) {LFX_HIP(c, hipMemcpyAsync(H + o_sx + (size_t)b * 4, c->d_sidx.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));}
+  if ((want_lab || want_curv || want_sidx) && P) {
+    // ring-major (fixed capacity per ring) -> the caller's point order (labels, curvature) and the dense list of
+    // angle-sorted indices, rings ascending; points that are in no ring (zero filter, over-long ring) stay Default / 0.
+    // All scans of the range in one launch and one copy per array (the buffers grow to the largest range asked for).
+    if (c->d_label.n < P) {
+      LFX_HIP(c, hipStreamSynchronize(st));
+      c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
+      if (c->d_label.alloc(P) != hipSuccess || c->d_curv.alloc(P) != hipSuccess || c->d_sidx.alloc(P) != hipSuccess) {
+        c->d_label.n = 0;
+        return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the per-point output buffers");
+      }
     }
+    LFX_HIP(c, hipMemsetAsync(c->d_label.p, 0, P, st));
+    LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, P * 8, st));
+    hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings, count), dim3(256), 0, st,
+      first, p0, c->scan_begin.p, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p,
+      c->d_curv.p, c->d_sidx.p, c->scan_info.p, c->xform.p);
+    LFX_HIP(c, hipGetLastError());
+    if (want_lab) {LFX_HIP(c, hipMemcpyAsync(H + o_lb, c->d_label.p, P, hipMemcpyDeviceToHost, st));}
+    if (want_curv) {LFX_HIP(c, hipMemcpyAsync(H + o_cv, c->d_curv.p, P * 8, hipMemcpyDeviceToHost, st));}
+    if (want_sidx) {LFX_HIP(c, hipMemcpyAsync(H + o_sx, c->d_sidx.p, P * 4, hipMemcpyDeviceToHost, st));}
   }
   LFX_HIP(c, hipStreamSynchronize(st));
   for (uint32_t k = 0; k < count; k++) {

@@ -2620,17 +2620,22 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Download path: one scan's per-point outputs from the ring-major layout.  sorted_index goes to a dense
+// Download path: the per-point outputs of the scans of a batch from the ring-major layout.  sorted_index goes to a dense
 // array, rings ascending; labels and curvature go straight to the CALLER's point order (label of input point k
 // at [k]) -- the scatter by original index is done here rather than in a host loop after the copy.  The host
 // zeroes d_label / d_curv first: points the zero filter dropped, or beyond a ring's capacity, stay Default / 0.
-// One workgroup per ring id.
+// One workgroup per (ring id, scan).
 __global__ __launch_bounds__(256) void densify_kernel(
-  uint32_t s, uint32_t max_rings, uint32_t cap, const uint32_t * __restrict__ ring_count,
+  uint32_t first, uint32_t p0, const uint32_t * __restrict__ scan_begin, uint32_t max_rings, uint32_t cap,
+  const uint32_t * __restrict__ ring_count,
   const uint8_t * __restrict__ label_s, const double * __restrict__ curv_s, const uint32_t * __restrict__ sidx,
-  uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx, uint32_t n_points,
+  uint8_t * __restrict__ d_label, double * __restrict__ d_curv, uint32_t * __restrict__ d_sidx,
   const uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ xform)
 {
+  // scan first + blockIdx.y of the batch; its outputs from record scan_begin[s] - p0 of the three arrays
+  const uint32_t s = first + blockIdx.y;
+  const uint32_t at = scan_begin[s] - p0, n_points = scan_begin[s + 1] - scan_begin[s];
+  d_label += at; d_curv += at; d_sidx += at;
   const uint32_t ring = blockIdx.x, tid = threadIdx.x;
   const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]);     // position i of the ring is point i * rings + ring
   __shared__ uint32_t part[256];
