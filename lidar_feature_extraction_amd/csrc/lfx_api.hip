@@ -1638,6 +1638,7 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   lfx_align_result * results, hipStream_t st)
 {
   static_assert(sizeof(lfx::AlignState) % 8 == 0, "AlignState is an array of doubles' worth");
+  if (n_clouds > 65535u) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "at most 65535 scans per alignment call");}   // (a launch's y extent)
   const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds, pose_d = 12 * (size_t)n_clouds;
   const size_t rows = pr.total3 + pr.total1;
   const size_t partial_d = (size_t)n_clouds * lfx::kAlignSlices * 64;
