@@ -3824,8 +3824,31 @@ __device__ inline double workgroup_select(const double * __restrict__ v, uint32_
 __device__ inline double workgroup_median(const double * __restrict__ v, uint32_t n, uint32_t * sh)
 {
   if (n & 1u) {return workgroup_select(v, n, (n - 1u) / 2u, sh);}
-  const double e0 = workgroup_select(v, n, n / 2u, sh);
+  // even n: the lower of the two middle values by selection, the upper one from it by one pass -- it is the same value
+  // again if more than n / 2 values are <= it, the smallest larger value otherwise
   const double e1 = workgroup_select(v, n, n / 2u - 1u, sh);
+  const int tid = threadIdx.x, T = blockDim.x;
+  uint32_t not_above = 0;
+  double next = INFINITY;
+  for (uint32_t i = tid; i < n; i += T) {
+    const double x = v[i];
+    not_above += x <= e1 ? 1u : 0u;
+    next = x > e1 && x < next ? x : next;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    not_above += (uint32_t)__shfl_xor((int)not_above, off, 64);
+    const double o = __shfl_xor(next, off, 64);
+    next = o < next ? o : next;
+  }
+  double * shd = reinterpret_cast<double *>(sh);             // 264 words: room for 4 counts and 4 doubles
+  if ((tid & 63) == 0) {sh[tid >> 6] = not_above; shd[4 + (tid >> 6)] = next;}
+  __syncthreads();
+  uint32_t total = 0;
+  double e0 = INFINITY;
+  for (int w = 0; w < T / 64; w++) {total += sh[w]; e0 = shd[4 + w] < e0 ? shd[4 + w] : e0;}
+  __syncthreads();
+  if (total > n / 2u) {e0 = e1;}
   return (e0 + e1) / 2.;
 }
 
