@@ -407,6 +407,9 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     Timed t(c, 2, st);
     auto kern = &lfx::ring_scatter_kernel<false, true>;
     if (canon) {kern = &lfx::ring_scatter_kernel<true, true>;}
+    if (fb_grid == batch) {                            // a row per scan: the form without the loop over list entries
+      kern = canon ? &lfx::ring_scatter_kernel<true, true, true> : &lfx::ring_scatter_kernel<false, true, true>;
+    }
     hipLaunchKernelGGL(kern, dim3(chunks, fb_grid), dim3(lfx::kChunkThreads), 0, st,
       pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
       c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p);

@@ -448,8 +448,11 @@ __device__ __forceinline__ void scatter_chunk(
 // The scans to bucket are those on the fall-back list (every scan of the batch when the organised-scan kernel is
 // not in use): workgroup (x, y) takes chunk x of list entries y, y + gridDim.y, ...  A chunk only ever waits for
 // lower chunks of the same scan, i.e. for workgroups (x' < x, y) at the same step of their loop: no cycle.
-template<bool CANON, bool LOOKBACK>
-__global__ __launch_bounds__(kChunkThreads, 4) void ring_scatter_kernel(
+// ONE = true: the grid has a row per scan of the batch (every scan may be on the list: a stream that is not organised), so a
+// workgroup has one entry at most and no loop -- the loop costs the kernel 40 registers, a handful of spills and, measured
+// on a ragged stream, a third of its speed.
+template<bool CANON, bool LOOKBACK, bool ONE = false>
+__global__ __launch_bounds__(kChunkThreads, ONE ? 1 : 4) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
   uint32_t * __restrict__ scan_info, float2 * __restrict__ sxy, float * __restrict__ sz,
@@ -457,6 +460,13 @@ __global__ __launch_bounds__(kChunkThreads, 4) void ring_scatter_kernel(
   const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
 {
   const uint32_t n_list = *fb_count;
+  if (ONE) {
+    if (blockIdx.y < n_list) {
+      scatter_chunk<CANON, LOOKBACK>(fb_list[blockIdx.y], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
+        sidx, max_chunks, max_rings, cap, drop_zero);
+    }
+    return;
+  }
   for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
     scatter_chunk<CANON, LOOKBACK>(fb_list[it], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
       sidx, max_chunks, max_rings, cap, drop_zero);

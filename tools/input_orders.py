@@ -12,8 +12,9 @@ import torch
 
 from lidar_feature_extraction_amd import FeatureExtraction, make_scan, concat
 
-batch = 64
-variants = {"sorted": {}, "rotated": {"start_col": 517}, "reversed": {"reverse": True}, "shuffled": {"shuffle": True}}
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+variants = {"sorted": {}, "rotated": {"start_col": 517}, "reversed": {"reverse": True}, "ragged": {"drop_fraction": 0.05},
+            "shuffled": {"shuffle": True}}
 for name, kw in variants.items():
     clouds = [make_scan(64, 1800, seed=1234 + i, **kw) for i in range(8)]
     tiled = [clouds[j % 8] for j in range(batch)]
