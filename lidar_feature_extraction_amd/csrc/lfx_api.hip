@@ -27,7 +27,7 @@ std::string g_create_error;
 const char * kKernelNames[LFX_N_KERNELS] = {
   "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_unit_kernel",
   "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel", "ring_totals_kernel",
-  "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel"};
+  "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel", "ring_stream_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -138,6 +138,7 @@ struct lfx_ctx
   // LFX_DEBUG_FUSED=0/1 pins it.
   bool fused_possible = false;
   int fused_env = -1;
+  bool walk_rings = false;                // the organised-scan kernel in its streaming form (ring_stream_kernel); LFX_DEBUG_STREAM=0: one wave per unit
   // Rings that arrive rotated / reversed (a driver that does not cut its scans at -pi, a clockwise sensor): while the
   // organised-scan kernel keeps giving scans up for their angle order alone, ring_cut_kernel finds every ring's
   // transform first and the kernel applies it in its loads (LFX_DEBUG_XFORM=0/1 pins it).
@@ -386,7 +387,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::ring_cut_kernel, dim3(batch), dim3(lfx::kCutThreads), 0, st,
         pts, c->scan_begin.p, c->max_rings, c->cap, c->xform.p, counters);
     }
-    Timed t(c, 9, st);
+    Timed t(c, c->walk_rings ? 11 : 9, st);
     const uint32_t groups = (c->max_rings + 3u) / 4u;
     void (*kern)(lfx::Params, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t *,
       const lfx::UnitTables *, const uint32_t *) = nullptr;
@@ -399,7 +400,19 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       kern = xf ? LFX_PICK_ORG(false, true) : LFX_PICK_ORG(false, false);
     }
 #undef LFX_PICK_ORG
-    hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
+#define LFX_PICK_STREAM(DEFV, XFV) \
+    (c->unit_chunks == 5 ? &lfx::ring_stream_kernel<5, DEFV, XFV> : c->unit_chunks == 4 ? &lfx::ring_stream_kernel<4, DEFV, XFV> : \
+     c->unit_chunks == 3 ? &lfx::ring_stream_kernel<3, DEFV, XFV> : &lfx::ring_stream_kernel<6, DEFV, XFV>)
+    if (c->walk_rings) {
+      // one workgroup per (ring group, scan): the waves walk their rings block by block
+      if (c->default_thresholds) {
+        kern = xf ? LFX_PICK_STREAM(true, true) : LFX_PICK_STREAM(true, false);
+      } else {
+        kern = xf ? LFX_PICK_STREAM(false, true) : LFX_PICK_STREAM(false, false);
+      }
+    }
+#undef LFX_PICK_STREAM
+    hipLaunchKernelGGL(kern, dim3(c->walk_rings ? groups : groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
       c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p);
   }
   // ---- the bucketing route, over the scans on the fall-back list
@@ -807,6 +820,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
   if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->fused_env = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_STREAM")) {c->walk_rings = std::atoi(dbg) != 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->short_tail_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_XFORM")) {c->xform_env = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;

@@ -1303,6 +1303,45 @@ __device__ inline void put_word(UnitLds<CH> & U, int arr, int k, uint64_t w)
 #endif
 }
 
+// The words of one bit array, gathered in a register pair before they go to LDS: lane k + 1 holds the word of chunk k
+// (lanes 0 and K + 1 ... the zero words on either side), so that the array is written by ONE ds_write_b64 instead of one
+// per chunk -- a store of a wave-uniform word occupies the LDS pipe like any other (6 cycles), the pipe is the busiest
+// resource of the kernel, and these stores were a third of its cycles.  v_writelane costs what the v_mov of the word
+// into a register cost before.
+struct WordVec
+{
+  uint32_t lo = 0u, hi = 0u;
+  __device__ __forceinline__ void set(int k, uint64_t w)
+  {
+    // (clang has no builtin for v_writelane.  One scalar register per VALU instruction is all gfx9's constant bus allows,
+    // so the lane select has to be a literal: k is a constant once the chunk loops are unrolled and the switch folds.
+    // s_nop 1: on gfx940 and later a VALU instruction must not read a scalar register within two wait states of the VALU
+    // instruction that wrote it -- the word is a v_cmp result as a rule -- and the compiler pads no hazard whose consumer
+    // is inside an asm string: without the nop the OLD register value was written and the pick rounds never ended)
+    const uint32_t wlo = __builtin_amdgcn_readfirstlane((uint32_t)w), whi = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
+#define LFX_WRITELANE(L) \
+  case L - 1: \
+    asm ("s_nop 1\n\tv_writelane_b32 %0, %2, " #L "\n\tv_writelane_b32 %1, %3, " #L : "+v"(lo), "+v"(hi) : "s"(wlo), "s"(whi)); \
+    break;
+    switch (k) {
+      LFX_WRITELANE(1) LFX_WRITELANE(2) LFX_WRITELANE(3) LFX_WRITELANE(4) LFX_WRITELANE(5) LFX_WRITELANE(6)
+      default: break;
+    }
+#undef LFX_WRITELANE
+    static_assert(kWaveChunks <= 6, "one case per chunk");
+  }
+};
+
+template<int CH>
+__device__ __forceinline__ void put_words(UnitLds<CH> & U, int arr, const WordVec & v, int lane)
+{
+#ifdef LFX_WHATIF_NOLDS
+  asm volatile ("" :: "v"(v.lo), "v"(v.hi));
+#else
+  if (lane < CH + 2) {*reinterpret_cast<u64_alias_t *>(&U.bits[arr][2 * lane]) = ((uint64_t)v.hi << 32) | v.lo;}
+#endif
+}
+
 // bit 16 + d of the result <-> position q + d of array `arr`, q = 64k + lane (+1 for the shifted constants)
 template<int CH>
 __device__ inline uint32_t get_win(const UnitLds<CH> & U, int arr, int k, const UnitWin & w)
@@ -1422,17 +1461,46 @@ struct OrgScan
 // 43 % of its life (profiles/r02_org1/sq_counters.json).  Measured: the interleaved chunks need 42 more scalar and 24
 // more vector registers than the wave has (spilled), 1700 vs 1440 us per 1024 scans.  Kept because it is what exposed
 // the aliasing hazard described at put_word().
-template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF = false>
-__device__ __forceinline__ void unit_body(
-  const Params & prm, UnitLds<CH> * __restrict__ slabs, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
-  uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
-  const float2 * __restrict__ sxy, const float * __restrict__ sz,
-  const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
-  uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list, bool second_pass, const OrgScan & og)
+// What a unit is, in ring positions i and in span coordinates q = i - g0 (wave-uniform, scalar registers).
+struct UnitGeom
 {
-  const int lane = threadIdx.x & 63;
-  UnitLds<CH> & U = slabs[ORG ? og.wave : 0u];
+  int N, b0, b1, o0, o1, g0, span, K, qb0, qb1, qo0, qo1, qlo, qhi;
+};
+
+__device__ inline UnitGeom unit_geometry(int N, int P, int B, int j, int b0, int b1, int chunks_all /* > 0: FULL */)
+{
+  UnitGeom G;
+  G.N = N; G.b0 = b0; G.b1 = b1;
+  G.o0 = j == 0 ? 0 : b0; G.o1 = j == B - 1 ? N : b1;
+  const int H = P + 1;
+  G.g0 = G.o0 - H; G.span = G.o1 + H - G.g0;
+  G.K = chunks_all > 0 ? chunks_all : (G.span + 63) >> 6;
+  G.qb0 = b0 - G.g0; G.qb1 = b1 - G.g0;          // the block in span coordinates
+  G.qo0 = G.o0 - G.g0; G.qo1 = G.o1 - G.g0;      // the owned positions
+  G.qlo = G.g0 < 0 ? -G.g0 : 0;                  // first / one-past-last position that is a ring point
+  G.qhi = (N - G.g0) < G.span ? (N - G.g0) : G.span;
+  return G;
+}
+
+// Stages B-G of a unit (see unit_body): x, y (zero outside the ring) are in registers AND in the wave's slab (U.pxy), z
+// in registers.  Returns 0, or the reason the unit cannot be taken here (kDeferOrder / kDeferOther); feature records go
+// to positions [rec_lo, ...) (edges, ascending) and (..., rec_hi) (surfaces, descending) of the ring's record arrays,
+// their numbers to n_edge / n_surface.
+struct NoHooks
+{
+  __device__ __forceinline__ void after_range() const {}
+  __device__ __forceinline__ void before_outputs() const {}
+};
+
+template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF, class Hooks = NoHooks>
+__device__ __forceinline__ uint32_t unit_core(
+  const Params & prm, UnitLds<CH> & U, const UnitGeom & G, uint32_t dbg_flags, uint32_t s, uint32_t slot, int j,
+  const float (&x)[CH], const float (&y)[CH], const float (&z)[CH], const uint32_t (&src)[CH],
+  const UnitTables * __restrict__ tab, bool second_pass, const OrgScan & og, size_t off,
+  uint32_t rec_lo, uint32_t rec_hi, uint32_t & n_edge, uint32_t & n_surface, const int lane, const Hooks & hooks = Hooks())
+{
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
+  (void)B;
   // DEF: the thresholds are the reference's code defaults (hyper_parameter.hpp:35-43; the host checks) and become
   // literals: seven fewer long-lived scalar values in a kernel that spills scalar registers (-3.4 % time)
   const double dist_diff = DEF ? 0.3 : prm.dist_diff;
@@ -1440,146 +1508,11 @@ __device__ __forceinline__ void unit_body(
   const double min_range = DEF ? 0.1 : prm.min_range, max_range = DEF ? 100.0 : prm.max_range;
   const double pb_ratio = DEF ? 0.02 : prm.pb_ratio;
   const float pb_ratio_f = DEF ? 0.02f : prm.pb_ratio_f;
-  int N;
-  uint32_t scan_first = 0;                 // ORG: index of the scan's first point
-  if (ORG) {
-    // the scan must be R rings x C columns, C within the ring capacity (every unit of the scan sees the same)
-    scan_first = og.scan_begin[s];
-    const uint32_t n = og.scan_begin[s + 1] - scan_first;
-    const uint32_t C = n / og.R;
-    N = (int)C;
-    if (C * og.R != n || C == 0u || C > ring_cap) {
-      if (blockIdx.x == 0 && og.wave == 0 && lane == 0) {scan_falls_back(tab, s);}
-      return;
-    }
-  } else {
-    N = (int)ring_count[s * kRings + slot];
-    if (N == 0) {return;}                                  // no such ring in this scan
-  }
-  const size_t off = ring_base(s, slot, max_rings, ring_cap);
-  // A deferred ring goes on `defer_list` once (the first unit to flag it appends it); the flag keeps
-  // the reasons: kDeferOrder = not angle-sorted as bucketed (ring_order_kernel repairs that and the
-  // ring gets a second pass here), kDeferOther = anything only the workgroup-per-ring kernel handles.
-  // ORG: the whole scan goes to the bucketing route instead.
-#define LFX_DEFER(reason) \
-  do { \
-    if (ORG) { \
-      if (lane == 0) {scan_falls_back(tab, s, (reason) == kDeferOrder);} \
-    } else if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
-      defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
-    } \
-    return; \
-  } while (0)
-  LFX_STAMP(0);
-  // skip conditions and over-long rings are the slow path's business (it also reports them)
-  // (ORG: the same for the four waves of the workgroup, which therefore leave together -- before the barrier)
-  if (N < 2 * P + 1 || N - 2 * P < B || (uint32_t)N > ring_cap) {
-    if (j == 0) {LFX_DEFER(kDeferOther);}
-    return;
-  }
-  // both boundaries from one evaluation of the f64 formula: even lanes take j, odd lanes j + 1
-  const int bj = block_boundary(N, P, B, j + (lane & 1));
-  const int b0 = __builtin_amdgcn_readlane(bj, 0), b1 = __builtin_amdgcn_readlane(bj, 1);
-  const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? N : b1;
-  const int H = P + 1, g0 = o0 - H, span = o1 + H - g0;
-  if (b1 - b0 < 2 || span > (64 * CH)) {LFX_DEFER(kDeferOther);}
-  const int K = FULL ? CH : (span + 63) >> 6;
-  const int qb0 = b0 - g0, qb1 = b1 - g0;          // the block in span coordinates
-  const int qo0 = o0 - g0, qo1 = o1 - g0;          // the owned positions
-  const int qlo = g0 < 0 ? -g0 : 0;                // first / one-past-last position that is a ring point
-  const int qhi = (N - g0) < span ? (N - g0) : span;
+  const int N = G.N, o0 = G.o0, o1 = G.o1, g0 = G.g0, span = G.span, K = G.K;
+  const int qb0 = G.qb0, qb1 = G.qb1, qo0 = G.qo0, qo1 = G.qo1, qlo = G.qlo, qhi = G.qhi;
+  (void)o0; (void)o1;
   const UnitWin W0{(uint32_t)(lane + 48) >> 5, (uint32_t)(lane + 16) & 31u};   // window around q
   const UnitWin W1{(uint32_t)(lane + 49) >> 5, (uint32_t)(lane + 17) & 31u};   // window around q + 1
-
-  LFX_STAMP(1);
-  // ---- A. load; x, y also to the wave's LDS slab (neighbours are read by position)
-  {
-    uint32_t * z = &U.bits[0][0];
-    z[lane] = 0u;
-    if (lane + 64 < kUnitBitArrays * UnitLds<CH>::kBitWords) {z[lane + 64] = 0u;}
-    static_assert(kUnitBitArrays * UnitLds<CH>::kBitWords <= 128, "two stores per lane zero the bit arrays");
-  }
-  // z and the original index are only needed for the feature records at the very end; loaded here,
-  // with x and y, their latency hides behind the whole computation instead of ending it (registers
-  // are not what limits the waves per CU of this kernel, LDS is)
-  float x[CH], y[CH], z[CH];
-  uint32_t src[CH];
-  if (ORG) {
-    // lane = (column cq of a 16-column piece, ring `sub` of the group): four neighbouring lanes read the four
-    // 32-byte records of one 128-byte line; wave w takes pieces w, w + 4, ... of the span
-    const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
-    const uint32_t rr = og.r0 + sub;
-    const uint32_t rload = rr < og.R ? rr : og.R - 1u;          // a group beyond the last ring loads nothing new
-    // Every loop of this stage runs over all CH chunks without a test of the span: the loads of every chunk are
-    // issued before anything waits for one of them (with a branch per chunk the compiler waits for a chunk's ring
-    // word before it issues the next chunk's loads: five memory round trips in a row at the head of every wave).
-    // Positions beyond the span are clamped to the ring's last point and masked out like the halo outside the ring.
-    float4 rec[CH];
-    uint32_t rw[CH];
-    const uint8_t * const base = og.pts + (size_t)scan_first * 32u;
-    // XF: the rings of the stream arrive rotated (scan not cut at -pi) or reversed (clockwise sensor): position i of a
-    // ring is column ring_column(xf, i, N), xf found per ring by ring_cut_kernel; the order check below still decides
-    const uint32_t xf = XF ? og.xform[s * kRings + rload] : 0u;
-#pragma unroll
-    for (int m = 0; m < CH; m++) {
-      const int q = 64 * m + 16 * (int)og.wave + (int)cq;
-      int i = g0 + q;
-      i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
-      const uint32_t col = XF ? ring_column(xf, (uint32_t)i, (uint32_t)N) : (uint32_t)i;
-      const uint8_t * p = base + (col * og.R + rload) * 32u;                // a scan is < 2^27 points (host check)
-      rec[m] = *reinterpret_cast<const float4 *>(p);
-      rw[m] = *reinterpret_cast<const uint32_t *>(p + 20);
-    }
-    __builtin_amdgcn_sched_barrier(0);                // (the scheduler otherwise pulls the first chunk's ring test up between the loads)
-    uint64_t wrong = 0;
-    f32_alias_t * zex = reinterpret_cast<f32_alias_t *>(slabs[sub].r);
-#pragma unroll
-    for (int m = 0; m < CH; m++) {
-      const int q = 64 * m + 16 * (int)og.wave + (int)cq;
-      const uint64_t in = in_span(q, qlo, qhi);
-      // the record must carry the ring id its place implies; with the zero-point filter on, a (0, 0, 0) record
-      // would not be part of the scan (convert.py:162-163,192): not this kernel's case either
-      uint64_t bad = bal((rw[m] & 0xFFFFu) != rr);
-      if (og.drop_zero) {bad |= bal(rec[m].x == 0.f) & bal(rec[m].y == 0.f) & bal(rec[m].z == 0.f);}
-      wrong |= bad & in;
-      const bool inl = lanes(in);
-      slabs[sub].pxy[q] = make_float2(inl ? rec[m].x : 0.f, inl ? rec[m].y : 0.f);
-      zex[q] = rec[m].z;
-    }
-    wrong &= bal(rr < og.R);
-    __syncthreads();                                  // the only workgroup barrier: the slabs are handed over
-    if (wrong != 0ull) {LFX_DEFER(kDeferOther);}
-    if (slot >= og.R) {return;}                       // ring count not a multiple of four: no such ring
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-      const int q = 64 * k + lane;
-      const float2 v = U.pxy[q];
-      x[k] = v.x; y[k] = v.y;
-      z[k] = reinterpret_cast<const f32_alias_t *>(U.r)[q];
-      src[k] = 0u;
-    }
-  } else {
-    float2 v[CH];
-#pragma unroll
-    for (int k = 0; k < CH; k++) {                    // (all loads first, as above)
-      const int q = 64 * k + lane;
-      int i = g0 + q;
-      i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
-      v[k] = sxy[off + i];
-      z[k] = sz[off + i];
-      src[k] = sidx[off + i];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-      const int q = 64 * k + lane;
-      const bool in = lanes(in_span(q, qlo, qhi));
-      x[k] = in ? v[k].x : 0.f;
-      y[k] = in ? v[k].y : 0.f;
-      U.pxy[q] = make_float2(x[k], y[k]);
-    }
-  }
-  LFX_WAVE_SYNC();
   LFX_STAMP(2);
   // ---- B. angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, else
   //         slow path; range (math.hpp:36-39)
@@ -1610,10 +1543,11 @@ __device__ __forceinline__ void unit_body(
         if (pair && !polar_less(x[k], y[k], nb.x, nb.y)) {really = true;}
       }
     }
-    if (__ballot(really) != 0ull) {LFX_DEFER(second_pass ? kDeferOther : kDeferOrder);}
+    if (__ballot(really) != 0ull) {return (uint32_t)(second_pass ? kDeferOther : kDeferOrder);}
   }
   LFX_WAVE_SYNC();
   LFX_STAMP(3);
+  hooks.after_range();    // (ring_stream_kernel requests the next unit's records here ...)
   // ---- C. links (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the
   //         occlusion test (occlusion.hpp:44-57, 67-79)
   {
@@ -1659,13 +1593,14 @@ __device__ __forceinline__ void unit_body(
         }
       }
     }
-    if (zero_pair != 0ull) {LFX_DEFER(kDeferOther);}
+    if (zero_pair != 0ull) {return (uint32_t)kDeferOther;}
     uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
+    WordVec vlk, vjl, vjr;
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       if (k < K) {
         const int q = 64 * k + lane;
-        put_word(U, kBitLK, k, lky[k]);
+        vlk.set(k, lky[k]);
         const int qm = q > 0 ? q - 1 : 0;
         double rw2[2];
         lds_window_f64(&U.r[q], rw2);
@@ -1677,10 +1612,15 @@ __device__ __forceinline__ void unit_body(
         const uint64_t jr = lk_prev & in_span(q, P + 1 - g0, qhi) & bal(U.r[qm] > rq);
         prev_top = lky[k] >> 63;
         if (LFX_STAGE_ON(256u)) {
-          put_word(U, kBitJL, k, jl);
-          put_word(U, kBitJR, k, jr);
+          vjl.set(k, jl);
+          vjr.set(k, jr);
         }
       }
+    }
+    put_words(U, kBitLK, vlk, lane);
+    if (LFX_STAGE_ON(256u)) {
+      put_words(U, kBitJL, vjl, lane);
+      put_words(U, kBitJR, vjr, lane);
     }
   }
   LFX_STAMP(4);
@@ -1783,6 +1723,7 @@ __device__ __forceinline__ void unit_body(
     uint64_t A[CH], SEL[CH];
     uint32_t Hp[CH];
     uint64_t any = 0;
+    WordVec va;                    // the live set as it stands in LDS
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       A[k] = 0; SEL[k] = 0; Hp[k] = 0;
@@ -1798,11 +1739,12 @@ __device__ __forceinline__ void unit_body(
           cd = in_span(q, qb0, qb1) & bal(c0 <= surf_thr) & ~bal((get_win(U, kBitSelE, k, W0) & reach[k]) != 0u);
         }
         A[k] = cd;
-        put_word(U, kBitA, k, cd);
+        va.set(k, cd);
         any |= cd;
       }
     }
     if (any == 0ull) {continue;}
+    put_words(U, kBitA, va, lane);
     // priority masks: which candidates in reach are visited first; bit 16 = the position itself
 #pragma unroll
     for (int k = 0; k < CH; k++) {
@@ -1820,12 +1762,15 @@ __device__ __forceinline__ void unit_body(
       uint64_t S[CH + 2];
       uint64_t picked = 0, left = 0;
       S[0] = 0; S[CH + 1] = 0;
+      WordVec vs;
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         S[k + 1] = 0;
         if (k < K) {
-          if (LFX_NOSKIP(FULL) || A[k] != 0ull) {S[k + 1] = bal((get_win(U, kBitA, k, W0) & Hp[k]) == (1u << 16));}
-          put_word(U, kBitS, k, S[k + 1]);
+          if (LFX_NOSKIP(FULL) || A[k] != 0ull) {
+            S[k + 1] = bal((get_win(U, kBitA, k, W0) & Hp[k]) == (1u << 16));
+            vs.set(k, S[k + 1]);
+          }
           SEL[k] |= S[k + 1];
           picked |= S[k + 1];
         }
@@ -1833,24 +1778,30 @@ __device__ __forceinline__ void unit_body(
       // With a total order the live candidate of highest priority is always picked.  No pick at all
       // means the order is inconsistent (NaN curvature from non-finite input): stop instead of spinning.
       if (picked == 0ull) {break;}
+      put_words(U, kBitS, vs, lane);
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         if (k < K) {
           if (LFX_NOSKIP(FULL) || (S[k] | S[k + 1] | S[k + 2]) != 0ull) {
             A[k] &= ~bal((get_win(U, kBitS, k, W0) & reach[k]) != 0u);
-            put_word(U, kBitA, k, A[k]);
+            va.set(k, A[k]);
           }
           left |= A[k];
         }
       }
       if (left == 0ull) {break;}
+      put_words(U, kBitA, va, lane);
 #ifdef LFX_WHATIF_NOLDS
       if (++whatif_rounds >= 2) {break;}
 #endif
     }
+    {
+      WordVec vsel;
 #pragma unroll
-    for (int k = 0; k < CH; k++) {
-      if (k < K) {put_word(U, sel_arr, k, SEL[k]);}
+      for (int k = 0; k < CH; k++) {
+        if (k < K) {vsel.set(k, SEL[k]);}
+      }
+      put_words(U, sel_arr, vsel, lane);
     }
   }
 #if defined(LFX_PROBE_VALU) || defined(LFX_PROBE_LDS) || defined(LFX_PROBE_SALU)
@@ -1880,6 +1831,7 @@ __device__ __forceinline__ void unit_body(
   }
 #endif
   LFX_STAMP(9);
+  hooks.before_outputs(); // (... and waits for them here, ahead of this unit's own stores)
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
   uint64_t pby[CH];
   {
@@ -1962,7 +1914,7 @@ __device__ __forceinline__ void unit_body(
         const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
         const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
         const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
-        const size_t at = l == kEdge ? off + o0 + pe + be : off + o1 - 1 - (ps + bs);
+        const size_t at = l == kEdge ? off + rec_lo + pe + be : off + rec_hi - 1 - (ps + bs);
         rec_pts[at] = rec;
         // ORG: position i of ring `slot` is point column * R + slot
         rec_idx[at] = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
@@ -1972,6 +1924,161 @@ __device__ __forceinline__ void unit_body(
     }
   }
   LFX_STAMP(11);
+  n_edge = pe;
+  n_surface = ps;
+  return 0u;
+}
+
+template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF = false>
+__device__ __forceinline__ void unit_body(
+  const Params & prm, UnitLds<CH> * __restrict__ slabs, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
+  uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
+  const float2 * __restrict__ sxy, const float * __restrict__ sz,
+  const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
+  uint32_t * __restrict__ defer_count, uint32_t * __restrict__ defer_list, bool second_pass, const OrgScan & og)
+{
+  const int lane = threadIdx.x & 63;
+  UnitLds<CH> & U = slabs[ORG ? og.wave : 0u];
+  const int P = PT > 0 ? PT : prm.P, B = prm.B;
+  int N;
+  uint32_t scan_first = 0;                 // ORG: index of the scan's first point
+  if (ORG) {
+    // the scan must be R rings x C columns, C within the ring capacity (every unit of the scan sees the same)
+    scan_first = og.scan_begin[s];
+    const uint32_t n = og.scan_begin[s + 1] - scan_first;
+    const uint32_t C = n / og.R;
+    N = (int)C;
+    if (C * og.R != n || C == 0u || C > ring_cap) {
+      if (blockIdx.x == 0 && og.wave == 0 && lane == 0) {scan_falls_back(tab, s);}
+      return;
+    }
+  } else {
+    N = (int)ring_count[s * kRings + slot];
+    if (N == 0) {return;}                                  // no such ring in this scan
+  }
+  const size_t off = ring_base(s, slot, max_rings, ring_cap);
+  // A deferred ring goes on `defer_list` once (the first unit to flag it appends it); the flag keeps
+  // the reasons: kDeferOrder = not angle-sorted as bucketed (ring_order_kernel repairs that and the
+  // ring gets a second pass here), kDeferOther = anything only the workgroup-per-ring kernel handles.
+  // ORG: the whole scan goes to the bucketing route instead.
+#define LFX_DEFER(reason) \
+  do { \
+    if (ORG) { \
+      if (lane == 0) {scan_falls_back(tab, s, (reason) == kDeferOrder);} \
+    } else if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
+      defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
+    } \
+    return; \
+  } while (0)
+  LFX_STAMP(0);
+  // skip conditions and over-long rings are the slow path's business (it also reports them)
+  // (ORG: the same for the four waves of the workgroup, which therefore leave together -- before the barrier)
+  if (N < 2 * P + 1 || N - 2 * P < B || (uint32_t)N > ring_cap) {
+    if (j == 0) {LFX_DEFER(kDeferOther);}
+    return;
+  }
+  // both boundaries from one evaluation of the f64 formula: even lanes take j, odd lanes j + 1
+  const int bj = block_boundary(N, P, B, j + (lane & 1));
+  const int b0 = __builtin_amdgcn_readlane(bj, 0), b1 = __builtin_amdgcn_readlane(bj, 1);
+  const UnitGeom G = unit_geometry(N, P, B, j, b0, b1, FULL ? CH : 0);
+  if (b1 - b0 < 2 || G.span > (64 * CH)) {LFX_DEFER(kDeferOther);}
+  const int o0 = G.o0, o1 = G.o1, g0 = G.g0, qlo = G.qlo, qhi = G.qhi;
+
+  LFX_STAMP(1);
+  // ---- A. load; x, y also to the wave's LDS slab (neighbours are read by position)
+  {
+    uint32_t * z = &U.bits[0][0];
+    z[lane] = 0u;
+    if (lane + 64 < kUnitBitArrays * UnitLds<CH>::kBitWords) {z[lane + 64] = 0u;}
+    static_assert(kUnitBitArrays * UnitLds<CH>::kBitWords <= 128, "two stores per lane zero the bit arrays");
+  }
+  // z and the original index are only needed for the feature records at the very end; loaded here,
+  // with x and y, their latency hides behind the whole computation instead of ending it (registers
+  // are not what limits the waves per CU of this kernel, LDS is)
+  float x[CH], y[CH], z[CH];
+  uint32_t src[CH];
+  if (ORG) {
+    // lane = (column cq of a 16-column piece, ring `sub` of the group): four neighbouring lanes read the four
+    // 32-byte records of one 128-byte line; wave w takes pieces w, w + 4, ... of the span
+    const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
+    const uint32_t rr = og.r0 + sub;
+    const uint32_t rload = rr < og.R ? rr : og.R - 1u;          // a group beyond the last ring loads nothing new
+    // Every loop of this stage runs over all CH chunks without a test of the span: the loads of every chunk are
+    // issued before anything waits for one of them (with a branch per chunk the compiler waits for a chunk's ring
+    // word before it issues the next chunk's loads: five memory round trips in a row at the head of every wave).
+    // Positions beyond the span are clamped to the ring's last point and masked out like the halo outside the ring.
+    float4 rec[CH];
+    uint32_t rw[CH];
+    const uint8_t * const base = og.pts + (size_t)scan_first * 32u;
+    // XF: the rings of the stream arrive rotated (scan not cut at -pi) or reversed (clockwise sensor): position i of a
+    // ring is column ring_column(xf, i, N), xf found per ring by ring_cut_kernel; the order check below still decides
+    const uint32_t xf = XF ? og.xform[s * kRings + rload] : 0u;
+#pragma unroll
+    for (int m = 0; m < CH; m++) {
+      const int q = 64 * m + 16 * (int)og.wave + (int)cq;
+      int i = g0 + q;
+      i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+      const uint32_t col = XF ? ring_column(xf, (uint32_t)i, (uint32_t)N) : (uint32_t)i;
+      const uint8_t * p = base + (col * og.R + rload) * 32u;                // a scan is < 2^27 points (host check)
+      rec[m] = *reinterpret_cast<const float4 *>(p);
+      rw[m] = *reinterpret_cast<const uint32_t *>(p + 20);
+    }
+    __builtin_amdgcn_sched_barrier(0);                // (the scheduler otherwise pulls the first chunk's ring test up between the loads)
+    uint64_t wrong = 0;
+    f32_alias_t * zex = reinterpret_cast<f32_alias_t *>(slabs[sub].r);
+#pragma unroll
+    for (int m = 0; m < CH; m++) {
+      const int q = 64 * m + 16 * (int)og.wave + (int)cq;
+      const uint64_t in = in_span(q, qlo, qhi);
+      // the record must carry the ring id its place implies; with the zero-point filter on, a (0, 0, 0) record
+      // would not be part of the scan (convert.py:162-163,192): not this kernel's case either
+      uint64_t bad = bal((rw[m] & 0xFFFFu) != rr);
+      if (og.drop_zero) {bad |= bal(rec[m].x == 0.f) & bal(rec[m].y == 0.f) & bal(rec[m].z == 0.f);}
+      wrong |= bad & in;
+      const bool inl = lanes(in);
+      slabs[sub].pxy[q] = make_float2(inl ? rec[m].x : 0.f, inl ? rec[m].y : 0.f);
+      zex[q] = rec[m].z;
+    }
+    wrong &= bal(rr < og.R);
+    __syncthreads();                                  // the only workgroup barrier: the slabs are handed over
+    if (wrong != 0ull) {LFX_DEFER(kDeferOther);}
+    if (slot >= og.R) {return;}                       // ring count not a multiple of four: no such ring
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      const int q = 64 * k + lane;
+      const float2 v = U.pxy[q];
+      x[k] = v.x; y[k] = v.y;
+      z[k] = reinterpret_cast<const f32_alias_t *>(U.r)[q];
+      src[k] = 0u;
+    }
+  } else {
+    float2 v[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {                    // (all loads first, as above)
+      const int q = 64 * k + lane;
+      int i = g0 + q;
+      i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+      v[k] = sxy[off + i];
+      z[k] = sz[off + i];
+      src[k] = sidx[off + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      const int q = 64 * k + lane;
+      const bool in = lanes(in_span(q, qlo, qhi));
+      x[k] = in ? v[k].x : 0.f;
+      y[k] = in ? v[k].y : 0.f;
+      U.pxy[q] = make_float2(x[k], y[k]);
+    }
+  }
+  LFX_WAVE_SYNC();
+  uint32_t pe = 0, ps = 0;
+  {
+    const uint32_t why = unit_core<PT, CH, DEF, ORG, FULL, XF>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, second_pass, og, off,
+      (uint32_t)o0, (uint32_t)o1, pe, ps, lane);
+    if (why != 0u) {LFX_DEFER(why);}
+  }
   if (lane == 0) {
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
     tab->unit_ne[ui] = pe;
@@ -2083,6 +2190,281 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   } else {
     unit_body<0, CH, false, true, false, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
       nullptr, false, og);
+  }
+}
+
+// ==========================================================================================
+// The streaming form of the organised-scan kernel: workgroup = the four ADJACENT rings 4g .. 4g+3 of scan blockIdx.y,
+// one ring per wave, and the waves WALK their ring block by block (feature_extraction.cpp:120-157 is one such walk per
+// ring).  While unit j is computed the 32-byte records of unit j+1 are already in flight: they are requested early in
+// unit j (lane = (column, ring of the group) as in ring_unit_org_kernel: every 128-byte line once) by LDS-DMA
+// (global_load_lds_dwordx3: x, y, z straight into a landing zone in LDS, no registers held meanwhile) and waited for
+// just before unit j's own stores, so that a wave's memory phases no longer run in series with its arithmetic
+// (31 % of a wave's life was parked in s_waitcnt); and the per-wave prologue -- scan shape, tables, skip
+// tests -- is paid once per ring instead of once per block.  One workgroup barrier per unit (the landed tile is read by
+// all four waves); that every wave has taken its part of the previous tile out of the landing zone before the next one
+// is requested into it is a counter in LDS, not a second barrier.  Feature records are packed per RING (edges ascending
+// from the ring's first position, surfaces descending from its last): one dense run of each kind for the compaction
+// instead of one per unit.
+constexpr int stream_waves_per_simd(int ch) {return ch <= 4 ? 5 : (ch == 5 ? 4 : 3);}      // (LDS: 4 workgroups per CU at 5 chunks, 3 at 6)
+
+// The landing zone: x, y and z planes; piece (m, w) = columns 64 m + 16 w .. + 15 of the four rings, requested by wave w,
+// lane l's record in element l.  (LDS-DMA puts lane l's data at M0 + instruction offset + 16 l for the dwordx3 and dwordx4
+// forms and at + 4 l for the dword form -- tools/probes/lds_dma_layout.hip --, so three dword transfers per piece land
+// in 12 bytes per record where one dwordx3 transfer would take 16: 15 KB instead of 20 per workgroup, the difference
+// between three and four workgroups per CU.)
+template<int CH>
+struct TileZone
+{
+  __attribute__((aligned(16))) float v[3][CH * kUnitWaves][64];
+};
+
+// Request the tile of unit geometry g0 (4 rings x the unit's span): CH pieces of 16 columns per wave.  The DMA is inline
+// asm (the compiler's own LDS-DMA would make every later LDS read wait for it); the ring words come by ordinary loads.
+template<int CH, bool XF>
+__device__ __forceinline__ void tile_request(
+  const OrgScan & og, const uint8_t * base, int N, int g0, uint32_t xf, uint32_t rload, uint32_t cq,
+  const TileZone<CH> & zone, uint32_t (&rw)[CH])
+{
+#pragma unroll
+  for (int m = 0; m < CH; m++) {
+    const int q = 64 * m + 16 * (int)og.wave + (int)cq;
+    int i = g0 + q;
+    i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);       // beyond the ring / the span: any valid record (masked out when taken)
+    const uint32_t col = XF ? ring_column(xf, (uint32_t)i, (uint32_t)N) : (uint32_t)i;
+    const uint8_t * p = base + (col * og.R + rload) * 32u;                // a scan is < 2^27 points (host check)
+    const int piece = m * kUnitWaves + (int)og.wave;
+    // (the instruction offset moves the LDS address with the global one: the y and z destinations are given less it)
+    const uint32_t dx = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(&zone.v[0][piece][0]));
+    const uint32_t dy = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(&zone.v[1][piece][0]) - 4u);
+    const uint32_t dz = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(&zone.v[2][piece][0]) - 8u);
+    uint32_t keep;
+    asm volatile (
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:4\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:8\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(p), "s"(dx), "s"(dy), "s"(dz) : "memory");
+    rw[m] = *reinterpret_cast<const uint32_t *>(p + 20);
+  }
+}
+
+// The pattern test of a landed tile (this wave's own pieces): every record inside the ring must carry the ring id its
+// place implies (and, with the zero-point filter on, must not be a (0, 0, 0) record: convert.py:162-163,192 would have
+// dropped it).
+template<int CH>
+__device__ __forceinline__ uint64_t tile_check(
+  const OrgScan & og, const UnitGeom & G, uint32_t rr, uint32_t cq, int lane, const TileZone<CH> & zone, const uint32_t (&rw)[CH])
+{
+  uint64_t wrong = 0;
+#pragma unroll
+  for (int m = 0; m < CH; m++) {
+    const int q = 64 * m + 16 * (int)og.wave + (int)cq;
+    uint64_t bad = bal((rw[m] & 0xFFFFu) != rr);
+    if (og.drop_zero) {
+      const int piece = m * kUnitWaves + (int)og.wave;
+      bad |= bal(zone.v[0][piece][lane] == 0.f) & bal(zone.v[1][piece][lane] == 0.f) & bal(zone.v[2][piece][lane] == 0.f);
+    }
+    wrong |= bad & in_span(q, G.qlo, G.qhi);
+  }
+  return wrong & bal(rr < og.R);
+}
+
+template<int CH, bool XF>
+struct TileHooks
+{
+  const OrgScan & og;
+  const UnitGeom & Gn;
+  const TileZone<CH> & zone;
+  volatile uint32_t * ctl;             // [0], [1] a wave gave the scan up (by unit parity), [2] parts of tiles taken out of the zone so far
+  const uint8_t * base;
+  uint32_t (&rw)[CH];
+  uint64_t & wrong;
+  int N, lane;
+  uint32_t xf, rload, rr, cq, taken_needed, give_up_at;
+  bool more;
+  __device__ __forceinline__ void after_range() const
+  {
+    if (!more) {return;}
+    // every wave has taken its ring's part of the current tile (it does so first thing in a unit); the wait is bounded
+    // (a few milliseconds): should a wave never get there the scan is given up rather than the GPU hung
+    uint32_t spins = 0;
+    while ((uint32_t)__builtin_amdgcn_readfirstlane(ctl[2]) < taken_needed) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 17)) {
+        if (lane == 0) {ctl[give_up_at] = 1u;}
+        return;
+      }
+    }
+    tile_request<CH, XF>(og, base, N, Gn.g0, xf, rload, cq, zone, rw);
+  }
+  __device__ __forceinline__ void before_outputs() const
+  {
+    if (!more) {return;}
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+    wrong = tile_check<CH>(og, Gn, rr, cq, lane, zone, rw);
+  }
+};
+
+template<int PT, int CH, bool DEF, bool XF>
+__device__ __forceinline__ void stream_body(
+  const Params & prm, UnitLds<CH> * __restrict__ slabs, TileZone<CH> & zone, volatile uint32_t * ctl, uint32_t ring_cap,
+  uint32_t max_rings, uint32_t dbg_flags, uint32_t s, const UnitTables * __restrict__ tab, const OrgScan & og)
+{
+  const int lane_id = threadIdx.x & 63;
+  UnitLds<CH> & U = slabs[og.wave];
+  const int P = PT > 0 ? PT : prm.P, B = prm.B;
+  const uint32_t slot = og.r0 + og.wave;
+  // the scan must be R rings x C columns, C within the ring capacity, and long enough for its blocks: the same for every
+  // wave of every workgroup of the scan, which therefore leave together
+  const uint32_t scan_first = og.scan_begin[s];
+  const uint32_t n = og.scan_begin[s + 1] - scan_first;
+  const uint32_t C = n / og.R;
+  const int N = (int)C;
+  if (C * og.R != n || C == 0u || C > ring_cap || N < 2 * P + 1 || N - 2 * P < B) {
+    if (og.r0 == 0u && og.wave == 0u && lane_id == 0) {scan_falls_back(tab, s);}
+    return;
+  }
+  const size_t off = ring_base(s, slot, max_rings, ring_cap);
+  const uint8_t * const base = og.pts + (size_t)scan_first * 32u;
+  // A wave that has to give the scan up says so in LDS; the workgroup leaves behind its next barrier.  Two words, by unit
+  // parity: what is written during unit j is read behind the barrier that opens unit j + 1 and nowhere else, so that the
+  // four waves always take the same decision (a wave still on its way from the barrier to the test of unit j must not
+  // see what a faster one writes during unit j).
+#define LFX_GIVE_UP(order_only, unit) \
+  do { \
+    if (lane == 0) { \
+      scan_falls_back(tab, s, (order_only)); \
+      ctl[((unit) + 1) & 1] = 1u; \
+    } \
+  } while (0)
+#define LFX_UNIT_GEOMETRY(G, jj) \
+  UnitGeom G; \
+  { \
+    const int bj_ = block_boundary(N, P, B, (jj) + (lane & 1));      /* even lanes j, odd lanes j + 1 */ \
+    G = unit_geometry(N, P, B, (jj), __builtin_amdgcn_readlane(bj_, 0), __builtin_amdgcn_readlane(bj_, 1), 0); \
+  }
+  uint32_t rw[CH];
+  UnitGeom G;
+  {
+    const int lane = lane_id;
+    const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
+    const uint32_t rr = og.r0 + sub;
+    const uint32_t rload = rr < og.R ? rr : og.R - 1u;          // a group beyond the last ring loads nothing new
+    const uint32_t xf = XF ? og.xform[s * kRings + rload] : 0u;
+    LFX_UNIT_GEOMETRY(G0, 0);
+    G = G0;
+    if (G.b1 - G.b0 < 2 || G.span > 64 * CH) {          // (wave-uniform and the same in the four waves)
+      if (og.wave == 0u && lane == 0) {scan_falls_back(tab, s);}
+      return;
+    }
+    tile_request<CH, XF>(og, base, N, G.g0, xf, rload, cq, zone, rw);
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tile_check<CH>(og, G, rr, cq, lane, zone, rw) != 0ull) {LFX_GIVE_UP(false, -1);}
+  }
+  uint32_t ring_ne = 0, ring_ns = 0;
+  bool gave_up = false;
+  for (int j = 0; j < B; j++) {
+    // (the lane index is made opaque per unit: everything derived from it -- LDS addresses, window shifts, span tests of
+    // every chunk -- is otherwise hoisted out of the loop and held in registers across it)
+    int lane = lane_id;
+    asm volatile ("" : "+v"(lane));
+    __syncthreads();                                     // the tile of unit j has landed, for every wave
+    if (__builtin_amdgcn_readfirstlane(ctl[j & 1]) != 0u) {return;}
+    const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
+    const uint32_t rr = og.r0 + sub;
+    const uint32_t rload = rr < og.R ? rr : og.R - 1u;
+    const uint32_t xf = XF ? og.xform[s * kRings + rload] : 0u;
+    const bool more = j + 1 < B;
+    LFX_UNIT_GEOMETRY(Gn, more ? j + 1 : j);
+    if (more && (Gn.b1 - Gn.b0 < 2 || Gn.span > 64 * CH)) {
+      if (og.wave == 0u && lane == 0) {scan_falls_back(tab, s);}
+      return;
+    }
+    uint64_t wrong = 0;
+    const TileHooks<CH, XF> hooks{og, Gn, zone, ctl, base, rw, wrong, N, lane, xf, rload, rr, cq, (uint32_t)kUnitWaves * (uint32_t)(j + 1),
+      (uint32_t)(j + 1) & 1u, more};
+    uint32_t why = 0u;
+    if (slot < og.R) {
+      // this ring's part of the tile: position q = 64 k + lane is record (lane & 15) * 4 + wave of piece (k, lane >> 4)
+      float x[CH], y[CH], z[CH];
+      uint32_t src[CH];
+      {
+        uint32_t * zb = &U.bits[0][0];
+        zb[lane] = 0u;
+        if (lane + 64 < kUnitBitArrays * UnitLds<CH>::kBitWords) {zb[lane + 64] = 0u;}
+      }
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const int q = 64 * k + lane;
+        const int piece = k * kUnitWaves + (lane >> 4), e = (lane & 15) * 4 + (int)og.wave;
+        const float xr = zone.v[0][piece][e], yr = zone.v[1][piece][e];
+        z[k] = zone.v[2][piece][e];
+        const bool in = lanes(in_span(q, G.qlo, G.qhi));
+        x[k] = in ? xr : 0.f;
+        y[k] = in ? yr : 0.f;
+        U.pxy[q] = make_float2(x[k], y[k]);
+        src[k] = 0u;
+      }
+      LFX_WAVE_SYNC();
+      if (lane == 0) {atomicAdd(const_cast<uint32_t *>(ctl + 2), 1u);}
+      uint32_t pe = 0, ps = 0;
+      why = unit_core<PT, CH, DEF, true, false, XF>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, false, og, off,
+        ring_ne, (uint32_t)N - ring_ns, pe, ps, lane, hooks);
+      ring_ne += pe;
+      ring_ns += ps;
+    } else {                                             // (ring count not a multiple of four: this wave only loads)
+      if (lane == 0) {atomicAdd(const_cast<uint32_t *>(ctl + 2), 1u);}
+      hooks.after_range();
+      hooks.before_outputs();
+    }
+    if (why != 0u) {LFX_GIVE_UP(why == (uint32_t)kDeferOrder, j); gave_up = true;}
+    if (!more) {break;}
+    if (why == 0u && wrong != 0ull) {LFX_GIVE_UP(false, j);}
+    G = Gn;
+  }
+#undef LFX_UNIT_GEOMETRY
+#undef LFX_GIVE_UP
+  if (slot >= og.R || gave_up) {return;}
+  // the ring's records are ONE unit for the compaction: [0, N) with all its edges and surfaces
+  if (lane_id < B) {
+    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + lane_id;
+    tab->unit_ne[ui] = lane_id == 0 ? ring_ne : 0u;
+    tab->unit_ns[ui] = lane_id == 0 ? ring_ns : 0u;
+    tab->unit_span[ui] = lane_id == 0 ? ((uint32_t)N << 16) : 0u;
+  }
+  if (lane_id == 0) {
+    tab->ring_status[s * kRings + slot] = kOk;
+    // what the bucketing kernel would have counted (it overwrites both if the scan falls back after all)
+    og.ring_count_out[s * kRings + slot] = (uint32_t)N;
+    if (slot == 0) {
+      tab->scan_info[s * 4 + kInfoRings] = og.R;
+      atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kScanFused);
+    }
+  }
+}
+
+template<int CH, bool DEF, bool XF>
+__global__ __launch_bounds__(64 * kUnitWaves, stream_waves_per_simd(CH)) void ring_stream_kernel(
+  Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
+  const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
+  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform)
+{
+  __shared__ UnitLds<CH> lds[kUnitWaves];
+  __shared__ TileZone<CH> zone;
+  __shared__ uint32_t ctl[4];
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x < 4) {ctl[threadIdx.x] = 0u;}
+  __syncthreads();
+  const uint32_t s = blockIdx.y;
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * blockIdx.x, wave, drop_zero, xform};
+  if (DEF || prm.P == 5) {
+    stream_body<5, CH, DEF, XF>(prm, lds, zone, ctl, ring_cap, max_rings, dbg_flags, s, tab, og);
+  } else if (prm.P == 2) {
+    stream_body<2, CH, false, XF>(prm, lds, zone, ctl, ring_cap, max_rings, dbg_flags, s, tab, og);
+  } else {
+    stream_body<0, CH, false, XF>(prm, lds, zone, ctl, ring_cap, max_rings, dbg_flags, s, tab, og);
   }
 }
 
