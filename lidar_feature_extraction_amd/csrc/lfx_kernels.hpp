@@ -1338,7 +1338,15 @@ __device__ __forceinline__ void put_words(UnitLds<CH> & U, int arr, const WordVe
 #ifdef LFX_WHATIF_NOLDS
   asm volatile ("" :: "v"(v.lo), "v"(v.hi));
 #else
-  if (lane < CH + 2) {*reinterpret_cast<u64_alias_t *>(&U.bits[arr][2 * lane]) = ((uint64_t)v.hi << 32) | v.lo;}
+  // Lanes 0 .. CH + 1 store.  The execution mask is set inside the statement: written as `if (lane < CH + 2)` the
+  // compiler (ROCm 7.2) placed window reads that FOLLOW the store inside the masked region, so that only those seven
+  // lanes read their windows (seen in the listing; the pick rounds then never ended).  An LDS write the compiler does
+  // not count only makes its own lgkmcnt waits conservative (LDS operations of a wave complete in order).
+  const uint32_t addr = (uint32_t)reinterpret_cast<uintptr_t>(&U.bits[arr][0]) + 8u * (uint32_t)lane;
+  const uint64_t data = ((uint64_t)v.hi << 32) | v.lo;
+  uint64_t saved;
+  asm volatile ("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0"
+    : "=&s"(saved) : "v"(addr), "v"(data), "n"((1u << (CH + 2)) - 1u) : "memory");
 #endif
 }
 
@@ -1746,6 +1754,8 @@ __device__ __forceinline__ uint32_t unit_core(
     if (any == 0ull) {continue;}
     put_words(U, kBitA, va, lane);
     // priority masks: which candidates in reach are visited first; bit 16 = the position itself
+    // (reading the windows of all chunks ahead of the per-chunk work, so that the wave waits for LDS once per step of a
+    // round rather than once per chunk, was measured and is slower: 1305 vs 1272 us, ten more registers live)
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       if (k < K && (LFX_NOSKIP(FULL) || A[k] != 0ull)) {
