@@ -284,6 +284,10 @@ void lfx_comm_destroy(lfx_comm *comm);
  *                       clouds do not fit, every rank returns LFX_ERR_CAPACITY and nothing is sent.
  * lfx_gather = both, one after the other.  Every rank must make the same sequence of calls. */
 int lfx_gather_counts(lfx_ctx *ctx, lfx_comm *comm, const uint32_t *d_offsets, uint32_t batch, void *stream);
+/* What this rank has posted on the communicator so far: [0] sends, [1] receives, [2] bytes sent, [3] bytes received,
+ * [4] all-gathers of totals.  `dst` of lfx_gather_payload may change from call to call (every rank gives the same). */
+#define LFX_COMM_STATS 5
+int lfx_comm_stats(const lfx_comm *comm, uint64_t out[LFX_COMM_STATS]);
 int lfx_gather_payload(lfx_ctx *ctx, lfx_comm *comm, int dst, const float *d_edge, const float *d_surface,
                        const uint32_t *d_offsets, uint32_t batch, uint32_t floats_per_point, float *d_edge_all,
                        float *d_surface_all, uint32_t *d_offsets_all, size_t capacity_points, uint64_t *counts_out,
@@ -399,7 +403,7 @@ int lfx_align_point_pairs(lfx_ctx *ctx, const double *d_source, const double *d_
  * (the reference uses 1.0), then lfx_scan_to_map_align on scan_edge and the downsampled cloud; nothing leaves the device
  * but the results. */
 int lfx_localize_batch(lfx_ctx *ctx, const lfx_map *edge_map, const lfx_map *surface_map, uint32_t n_neighbors, int max_iter,
-                       float surface_leaf,
+                       float surface_leaf, uint32_t n_scans /* = scans of the last batch: sizes initial_poses[n][12], results[n] */,
                        const double *initial_poses, lfx_align_result *results, void *stream);
 
 /* Localizer::Update for one scan whose two clouds are on the host -- the consumer in a process of its own, handed

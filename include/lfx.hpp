@@ -200,7 +200,7 @@ public:
   bool Update()
   {
     lfx_align_result r{};
-    const int rc = lfx_localize_batch(ctx_, edge_, surface_, kNeighbors, max_iter_, 1.0f, last_.pose, &r, nullptr);
+    const int rc = lfx_localize_batch(ctx_, edge_, surface_, kNeighbors, max_iter_, 1.0f, 1u, last_.pose, &r, nullptr);
     if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
     last_ = r;
     return LFX_ALIGN_SUCCESS(r.code);

@@ -81,7 +81,7 @@ EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
     "lfx_status_string", "lfx_ring_message", "lfx_range_message", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
     "lfx_device_results", "lfx_batch_status", "lfx_scan_routes", "lfx_host_alloc", "lfx_host_free", "lfx_comm_unique_id", "lfx_comm_create",
-    "lfx_comm_destroy", "lfx_gather_counts", "lfx_gather_payload", "lfx_gather", "lfx_voxel_downsample", "lfx_downsample_surface",
+    "lfx_comm_destroy", "lfx_comm_stats", "lfx_gather_counts", "lfx_gather_payload", "lfx_gather", "lfx_voxel_downsample", "lfx_downsample_surface",
     "lfx_map_create", "lfx_map_create_host", "lfx_map_destroy", "lfx_map_info", "lfx_map_nearest",
     "lfx_scan_to_map_residuals", "lfx_edge_residuals", "lfx_align_message", "lfx_scan_to_map_align", "lfx_align_point_pairs",
     "lfx_localize_batch", "lfx_localize_host",
@@ -135,6 +135,7 @@ def load():
     L.lfx_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
     L.lfx_comm_destroy.argtypes = [vp]
     L.lfx_comm_destroy.restype = None
+    L.lfx_comm_stats.argtypes = [vp, vp]
     L.lfx_gather_counts.argtypes = [vp, vp, vp, u32, vp]
     L.lfx_gather_payload.argtypes = [vp, vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]
     L.lfx_voxel_downsample.argtypes = [vp, vp, vp, vp, u32, u32, C.c_size_t, C.c_float, vp, vp, vp, vp]
@@ -152,7 +153,7 @@ def load():
     L.lfx_scan_to_map_align.argtypes = [vp, vp, vp, u32, i32, vp, vp, vp, u32, u32, C.c_size_t, vp, vp, vp, u32, u32,
                                         C.c_size_t, u32, pd, pres, vp]
     L.lfx_align_point_pairs.argtypes = [vp, vp, vp, vp, vp, u32, C.c_size_t, u32, i32, pd, pres, vp]
-    L.lfx_localize_batch.argtypes = [vp, vp, vp, u32, i32, C.c_float, pd, pres, vp]
+    L.lfx_localize_batch.argtypes = [vp, vp, vp, u32, i32, C.c_float, u32, pd, pres, vp]
     L.lfx_localize_host.argtypes = [vp, vp, vp, u32, i32, C.c_float, vp, u32, vp, u32, pd, pres, vp]
     L.lfx_downsample_surface.argtypes = [vp, C.c_float, vp, vp, vp, vp]
     L.lfx_gather.argtypes = [vp, vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]

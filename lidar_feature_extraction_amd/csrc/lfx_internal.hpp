@@ -1,0 +1,179 @@
+// lfx_internal.hpp -- what the translation units of liblfx.so share: the context behind lfx_ctx, device / pinned
+// buffers, error plumbing.  Not part of the C ABI (include/lfx.h is).
+#pragma once
+
+#include "../../include/lfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "lfx_kernels_common.hpp"
+
+namespace lfx
+{
+struct UnitTables;      // lfx_kernels_extract.hpp
+}
+
+namespace lfx_host
+{
+
+template<typename T>
+struct DevBuf
+{
+  T * p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count)
+  {
+    n = count;
+    return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T) + 16);
+  }
+  void release()
+  {
+    if (p) {(void)hipFree(p);}
+    p = nullptr;
+  }
+};
+
+struct HostScan          // the per-ring lists of one scan (the large arrays live in the pinned result block)
+{
+  std::vector<uint8_t> ring_status;
+  std::vector<uint32_t> ring_count, ring_offset;
+  std::vector<uint16_t> ring_id;
+};
+
+// Pinned host memory that only ever grows (the results handed to the caller stay valid until the next call).
+struct PinnedBuf
+{
+  uint8_t * p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t need)
+  {
+    if (need <= bytes) {return hipSuccess;}
+    // (growing is rare; a copy queued on the old block by a call that returned early with an error must not outlive it)
+    if (p) {(void)hipDeviceSynchronize(); (void)hipHostFree(p);}
+    p = nullptr;
+    bytes = 0;
+    const size_t want = need + need / 4 + 4096;
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault);
+    if (e == hipSuccess) {bytes = want;}
+    return e;
+  }
+  void release()
+  {
+    if (p) {(void)hipHostFree(p);}
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace lfx_host
+
+struct lfx_ctx
+{
+  int device = 0;
+  lfx_params params{};
+  lfx::Params dev{};
+  lfx::Layout layout{};
+  uint32_t max_points = 0, max_batch = 0, cap = 0, max_chunks = 0, max_rings = 0, ring_threads = 0, slow_grid = 0;
+  size_t total_cap = 0, ring_lds = 0, order_lds = 0;
+  uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
+  uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
+  bool default_thresholds = false;       // padding 5 and the seven thresholds of hyper_parameter.hpp:35-43: literal-threshold unit kernel
+  uint32_t unit_chunks = 6;              // chunks of 64 positions per unit wave (3..6), from the configured ring length
+  uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
+  uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
+  bool single_pass = true;               // look-back bucketing; LFX_DEBUG_TWO_PASS selects histogram + scan + scatter
+  // Order repair BEFORE the unit kernel (ring_order_kernel over every ring), switched on while the stream keeps
+  // arriving rotated / reversed: decided from the counters of earlier batches, which arrive in pinned host
+  // memory without anyone waiting for them.  LFX_DEBUG_PRE_ORDER=0/1 pins it.
+  int pre_order_env = -1;
+  bool pre_order = false;
+  uint32_t * h_counters = nullptr;       // pinned [lfx::kCounters]: deferred, repaired after the first pass, slow, repaired before it,
+                                         // scans on the fall-back list, organised-scan kernel ran, scans of that batch
+  // The organised-scan kernel (lfx_kernels.hpp, unit_body<ORG>) reads a driver's column-major scan directly; scans that are
+  // not of that form fall back to the bucketing route inside the same call.  While most scans of a stream fall back the
+  // kernel is not launched at all (decided from the counters of earlier batches; every 16th batch tries again).
+  // LFX_DEBUG_FUSED=0/1 pins it.
+  bool fused_possible = false;
+  int fused_env = -1;
+  bool walk_rings = false;                // the organised-scan kernel in its streaming form (ring_stream_kernel); LFX_DEBUG_STREAM=0: one wave per unit
+  // Rings that arrive rotated / reversed (a driver that does not cut its scans at -pi, a clockwise sensor): while the
+  // organised-scan kernel keeps giving scans up for their angle order alone, ring_cut_kernel finds every ring's
+  // transform first and the kernel applies it in its loads (LFX_DEBUG_XFORM=0/1 pins it).
+  int xform_env = -1;
+  bool use_xform = false;
+  bool last_used_xform = false;          // the last batch's organised-scan kernel ran with the transforms
+  int short_tail_env = -1;               // LFX_DEBUG_SHORT_TAIL=0/1 pins the two-launch tail of the bucketing route (tests)
+  bool bucket_all = false;               // the stream is not organised: bucketing route for every scan
+  uint32_t retry_in = 0;
+  uint32_t redo_cap_env = 0;             // LFX_DEBUG_REDO_CAP: rings the second unit pass is launched for (tests)
+  uint32_t h_rings_seen = 0;             // rings of the batch those counters belong to
+  bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
+  std::string err;
+
+  // device scratch
+  lfx_host::DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
+    ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list, xform,
+    sidx, rec_idx, edge_idx,
+    surf_idx, d_sidx;
+  lfx_host::DevBuf<uint16_t> chunk_hist;
+  lfx_host::DevBuf<uint8_t> ring_status, label_s, staging, d_label;
+  lfx_host::DevBuf<double> d_curv;
+  lfx_host::DevBuf<float2> sxy;
+  lfx_host::DevBuf<float> sz;
+  lfx_host::DevBuf<double> curv_s;
+  lfx_host::DevBuf<float4> edge_pts, surf_pts, rec_pts;
+  lfx_host::DevBuf<lfx::UnitTables> unit_tab;      // the unit kernel's output pointers (one element)
+  lfx_host::DevBuf<uint32_t> vox_scratch;          // lfx_voxel_downsample: sort keys / values, allocated on first use
+  lfx_host::DevBuf<double> align_scratch;          // lfx_scan_to_map_align: states, rows, errors; allocated on first use
+  lfx_host::DevBuf<float> align_surface;           // lfx_localize_batch: the downsampled surface clouds (+ counts, status)
+  lfx_host::PinnedBuf h_align;                     // the alignment's small copies to and from the host (poses, counts, states)
+
+  hipStream_t stream = nullptr;          // used by the synchronous host entry points
+  std::vector<uint32_t> h_scan_begin;    // of the last batch
+  std::vector<uint32_t> uploaded_begin;  // what scan_begin on the device currently holds
+  uint32_t last_batch = 0;
+  const void * last_points = nullptr;
+  std::vector<lfx_host::HostScan> host;
+  uint32_t outputs = LFX_OUT_ALL;        // lfx_config::outputs
+  lfx_host::PinnedBuf h_in, h_out;                 // staging of the synchronous host API (allocated on first use)
+  uint32_t * h_status = nullptr;         // pinned, lfx_batch_status
+
+  bool profiling = false;
+  uint32_t profile_every = 1, batch_no = 0;   // lfx_set_profiling_interval: events around every n-th batch only
+  bool profile_now = false;
+  struct Span { hipEvent_t a, b; int k; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> free_events;
+  double ms[LFX_N_KERNELS] = {};
+  uint64_t launches[LFX_N_KERNELS] = {};
+};
+
+namespace lfx_host
+{
+
+std::string & create_error();          // what lfx_last_error(NULL) reports (lfx_api.hip)
+
+#define LFX_HIP(ctx, call) \
+  do { \
+    const hipError_t e_ = (call); \
+    if (e_ != hipSuccess) { \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      return LFX_ERR_HIP; \
+    } \
+  } while (0)
+
+inline int fail(lfx_ctx * ctx, int code, const std::string & msg)
+{
+  if (ctx) {ctx->err = msg;}
+  return code;
+}
+
+}  // namespace lfx_host

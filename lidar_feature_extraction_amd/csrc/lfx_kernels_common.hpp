@@ -1,0 +1,137 @@
+// lfx_kernels_common.hpp -- what every kernel header shares (record layout, parameters, scan_info bits, ring-major
+// addressing).  The hand-written HIP kernels (gfx950 / MI355X) of the per-scan lidar feature extraction path are in
+// lfx_kernels_extract.hpp; wire formats, Downsample and the localizer in lfx_kernels_wire / _downsample / _localize.hpp.  Semantics follow /root/reference/extraction (file:line cited per routine);
+// the structure does not: the reference walks rings and blocks sequentially on one CPU thread
+// and decides edge/surface points by argsort + greedy suppression.  Per batch of scans:
+//
+//   ring_scatter_kernel     the ONE pass over the input: stable counting sort of the points by ring
+//                           (MakePointIndices, ring.hpp:114-125) into ring-major arrays, the prefix
+//                           over earlier chunks obtained by look-back inside the launch
+//   ring_unit_kernel        fast path: one WAVE per (ring, block): angle-order check, range,
+//                           curvature, links, block labelling, occlusion / out-of-range /
+//                           parallel-beam masks, per-unit feature records; no workgroup barrier;
+//                           point sets as ballot words in LDS bit arrays (one read + v_alignbit per
+//                           32-position window); instantiated per span (3..6 chunks of 64) and, for the
+//                           reference's default parameter set, with the thresholds as literals
+//   ring_order_kernel       order repair: a ring that arrives as a rotation / reversal of its angle order
+//                           is put in order by index arithmetic, anything else by an LDS bitonic sort;
+//                           after the first unit pass (then a second pass takes the repaired rings) or,
+//                           while a stream keeps arriving rotated, ahead of it over every ring
+//   ring_extract_kernel     slow path for what neither pass takes (skip conditions, blocks that do not
+//                           fit a wave, exactly tied directions): one workgroup per ring in LDS
+//   ring_totals_kernel, feature_compact_kernel   per-unit records -> the scan's edge / surface clouds
+//   (ring_histogram_kernel, ring_scan_kernel: two-pass bucketing kept as a fallback)
+//
+// Labelling without a sort.  The reference's per-block pass (label.hpp:72-95,113-134) visits
+// points in curvature order and lets every pick suppress what its link-aware +-P fill reaches
+// (fill.hpp:101-117).  "j reaches i" is symmetric (|i-j| <= P, same block, every link between
+// them intact), so the picked set is the lexicographically first maximal independent set of the
+// candidates in priority order.  That set is computed exactly by rounds of "a live candidate
+// with no live higher-priority candidate in reach is picked; everything a pick reaches dies":
+// each round is a few AND/shift operations on 32-bit windows of point-set bit masks, and the
+// priority comparisons (f64 curvature, index as tie-break) are done once per point.
+//
+// Floating point: every operation the reference performs in IEEE f64/f32 is performed here in the
+// same type and order, unfused (contract off), so integer results (labels, index sets) are
+// bit-exact and curvature is bit-equal.  Threshold tests on quotients are pre-classified with
+// cheaper arithmetic and fall back to the exact division next to the threshold (unit_body).  The
+// only libm call on the path, acos() in CalcRadian (math.cpp:34-46), is only ever compared with a
+// threshold; the host turns that threshold into the equivalent bound on the cosine with the host's
+// own acos (lfx_api.hip: cos_bound()).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace lfx
+{
+
+constexpr int kChunkPoints = 2048;     // points per workgroup in the ring bucketing kernels
+constexpr int kChunkThreads = 256;
+constexpr int kChunkSlots = kChunkPoints / kChunkThreads;
+constexpr int kRings = 256;            // ring ids 0..255
+constexpr uint32_t kSentinel = 0xFFFFFFFFu;
+
+struct Layout { uint32_t step, ox, oy, oz, oring, rtype, be; };   // rtype: PointField datatype of ring; be: big-endian
+
+// One f32 field / the ring field of a record as a PointCloud2 describes them.  Byte-wise access to
+// fields that are not naturally aligned is left to the hardware (unaligned dword loads are legal).
+__device__ inline float load_f32(const uint8_t * p, uint32_t be)
+{
+  uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+  if (be) {v = __builtin_bswap32(v);}
+  return __uint_as_float(v);
+}
+
+__device__ inline uint32_t load_ring(const uint8_t * p, uint32_t rtype, uint32_t be)
+{
+  switch (rtype) {
+    case 1: return (uint32_t)(int32_t)*reinterpret_cast<const int8_t *>(p);          // negative ids end up >= max_rings
+    case 2: return *p;
+    case 3: {uint16_t v = *reinterpret_cast<const uint16_t *>(p); if (be) {v = __builtin_bswap16(v);} return (uint32_t)(int32_t)(int16_t)v;}
+    case 5:
+    case 6: {uint32_t v = *reinterpret_cast<const uint32_t *>(p); if (be) {v = __builtin_bswap32(v);} return v;}
+    default: {uint16_t v = *reinterpret_cast<const uint16_t *>(p); if (be) {v = __builtin_bswap16(v);} return v;}
+  }
+}
+
+struct Params
+{
+  int P;                 // convolution_padding
+  int B;                 // n_blocks
+  double cos_bound;      // IsNeighborXY(i,i+1)  <=>  cos_bound <= cos_angle <= 1   (neighbor.hpp:44-48)
+  float cos_bound_f;     // (float)cos_bound, +-inf kept: the f32 pre-filter of the same test
+  double dist_diff;      // distance_diff_threshold
+  double pb_ratio;       // parallel_beam_min_range_ratio
+  float pb_ratio_f;      // (float)pb_ratio for the f32 pre-filter
+  double edge_thr, surf_thr;
+  double min_range, max_range;
+};
+
+// scan_info[s][4]
+enum { kInfoRings = 0, kInfoError = 1, kInfoEdge = 2, kInfoSurface = 3 };
+// bits of scan_info[s][kInfoError]: errors, and the route the scan took.  kScanFused: the organised-scan kernel took
+// the scan (ring r's position k IS input point k * rings + r: nothing was staged, sxy / sz / sidx hold nothing for
+// it); kScanFellBack: that kernel (or the host) handed the scan to the bucketing route, whose staged arrays are valid.
+enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u, kScanOrderFell = 0x400u };
+__host__ __device__ inline bool scan_is_organised(uint32_t err) {return (err & (kScanFused | kScanFellBack)) == kScanFused;}
+// counters[8] behind ring_flags: rings deferred by the first unit pass, repaired after it, sent to the workgroup-per-ring
+// kernel, repaired before it; scans on the fall-back list; whether the organised-scan kernel ran; scans in the batch
+// ... scans the organised-scan kernel gave up on because a ring was not in angle order (the rest of the pattern held);
+// rings ring_cut_kernel found rotated / reversed; whether it ran
+enum { kCntDefer = 0, kCntRedo = 1, kCntSlow = 2, kCntPreFixed = 3, kCntFallback = 4, kCntFusedRan = 5, kCntBatch = 6,
+       kCntOrderFell = 7, kCntTurned = 8, kCntCutRan = 9, kCounters = 12 };
+// Ring transform of an organised scan (ring_cut_kernel): position k of the ring is column (start + k) mod C, or
+// (start - k) mod C for a clockwise sensor; 0 = the ring arrives in angle order.
+constexpr uint32_t kXformReversed = 0x80000000u;
+__host__ __device__ inline uint32_t ring_column(uint32_t xf, uint32_t k, uint32_t C)
+{
+  const uint32_t start = xf & ~kXformReversed;
+  if (xf & kXformReversed) {return k <= start ? start - k : start + C - k;}
+  return start + k < C ? start + k : start + k - C;
+}
+
+enum RingStatus : uint8_t
+{
+  kOk = 0, kSparse = 1, kTooFewConv = 2, kTooFewBlocks = 3, kBlockTooSmall = 4, kZeroNormPair = 5,
+  kTooLarge = 7
+};
+
+enum Label : uint8_t
+{
+  kDefault = 0, kEdge = 1, kEdgeNeighbor = 2, kSurface = 3, kSurfaceNeighbor = 4, kOutOfRange = 5,
+  kOccluded = 6, kParallelBeam = 7
+};
+
+// ------------------------------------------------------------------------------------------
+// Ring-major layout: ring `r` of scan `s` owns positions [((s * max_rings) + r) * cap, + cap) of every
+// per-point array (fixed capacity per ring id, so no global prefix over rings is needed).
+__host__ __device__ inline size_t ring_base(uint32_t s, uint32_t ring, uint32_t max_rings, uint32_t cap)
+{
+  return ((size_t)s * max_rings + ring) * cap;
+}
+
+
+}  // namespace lfx

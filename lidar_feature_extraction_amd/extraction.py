@@ -235,8 +235,8 @@ class FeatureExtraction:
         poses = np.ascontiguousarray(initial_poses, np.float64).reshape(-1, 12)
         res = (B.AlignResult * len(poses))()
         B.check(self._ctx, self._L.lfx_localize_batch(
-            self._ctx, edge_map.handle, surface_map.handle, int(n_neighbors), int(max_iter), float(surface_leaf), poses.ctypes.data_as(C.POINTER(C.c_double)), res,
-            C.c_void_p(int(stream))))
+            self._ctx, edge_map.handle, surface_map.handle, int(n_neighbors), int(max_iter), float(surface_leaf), len(poses),
+            poses.ctypes.data_as(C.POINTER(C.c_double)), res, C.c_void_p(int(stream))))
         return self._align_results(res)
 
     def localize_host(self, edge_map, surface_map, edge_points, surface_points, initial_pose, n_neighbors=15, max_iter=20,

@@ -48,6 +48,12 @@ class RcclGather:
             self._L.lfx_comm_destroy(self._comm)
             self._comm = C.c_void_p()
 
+    def stats(self):
+        """lfx_comm_stats: {sends, receives, bytes_sent, bytes_received, all_gathers} posted by this rank so far."""
+        out = (C.c_uint64 * 5)()
+        self._L.lfx_comm_stats(self._comm, C.cast(out, C.c_void_p))
+        return dict(zip(("sends", "receives", "bytes_sent", "bytes_received", "all_gathers"), [int(v) for v in out]))
+
     def counts(self, d_offsets, batch, stream=0):
         B.check(self._fx._ctx, self._L.lfx_gather_counts(self._fx._ctx, self._comm, C.c_void_p(int(d_offsets)), batch,
                                                          C.c_void_p(int(stream))))
@@ -83,14 +89,17 @@ class CloudGather:
     the receive buffers, valid once `done` has passed; None elsewhere).  flush() completes the last one."""
 
     def __init__(self, fx, rank, world, unique_id, dst=0, device=None, capacity_points=0, batch=1, floats_per_point=3):
-        self.dst, self.rank, self.world = dst, rank, world
+        # dst = "rotate": step k's clouds go to rank k mod world (every rank then needs receive buffers): no single
+        # rank's links carry all of the ingest
+        self.rotate = dst == "rotate"
+        self.dst, self.rank, self.world = (0 if self.rotate else int(dst)), rank, world
         self.fpp, self.batch, self.cap = floats_per_point, batch, int(capacity_points)
         self.rccl = RcclGather(fx, rank, world, unique_id)
         self.side = torch.cuda.Stream(device=device)
         self.pending = None
         self.buffer_free = {}          # data_ptr of a send buffer -> event recorded after the gather that read it
         self.done = None               # event after the last completed gather's receives
-        if rank == dst:
+        if self.rotate or rank == self.dst:
             # two receive sets, so that a consumer may still read step k-2's clouds while step k-1's arrive
             self.recv = [(torch.zeros((self.cap, self.fpp), dtype=torch.float32, device=device),
                           torch.zeros((self.cap, self.fpp), dtype=torch.float32, device=device),
@@ -122,8 +131,10 @@ class CloudGather:
     def _finish(self, p):
         edge, surface, offsets, batch = p
         ea, sa, oa = self.recv[self.step % 2]
+        dst = self.step % self.world if self.rotate else self.dst
+        self.last_dst = dst
         self.step += 1
-        counts = self.rccl.payload(self.dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
+        counts = self.rccl.payload(dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
                                    ea.data_ptr() if ea is not None else 0, sa.data_ptr() if sa is not None else 0,
                                    oa.data_ptr() if oa is not None else 0, self.cap, self.side.cuda_stream)
         ev = torch.cuda.Event()
@@ -131,7 +142,7 @@ class CloudGather:
         for t in (edge, surface, offsets):
             self.buffer_free[t.data_ptr()] = ev
         self.done = ev
-        if self.rank != self.dst:
+        if self.rank != dst:
             return None
         return split_gathered(ea, sa, oa, counts, batch)
 

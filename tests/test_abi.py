@@ -187,6 +187,6 @@ def test_alignment_texts_and_null_arguments(lib):
     assert lib.lfx_map_create_host(null, null, 10, C.c_float(1.0), null, null) == -1
     assert lib.lfx_map_info(null, None, None, None) == -1
     assert lib.lfx_map_nearest(null, null, null, 1, 1, null, null, null, null) == -1
-    assert lib.lfx_localize_batch(null, null, null, 15, 20, C.c_float(1.0), None, None, null) == -1
+    assert lib.lfx_localize_batch(null, null, null, 15, 20, C.c_float(1.0), 1, None, None, null) == -1
     assert lib.lfx_localize_host(null, null, null, 15, 20, C.c_float(1.0), null, 0, null, 0, None, None, null) == -1
     lib.lfx_map_destroy(null)                 # a no-op

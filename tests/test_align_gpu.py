@@ -211,6 +211,9 @@ def test_localize_batch_against_the_oracle(batch):
         assert got[s]["success"] == w["success"]
         moved += int(np.abs(got[s]["pose"] - poses[s]).max() > 1e-4)
     assert moved >= max(batch - 1, 1)
+    # a pose array that is not one pose per scan of the batch is refused (it sizes the result array too)
+    with pytest.raises(Exception, match="n_scans"):
+        fx.localize_batch(emap, smap, np.concatenate([poses, poses[:1]]), k, max_iter, 1.0, stream)
     fx.close()
 
 

@@ -1,15 +1,17 @@
 #!/bin/bash
-# tools/ab.sh REV  -- build the kernels of git revision REV as _lib/ab_A.so next to the working tree's
+# tools/ab.sh REV [NAME]  -- build the library of git revision REV as _lib/NAME.so (default ab_A) next to the working tree's
 # build (_lib/liblfx.so) so that both can be timed on ONE device in one gpurun call:
-#   for i in 1 2 3; do LFX_LIB_PATH=$PWD/lidar_feature_extraction_amd/_lib/ab_A.so python bench.py ...; python bench.py ...; done
+#   tools/ab_env.sh 3 "LFX_LIB_PATH=$PWD/lidar_feature_extraction_amd/_lib/ab_A.so" ""
 set -e
-REV=${1:-HEAD}
+REV=${1:-HEAD}; NAME=${2:-ab_A}
 T=$(mktemp -d)
-mkdir -p $T/lidar_feature_extraction_amd/csrc $T/include
-git show $REV:lidar_feature_extraction_amd/csrc/lfx_kernels.hpp > $T/lidar_feature_extraction_amd/csrc/lfx_kernels.hpp
-git show $REV:lidar_feature_extraction_amd/csrc/lfx_api.hip > $T/lidar_feature_extraction_amd/csrc/lfx_api.hip
-git show $REV:include/lfx.h > $T/include/lfx.h
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -shared \
-  -o lidar_feature_extraction_amd/_lib/ab_A.so $T/lidar_feature_extraction_amd/csrc/lfx_api.hip
+git archive $REV lidar_feature_extraction_amd/csrc include | tar -x -C $T
+if [ -f $T/lidar_feature_extraction_amd/csrc/lfx_wire.hip ]; then
+  make -s -j5 -C $T/lidar_feature_extraction_amd/csrc all
+  cp $T/lidar_feature_extraction_amd/_lib/liblfx.so lidar_feature_extraction_amd/_lib/$NAME.so
+else    # revisions of the single-file layout (rounds 1 and 2)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -shared \
+    -o lidar_feature_extraction_amd/_lib/$NAME.so $T/lidar_feature_extraction_amd/csrc/lfx_api.hip
+fi
 rm -rf $T
-echo built ab_A.so from $REV
+echo built $NAME.so from $REV

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """tools/kernel_resources.py [ASM] [substring] -- registers, spills, LDS and occupancy of every kernel in the device
-assembly (lidar_feature_extraction_amd/_lib/lfx_gfx950.s, `make -C lidar_feature_extraction_amd/csrc asmfile`)."""
+assembly (lidar_feature_extraction_amd/_build/lfx_api_gfx950.s, `make -C lidar_feature_extraction_amd/csrc asmfile`)."""
 import re
 import subprocess
 import sys
 
-path = sys.argv[1] if len(sys.argv) > 1 else "lidar_feature_extraction_amd/_lib/lfx_gfx950.s"
+path = sys.argv[1] if len(sys.argv) > 1 else "lidar_feature_extraction_amd/_build/lfx_api_gfx950.s"
 want = sys.argv[2] if len(sys.argv) > 2 else ""
 text = open(path).read()
 rows = []
