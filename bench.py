@@ -20,6 +20,7 @@ measured live with HIP events on the launch stream; "cpu_baseline" is the CPU or
 the reference algorithm, oracle/) timed on this host on a bounded sample of the same scans.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -47,6 +48,15 @@ def parse():
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic scans per GPU (tiled to --batch)")
     ap.add_argument("--start-col", type=int, default=0, help="first column of every scan (a driver that does not cut its scans at -pi: every ring arrives rotated)")
     ap.add_argument("--reverse", action="store_true", help="clockwise sensor: every ring arrives in descending angle order")
+    ap.add_argument("--drop-fraction", type=float, default=0.0,
+                    help="a driver that omits invalid returns: this share of the records is missing (ragged rings: the bucketing route)")
+    ap.add_argument("--drop-zero", action="store_true",
+                    help="a driver that keeps the grid and writes invalid returns as (0, 0, 0): --drop-fraction of the records are zeroed "
+                         "instead of removed and the context filters them (lfx_config.drop_zero_points, convert.py:162-163)")
+    ap.add_argument("--shuffle", action="store_true", help="records in arbitrary order (the reference's documented input contract)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (--steps steps between two fences) is run this many times; value = the median")
+    ap.add_argument("--gather-dst", default="0", help="destination rank of the per-step gather: a rank, or 'rotate' (step k -> rank k mod N)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
@@ -54,6 +64,15 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (each with its own context and scratch) the steps alternate over")
     return ap.parse_args()
+
+
+def kernels_sha256():
+    """Hash of the extraction kernels' sources: ties profiles/pmc_traffic.json to the code it was measured on."""
+    h = hashlib.sha256()
+    for name in ("lfx_kernels_common.hpp", "lfx_kernels_extract.hpp"):
+        with open(os.path.join(ROOT, "lidar_feature_extraction_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def main():
@@ -81,8 +100,15 @@ def main():
     # ---- synthetic stream: scan i -> rank i mod world; seeds 1234 + scan id
     n_unique = max(1, min(a.unique, a.batch))
     clouds = [make_scan(a.rings, a.cols, seed=1234 + (j * world + rank), vfov_deg=22.5 if a.rings >= 128 else 15.0,
-                        start_col=a.start_col, reverse=a.reverse) for j in range(n_unique)]
-    n_pts = len(clouds[0])
+                        start_col=a.start_col, reverse=a.reverse, shuffle=a.shuffle,
+                        drop_fraction=0.0 if a.drop_zero else a.drop_fraction) for j in range(n_unique)]
+    if a.drop_zero and a.drop_fraction > 0.0:
+        for j, c in enumerate(clouds):            # the grid stays, the invalid returns are (0, 0, 0) records
+            gone = np.random.Generator(np.random.PCG64(99 + j)).uniform(0.0, 1.0, len(c)) < a.drop_fraction
+            for f in ("x", "y", "z"):
+                c[f][gone] = 0.0
+    n_pts = max(len(c) for c in clouds)
+    valid = [((c["x"] != 0) | (c["y"] != 0) | (c["z"] != 0)) if a.drop_zero else np.ones(len(c), bool) for c in clouds]
     tiled = [clouds[j % n_unique] for j in range(a.batch)]
     host = concat(tiled).view(np.uint8)
     d_points = torch.from_numpy(host).to(dev)
@@ -94,7 +120,7 @@ def main():
     # durations in "roofline" are those of undisturbed kernels
     n_streams = max(1, a.streams)
     fxs = [FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
-                             max_points_per_ring=cap, max_rings=a.rings) for _ in range(n_streams)]
+                             max_points_per_ring=cap, max_rings=a.rings, drop_zero_points=a.drop_zero) for _ in range(n_streams)]
     fx = fxs[0]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     stream = streams[0].cuda_stream
@@ -118,18 +144,27 @@ def main():
         # its exchange is worth more than none.
         gather, gather_error = None, None
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        # every rank first checks that it CAN enter the collective initialisation (the RCCL library opens and has the
+        # entry points: making an id proves both) and the ranks agree on that before anyone calls ncclCommInitRank --
+        # a rank that failed earlier would otherwise leave the others waiting inside it
         try:
+            my_id = RcclGather.unique_id()
             if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(RcclGather.unique_id()), dtype=torch.uint8))
+                idt.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
         except Exception as e:             # noqa: BLE001
-            gather_error = "rank 0: %s" % e
+            gather_error = "rank %d: %s" % (rank, e)
         if world > 1:
+            cannot = torch.tensor([0 if gather_error is None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(cannot, op=dist.ReduceOp.MAX)
+            if int(cannot.item()) and gather_error is None:
+                gather_error = "another rank cannot open its RCCL library"
             dist.broadcast(idt, 0)
         if gather_error is None and not bool(idt.any().item()):
             gather_error = "no communicator id from rank 0"
         if gather_error is None:
             try:
-                gather = CloudGather(fx, rank, world, bytes(idt.cpu().numpy().tobytes()), dst=0, device=dev,
+                gather = CloudGather(fx, rank, world, bytes(idt.cpu().numpy().tobytes()),
+                                     dst="rotate" if a.gather_dst == "rotate" else int(a.gather_dst), device=dev,
                                      capacity_points=feat_cap * world, batch=a.batch)
             except Exception as e:         # noqa: BLE001
                 gather_error = "rank %d: %s" % (rank, e)
@@ -174,15 +209,22 @@ def main():
     # ~7 % of the throughput being measured (0.815 vs 0.761 ms/step), which the sampled form avoids.
     for f in fxs:
         f.set_profiling(True, every=int(os.environ.get("LFX_BENCH_EVENT_EVERY", max(1, min(4, a.steps // 2)))))
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # The timed region -- exactly --steps steps between two fences (barrier + synchronize) -- is run --repeats times back
+    # to back; `value` is the median of the repeats (one 30 ms sample moved by +-4 % from box to box and run to run), the
+    # spread is reported beside it.  Every repeat's time is the maximum over the ranks.
+    dts = []
+    for _ in range(max(1, a.repeats)):
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        dts.append(dt)
+    dt = float(np.median(dts))
     scans_total = a.batch * a.steps * world
     value = scans_total / dt
 
@@ -203,20 +245,28 @@ def main():
         feats.append(len(g.edge_index) + len(g.surface_index))
         if j == 0 and rank == 0:
             from oracle import binding as oracle          # checker only (never timed as the product)
-            w = oracle.extract(clouds[0], canonical_ties=False)
-            parity = bool(np.array_equal(g.labels, w["labels"]) and g.curvature.tobytes() == w["curvature"].tobytes()
-                          and np.array_equal(g.edge_index, w["edge_index"].astype(np.uint32))
-                          and np.array_equal(g.surface_index, w["surface_index"].astype(np.uint32)))
+            # (with the zero filter on, the reference sees the cloud without its (0, 0, 0) records: convert.py:162-163)
+            keep = np.nonzero(valid[0])[0]
+            w = oracle.extract(np.ascontiguousarray(clouds[0][keep]), canonical_ties=False)
+            parity = bool(np.array_equal(g.labels[keep], w["labels"]) and g.curvature[keep].tobytes() == w["curvature"].tobytes()
+                          and np.array_equal(g.edge_index, keep[w["edge_index"]].astype(np.uint32))
+                          and np.array_equal(g.surface_index, keep[w["surface_index"]].astype(np.uint32)))
     feat_batch = sum(feats[j % n_unique] for j in range(a.batch))
-    algo_bytes = 25 * n_pts * a.batch + 16 * feat_batch
+    # (points = the records the path labels: with the zero filter on, the (0, 0, 0) records are not among them)
+    pts_batch = sum(int(valid[j % n_unique].sum()) for j in range(a.batch))
+    algo_bytes = 25 * pts_batch + 16 * feat_batch
     achieved = algo_bytes / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9
-    traffic = None                                    # not measured in this run: read from the committed PMC profile of this workload
+    traffic, traffic_stale = None, False              # not measured in this run: read from the committed PMC profile of this workload
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("batch") == a.batch and tj.get("rings") == a.rings and tj.get("cols") == a.cols:
-                traffic = tj.get("hbm_bytes_per_launch", {}).get(dominant)
+                # the counters were collected on kernels whose source the file names by hash; after an edit they say nothing
+                if tj.get("kernels_sha256") == kernels_sha256():
+                    traffic = tj.get("hbm_bytes_per_launch", {}).get(dominant)
+                else:
+                    traffic_stale = True
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -224,7 +274,7 @@ def main():
                 # the kernel's real HBM rate: PMC bytes (profiles/pmc_traffic.json) over the live duration
                 "traffic_gbs": (round(traffic / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9, 1) if traffic else None),
                 "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh, FETCH doubled), not this run"
-                                   if traffic else None),
+                                   if traffic else ("stale: profiles/pmc_traffic.json was measured on other kernel sources" if traffic_stale else None)),
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items()},
                 "whole_path_frac": round(algo_bytes / (max(sum_us, 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -233,10 +283,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import binding as oracle
-        oracle.extract(clouds[0], canonical_ties=False)   # warm
+        seen = [np.ascontiguousarray(c[v]) for c, v in zip(clouds, valid)]      # what the reference node would be handed
+        oracle.extract(seen[0], canonical_ties=False)   # warm
         done, t1 = 0, time.perf_counter()
         while True:
-            oracle.extract(clouds[done % n_unique], canonical_ties=False)
+            oracle.extract(seen[done % n_unique], canonical_ties=False)
             done += 1
             el = time.perf_counter() - t1
             if el >= a.cpu_seconds or done >= 2000:
@@ -254,7 +305,7 @@ def main():
         def work(t):
             k = 0
             while time.perf_counter() < t_end:
-                oracle.extract(clouds[(t + k) % n_unique], canonical_ties=False)
+                oracle.extract(seen[(t + k) % n_unique], canonical_ties=False)
                 k += 1
             return k
         t2 = time.perf_counter()
@@ -271,12 +322,26 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from lidar_feature_extraction_amd import binding as LB
 
+        piped = []
+
         def timed(fe, scans, reps):
             fe.ExtractFeatures(scans[0])
             t3 = time.perf_counter()
             for j in range(reps):
                 fe.ExtractFeatures(scans[j % len(scans)])
             one = (time.perf_counter() - t3) / reps
+            # pipelined: submit scan k + 1, then wait for scan k (two in flight: the upload of one beside the kernels of the other)
+            reps_p = 4 * reps
+            tk = fe.submit(scans[0])
+            fe.wait(tk, raw=True)
+            t3 = time.perf_counter()
+            prev = fe.submit(scans[0])
+            for j in range(1, reps_p):
+                cur = fe.submit(scans[j % len(scans)])
+                fe.wait(prev, raw=True)
+                prev = cur
+            fe.wait(prev, raw=True)
+            piped.append(round(1e3 * (time.perf_counter() - t3) / reps_p, 4))
             some = [scans[j % len(scans)] for j in range(16)]
             fe.extract_batch(some)
             t3 = time.perf_counter()
@@ -297,12 +362,14 @@ def main():
                                max_points_per_ring=cap, max_rings=a.rings)
         one_all, many_all = timed(fe, clouds, 16)
         fe.close()
-        end_to_end = {"ms_per_scan_one_at_a_time": one, "ms_per_scan_batches_of_16": many,
+        end_to_end = {"ms_per_scan_one_at_a_time": one, "ms_per_scan_batches_of_16": many, "pipelined_ms_per_scan": piped[0],
                       "note": "lfx_extract / lfx_extract_batch through the Python binding: H2D of the 32-byte records, every kernel, the two "
                               "clouds written into pinned host memory, one synchronise; input in pinned memory (lfx_host_alloc), outputs = the "
                               "two clouds (what the node publishes)",
-                      "pageable_input": {"ms_per_scan_one_at_a_time": one_pg, "ms_per_scan_batches_of_16": many_pg},
-                      "pageable_input_all_outputs": {"ms_per_scan_one_at_a_time": one_all, "ms_per_scan_batches_of_16": many_all}}
+                      "pipelined_note": "lfx_extract_submit / lfx_extract_wait, one scan at a time, two in flight (nothing is copied out of the pinned result block)",
+                      "pageable_input": {"ms_per_scan_one_at_a_time": one_pg, "ms_per_scan_batches_of_16": many_pg, "pipelined_ms_per_scan": piped[1]},
+                      "pageable_input_all_outputs": {"ms_per_scan_one_at_a_time": one_all, "ms_per_scan_batches_of_16": many_all,
+                                                     "pipelined_ms_per_scan": piped[2]}}
 
     # ---- the consumer of the two clouds: Localizer::Update on the device, one scan and a batch
     consumer = None
@@ -331,14 +398,17 @@ def main():
         out = {
             "metric": "scans/sec (%d-ring x %d synthetic scans, extraction hot path, inputs resident in HBM)" % (a.rings, a.cols),
             "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "repeats": len(dts), "value_min": round(scans_total / max(dts), 2), "value_max": round(scans_total / min(dts), 2),
             "ms_per_step": round(1e3 * dt / a.steps, 4), "ms_per_scan": round(1e3 * dt / (a.batch * a.steps), 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "rings": a.rings, "cols": a.cols,
                        "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": "code defaults",
-                       "input_order": ("rings in angle order" if not (a.start_col or a.reverse) else
-                                       "rings %s%s" % ("reversed " if a.reverse else "", "rotated by %d columns" % a.start_col if a.start_col else "")),
+                       "input_order": ("shuffled" if a.shuffle else ("rings in angle order" if not (a.start_col or a.reverse) else
+                                       "rings %s%s" % ("reversed " if a.reverse else "", "rotated by %d columns" % a.start_col if a.start_col else ""))) +
+                                      ((", %.0f %% of the returns %s" % (100 * a.drop_fraction, "written as (0, 0, 0) and filtered" if a.drop_zero else "missing"))
+                                       if a.drop_fraction > 0 else ""),
                        "streams": 1 if use_gather else n_streams,
-                       "sharding": "scan i -> gpu i mod N" + (", RCCL gather of clouds to rank 0 per step" if use_gather else "") +
+                       "sharding": "scan i -> gpu i mod N" + ((", RCCL gather of clouds to rank %s per step" % ("k mod N of step k" if a.gather_dst == "rotate" else a.gather_dst)) if use_gather else "") +
                                    (" (gather unavailable: %s)" % gather_error if gather_error else "")},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
         }

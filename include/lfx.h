@@ -203,6 +203,18 @@ int lfx_range_message(int kind, const char *value_name, const char *range_name, 
 /* --- the operator: feature_extraction.cpp:114-157 ---------------------------------------- */
 /* Host points in, host results out (synchronous; H2D + kernels + D2H). */
 int lfx_extract(lfx_ctx *ctx, const void *points, size_t n_points, lfx_scan_result *out);
+/* The same in two halves, for a caller that keeps the next scan coming while this one is on the device (the node's
+ * callback, feature_extraction.cpp:92-171, called by a spinning executor, :185): lfx_extract_submit queues the upload of
+ * `points` (on a stream of its own, so that it runs beside the kernels of the scan before), the kernels and the download,
+ * and returns at once with a ticket; lfx_extract_wait(ticket) waits for that scan alone and fills `out`.  Two scans may
+ * be in flight: a third lfx_extract_submit before the first lfx_extract_wait fails with LFX_ERR_INVALID_ARGUMENT.
+ * Tickets are waited for in the order they were issued.  `points`: pageable memory is copied at once and may be reused
+ * when lfx_extract_submit returns; pinned memory (lfx_host_alloc) is read by DMA and must stay untouched until that
+ * ticket's lfx_extract_wait returns.  `out` and what it points to stay valid until the SECOND lfx_extract_submit after
+ * this lfx_extract_wait (each of the two slots has a result block of its own).  Not to be mixed with lfx_extract /
+ * lfx_extract_batch / lfx_extract_batch_device while a ticket is outstanding (LFX_ERR_INVALID_ARGUMENT). */
+int lfx_extract_submit(lfx_ctx *ctx, const void *points, size_t n_points, uint64_t *ticket);
+int lfx_extract_wait(lfx_ctx *ctx, uint64_t ticket, lfx_scan_result *out);
 int lfx_extract_batch(lfx_ctx *ctx, const void *const *points, const size_t *n_points, uint32_t batch,
                       lfx_scan_result *out /* [batch] */);
 

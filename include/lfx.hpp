@@ -109,6 +109,24 @@ public:
     return r;
   }
 
+  // The pipelined pair (lfx_extract_submit / lfx_extract_wait): Submit returns at once with a ticket, Wait gives that
+  // scan's view.  Two scans may be in flight; the upload of one runs beside the kernels of the one before.  For the
+  // node: Submit the cloud that just arrived, Wait for (and publish) the one submitted by the previous callback.
+  std::uint64_t Submit(const PointXYZIR * points, std::size_t n) const
+  {
+    std::uint64_t ticket = 0;
+    const int rc = lfx_extract_submit(ctx_, points, n, &ticket);
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+    return ticket;
+  }
+  lfx_scan_result Wait(std::uint64_t ticket) const
+  {
+    lfx_scan_result r{};
+    const int rc = lfx_extract_wait(ctx_, ticket, &r);
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+    return r;
+  }
+
   // The same, copied into containers the caller keeps.
   Features ExtractFeatures(const PointXYZIR * points, std::size_t n) const
   {

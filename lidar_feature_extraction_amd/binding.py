@@ -79,7 +79,7 @@ class DeviceView(C.Structure):
 
 EXPORTS = [
     "lfx_default_params", "lfx_launch_params", "lfx_create", "lfx_destroy", "lfx_last_error",
-    "lfx_status_string", "lfx_ring_message", "lfx_range_message", "lfx_extract", "lfx_extract_batch", "lfx_extract_batch_device",
+    "lfx_status_string", "lfx_ring_message", "lfx_range_message", "lfx_extract", "lfx_extract_submit", "lfx_extract_wait", "lfx_extract_batch", "lfx_extract_batch_device",
     "lfx_device_results", "lfx_batch_status", "lfx_scan_routes", "lfx_host_alloc", "lfx_host_free", "lfx_comm_unique_id", "lfx_comm_create",
     "lfx_comm_destroy", "lfx_comm_stats", "lfx_gather_counts", "lfx_gather_payload", "lfx_gather", "lfx_voxel_downsample", "lfx_downsample_surface",
     "lfx_map_create", "lfx_map_create_host", "lfx_map_destroy", "lfx_map_info", "lfx_map_nearest",
@@ -123,6 +123,8 @@ def load():
     L.lfx_ring_message.argtypes = [i32, u32, C.POINTER(Params), C.c_char_p, C.c_size_t]
     L.lfx_range_message.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_size_t]
     L.lfx_extract.argtypes = [vp, vp, C.c_size_t, C.POINTER(ScanResult)]
+    L.lfx_extract_submit.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.lfx_extract_wait.argtypes = [vp, C.c_uint64, C.POINTER(ScanResult)]
     L.lfx_extract_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), u32, C.POINTER(ScanResult)]
     L.lfx_extract_batch_device.argtypes = [vp, vp, C.POINTER(u32), u32, vp]
     L.lfx_device_results.argtypes = [vp, C.POINTER(DeviceView)]

@@ -384,13 +384,22 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
 
 size_t align16(size_t v) {return (v + 15u) & ~(size_t)15u;}
 
-// Results of scans [first, first + count) of the last batch to pinned host memory: everything is queued on `st`
-// (the pack kernel writes headers and clouds straight into the pinned block; labels / curvature / sorted_index, when
-// asked for, are un-permuted on the device and copied) and the host waits ONCE.
-int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t mask, lfx_scan_result * out)
+// Results of scans [first, first + count) of the last batch to pinned host memory, in two halves: fetch_queue puts
+// everything on `st` (the pack kernel writes headers and clouds straight into the pinned block; labels / curvature /
+// sorted_index, when asked for, are un-permuted on the device and copied); fetch_finish, once the stream has got there,
+// reads the headers and fills the caller's structures.  The synchronous entry points run one after the other around ONE
+// wait; the pipelined ones (lfx_extract_submit / _wait) keep a plan per scan in flight.
+struct FetchPlan
+{
+  uint32_t first = 0, count = 0, p0 = 0, mask = 0;
+  size_t o_hdr = 0, o_ep = 0, o_sp = 0, o_cv = 0, o_ei = 0, o_si = 0, o_sx = 0, o_lb = 0;
+  uint8_t * H = nullptr;
+  std::vector<uint32_t> begin;        // scan_begin[first .. first + count] as the batch had it
+};
+
+int fetch_queue(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t mask, PinnedBuf & block, FetchPlan & plan)
 {
   if (count == 0 || first + count > c->last_batch) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "scan index outside the last batch");}
-  if (c->host.size() < c->last_batch) {c->host.resize(c->last_batch);}
   const uint32_t p0 = c->h_scan_begin[first];
   const size_t P = c->h_scan_begin[first + count] - p0;
   const bool want_lab = mask & LFX_OUT_LABELS, want_curv = mask & LFX_OUT_CURVATURE, want_sidx = mask & LFX_OUT_SORTED_INDEX;
@@ -398,8 +407,11 @@ int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t 
   const size_t o_hdr = 0, o_ep = align16((size_t)count * lfx::kResultHeaderBytes), o_sp = o_ep + P * 16, o_cv = o_sp + P * 16,
     o_ei = o_cv + (want_curv ? P * 8 : 0), o_si = o_ei + P * 4, o_sx = o_si + P * 4, o_lb = o_sx + (want_sidx ? P * 4 : 0),
     total = o_lb + (want_lab ? P : 0) + 16;
-  if (c->h_out.reserve(total) != hipSuccess) {return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the pinned result block");}
-  uint8_t * H = c->h_out.p;
+  if (block.reserve(total) != hipSuccess) {return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the pinned result block");}
+  uint8_t * H = block.p;
+  plan.first = first; plan.count = count; plan.p0 = p0; plan.mask = mask; plan.H = H;
+  plan.o_hdr = o_hdr; plan.o_ep = o_ep; plan.o_sp = o_sp; plan.o_cv = o_cv; plan.o_ei = o_ei; plan.o_si = o_si; plan.o_sx = o_sx; plan.o_lb = o_lb;
+  plan.begin.assign(c->h_scan_begin.begin() + first, c->h_scan_begin.begin() + first + count + 1);
   hipLaunchKernelGGL(lfx::result_pack_kernel, dim3(8, count), dim3(256), 0, st,
     first, p0, c->scan_begin.p, c->scan_info.p, c->ring_count.p, c->ring_status.p, c->edge_pts.p, c->edge_idx.p,
     c->surf_pts.p, c->surf_idx.p, H + o_hdr, reinterpret_cast<float4 *>(H + o_ep), reinterpret_cast<float4 *>(H + o_sp),
@@ -427,10 +439,17 @@ int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t 
     if (want_curv) {LFX_HIP(c, hipMemcpyAsync(H + o_cv, c->d_curv.p, P * 8, hipMemcpyDeviceToHost, st));}
     if (want_sidx) {LFX_HIP(c, hipMemcpyAsync(H + o_sx, c->d_sidx.p, P * 4, hipMemcpyDeviceToHost, st));}
   }
-  LFX_HIP(c, hipStreamSynchronize(st));
-  for (uint32_t k = 0; k < count; k++) {
-    const uint32_t s = first + k, b = c->h_scan_begin[s] - p0, n = c->h_scan_begin[s + 1] - c->h_scan_begin[s];
-    const uint32_t * hdr = reinterpret_cast<const uint32_t *>(H + o_hdr + (size_t)k * lfx::kResultHeaderBytes);
+  return LFX_OK;
+}
+
+// (hosts: one HostScan per scan of the plan; the ring lists the results point into live there)
+int fetch_finish(lfx_ctx * c, const FetchPlan & plan, HostScan * hosts, lfx_scan_result * out)
+{
+  uint8_t * H = plan.H;
+  const bool want_lab = plan.mask & LFX_OUT_LABELS, want_curv = plan.mask & LFX_OUT_CURVATURE, want_sidx = plan.mask & LFX_OUT_SORTED_INDEX;
+  for (uint32_t k = 0; k < plan.count; k++) {
+    const uint32_t b = plan.begin[k] - plan.p0, n = plan.begin[k + 1] - plan.begin[k];
+    const uint32_t * hdr = reinterpret_cast<const uint32_t *>(H + plan.o_hdr + (size_t)k * lfx::kResultHeaderBytes);
     const uint32_t * rcount = hdr + 4;
     const uint8_t * rstat = reinterpret_cast<const uint8_t *>(hdr + 4 + lfx::kRings);
     if (hdr[lfx::kInfoError] & lfx::kErrRingId) {
@@ -439,7 +458,7 @@ int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t 
     if (hdr[lfx::kInfoError] & lfx::kErrTimeout) {
       return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
     }
-    HostScan & h = c->host[s];
+    HostScan & h = hosts[k];
     h.ring_id.clear(); h.ring_count.clear(); h.ring_offset.clear(); h.ring_status.clear();
     uint32_t dense = 0, nr = 0;
     for (uint32_t r = 0; r < c->max_rings; r++) {
@@ -457,20 +476,53 @@ int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t 
     lfx_scan_result & o = out[k];
     o.n_points = n;
     o.n_sorted = dense;             // = n less the points the zero filter dropped
-    o.labels = want_lab ? H + o_lb + b : nullptr;
-    o.curvature = want_curv ? reinterpret_cast<const double *>(H + o_cv) + b : nullptr;
-    o.sorted_index = want_sidx ? reinterpret_cast<const uint32_t *>(H + o_sx) + b : nullptr;
+    o.labels = want_lab ? H + plan.o_lb + b : nullptr;
+    o.curvature = want_curv ? reinterpret_cast<const double *>(H + plan.o_cv) + b : nullptr;
+    o.sorted_index = want_sidx ? reinterpret_cast<const uint32_t *>(H + plan.o_sx) + b : nullptr;
     o.n_rings = nr;
     o.ring_id = h.ring_id.data();
     o.ring_count = h.ring_count.data();
     o.ring_offset = h.ring_offset.data();
     o.ring_status = h.ring_status.data();
     o.n_edge = hdr[lfx::kInfoEdge];
-    o.edge_points = reinterpret_cast<const float *>(H + o_ep) + (size_t)b * 4;
-    o.edge_index = reinterpret_cast<const uint32_t *>(H + o_ei) + b;
+    o.edge_points = reinterpret_cast<const float *>(H + plan.o_ep) + (size_t)b * 4;
+    o.edge_index = reinterpret_cast<const uint32_t *>(H + plan.o_ei) + b;
     o.n_surface = hdr[lfx::kInfoSurface];
-    o.surface_points = reinterpret_cast<const float *>(H + o_sp) + (size_t)b * 4;
-    o.surface_index = reinterpret_cast<const uint32_t *>(H + o_si) + b;
+    o.surface_points = reinterpret_cast<const float *>(H + plan.o_sp) + (size_t)b * 4;
+    o.surface_index = reinterpret_cast<const uint32_t *>(H + plan.o_si) + b;
+  }
+  return LFX_OK;
+}
+
+int fetch(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uint32_t mask, lfx_scan_result * out)
+{
+  FetchPlan plan;
+  const int rc = fetch_queue(c, first, count, st, mask, c->h_out, plan);
+  if (rc != LFX_OK) {return rc;}
+  LFX_HIP(c, hipStreamSynchronize(st));
+  if (c->host.size() < c->last_batch) {c->host.resize(c->last_batch);}
+  return fetch_finish(c, plan, c->host.data() + first, out);
+}
+
+// Copy one scan's records to a device buffer on `st`: a pinned buffer (lfx_host_alloc, or anything the caller registered
+// with HIP) goes by DMA as it stands; pageable memory is copied through `stage` (pinned) in pieces, each piece's DMA
+// running while the next is being copied.
+int upload_scan(lfx_ctx * c, uint8_t * d_dst, const void * points, size_t bytes, PinnedBuf & stage, size_t stage_at, hipStream_t st)
+{
+  if (bytes == 0) {return LFX_OK;}
+  hipPointerAttribute_t attr;
+  const bool pinned = hipPointerGetAttributes(&attr, points) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (!pinned) {(void)hipGetLastError();}              // a plain pointer is "invalid value" to the query: not an error here
+  if (pinned) {
+    LFX_HIP(c, hipMemcpyAsync(d_dst, points, bytes, hipMemcpyHostToDevice, st));
+    return LFX_OK;
+  }
+  constexpr size_t kPiece = 1u << 20;
+  const uint8_t * src = static_cast<const uint8_t *>(points);
+  for (size_t o = 0; o < bytes; o += kPiece) {
+    const size_t len = bytes - o < kPiece ? bytes - o : kPiece;
+    std::memcpy(stage.p + stage_at + o, src + o, len);
+    LFX_HIP(c, hipMemcpyAsync(d_dst + o, stage.p + stage_at + o, len, hipMemcpyHostToDevice, st));
   }
   return LFX_OK;
 }
@@ -751,6 +803,14 @@ void lfx_destroy(lfx_ctx * c)
   c->staging.release();
   c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release(); c->h_align.release();
   if (c->h_status) {(void)hipHostFree(c->h_status); c->h_status = nullptr;}
+  if (c->copy_stream) {(void)hipStreamSynchronize(c->copy_stream);}
+  for (auto & sl : c->slots) {
+    sl.in.release(); sl.hin.release(); sl.hout.release();
+    if (sl.uploaded) {(void)hipEventDestroy(sl.uploaded);}
+    if (sl.done) {(void)hipEventDestroy(sl.done);}
+    delete static_cast<FetchPlan *>(sl.plan);
+  }
+  if (c->copy_stream) {(void)hipStreamDestroy(c->copy_stream);}
   if (c->stream) {(void)hipStreamDestroy(c->stream);}
   delete c;
 }
@@ -758,6 +818,7 @@ void lfx_destroy(lfx_ctx * c)
 int lfx_extract_batch_device(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uint32_t batch, void * stream)
 {
   if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->slots[0].busy || c->slots[1].busy) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "a submitted scan is still in flight (lfx_extract_wait)");}
   return run_batch(c, d_points, n_points, batch, static_cast<hipStream_t>(stream));
 }
 
@@ -852,6 +913,7 @@ int extract_batch_impl(
 {
   if (!c || !points || !n_points || !out || batch == 0) {return LFX_ERR_INVALID_ARGUMENT;}
   if (batch > c->max_batch) {return fail(c, LFX_ERR_CAPACITY, "batch exceeds max_batch");}
+  if (c->slots[0].busy || c->slots[1].busy) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "a submitted scan is still in flight (lfx_extract_wait)");}
   LFX_HIP(c, hipSetDevice(c->device));
   std::vector<uint32_t> n32(batch);
   size_t total = 0;
@@ -870,35 +932,23 @@ int extract_batch_impl(
       return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the input staging buffer");
     }
   }
-  // Input: a pinned buffer (lfx_host_alloc, or anything the caller registered with HIP) goes to the device by DMA;
-  // pageable memory is copied through the context's pinned staging buffer in pieces, each piece's DMA running while
-  // the next is being copied.
+  // Input: pinned buffers go to the device by DMA, pageable ones through the context's pinned staging buffer (upload_scan)
+  if (c->h_in.bytes < total * c->layout.step) {
+    bool pageable = false;
+    for (uint32_t s = 0; s < batch && !pageable; s++) {
+      hipPointerAttribute_t attr;
+      pageable = n_points[s] && !(hipPointerGetAttributes(&attr, points[s]) == hipSuccess && attr.type == hipMemoryTypeHost);
+    }
+    (void)hipGetLastError();
+    if (pageable && c->h_in.reserve(total * c->layout.step) != hipSuccess) {     // (reserve waits for the device before it frees)
+      return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the pinned input staging buffer");
+    }
+  }
   size_t at = 0;
   for (uint32_t s = 0; s < batch; s++) {
     const size_t bytes = n_points[s] * c->layout.step;
-    if (bytes) {
-      hipPointerAttribute_t attr;
-      const bool pinned = hipPointerGetAttributes(&attr, points[s]) == hipSuccess && attr.type == hipMemoryTypeHost;
-      if (!pinned) {(void)hipGetLastError();}              // a plain pointer is "invalid value" to the query: not an error here
-      if (pinned) {
-        LFX_HIP(c, hipMemcpyAsync(c->staging.p + at, points[s], bytes, hipMemcpyHostToDevice, c->stream));
-      } else {
-        if (c->h_in.bytes < at + bytes) {
-          // (growing the staging buffer must not pull the rug from under copies already queued)
-          LFX_HIP(c, hipStreamSynchronize(c->stream));
-          if (c->h_in.reserve(total * c->layout.step) != hipSuccess) {
-            return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the pinned input staging buffer");
-          }
-        }
-        constexpr size_t kPiece = 1u << 20;
-        const uint8_t * src = static_cast<const uint8_t *>(points[s]);
-        for (size_t o = 0; o < bytes; o += kPiece) {
-          const size_t len = bytes - o < kPiece ? bytes - o : kPiece;
-          std::memcpy(c->h_in.p + at + o, src + o, len);
-          LFX_HIP(c, hipMemcpyAsync(c->staging.p + at + o, c->h_in.p + at + o, len, hipMemcpyHostToDevice, c->stream));
-        }
-      }
-    }
+    const int urc = upload_scan(c, c->staging.p + at, points[s], bytes, c->h_in, at, c->stream);
+    if (urc != LFX_OK) {return urc;}
     at += bytes;
   }
   const int rc = run_batch(c, c->staging.p, n32.data(), batch, c->stream);
@@ -919,6 +969,66 @@ int lfx_extract(lfx_ctx * c, const void * points, size_t n_points, lfx_scan_resu
   const void * p[1] = {points};
   const size_t n[1] = {n_points};
   return lfx_extract_batch(c, p, n, 1, out);
+}
+
+// The pipelined pair.  The kernels of consecutive scans run in order on the context's stream (they share the device
+// scratch); what overlaps them is the NEXT scan's upload (copy_stream, a device input buffer per slot) and the host's own
+// work of queueing it -- nothing here waits for the device.
+int lfx_extract_submit(lfx_ctx * c, const void * points, size_t n_points, uint64_t * ticket)
+{
+  if (!c || !ticket || (n_points && !points)) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (n_points == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "an empty scan");}
+  if (n_points > c->max_points) {return fail(c, LFX_ERR_CAPACITY, "scan exceeds max_points_per_scan");}
+  lfx_ctx::Slot & sl = c->slots[c->next_ticket % 2];
+  if (sl.busy) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "two scans are in flight: lfx_extract_wait for the older one first");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  if (!c->copy_stream) {LFX_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));}
+  if (!sl.uploaded) {
+    LFX_HIP(c, hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+    LFX_HIP(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    sl.plan = new FetchPlan();
+  }
+  const size_t bytes = n_points * c->layout.step;
+  if (!sl.in.p && sl.in.alloc((size_t)c->max_points * c->layout.step) != hipSuccess) {
+    sl.in.p = nullptr;
+    return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the slot's input buffer");
+  }
+  if (sl.hin.bytes < bytes) {
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, points) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (!pinned && sl.hin.reserve((size_t)c->max_points * c->layout.step) != hipSuccess) {
+      return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the slot's pinned staging buffer");
+    }
+  }
+  // (the slot's previous scan has been waited for, so nothing reads its input buffer or writes its result block any more)
+  int rc = upload_scan(c, sl.in.p, points, bytes, sl.hin, 0, c->copy_stream);
+  if (rc != LFX_OK) {return rc;}
+  LFX_HIP(c, hipEventRecord(sl.uploaded, c->copy_stream));
+  LFX_HIP(c, hipStreamWaitEvent(c->stream, sl.uploaded, 0));
+  const uint32_t n32 = (uint32_t)n_points;
+  rc = run_batch(c, sl.in.p, &n32, 1, c->stream);
+  if (rc != LFX_OK) {return rc;}
+  rc = fetch_queue(c, 0, 1, c->stream, c->outputs, sl.hout, *static_cast<FetchPlan *>(sl.plan));
+  if (rc != LFX_OK) {return rc;}
+  LFX_HIP(c, hipEventRecord(sl.done, c->stream));
+  sl.busy = true;
+  sl.ticket = c->next_ticket;
+  *ticket = c->next_ticket++;
+  return LFX_OK;
+}
+
+int lfx_extract_wait(lfx_ctx * c, uint64_t ticket, lfx_scan_result * out)
+{
+  if (!c || !out) {return LFX_ERR_INVALID_ARGUMENT;}
+  lfx_ctx::Slot & sl = c->slots[ticket % 2];
+  if (!sl.busy || sl.ticket != ticket) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "no such ticket in flight");}
+  if (ticket != c->next_wait) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "tickets are waited for in the order they were issued");}
+  LFX_HIP(c, hipSetDevice(c->device));
+  LFX_HIP(c, hipEventSynchronize(sl.done));
+  sl.busy = false;
+  c->next_wait = ticket + 1;
+  return fetch_finish(c, *static_cast<FetchPlan *>(sl.plan), &sl.host, out);
 }
 
 // ---------------------------------------------------------------------------- stage entry points

@@ -144,6 +144,21 @@ struct lfx_ctx
   std::vector<lfx_host::HostScan> host;
   uint32_t outputs = LFX_OUT_ALL;        // lfx_config::outputs
   lfx_host::PinnedBuf h_in, h_out;                 // staging of the synchronous host API (allocated on first use)
+  // lfx_extract_submit / lfx_extract_wait: two scans in flight, each with its own device input, pinned staging and result
+  // block; the uploads run on copy_stream beside the kernels of the scan before
+  struct Slot
+  {
+    lfx_host::DevBuf<uint8_t> in;
+    lfx_host::PinnedBuf hin, hout;
+    hipEvent_t uploaded = nullptr, done = nullptr;
+    uint64_t ticket = 0;
+    bool busy = false;
+    void * plan = nullptr;               // FetchPlan (lfx_api.hip)
+    lfx_host::HostScan host;
+  };
+  Slot slots[2];
+  hipStream_t copy_stream = nullptr;
+  uint64_t next_ticket = 1, next_wait = 1;
   uint32_t * h_status = nullptr;         // pinned, lfx_batch_status
 
   bool profiling = false;

@@ -146,6 +146,22 @@ class FeatureExtraction:
         B.check(self._ctx, self._L.lfx_extract_batch(self._ctx, ptrs, ns, nb, res))
         return [_result(res[i]) for i in range(nb)]
 
+    def submit(self, cloud):
+        """lfx_extract_submit: queue one scan (upload, kernels, download) and return its ticket at once; at most two
+        tickets may be outstanding.  A pinned `cloud` (pinned_like) must stay untouched until wait(ticket) returns."""
+        cloud = np.ascontiguousarray(cloud)
+        if cloud.dtype.itemsize != self._step:
+            raise TypeError("clouds must be arrays of %d-byte records (POINT_DTYPE for PointXYZIR)" % self._step)
+        t = C.c_uint64(0)
+        B.check(self._ctx, self._L.lfx_extract_submit(self._ctx, C.c_void_p(cloud.ctypes.data), len(cloud), C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket, raw=False):
+        """lfx_extract_wait: the ScanFeatures of that ticket (raw=True: the ctypes result, nothing copied)."""
+        res = B.ScanResult()
+        B.check(self._ctx, self._L.lfx_extract_wait(self._ctx, C.c_uint64(int(ticket)), C.byref(res)))
+        return res if raw else _result(res)
+
     def pinned_like(self, cloud):
         """A copy of `cloud` in pinned host memory (lfx_host_alloc): lfx_extract reads such a buffer by DMA instead of
         staging it.  Owned by this object (freed by close())."""

@@ -476,6 +476,26 @@ def test_every_unit_kernel_variant(chunks):
     f.close()
 
 
+def test_streaming_form_of_the_organised_kernel(monkeypatch):
+    """LFX_DEBUG_STREAM=1: ring_stream_kernel (the waves walk their rings block by block, the next unit's records arriving by
+    LDS-DMA meanwhile) instead of one wave per unit.  Slower as measured, kept as the record of the experiment:
+    it must stay correct.  Scans in order, a scan that breaks the pattern half-way (falls back), rotated rings."""
+    monkeypatch.setenv("LFX_DEBUG_STREAM", "1")
+    f = FeatureExtraction(device=0, max_points_per_scan=64 * 1800, max_batch=4, max_points_per_ring=1800, max_rings=64)
+    clouds = [make_scan(64, 1800, seed=880 + i) for i in range(4)]
+    clouds[2] = clouds[2].copy()
+    a, b = 64 * 1000 + 5, 64 * 1001 + 5                 # two neighbouring records of ring 5 change places, in a late unit:
+    clouds[2][[a, b]] = clouds[2][[b, a]]               # the angle order breaks there and the scan is given up half-way
+    for got, c in zip(f.extract_batch(clouds), clouds):
+        assert_scan_equal(got, OB.extract(c, canonical_ties=False))
+    rot = [make_scan(64, 1800, seed=890 + i, start_col=300) for i in range(4)]
+    for _ in range(3):                                  # (the ring transforms are switched on from the second batch on)
+        res = f.extract_batch(rot)
+    for got, c in zip(res, rot):
+        assert_scan_equal(got, OB.extract(c, canonical_ties=False))
+    f.close()
+
+
 @pytest.mark.parametrize("env", ["LFX_DEBUG_TWO_PASS", "LFX_DEBUG_NO_FAST_PATH", "LFX_DEBUG_GENERIC_THRESHOLDS"])
 def test_fallback_paths_give_the_same_results(env):
     """The two-pass ring bucketing (histogram + scan + scatter) and the workgroup-per-ring kernel for

@@ -40,7 +40,12 @@ def mean_per_kernel(d, counter=None):
 fetch = {k: v["FETCH_SIZE"] for k, v in mean_per_kernel(out + "/pmc_fetch", "FETCH_SIZE").items()}
 write = {k: v["WRITE_SIZE"] for k, v in mean_per_kernel(out + "/pmc_write", "WRITE_SIZE").items()}
 hbm = {k: int(2 * fetch.get(k, 0) * 1024 + write.get(k, 0) * 1024) for k in set(fetch) | set(write)}
+import hashlib, os
+h = hashlib.sha256()
+for name in ("lfx_kernels_common.hpp", "lfx_kernels_extract.hpp"):
+    h.update(open(os.path.join("lidar_feature_extraction_amd", "csrc", name), "rb").read())
 json.dump({"batch": opt("--batch", 1024), "rings": opt("--rings", 64), "cols": opt("--cols", 1800),
+           "kernels_sha256": h.hexdigest(),      # bench.py quotes these bytes only for the sources they were measured on
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB per dispatch, mean over dispatches); "
                    "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md: it counts 128-B requests at 64 B)",
            "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": hbm,
@@ -49,7 +54,7 @@ json.dump({"batch": opt("--batch", 1024), "rings": opt("--rings", 64), "cols": o
 sq = mean_per_kernel(out + "/pmc_sq1")
 for k, v in mean_per_kernel(out + "/pmc_sq2").items():
     sq.setdefault(k, {}).update(v)
-keep = {k: v for k, v in sq.items() if k.startswith(("ring_unit", "ring_scatter", "feature_compact"))}
+keep = {k: v for k, v in sq.items() if k.startswith(("ring_unit", "ring_stream", "ring_scatter", "feature_compact"))}
 for k, v in keep.items():
     w = v.get("SQ_WAVES", 0) or 1
     v["per_wave"] = {c: round(v[c] / w, 1) for c in v if c.startswith(("SQ_INSTS", "SQ_WAVE_CYCLES", "SQ_ACTIVE", "SQ_WAIT"))}
