@@ -59,14 +59,20 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
     }
     const long long dx = (long long)((hi[0] - lo[0]) * inv) + 1, dy = (long long)((hi[1] - lo[1]) * inv) + 1,
       dz = (long long)((hi[2] - lo[2]) * inv) + 1;
-    int bad = !(dx * dy * dz <= 2147483647LL);       // PCL: "leaf size is too small for the input dataset" (also catches non-finite bounds)
+    // PCL: "leaf size is too small for the input dataset" (also catches non-finite bounds); factor by factor, three extents of
+    // a few million cells overflow 64 bits
+    const long long lim = 2147483647LL;
+    int bad = !(dx >= 1 && dy >= 1 && dz >= 1 && dx <= lim && dy <= lim && dz <= lim && dx * dy <= lim && dx * dy * dz <= lim);
     int min_b[3], div_b[3];
     for (int a = 0; a < 3; a++) {
       min_b[a] = (int)floorf(lo[a] * inv);
       div_b[a] = (int)floorf(hi[a] * inv) - min_b[a] + 1;
     }
-    const long long cells = (long long)div_b[0] * div_b[1] * div_b[2];
-    if (!(cells > 0 && cells <= 2147483647LL)) {bad = 1;}
+    long long cells = 0;
+    if (!bad && div_b[0] > 0 && div_b[1] > 0 && div_b[2] > 0 && (long long)div_b[0] * div_b[1] <= lim) {
+      cells = (long long)div_b[0] * div_b[1] * div_b[2];
+    }
+    if (!(cells > 0 && cells <= lim)) {bad = 1;}
     const uint32_t maxkey = bad ? 0u : (uint32_t)(cells - 1);
     geo[0] = min_b[0]; geo[1] = min_b[1]; geo[2] = min_b[2];
     geo[3] = div_b[0]; geo[4] = div_b[0] * div_b[1];

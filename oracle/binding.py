@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "liblfx_oracle.so")
+# LFX_ORACLE_LIB: another build of the same sources (the sanitizer build, `make -C oracle asan`)
+_LIB = os.environ.get("LFX_ORACLE_LIB") or os.path.join(_HERE, "_build", "liblfx_oracle.so")
 _REF = os.path.join(_HERE, "_ref", "libref_pieces.so")
 
 LABEL_NAMES = ["Default", "Edge", "EdgeNeighbor", "Surface", "SurfaceNeighbor", "OutOfRange",
@@ -38,6 +39,8 @@ def launch_params():
 
 
 def build(force=False):
+    if os.environ.get("LFX_ORACLE_LIB"):
+        return _LIB
     srcs = [os.path.join(_HERE, f) for f in ("lfx_oracle.cpp", "lfx_oracle_loc.cpp", "lfx_oracle.h")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + ["all"])

@@ -648,7 +648,10 @@ int orc_voxel_downsample(const float * points, int n, float leaf, float * out, i
   const float inv = 1.0f / leaf;                                 // inverse_leaf_size_ = Ones / leaf_size_
   const long long dx = static_cast<long long>((mx[0] - mn[0]) * inv) + 1, dy = static_cast<long long>((mx[1] - mn[1]) * inv) + 1,
     dz = static_cast<long long>((mx[2] - mn[2]) * inv) + 1;
-  if (dx * dy * dz > 2147483647LL) {return 1;}                    // "Leaf size is too small for the input dataset"
+  // "Leaf size is too small for the input dataset": the product against INT_MAX, factor by factor (three extents of a few
+  // million cells overflow 64 bits: found by the sanitizer build, `make asan`)
+  const long long lim = 2147483647LL;
+  if (dx > lim || dy > lim || dz > lim || dx * dy > lim || dx * dy * dz > lim) {return 1;}
   int min_b[3], div_b[3];
   for (int a = 0; a < 3; a++) {
     min_b[a] = static_cast<int>(std::floor(mn[a] * inv));
