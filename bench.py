@@ -377,7 +377,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
             import localize_bench
-            one = localize_bench.run(rings=a.rings, cols=a.cols, batch=1, map_scans=16, steps=9, device=local_rank)
+            one = localize_bench.run(rings=a.rings, cols=a.cols, batch=1, map_scans=16, steps=9, device=local_rank, kd_scans=1)
             many = localize_bench.run(rings=a.rings, cols=a.cols, batch=32, map_scans=16, steps=3, device=local_rank)
         except Exception as e:             # noqa: BLE001  (a side measurement must not cost the line its headline)
             one = many = None
@@ -386,6 +386,15 @@ def main():
             consumer = {"localize_ms_one_scan": one["localize_ms_per_scan"], "localize_ms_per_scan_batches_of_32": many["localize_ms_per_scan"],
                         "iterations_mean": many["iterations_mean"], "edge_map_points": one["edge_map_points"],
                         "surface_map_points": one["surface_map_points"],
+                        # the consumer's own baseline and roof: a KD-tree on this host (search only: a lower bound of the reference's
+                        # Update) and the bytes its neighbour search has to read over the time the whole Update takes
+                        "cpu_baseline": dict(one["kdtree_host"], unit="ms/scan", kind="port"),
+                        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                     "achieved": round(one["search_bytes_per_scan"] / (1e-3 * one["localize_ms_per_scan"]) / 1e9, 2),
+                                     "frac": round(one["search_bytes_per_scan"] / (1e-3 * one["localize_ms_per_scan"]) / 1e9 / HBM_PEAK_GBS, 5),
+                                     "bytes_per_scan": one["search_bytes_per_scan"],
+                                     "note": "16 B x the map points of the 27 grid cells around every query x iterations, over the time of one scan's "
+                                             "Update: latency- and launch-bound (three launches and ~160 us per iteration), nowhere near a roof"},
                         "note": "lfx_localize_batch after extraction (Downsample + Optimizer::Run of the reference localizer, localizer.hpp:71-80; "
                                 "clouds never leave the device); maps = the features of 16 scans along a track, grid cells of 1 m; "
                                 "parity with Eigen / nanoflann / PCL arithmetic unpinned (DESIGN.md 7)"}

@@ -17,10 +17,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(rings=64, cols=1800, batch=64, map_scans=40, cell=1.0, steps=5, max_iter=20, cpu_scans=0, whole_map=False, device=0):
+def run(rings=64, cols=1800, batch=64, map_scans=40, cell=1.0, steps=5, max_iter=20, cpu_scans=0, whole_map=False, device=0, kd_scans=0):
     """The measurement as a function (bench.py reports it beside the extraction numbers)."""
     return _measure(argparse.Namespace(rings=rings, cols=cols, batch=batch, map_scans=map_scans, cell=cell, steps=steps, max_iter=max_iter,
-                                       cpu_scans=cpu_scans, whole_map=whole_map, device=device))
+                                       cpu_scans=cpu_scans, whole_map=whole_map, device=device, kd_scans=kd_scans))
 
 
 def main():
@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=20)
     ap.add_argument("--cpu-scans", type=int, default=2)
     ap.add_argument("--whole-map", action="store_true", help="also time maps without a grid")
+    ap.add_argument("--kd-scans", type=int, default=2, help="scans of the KD-tree host baseline (scipy.spatial.cKDTree, one thread)")
     a = ap.parse_args()
     a.device = 0
     print(json.dumps(_measure(a)))
@@ -141,10 +142,66 @@ def _measure(a):
         out["cpu_oracle_ms_per_scan"] = round(1e3 * float(np.mean(t_cpu)), 1)
         out["cpu_oracle_note"] = "exhaustive neighbour search, one core; not the reference's KD-tree"
         out["max_pose_difference_to_oracle"] = max(same)
+    if getattr(a, "kd_scans", 0):
+        # A KD-tree on the host, the structure the reference searches (kdtree.hpp:50-71 builds a nanoflann tree per map):
+        # scipy's cKDTree, one thread, the same queries -- every edge point and every downsampled surface point of a scan,
+        # k = 15, once per iteration the device needed.  Only the search: the rows and the solve of Optimizer::Run are not
+        # in it, so this is a LOWER bound of the reference's Update on this host.
+        from scipy.spatial import cKDTree
+        from oracle import binding as OB
+        L = OB.lib()
+        PF = C.POINTER(C.c_float)
+        t0 = time.perf_counter()
+        te, ts = cKDTree(edge_map[:, :3].astype(np.float64)), cKDTree(surf_map[:, :3].astype(np.float64))
+        t_tree = time.perf_counter() - t0
+        e, s = features(clouds[:a.kd_scans])
+        t_kd, n_q, visited = [], [], []
+        cells_e = _cell_counts(edge_map, a.cell)
+        cells_s = _cell_counts(surf_map, a.cell)
+        for i in range(a.kd_scans):
+            pts = np.ascontiguousarray(s[i], np.float32)
+            down, n_down = np.zeros_like(pts), C.c_int(0)
+            L.orc_voxel_downsample(OB.ptr(pts, PF), len(pts), C.c_float(1.0), OB.ptr(down, PF), C.byref(n_down))
+            R, tr = res[i]["pose"][:, :3], res[i]["pose"][:, 3]
+            qe = e[i][:, :3].astype(np.float64) @ R.T + tr
+            qs = down[:n_down.value, :3].astype(np.float64) @ R.T + tr
+            iters = max(1, int(res[i]["iteration"]) + 1)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                te.query(qe, k=15, workers=1)
+                ts.query(qs, k=15, workers=1)
+            t_kd.append(time.perf_counter() - t0)
+            n_q.append((len(qe) + len(qs)) * iters)
+            visited.append((_cube_points(cells_e, qe, a.cell) + _cube_points(cells_s, qs, a.cell)) * iters)
+        out["kdtree_host"] = {"ms_per_scan": round(1e3 * float(np.mean(t_kd)), 2), "tree_build_ms": round(1e3 * t_tree, 1),
+                              "queries_per_scan": int(np.mean(n_q)), "cores": 1,
+                              "what": "scipy.spatial.cKDTree, k = 15, every edge and downsampled surface point, once per iteration the device "
+                                      "needed; the search only (rows and solve not included): a lower bound of the reference's Update"}
+        # what the device's search has to read: the map points of the 3 x 3 x 3 cells around each query (the first cube of
+        # nearest_in_grid_wave; it grows only where 16 neighbours are not inside it), 16 bytes per point
+        out["search_bytes_per_scan"] = int(16 * np.mean(visited))
     emap.close()
     smap.close()
     fx.close()
     return out
+
+
+def _cell_counts(map_points, cell):
+    """Occupancy of the grid cells of a map: {(ix, iy, iz): points}."""
+    idx = np.floor(map_points[:, :3].astype(np.float64) / cell).astype(np.int64)
+    keys, counts = np.unique(idx, axis=0, return_counts=True)
+    return {tuple(k): int(c) for k, c in zip(keys.tolist(), counts.tolist())}
+
+
+def _cube_points(cells, queries, cell):
+    """Map points in the 27 cells around each query, summed over the queries."""
+    idx = np.floor(queries / cell).astype(np.int64)
+    total = 0
+    offs = [(dx, dy, dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]
+    uniq, n = np.unique(idx, axis=0, return_counts=True)
+    for k, m in zip(uniq.tolist(), n.tolist()):
+        total += m * sum(cells.get((k[0] + o[0], k[1] + o[1], k[2] + o[2]), 0) for o in offs)
+    return total
 
 
 if __name__ == "__main__":
