@@ -142,7 +142,8 @@ def _measure(a):
         out["cpu_oracle_ms_per_scan"] = round(1e3 * float(np.mean(t_cpu)), 1)
         out["cpu_oracle_note"] = "exhaustive neighbour search, one core; not the reference's KD-tree"
         out["max_pose_difference_to_oracle"] = max(same)
-    if getattr(a, "kd_scans", 0):
+    a.kd_scans = min(getattr(a, "kd_scans", 0), a.batch)
+    if a.kd_scans:
         # A KD-tree on the host, the structure the reference searches (kdtree.hpp:50-71 builds a nanoflann tree per map):
         # scipy's cKDTree, one thread, the same queries -- every edge point and every downsampled surface point of a scan,
         # k = 15, once per iteration the device needed.  Only the search: the rows and the solve of Optimizer::Run are not
