@@ -337,7 +337,8 @@ template<bool SURFACE, int SEARCH>
 __device__ __forceinline__ void scan_to_map_rows(
   uint32_t bx, const MapIndex & mi, MapPose P, uint32_t k, const float4 * __restrict__ pts,
   const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
-  double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align)
+  double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align,
+  const uint32_t * __restrict__ row_begin /* where the scan's rows start; null: where its points do */)
 {
   constexpr int KM = kNearestMax, T = 128;
   const uint32_t s = blockIdx.y, tid = threadIdx.x;
@@ -347,6 +348,7 @@ __device__ __forceinline__ void scan_to_map_rows(
   }
   const float4 * __restrict__ map = mi.pts;
   const uint32_t b = begin[s], n = count[(size_t)s * count_stride];
+  const uint32_t rb = row_begin ? row_begin[s] : b;
   // kSearchGridWave: a workgroup is one wave and has one query, the same in every lane
   const uint32_t i = SEARCH == kSearchGridWave ? bx : bx * T + tid;
   if ((SEARCH == kSearchGridWave ? bx : bx * T) >= n) {return;}                        // the whole workgroup is beyond this cloud
@@ -402,7 +404,7 @@ __device__ __forceinline__ void scan_to_map_rows(
     const D3 p1{mx - u.x, my - u.y, mz - u.z}, p2{mx + u.x, my + u.y, mz + u.z};
     const D3 e = d3_sub(p2, p1);
     const double K[9] = {0., -e.z, e.y, e.z, 0., -e.x, -e.y, e.x, 0.};       // Hat(p2 - p1)
-    double * J = jacobian + 21 * (size_t)(b + i);
+    double * J = jacobian + 21 * (size_t)(rb + i);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
 #pragma unroll
@@ -411,7 +413,7 @@ __device__ __forceinline__ void scan_to_map_rows(
       for (int cc = 0; cc < 3; cc++) {J[7 * r + 4 + cc] = K[3 * r + cc];}
     }
     const D3 rr = d3_cross(d3_sub(q, p1), d3_sub(q, p2));                  // MakeEdgeResidual
-    double * R = residual + 3 * (size_t)(b + i);
+    double * R = residual + 3 * (size_t)(rb + i);
     R[0] = rr.x; R[1] = rr.y; R[2] = rr.z;
   } else {
     // plane coefficients: least squares X w = -1 by Householder QR (surface.hpp:78-83, math.hpp:36-40)
@@ -458,11 +460,11 @@ __device__ __forceinline__ void scan_to_map_rows(
     w[0] = (g[0] - X[0][1] * w[1] - X[0][2] * w[2]) / X[0][0];
     const double norm = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     const double u[3] = {w[0] / norm, w[1] / norm, w[2] / norm};
-    double * J = jacobian + 7 * (size_t)(b + i);
+    double * J = jacobian + 7 * (size_t)(rb + i);
 #pragma unroll
     for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
     J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
-    residual[b + i] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+    residual[rb + i] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
   }
 }
 
@@ -470,9 +472,10 @@ template<bool SURFACE, int SEARCH>
 __global__ __launch_bounds__(128) void scan_to_map_kernel(
   MapIndex mi, MapPose P, uint32_t k, const float4 * __restrict__ pts,
   const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
-  double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align)
+  double * __restrict__ residual, double * __restrict__ jacobian, const AlignState * __restrict__ align,
+  const uint32_t * __restrict__ row_begin)
 {
-  scan_to_map_rows<SURFACE, SEARCH>(blockIdx.x, mi, P, k, pts, begin, count, count_stride, residual, jacobian, align);
+  scan_to_map_rows<SURFACE, SEARCH>(blockIdx.x, mi, P, k, pts, begin, count, count_stride, residual, jacobian, align, row_begin);
 }
 
 // Problem::Make of the localizer in one launch (loam_optimization_problem.hpp:62-84: edge rows and surface rows of the same
@@ -485,6 +488,7 @@ struct RowsOfKind
   const uint32_t * begin, * count;
   uint32_t count_stride;
   double * residual, * jacobian;
+  const uint32_t * row_begin;
 };
 template<int SEARCH>
 __global__ __launch_bounds__(128) void scan_to_map_both_kernel(
@@ -492,10 +496,10 @@ __global__ __launch_bounds__(128) void scan_to_map_both_kernel(
 {
   if (blockIdx.x < x_edge) {
     scan_to_map_rows<false, SEARCH>(blockIdx.x, edge.mi, P, k, edge.pts, edge.begin, edge.count, edge.count_stride, edge.residual,
-      edge.jacobian, align);
+      edge.jacobian, align, edge.row_begin);
   } else {
     scan_to_map_rows<true, SEARCH>(blockIdx.x - x_edge, surface.mi, P, k, surface.pts, surface.begin, surface.count, surface.count_stride,
-      surface.residual, surface.jacobian, align);
+      surface.residual, surface.jacobian, align, surface.row_begin);
   }
 }
 

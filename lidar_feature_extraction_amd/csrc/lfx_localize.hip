@@ -19,13 +19,13 @@ namespace
 {
 void launch_rows(bool surface, const lfx::MapIndex & mi, const lfx::MapPose & P, uint32_t k, const float * d_points,
   const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride, uint32_t n_clouds, uint32_t longest, double * d_residual,
-  double * d_jacobian, const lfx::AlignState * states, hipStream_t st)
+  double * d_jacobian, const lfx::AlignState * states, hipStream_t st, const uint32_t * d_row_begin = nullptr)
 {
   const bool wave = mi.start != nullptr;              // a grid: one query per wave; no grid: one per thread, the map through LDS
   const dim3 grid(wave ? longest : (longest + 127u) / 128u, n_clouds), block(wave ? 64 : 128);
   const float4 * pts = reinterpret_cast<const float4 *>(d_points);
 #define LFX_ROWS(S, M) hipLaunchKernelGGL((lfx::scan_to_map_kernel<S, M>), grid, block, 0, st, mi, P, k, pts, d_begin, d_count, \
-    count_stride, d_residual, d_jacobian, states)
+    count_stride, d_residual, d_jacobian, states, d_row_begin)
   if (wave) {
     if (surface) {LFX_ROWS(true, lfx::kSearchGridWave);} else {LFX_ROWS(false, lfx::kSearchGridWave);}
   } else {
@@ -262,6 +262,10 @@ struct AlignProblem                     // what Problem::Make reads, per kind
   const float * surface_points = nullptr;
   const uint32_t * begin1 = nullptr, * count1 = nullptr; uint32_t stride1 = 1, longest1 = 0; size_t total1 = 0;
   uint32_t n_neighbors = 0;
+  // where each cloud's ROWS start in r3 / J3 and r1 / J1 (device, [n_clouds]); null: where its points start.  total3 /
+  // total1 count rows: with compact row starts the scratch is sized by the clouds' real lengths, not by the layout the
+  // points happen to lie in (lfx_localize_batch: scan s's clouds start at its first input point)
+  const uint32_t * rbegin3 = nullptr, * rbegin1 = nullptr;
 };
 
 int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_iter, const double * initial_poses,
@@ -312,26 +316,29 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
       // rows' QR) would halve the edge searches' occupancy: 64 scans took 13.4 ms that way against 8.4 ms.
       const bool few = (uint64_t)n_clouds * ((uint64_t)pr.longest3 + pr.longest1) <= 32768u;
       if (pr.longest3 && pr.longest1 && both_grids && few) {
-        const lfx::RowsOfKind e{pr.edge_map->index, reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3};
+        const lfx::RowsOfKind e{pr.edge_map->index, reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3,
+          pr.rbegin3};
         const lfx::RowsOfKind f{pr.surface_map->index, reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1,
-          r1, J1};
+          r1, J1, pr.rbegin1};
         hipLaunchKernelGGL(lfx::scan_to_map_both_kernel<lfx::kSearchGridWave>, dim3(pr.longest3 + pr.longest1, n_clouds), dim3(64), 0, st,
           e, f, pr.longest3, none, pr.n_neighbors, states);
       } else {
         if (pr.longest3) {
           launch_rows(false, pr.edge_map->index, none, pr.n_neighbors, pr.edge_points, pr.begin3, pr.count3, pr.stride3, n_clouds,
-            pr.longest3, r3, J3, states, st);
+            pr.longest3, r3, J3, states, st, pr.rbegin3);
         }
         if (pr.longest1) {
           launch_rows(true, pr.surface_map->index, none, pr.n_neighbors, pr.surface_points, pr.begin1, pr.count1, pr.stride1, n_clouds,
-            pr.longest1, r1, J1, states, st);
+            pr.longest1, r1, J1, states, st, pr.rbegin1);
         }
       }
     }
-    hipLaunchKernelGGL(lfx::align_scale_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, r3, pr.begin3, pr.count3,
-      pr.stride3, r1, pr.begin1, pr.count1, pr.stride1, d_weights, d_active);
+    // (the step kernels only address rows)
+    const uint32_t * rb3 = pr.rbegin3 ? pr.rbegin3 : pr.begin3, * rb1 = pr.rbegin1 ? pr.rbegin1 : pr.begin1;
+    hipLaunchKernelGGL(lfx::align_scale_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, r3, rb3, pr.count3,
+      pr.stride3, r1, rb1, pr.count1, pr.stride1, d_weights, d_active);
     hipLaunchKernelGGL(lfx::align_update_kernel, dim3(lfx::kAlignSlices, n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter,
-      max_iter, r3, J3, pr.begin3, pr.count3, pr.stride3, r1, J1, pr.begin1, pr.count1, pr.stride1, d_weights, d_partials, d_tickets,
+      max_iter, r3, J3, rb3, pr.count3, pr.stride3, r1, J1, rb1, pr.count1, pr.stride1, d_weights, d_partials, d_tickets,
       d_active);
     // the kernels of a finished scan return at once, but a launch is a launch: now and then ask whether any scan still iterates
     if ((iter == 2 || iter == 4 || iter == 7 || iter == 11 || iter == 15) && iter + 1 < max_iter) {
@@ -368,13 +375,16 @@ const char * lfx_align_message(int code)
   }
 }
 
-int lfx_scan_to_map_align(
+namespace
+{
+int align_clouds(
   lfx_ctx * c, const lfx_map * edge_map, const lfx_map * surface_map, uint32_t n_neighbors, int max_iter,
   const float * d_edge_points, const uint32_t * d_edge_begin, const uint32_t * d_edge_count, uint32_t edge_count_stride,
   uint32_t max_edge_points_per_cloud, size_t total_edge_points,
   const float * d_surface_points, const uint32_t * d_surface_begin, const uint32_t * d_surface_count,
   uint32_t surface_count_stride, uint32_t max_surface_points_per_cloud, size_t total_surface_points,
-  uint32_t n_clouds, const double * initial_poses, lfx_align_result * results, void * stream)
+  uint32_t n_clouds, const double * initial_poses, lfx_align_result * results, void * stream,
+  const uint32_t * d_edge_row_begin, const uint32_t * d_surface_row_begin)
 {
   if (!c || !edge_map || !surface_map || !d_edge_points || !d_edge_begin || !d_edge_count || !d_surface_points ||
     !d_surface_begin || !d_surface_count || !initial_poses || !results || n_clouds == 0 || edge_count_stride == 0 ||
@@ -396,7 +406,22 @@ int lfx_scan_to_map_align(
   pr.begin1 = d_surface_begin; pr.count1 = d_surface_count; pr.stride1 = surface_count_stride;
   pr.longest1 = max_surface_points_per_cloud; pr.total1 = total_surface_points;
   pr.n_neighbors = n_neighbors;
+  pr.rbegin3 = d_edge_row_begin; pr.rbegin1 = d_surface_row_begin;
   return run_align(c, pr, n_clouds, max_iter, initial_poses, results, static_cast<hipStream_t>(stream));
+}
+}  // namespace
+
+int lfx_scan_to_map_align(
+  lfx_ctx * c, const lfx_map * edge_map, const lfx_map * surface_map, uint32_t n_neighbors, int max_iter,
+  const float * d_edge_points, const uint32_t * d_edge_begin, const uint32_t * d_edge_count, uint32_t edge_count_stride,
+  uint32_t max_edge_points_per_cloud, size_t total_edge_points,
+  const float * d_surface_points, const uint32_t * d_surface_begin, const uint32_t * d_surface_count,
+  uint32_t surface_count_stride, uint32_t max_surface_points_per_cloud, size_t total_surface_points,
+  uint32_t n_clouds, const double * initial_poses, lfx_align_result * results, void * stream)
+{
+  return align_clouds(c, edge_map, surface_map, n_neighbors, max_iter, d_edge_points, d_edge_begin, d_edge_count, edge_count_stride,
+           max_edge_points_per_cloud, total_edge_points, d_surface_points, d_surface_begin, d_surface_count, surface_count_stride,
+           max_surface_points_per_cloud, total_surface_points, n_clouds, initial_poses, results, stream, nullptr, nullptr);
 }
 
 int lfx_align_point_pairs(
@@ -427,7 +452,7 @@ int lfx_localize_batch(
   LFX_HIP(c, hipSetDevice(c->device));
   const uint32_t batch = c->last_batch;
   const size_t total = c->h_scan_begin[batch];
-  const size_t need = 4 * total + 2 * (size_t)batch;
+  const size_t need = 4 * total + 4 * (size_t)batch;        // the clouds, then counts, status and the two tables of row starts
   if (c->align_surface.n < need) {
     c->align_surface.release();
     if (c->align_surface.alloc(need) != hipSuccess) {
@@ -437,6 +462,7 @@ int lfx_localize_batch(
   }
   float * down = c->align_surface.p;
   uint32_t * down_count = reinterpret_cast<uint32_t *>(down + 4 * total), * down_status = down_count + batch;
+  uint32_t * d_row3 = down_status + batch, * d_row1 = d_row3 + batch;
   const int rc = lfx_downsample_surface(c, surface_leaf, down, down_count, down_status, stream);
   if (rc != LFX_OK) {return rc;}
   // where PCL gives the cloud back unfiltered (leaf too small for its extent) the rows are built from all surface points
@@ -446,19 +472,31 @@ int lfx_localize_batch(
   // the longest edge cloud and the longest downsampled surface cloud size the launches (and choose between one query per
   // thread and one per wave): two small copies, and the call is synchronous anyway
   hipStream_t st = static_cast<hipStream_t>(stream);
-  LFX_HIP(c, c->h_align.reserve(20 * (size_t)batch));
+  // (the pinned block as run_align lays it out -- poses | states | counter | 20 spare bytes per scan --, reserved here so that
+  // it does not move later: the row starts go into the spare part, which run_align does not touch, and are still being
+  // read by the copy queued below when run_align writes the poses at the front)
+  const size_t spare_at = 96 * (size_t)batch + sizeof(lfx::AlignState) * (size_t)batch + 16;
+  LFX_HIP(c, c->h_align.reserve(spare_at + 20 * (size_t)batch));
   uint32_t * info = reinterpret_cast<uint32_t *>(c->h_align.p), * down_n = info + 4 * (size_t)batch;
+  uint32_t * rows = reinterpret_cast<uint32_t *>(c->h_align.p + spare_at);
   LFX_HIP(c, hipMemcpyAsync(info, c->scan_info.p, sizeof(uint32_t) * 4 * batch, hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipMemcpyAsync(down_n, down_count, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, st));
   LFX_HIP(c, hipStreamSynchronize(st));
+  // The clouds of scan s start at its first input point; their ROWS are packed: scan s's rows start at the number of edge
+  // (downsampled surface) points of the scans before it, so that the scratch (272 bytes per row) is sized by the clouds'
+  // real lengths -- a few thousand rows per scan -- not by the 115 200 input points per scan they are spread over.
   uint32_t longest_edge = 0, longest_surface = 0;
+  size_t rows3 = 0, rows1 = 0;
   for (uint32_t s = 0; s < batch; s++) {
+    rows[s] = (uint32_t)rows3; rows[batch + s] = (uint32_t)rows1;
+    rows3 += info[4 * s + lfx::kInfoEdge]; rows1 += down_n[s];
     longest_edge = std::max(longest_edge, info[4 * s + lfx::kInfoEdge]);
     longest_surface = std::max(longest_surface, down_n[s]);
   }
-  return lfx_scan_to_map_align(c, edge_map, surface_map, n_neighbors, max_iter,
-           reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest_edge, total,
-           down, c->scan_begin.p, down_count, 1, longest_surface, total, batch, initial_poses, results, stream);
+  LFX_HIP(c, hipMemcpyAsync(d_row3, rows, sizeof(uint32_t) * 2 * batch, hipMemcpyHostToDevice, st));
+  return align_clouds(c, edge_map, surface_map, n_neighbors, max_iter,
+           reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest_edge, rows3,
+           down, c->scan_begin.p, down_count, 1, longest_surface, rows1, batch, initial_poses, results, stream, d_row3, d_row1);
 }
 
 int lfx_localize_host(
