@@ -87,7 +87,15 @@ typedef struct lfx_config {
                                    * (13 bytes per point over PCIe) that the node itself does not consume
                                    * (feature_extraction.cpp:161-170 publishes the two clouds; labels only feed the
                                    * colored_scan debug cloud): a caller that does not need them leaves them out     */
+  uint32_t stream_hint;           /* LFX_STREAM_*: what the caller knows about the order its driver publishes in.  The
+                                   * library finds the route for a stream from what the first batches report (nothing to
+                                   * configure); a hint only spares the FIRST batch of a stream the slower route         */
 } lfx_config;
+
+#define LFX_STREAM_UNKNOWN 0u      /* start on the organised route, adapt                                               */
+#define LFX_STREAM_TURNED_RINGS 1u /* a grid whose rings arrive rotated / reversed (scans not cut at -pi, a clockwise
+                                    * sensor): find the rings' transforms from the first batch on                        */
+#define LFX_STREAM_NO_GRID 2u      /* records missing or in arbitrary order: the bucketing route from the first batch on */
 
 #define LFX_OUT_FEATURES 1u        /* always on */
 #define LFX_OUT_LABELS 2u

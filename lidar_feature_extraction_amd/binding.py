@@ -48,10 +48,11 @@ INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64 = range(1, 9)
 class Config(C.Structure):
     _fields_ = [("max_points_per_scan", C.c_uint32), ("max_batch", C.c_uint32),
                 ("max_points_per_ring", C.c_uint32), ("max_rings", C.c_uint32), ("drop_zero_points", C.c_uint32),
-                ("layout", Layout), ("outputs", C.c_uint32)]
+                ("layout", Layout), ("outputs", C.c_uint32), ("stream_hint", C.c_uint32)]
 
 
 OUT_FEATURES, OUT_LABELS, OUT_CURVATURE, OUT_SORTED_INDEX, OUT_ALL = 1, 2, 4, 8, 15
+STREAM_UNKNOWN, STREAM_TURNED_RINGS, STREAM_NO_GRID = 0, 1, 2
 
 
 class ScanResult(C.Structure):

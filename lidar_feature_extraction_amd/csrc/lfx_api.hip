@@ -683,6 +683,14 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     c->layout = lfx::Layout{L.point_step, L.off_x, L.off_y, L.off_z, L.off_ring, rtype, L.big_endian ? 1u : 0u};
   }
   c->drop_zero = config->drop_zero_points ? 1u : 0u;
+  // what the caller knows about its stream: the state the route selection would otherwise reach after a batch or two
+  if (config->stream_hint == LFX_STREAM_TURNED_RINGS) {c->use_xform = true;}
+  if (config->stream_hint == LFX_STREAM_NO_GRID) {c->bucket_all = true; c->retry_in = 16;}
+  if (config->stream_hint > LFX_STREAM_NO_GRID) {
+    g_create_error = "stream_hint must be LFX_STREAM_UNKNOWN, LFX_STREAM_TURNED_RINGS or LFX_STREAM_NO_GRID";
+    delete c;
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
   c->outputs = (config->outputs ? config->outputs : (uint32_t)LFX_OUT_ALL) | LFX_OUT_FEATURES;
   c->max_points = config->max_points_per_scan;
   c->max_batch = config->max_batch;

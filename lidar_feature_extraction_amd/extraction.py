@@ -92,7 +92,7 @@ class FeatureExtraction:
     """One context = one GPU = one calling thread (feature_extraction.cpp:65-87,185)."""
 
     def __init__(self, params=None, device=0, max_points_per_scan=262144, max_batch=1,
-                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None, outputs=0):
+                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None, outputs=0, stream_hint=0):
         self._L = B.load()
         self.params = params or HyperParameters()
         self._ctx = C.c_void_p()
@@ -106,7 +106,9 @@ class FeatureExtraction:
             lay = B.Layout(*(tuple(layout) + (0, 0))[:7])
         self._step = lay.point_step or 32
         # outputs: B.OUT_* mask of what ExtractFeatures / extract_batch bring back (0 = everything); the two clouds always do
-        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay, int(outputs))
+        # stream_hint: B.STREAM_* (what the caller knows about the order its driver publishes in; spares the first batch a slower route)
+        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay, int(outputs),
+                       int(stream_hint))
         self._pinned = []
         cp = self.params.to_c()
         rc = self._L.lfx_create(C.byref(self._ctx), device, C.byref(cp), C.byref(cfg))

@@ -1072,3 +1072,25 @@ def test_refvec_append_xyzir(fx, refvec):
     a = refvec["append_xyzir"]
     for (x, y, z, _i, _r), cv, want in zip(a["points_xyzir"], a["curvature"], a["expect_xyzir"]):
         assert [np.float32(x), np.float32(y), np.float32(z), np.float32(cv)] == want[:4]
+
+
+def test_stream_hint_spares_the_first_batch_the_slow_route():
+    """lfx_config.stream_hint: a caller that knows its driver's order says so, and the FIRST batch already takes the route the
+    library would otherwise reach from the reports of a batch or two (lfx_scan_routes: 2 = in place through ring transforms,
+    0 = bucketed, 1 = in place)."""
+    rot = [make_scan(32, 1024, seed=8100 + k, start_col=300) for k in range(3)]
+    want = [OB.extract(c, canonical_ties=False) for c in rot]
+    for hint, first in ((LB.STREAM_UNKNOWN, [0, 0, 0]), (LB.STREAM_TURNED_RINGS, [2, 2, 2]), (LB.STREAM_NO_GRID, [0, 0, 0])):
+        f = FeatureExtraction(device=0, max_points_per_scan=32 * 1024, max_batch=3, max_points_per_ring=1024, max_rings=32, stream_hint=hint)
+        res = f.extract_batch(rot)
+        assert f.scan_routes(3).tolist() == first, (hint, f.scan_routes(3).tolist())
+        for got, w in zip(res, want):
+            assert_scan_equal(got, w)
+        if hint == LB.STREAM_NO_GRID:
+            # (no organised-scan launch at all for such a stream: the kernel's time stays zero)
+            f.set_profiling(True)
+            f.extract_batch(rot)
+            assert f.kernel_times()["ring_unit_org_kernel"][1] == 0
+        f.close()
+    with pytest.raises(LB.LfxError):
+        FeatureExtraction(device=0, max_points_per_scan=1000, stream_hint=7)
