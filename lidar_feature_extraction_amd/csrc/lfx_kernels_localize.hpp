@@ -329,6 +329,104 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
   }
 }
 
+// The row(s) of one scan point from its k nearest map points, idx[] in order of distance (positions in mi.pts): an edge point's
+// 3 x 7 Jacobian and residual at J_out[21] / R_out[3], a surface point's 1 x 7 row and residual at J_out[7] / R_out[1].
+template<bool SURFACE>
+__device__ __forceinline__ void row_from_neighbours(
+  const MapPose & P, D3 p0, D3 q, uint32_t kk, const uint32_t (&idx)[kNearestMax], const float4 * __restrict__ map,
+  double * __restrict__ J_out, double * __restrict__ R_out)
+{
+  constexpr int KM = kNearestMax;
+  double d[12];
+  drp_dq(P, p0, d);
+  if (!SURFACE) {
+    // mean and covariance of the k neighbours (edge.cpp:38-49), in order of distance
+    double mx = 0., my = 0., mz = 0.;
+#pragma unroll
+    for (int j = 0; j < KM; j++) {
+      if ((uint32_t)j < kk) {const float4 m4 = map[idx[j]]; mx += (double)m4.x; my += (double)m4.y; mz += (double)m4.z;}
+    }
+    const double nk = (double)kk;
+    mx /= nk; my /= nk; mz /= nk;
+    double c[6] = {0., 0., 0., 0., 0., 0.};
+#pragma unroll
+    for (int j = 0; j < KM; j++) {
+      if ((uint32_t)j < kk) {
+        const float4 m4 = map[idx[j]];
+        const double ex = (double)m4.x - mx, ey = (double)m4.y - my, ez = (double)m4.z - mz;
+        c[0] += ex * ex; c[1] += ex * ey; c[2] += ex * ez; c[3] += ey * ey; c[4] += ey * ez; c[5] += ez * ez;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {c[a] /= nk;}
+    const D3 u = principal_direction(c);
+    const D3 p1{mx - u.x, my - u.y, mz - u.z}, p2{mx + u.x, my + u.y, mz + u.z};
+    const D3 e = d3_sub(p2, p1);
+    const double K[9] = {0., -e.z, e.y, e.z, 0., -e.x, -e.y, e.x, 0.};       // Hat(p2 - p1)
+    double * J = J_out;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) {J[7 * r + cc] = K[3 * r] * d[cc] + K[3 * r + 1] * d[4 + cc] + K[3 * r + 2] * d[8 + cc];}
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) {J[7 * r + 4 + cc] = K[3 * r + cc];}
+    }
+    const D3 rr = d3_cross(d3_sub(q, p1), d3_sub(q, p2));                  // MakeEdgeResidual
+    double * R = R_out;
+    R[0] = rr.x; R[1] = rr.y; R[2] = rr.z;
+  } else {
+    // plane coefficients: least squares X w = -1 by Householder QR (surface.hpp:78-83, math.hpp:36-40)
+    double X[KM][3], g[KM];
+#pragma unroll
+    for (int j = 0; j < KM; j++) {
+      X[j][0] = 0.; X[j][1] = 0.; X[j][2] = 0.; g[j] = 0.;
+      if ((uint32_t)j < kk) {const float4 m4 = map[idx[j]]; X[j][0] = (double)m4.x; X[j][1] = (double)m4.y; X[j][2] = (double)m4.z; g[j] = -1.0;}
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double norm = 0.;
+#pragma unroll
+      for (int r = 0; r < KM; r++) {if (r >= c) {norm += X[r][c] * X[r][c];}}       // rows >= kk hold zeros
+      norm = sqrt(norm);
+      const double alpha = X[c][c] > 0. ? -norm : norm;
+      double v[KM];
+      double vv = 0.;
+#pragma unroll
+      for (int r = 0; r < KM; r++) {v[r] = r >= c ? X[r][c] : 0.; if (r == c) {v[r] -= alpha;} vv += v[r] * v[r];}
+      if (vv > 0.) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          if (cc >= c) {
+            double sdot = 0.;
+#pragma unroll
+            for (int r = 0; r < KM; r++) {sdot += v[r] * X[r][cc];}
+            sdot = 2. * sdot / vv;
+#pragma unroll
+            for (int r = 0; r < KM; r++) {X[r][cc] -= sdot * v[r];}
+          }
+        }
+        double sdot = 0.;
+#pragma unroll
+        for (int r = 0; r < KM; r++) {sdot += v[r] * g[r];}
+        sdot = 2. * sdot / vv;
+#pragma unroll
+        for (int r = 0; r < KM; r++) {g[r] -= sdot * v[r];}
+      }
+    }
+    double w[3];
+    w[2] = g[2] / X[2][2];
+    w[1] = (g[1] - X[1][2] * w[2]) / X[1][1];
+    w[0] = (g[0] - X[0][1] * w[1] - X[0][2] * w[2]) / X[0][0];
+    const double norm = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double u[3] = {w[0] / norm, w[1] / norm, w[2] / norm};
+    double * J = J_out;
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
+    J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
+    R_out[0] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+  }
+}
+
 // how a query finds its neighbours
 enum : int {kSearchWholeMap = 0, kSearchGridWave = 2};
 
@@ -378,93 +476,10 @@ __device__ __forceinline__ void scan_to_map_rows(
     nearest_whole_map<T>(mi, q, dist, idx, tile);
   }
   if (!valid) {return;}
-  double d[12];
-  drp_dq(P, p0, d);
-  if (!SURFACE) {
-    // mean and covariance of the k neighbours (edge.cpp:38-49), in order of distance
-    double mx = 0., my = 0., mz = 0.;
-#pragma unroll
-    for (int j = 0; j < KM; j++) {
-      if ((uint32_t)j < kk) {const float4 m4 = map[idx[j]]; mx += (double)m4.x; my += (double)m4.y; mz += (double)m4.z;}
-    }
-    const double nk = (double)kk;
-    mx /= nk; my /= nk; mz /= nk;
-    double c[6] = {0., 0., 0., 0., 0., 0.};
-#pragma unroll
-    for (int j = 0; j < KM; j++) {
-      if ((uint32_t)j < kk) {
-        const float4 m4 = map[idx[j]];
-        const double ex = (double)m4.x - mx, ey = (double)m4.y - my, ez = (double)m4.z - mz;
-        c[0] += ex * ex; c[1] += ex * ey; c[2] += ex * ez; c[3] += ey * ey; c[4] += ey * ez; c[5] += ez * ez;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++) {c[a] /= nk;}
-    const D3 u = principal_direction(c);
-    const D3 p1{mx - u.x, my - u.y, mz - u.z}, p2{mx + u.x, my + u.y, mz + u.z};
-    const D3 e = d3_sub(p2, p1);
-    const double K[9] = {0., -e.z, e.y, e.z, 0., -e.x, -e.y, e.x, 0.};       // Hat(p2 - p1)
-    double * J = jacobian + 21 * (size_t)(rb + i);
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-      for (int cc = 0; cc < 4; cc++) {J[7 * r + cc] = K[3 * r] * d[cc] + K[3 * r + 1] * d[4 + cc] + K[3 * r + 2] * d[8 + cc];}
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) {J[7 * r + 4 + cc] = K[3 * r + cc];}
-    }
-    const D3 rr = d3_cross(d3_sub(q, p1), d3_sub(q, p2));                  // MakeEdgeResidual
-    double * R = residual + 3 * (size_t)(rb + i);
-    R[0] = rr.x; R[1] = rr.y; R[2] = rr.z;
+  if (SURFACE) {
+    row_from_neighbours<true>(P, p0, q, kk, idx, map, jacobian + 7 * (size_t)(rb + i), residual + (size_t)(rb + i));
   } else {
-    // plane coefficients: least squares X w = -1 by Householder QR (surface.hpp:78-83, math.hpp:36-40)
-    double X[KM][3], g[KM];
-#pragma unroll
-    for (int j = 0; j < KM; j++) {
-      X[j][0] = 0.; X[j][1] = 0.; X[j][2] = 0.; g[j] = 0.;
-      if ((uint32_t)j < kk) {const float4 m4 = map[idx[j]]; X[j][0] = (double)m4.x; X[j][1] = (double)m4.y; X[j][2] = (double)m4.z; g[j] = -1.0;}
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      double norm = 0.;
-#pragma unroll
-      for (int r = 0; r < KM; r++) {if (r >= c) {norm += X[r][c] * X[r][c];}}       // rows >= kk hold zeros
-      norm = sqrt(norm);
-      const double alpha = X[c][c] > 0. ? -norm : norm;
-      double v[KM];
-      double vv = 0.;
-#pragma unroll
-      for (int r = 0; r < KM; r++) {v[r] = r >= c ? X[r][c] : 0.; if (r == c) {v[r] -= alpha;} vv += v[r] * v[r];}
-      if (vv > 0.) {
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++) {
-          if (cc >= c) {
-            double sdot = 0.;
-#pragma unroll
-            for (int r = 0; r < KM; r++) {sdot += v[r] * X[r][cc];}
-            sdot = 2. * sdot / vv;
-#pragma unroll
-            for (int r = 0; r < KM; r++) {X[r][cc] -= sdot * v[r];}
-          }
-        }
-        double sdot = 0.;
-#pragma unroll
-        for (int r = 0; r < KM; r++) {sdot += v[r] * g[r];}
-        sdot = 2. * sdot / vv;
-#pragma unroll
-        for (int r = 0; r < KM; r++) {g[r] -= sdot * v[r];}
-      }
-    }
-    double w[3];
-    w[2] = g[2] / X[2][2];
-    w[1] = (g[1] - X[1][2] * w[2]) / X[1][1];
-    w[0] = (g[0] - X[0][1] * w[1] - X[0][2] * w[2]) / X[0][0];
-    const double norm = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-    const double u[3] = {w[0] / norm, w[1] / norm, w[2] / norm};
-    double * J = jacobian + 7 * (size_t)(rb + i);
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
-    J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
-    residual[rb + i] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+    row_from_neighbours<false>(P, p0, q, kk, idx, map, jacobian + 21 * (size_t)(rb + i), residual + 3 * (size_t)(rb + i));
   }
 }
 
@@ -478,9 +493,13 @@ __global__ __launch_bounds__(128) void scan_to_map_kernel(
   scan_to_map_rows<SURFACE, SEARCH>(blockIdx.x, mi, P, k, pts, begin, count, count_stride, residual, jacobian, align, row_begin);
 }
 
-// Problem::Make of the localizer in one launch (loam_optimization_problem.hpp:62-84: edge rows and surface rows of the same
-// scans against their two maps): workgroups [0, x_edge) along x build edge rows, the rest surface rows, so that the short
-// surface part runs beside the edge part instead of after it.
+// Problem::Make of the localizer (loam_optimization_problem.hpp:62-84: edge rows and surface rows of the same scans against
+// their two maps) in two launches.  The SEARCH: one wave per query, workgroups [0, x_edge) along x take edge points, the rest
+// surface points (the short surface part runs beside the edge part instead of after it); it leaves the places of the k
+// nearest map points in `nbr`, 16 words per row, and needs few registers -- every query of a scan is resident at once.  The
+// ROWS: one THREAD per query turns the neighbours into Jacobian and residual.  (In one kernel -- the search by the wave, the
+// row by its lane 0 -- the row's arithmetic ran at a 64th of the machine's rate in every one of the waves and its registers
+// (the 16 x 3 QR of a surface row) halved the number of searches in flight: 67 us per iteration for one 64 x 1800 scan.)
 struct RowsOfKind
 {
   MapIndex mi;
@@ -489,17 +508,61 @@ struct RowsOfKind
   uint32_t count_stride;
   double * residual, * jacobian;
   const uint32_t * row_begin;
+  uint32_t * nbr;                          // [rows][kNearestMax]
 };
-template<int SEARCH>
-__global__ __launch_bounds__(128) void scan_to_map_both_kernel(
-  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge, MapPose P, uint32_t k, const AlignState * __restrict__ align)
+
+__device__ __forceinline__ D3 to_map(const MapPose & P, D3 p)
 {
-  if (blockIdx.x < x_edge) {
-    scan_to_map_rows<false, SEARCH>(blockIdx.x, edge.mi, P, k, edge.pts, edge.begin, edge.count, edge.count_stride, edge.residual,
-      edge.jacobian, align, edge.row_begin);
+  return {P.m[0] * p.x + P.m[1] * p.y + P.m[2] * p.z + P.m[3], P.m[4] * p.x + P.m[5] * p.y + P.m[6] * p.z + P.m[7],
+    P.m[8] * p.x + P.m[9] * p.y + P.m[10] * p.z + P.m[11]};
+}
+
+__global__ __launch_bounds__(64) void map_search_kernel(
+  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge, uint32_t k, const AlignState * __restrict__ align)
+{
+  const uint32_t s = blockIdx.y;
+  if (align[s].done) {return;}
+  const bool surf = blockIdx.x >= x_edge;
+  const RowsOfKind & R = surf ? surface : edge;
+  const uint32_t i = surf ? blockIdx.x - x_edge : blockIdx.x;
+  if (i >= R.count[(size_t)s * R.count_stride]) {return;}
+  const uint32_t b = R.begin[s], rb = R.row_begin ? R.row_begin[s] : b;
+  const float4 pf = R.pts[b + i];
+  const D3 q = to_map(align[s].pose, D3{(double)pf.x, (double)pf.y, (double)pf.z});
+  const uint32_t kk = k < (uint32_t)kNearestMax ? k : (uint32_t)kNearestMax;
+  double ld;
+  uint32_t li;
+  nearest_in_grid_wave(R.mi, q, kk, ld, li);
+  if (threadIdx.x < (uint32_t)kNearestMax) {R.nbr[(size_t)(rb + i) * kNearestMax + threadIdx.x] = li;}
+}
+
+constexpr int kRowThreads = 64;
+__global__ __launch_bounds__(kRowThreads) void rows_from_neighbours_kernel(
+  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge /* workgroups of edge rows */, uint32_t k, const AlignState * __restrict__ align)
+{
+  const uint32_t s = blockIdx.y;
+  if (align[s].done) {return;}
+  const bool surf = blockIdx.x >= x_edge;
+  const RowsOfKind & R = surf ? surface : edge;
+  const uint32_t i = (surf ? blockIdx.x - x_edge : blockIdx.x) * kRowThreads + threadIdx.x;
+  if (i >= R.count[(size_t)s * R.count_stride]) {return;}
+  const uint32_t b = R.begin[s], rb = R.row_begin ? R.row_begin[s] : b;
+  const MapPose P = align[s].pose;
+  const float4 pf = R.pts[b + i];
+  const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
+  const D3 q = to_map(P, p0);
+  const uint32_t kk = k < (uint32_t)kNearestMax ? k : (uint32_t)kNearestMax;
+  uint32_t idx[kNearestMax];
+  const uint4 * src = reinterpret_cast<const uint4 *>(R.nbr + (size_t)(rb + i) * kNearestMax);
+#pragma unroll
+  for (int j = 0; j < kNearestMax / 4; j++) {
+    const uint4 v = src[j];
+    idx[4 * j] = v.x; idx[4 * j + 1] = v.y; idx[4 * j + 2] = v.z; idx[4 * j + 3] = v.w;
+  }
+  if (surf) {
+    row_from_neighbours<true>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 7 * (size_t)(rb + i), R.residual + (size_t)(rb + i));
   } else {
-    scan_to_map_rows<true, SEARCH>(blockIdx.x - x_edge, surface.mi, P, k, surface.pts, surface.begin, surface.count, surface.count_stride,
-      surface.residual, surface.jacobian, align, surface.row_begin);
+    row_from_neighbours<false>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 21 * (size_t)(rb + i), R.residual + 3 * (size_t)(rb + i));
   }
 }
 

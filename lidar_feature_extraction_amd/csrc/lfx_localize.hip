@@ -276,7 +276,8 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds, pose_d = 12 * (size_t)n_clouds;
   const size_t rows = pr.total3 + pr.total1;
   const size_t partial_d = (size_t)n_clouds * lfx::kAlignSlices * 64;
-  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + (n_clouds + 1) / 2 + 9;
+  const size_t nbr_d = (size_t)lfx::kNearestMax / 2 * rows;                   // the searches' results: 16 words per row
+  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + nbr_d + (n_clouds + 1) / 2 + 9;
   if (c->align_scratch.n < need) {
     c->align_scratch.release();
     if (c->align_scratch.alloc(need) != hipSuccess) {
@@ -293,6 +294,7 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   double * J1 = w; w += 7 * pr.total1;
   double * d_weights = w; w += rows;
   double * d_partials = w; w += partial_d;
+  uint32_t * nbr3 = reinterpret_cast<uint32_t *>(w), * nbr1 = nbr3 + (size_t)lfx::kNearestMax * pr.total3; w += nbr_d;
   uint32_t * d_tickets = reinterpret_cast<uint32_t *>(w); w += (n_clouds + 1) / 2;
   uint32_t * d_active = reinterpret_cast<uint32_t *>(w);
   LFX_HIP(c, hipMemsetAsync(d_tickets, 0, sizeof(uint32_t) * n_clouds, st));
@@ -311,17 +313,19 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
       }
     } else {
       const bool both_grids = pr.edge_map->index.start && pr.surface_map->index.start;
-      // a few scans: edge and surface rows in one launch, side by side (the short surface part otherwise runs after the edge
-      // part on a mostly idle chip).  Many scans fill the chip anyway, and the one kernel's register count (the surface
-      // rows' QR) would halve the edge searches' occupancy: 64 scans took 13.4 ms that way against 8.4 ms.
-      const bool few = (uint64_t)n_clouds * ((uint64_t)pr.longest3 + pr.longest1) <= 32768u;
-      if (pr.longest3 && pr.longest1 && both_grids && few) {
+      if (both_grids) {
+        // the searches of both kinds in one launch, one wave per query; then the rows, one thread per query
         const lfx::RowsOfKind e{pr.edge_map->index, reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3,
-          pr.rbegin3};
+          pr.rbegin3, nbr3};
         const lfx::RowsOfKind f{pr.surface_map->index, reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1,
-          r1, J1, pr.rbegin1};
-        hipLaunchKernelGGL(lfx::scan_to_map_both_kernel<lfx::kSearchGridWave>, dim3(pr.longest3 + pr.longest1, n_clouds), dim3(64), 0, st,
-          e, f, pr.longest3, none, pr.n_neighbors, states);
+          r1, J1, pr.rbegin1, nbr1};
+        if (pr.longest3 + pr.longest1) {
+          hipLaunchKernelGGL(lfx::map_search_kernel, dim3(pr.longest3 + pr.longest1, n_clouds), dim3(64), 0, st, e, f, pr.longest3,
+            pr.n_neighbors, states);
+          const uint32_t g3 = (pr.longest3 + lfx::kRowThreads - 1u) / lfx::kRowThreads, g1 = (pr.longest1 + lfx::kRowThreads - 1u) / lfx::kRowThreads;
+          hipLaunchKernelGGL(lfx::rows_from_neighbours_kernel, dim3(g3 + g1, n_clouds), dim3(lfx::kRowThreads), 0, st, e, f, g3,
+            pr.n_neighbors, states);
+        }
       } else {
         if (pr.longest3) {
           launch_rows(false, pr.edge_map->index, none, pr.n_neighbors, pr.edge_points, pr.begin3, pr.count3, pr.stride3, n_clouds,
