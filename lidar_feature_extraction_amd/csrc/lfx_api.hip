@@ -809,7 +809,7 @@ void lfx_destroy(lfx_ctx * c)
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
-  c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release(); c->h_align.release();
+  c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release(); c->h_align.release(); c->h_loc.release();
   if (c->h_status) {(void)hipHostFree(c->h_status); c->h_status = nullptr;}
   if (c->copy_stream) {(void)hipStreamSynchronize(c->copy_stream);}
   for (auto & sl : c->slots) {

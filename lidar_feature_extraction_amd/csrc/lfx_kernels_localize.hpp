@@ -38,6 +38,14 @@ struct AlignState
   int32_t iteration, code, done, pad;
 };
 
+// what the host reads when a scan has stopped iterating: written by the thread that stops it, straight into pinned host memory
+struct AlignOut
+{
+  double pose[12];
+  double error, scale;
+  int32_t iteration, code, done, pad;
+};
+
 struct D3 { double x, y, z; };
 __device__ inline D3 d3_sub(D3 a, D3 b) {return {a.x - b.x, a.y - b.y, a.z - b.z};}
 __device__ inline D3 d3_cross(D3 a, D3 b) {return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};}
@@ -236,13 +244,18 @@ __device__ __forceinline__ void wave_sort_steps(double & d, uint32_t & orig, uin
 // one wave, one query (the same q in every lane): rho grown until GridCube::done.  The 64 lanes take 64 consecutive points
 // of a run of cells at a time; the list of the KM nearest so far lives in lanes 0..KM-1 (distance, position, original
 // index), its last distance is the bar a point has to pass, and the few points that pass are inserted one at a time (a
-// shift along the lanes).  The query's own row of cells first: its points set a low bar early.  All 64 lanes must be
-// here; the list comes back in lanes 0..KM-1.
+// shift along the lanes).  All 64 lanes must be here; the list comes back in lanes 0..KM-1.
 // (Measured against one query per thread -- lists in registers with batched insertion, or heaps in LDS: a thread inserts
 // for a few points in a hundred, but some thread of 64 does at nearly every point, so the wave paid the insertion at every
 // point; this form was 2-4x faster from one scan to 64 and level at 256, and it is the only one kept.)
+#ifdef LFX_SEARCH_STAMPS
+#define LFX_SS(...) __VA_ARGS__
+#else
+#define LFX_SS(...)
+#endif
 __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, uint32_t kk, double & ldist, uint32_t & lidx)
 {
+  LFX_SS(const unsigned long long ss_t0 = __builtin_amdgcn_s_memtime(); unsigned long long ss_t1 = 0; uint32_t ss_runs = 0, ss_steps = 0, ss_cand = 0, ss_single = 0, ss_bulk = 0, ss_pass = 0;)
   constexpr int KM = kNearestMax;
   const int lane = threadIdx.x & 63;
   GridCube cube;
@@ -256,10 +269,10 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
     asm volatile("" : "+v"(ldist));
     double bar = wave_read(ldist, KM - 1);
     uint32_t bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
-    auto row = [&](int z, int y) __attribute__((always_inline)) {
-        const size_t cell0 = ((size_t)z * mi.ny + y) * mi.nx;
-        const uint32_t a = mi.start[cell0 + cube.xlo], b = mi.start[cell0 + cube.xhi + 1];
+    auto run = [&](uint32_t a, uint32_t b) __attribute__((always_inline)) {
+        LFX_SS(ss_runs++; ss_cand += b - a;)
         for (uint32_t base = a; base < b; base += 64u * kGridUnroll) {
+          LFX_SS(ss_steps++;)
           float4 mpts[kGridUnroll];
 #pragma unroll
           for (int u = 0; u < kGridUnroll; u++) {
@@ -277,6 +290,7 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
             const uint32_t orig = __float_as_uint(mpt.w);
             uint64_t pass = __ballot(live && (d < bar || (d == bar && orig < bar_orig)));
             if (__popcll(pass) >= kBulkInsert) {
+              LFX_SS(ss_bulk++;)
               // many at once (the first points of a query, before there is a bar worth the name): sort the 64 of them, merge
               // their 16 smallest with the list -- the cost of about eight single insertions, whatever their number
               const bool mine = ((pass >> lane) & 1ull) != 0ull;
@@ -296,6 +310,7 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
               pass = 0;
             }
             while (pass) {
+              LFX_SS(ss_single++;)
               const int src = __ffsll((unsigned long long)pass) - 1;
               pass &= pass - 1;
               const double cd = wave_read(d, src);
@@ -315,16 +330,51 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
           }
         }
       };
-    if (cube.xlo <= cube.xhi) {
-      const bool own = cube.cy >= cube.ylo && cube.cy <= cube.yhi && cube.cz >= cube.zlo && cube.cz <= cube.zhi;
-      if (own) {row(cube.cz, cube.cy);}
+    const int ny_c = cube.yhi - cube.ylo + 1, n_rows = ny_c * (cube.zhi - cube.zlo + 1);
+    if (cube.xlo <= cube.xhi && n_rows <= 64) {
+      // Lane r holds row r of the cube (a run of cells along x = one run of points): both ends of its run, fetched by all lanes
+      // at once, and the squared distance below which none of its points can lie (its gaps to the query along y and z; 1e-7
+      // cells of slack as in GridCube::done).  The rows are visited nearest first -- the query's own row sets a low bar at
+      // once -- and the visit ends when the nearest row left lies beyond the bar: with 1 m cells and 15 neighbours within
+      // half a metre that is most of the 9 rows.  Exact: a row is left out only if each of its points is farther than the
+      // 16th nearest found so far.
+      const int rz = lane / ny_c, ry = lane - rz * ny_c;
+      const bool has = lane < n_rows;
+      uint32_t a = 0u, b = 0u;
+      if (has) {
+        const size_t cell0 = ((size_t)(cube.zlo + rz) * mi.ny + (cube.ylo + ry)) * mi.nx;
+        a = mi.start[cell0 + cube.xlo]; b = mi.start[cell0 + cube.xhi + 1];
+      }
+      const double y0 = (double)(cube.ylo + ry), z0 = (double)(cube.zlo + rz);
+      const double gy = fmax(fmax(y0 - cube.uy, cube.uy - (y0 + 1.)) - 1e-7, 0.), gz = fmax(fmax(z0 - cube.uz, cube.uz - (z0 + 1.)) - 1e-7, 0.);
+      const double far2 = (gy * gy + gz * gz) * (mi.h * mi.h);
+      uint64_t todo = __ballot(has && a != b);
+      LFX_SS(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ss_t1 = __builtin_amdgcn_s_memtime(); ss_pass++;)
+      while (todo) {
+        double m = ((todo >> lane) & 1ull) ? far2 : INFINITY;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {const double o = __shfl_xor(m, off, 64); m = o < m ? o : m;}
+        if (m > bar) {break;}
+        const int pick = __ffsll((unsigned long long)(__ballot(far2 == m) & todo)) - 1;
+        todo &= ~(1ull << pick);
+        run((uint32_t)__builtin_amdgcn_readlane((int)a, pick), (uint32_t)__builtin_amdgcn_readlane((int)b, pick));
+      }
+    } else if (cube.xlo <= cube.xhi) {
+      // (a cube of more than 64 rows: the query lies far outside the map or its surroundings are empty)
       for (int z = cube.zlo; z <= cube.zhi; z++) {
         for (int y = cube.ylo; y <= cube.yhi; y++) {
-          if (!(own && z == cube.cz && y == cube.cy)) {row(z, y);}
+          const size_t cell0 = ((size_t)z * mi.ny + y) * mi.nx;
+          run(mi.start[cell0 + cube.xlo], mi.start[cell0 + cube.xhi + 1]);
         }
       }
     }
-    if (cube.done(mi, wave_read(ldist, (int)kk - 1))) {return;}
+    if (cube.done(mi, wave_read(ldist, (int)kk - 1))) {
+      LFX_SS(const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      if (lane == 0 && blockIdx.y == 0 && t2 - ss_t0 > 50000ull) {
+        printf("SS x=%u rho=%d table=%llu total=%llu passes=%u runs=%u steps=%u cand=%u single=%u bulk=%u\n", blockIdx.x, cube.rho, ss_t1 - ss_t0, t2 - ss_t0, ss_pass, ss_runs, ss_steps, ss_cand, ss_single, ss_bulk);
+      })
+      return;
+    }
     cube.grow(mi);
   }
 }
@@ -517,23 +567,29 @@ __device__ __forceinline__ D3 to_map(const MapPose & P, D3 p)
     P.m[8] * p.x + P.m[9] * p.y + P.m[10] * p.z + P.m[11]};
 }
 
-__global__ __launch_bounds__(64) void map_search_kernel(
-  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge, uint32_t k, const AlignState * __restrict__ align)
+constexpr int kSearchWaves = 4;          // queries per workgroup (nothing is shared between them: a workgroup of one wave each made
+                                         // the dispatch of 4 500 workgroups the longest part of a single scan's search)
+__global__ __launch_bounds__(64 * kSearchWaves) void map_search_kernel(
+  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge /* workgroups of edge queries */, uint32_t k, const AlignState * __restrict__ align)
 {
   const uint32_t s = blockIdx.y;
   if (align[s].done) {return;}
   const bool surf = blockIdx.x >= x_edge;
   const RowsOfKind & R = surf ? surface : edge;
-  const uint32_t i = surf ? blockIdx.x - x_edge : blockIdx.x;
-  if (i >= R.count[(size_t)s * R.count_stride]) {return;}
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  // (the launch is sized from what the host knows of the clouds' lengths -- a bound, or what the previous call saw: the
+  // workgroups of a kind stride over its queries)
+  const uint32_t n = R.count[(size_t)s * R.count_stride], stride = (surf ? gridDim.x - x_edge : x_edge) * kSearchWaves;
   const uint32_t b = R.begin[s], rb = R.row_begin ? R.row_begin[s] : b;
-  const float4 pf = R.pts[b + i];
-  const D3 q = to_map(align[s].pose, D3{(double)pf.x, (double)pf.y, (double)pf.z});
   const uint32_t kk = k < (uint32_t)kNearestMax ? k : (uint32_t)kNearestMax;
-  double ld;
-  uint32_t li;
-  nearest_in_grid_wave(R.mi, q, kk, ld, li);
-  if (threadIdx.x < (uint32_t)kNearestMax) {R.nbr[(size_t)(rb + i) * kNearestMax + threadIdx.x] = li;}
+  for (uint32_t i = (surf ? blockIdx.x - x_edge : blockIdx.x) * kSearchWaves + wave; i < n; i += stride) {
+    const float4 pf = R.pts[b + i];
+    const D3 q = to_map(align[s].pose, D3{(double)pf.x, (double)pf.y, (double)pf.z});
+    double ld;
+    uint32_t li;
+    nearest_in_grid_wave(R.mi, q, kk, ld, li);
+    if (lane < (uint32_t)kNearestMax) {R.nbr[(size_t)(rb + i) * kNearestMax + lane] = li;}
+  }
 }
 
 constexpr int kRowThreads = 64;
@@ -544,25 +600,26 @@ __global__ __launch_bounds__(kRowThreads) void rows_from_neighbours_kernel(
   if (align[s].done) {return;}
   const bool surf = blockIdx.x >= x_edge;
   const RowsOfKind & R = surf ? surface : edge;
-  const uint32_t i = (surf ? blockIdx.x - x_edge : blockIdx.x) * kRowThreads + threadIdx.x;
-  if (i >= R.count[(size_t)s * R.count_stride]) {return;}
+  const uint32_t n = R.count[(size_t)s * R.count_stride], stride = (surf ? gridDim.x - x_edge : x_edge) * kRowThreads;
   const uint32_t b = R.begin[s], rb = R.row_begin ? R.row_begin[s] : b;
   const MapPose P = align[s].pose;
-  const float4 pf = R.pts[b + i];
-  const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
-  const D3 q = to_map(P, p0);
   const uint32_t kk = k < (uint32_t)kNearestMax ? k : (uint32_t)kNearestMax;
-  uint32_t idx[kNearestMax];
-  const uint4 * src = reinterpret_cast<const uint4 *>(R.nbr + (size_t)(rb + i) * kNearestMax);
+  for (uint32_t i = (surf ? blockIdx.x - x_edge : blockIdx.x) * kRowThreads + threadIdx.x; i < n; i += stride) {
+    const float4 pf = R.pts[b + i];
+    const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
+    const D3 q = to_map(P, p0);
+    uint32_t idx[kNearestMax];
+    const uint4 * src = reinterpret_cast<const uint4 *>(R.nbr + (size_t)(rb + i) * kNearestMax);
 #pragma unroll
-  for (int j = 0; j < kNearestMax / 4; j++) {
-    const uint4 v = src[j];
-    idx[4 * j] = v.x; idx[4 * j + 1] = v.y; idx[4 * j + 2] = v.z; idx[4 * j + 3] = v.w;
-  }
-  if (surf) {
-    row_from_neighbours<true>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 7 * (size_t)(rb + i), R.residual + (size_t)(rb + i));
-  } else {
-    row_from_neighbours<false>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 21 * (size_t)(rb + i), R.residual + 3 * (size_t)(rb + i));
+    for (int j = 0; j < kNearestMax / 4; j++) {
+      const uint4 v = src[j];
+      idx[4 * j] = v.x; idx[4 * j + 1] = v.y; idx[4 * j + 2] = v.z; idx[4 * j + 3] = v.w;
+    }
+    if (surf) {
+      row_from_neighbours<true>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 7 * (size_t)(rb + i), R.residual + (size_t)(rb + i));
+    } else {
+      row_from_neighbours<false>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 21 * (size_t)(rb + i), R.residual + 3 * (size_t)(rb + i));
+    }
   }
 }
 
@@ -742,11 +799,14 @@ __global__ __launch_bounds__(128) void map_nearest_kernel(
 // returns the input cloud (downsample.hpp:37-51 -> pcl::VoxelGrid::applyFilter), so the rows are built from all its points.
 __global__ void downsample_passthrough_kernel(
   const float4 * __restrict__ pts, const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count, uint32_t count_stride,
-  float4 * __restrict__ out, uint32_t * __restrict__ out_count, const uint32_t * __restrict__ status)
+  float4 * __restrict__ out, uint32_t * __restrict__ out_count, const uint32_t * __restrict__ status,
+  const uint32_t * __restrict__ edge_count, uint32_t * __restrict__ lengths /* pinned host memory or null: [scans][2] */)
 {
   const uint32_t s = blockIdx.x;
-  if (status[s] == 0u) {return;}
   const uint32_t n = count[(size_t)s * count_stride], b = begin[s];
+  // (what the next call sizes its launches by: this scan's edge points and downsampled surface points)
+  if (lengths && threadIdx.x == 0) {lengths[2 * s] = edge_count[(size_t)s * count_stride]; lengths[2 * s + 1] = status[s] == 0u ? out_count[s] : n;}
+  if (status[s] == 0u) {return;}
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const float4 p = pts[b + i];
     out[b + i] = make_float4(p.x, p.y, p.z, 1.f);
@@ -801,12 +861,15 @@ __device__ inline void refresh_pose(AlignState & a)
   a.pose.qw = qw; a.pose.qx = v[0]; a.pose.qy = v[1]; a.pose.qz = v[2];
 }
 
+// (initial: the caller's poses where the host put them -- pinned host memory, read from there; out: the results' place, likewise)
 __global__ void align_begin_kernel(AlignState * __restrict__ states, const double * __restrict__ initial /* [n][12] */, uint32_t n,
-  uint32_t * __restrict__ active)
+  uint32_t * __restrict__ active, uint32_t * __restrict__ tickets, AlignOut * __restrict__ out)
 {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s == 0) {*active = n;}                            // scans still iterating; the host looks at it now and then
+  if (s == 0) {*active = n;}                            // scans still iterating
   if (s >= n) {return;}
+  tickets[s] = 0u;
+  out[s].done = 0;
   AlignState a;
   double m[12];
   for (int i = 0; i < 12; i++) {m[i] = initial[12 * (size_t)s + i];}
@@ -818,6 +881,18 @@ __global__ void align_begin_kernel(AlignState * __restrict__ states, const doubl
   a.error = 0.; a.scale = 0.; a.cur_error = 0.; a.cur_scale = 0.; a.iteration = 0; a.code = kAlignMaxIteration; a.done = 0; a.pad = 0;
   refresh_pose(a);
   states[s] = a;
+}
+
+// the end of a scan's Optimizer::Run: its OptimizationResult (optimization_result.hpp:43-79) and pose, for the kernels still
+// to come (done) and for the host
+__device__ inline void align_finish(AlignState & st, AlignOut & o, int iteration, double error, double scale, int code, uint32_t * active)
+{
+  st.iteration = iteration; st.error = error; st.scale = scale; st.code = code; st.done = 1;
+  atomicSub(active, 1u);
+  for (int i = 0; i < 12; i++) {o.pose[i] = st.pose.m[i];}
+  o.error = error; o.scale = scale; o.iteration = iteration; o.code = code;
+  __threadfence_system();
+  *reinterpret_cast<volatile int32_t *>(&o.done) = 1;
 }
 
 // AlignmentProblem::Make (alignment.cpp:33-78), the problem the reference's optimizer tests run: rows [DRpDq(q, x), I],
@@ -854,10 +929,10 @@ __global__ __launch_bounds__(128) void pair_rows_kernel(
 // workgroup (256 threads) calls it and gets the value.  sh: 264 words of LDS.
 __device__ inline double workgroup_select(const double * __restrict__ v, uint32_t n, uint32_t k, uint32_t * sh)
 {
-  const int tid = threadIdx.x, T = blockDim.x;           // T == 256: one thread per bin
+  const int tid = threadIdx.x, T = blockDim.x;           // T >= 256: threads 0..255 are the bins
   uint64_t prefix = 0, mask = 0;
   for (int shift = 56; shift >= 0; shift -= 8) {
-    sh[tid] = 0u;
+    if (tid < 256) {sh[tid] = 0u;}
     __syncthreads();
     for (uint32_t i = tid; i < n; i += T) {
       const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
@@ -865,19 +940,24 @@ __device__ inline double workgroup_select(const double * __restrict__ v, uint32_
     }
     __syncthreads();
     // the bin that holds rank k: inclusive prefix sums of the 256 counts (lanes of a wave, then the four waves)
-    const uint32_t mine = sh[tid];
-    uint32_t incl = mine;
+    uint32_t mine = 0, incl = 0;
+    if (tid < 256) {
+      mine = sh[tid];
+      incl = mine;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-      if ((tid & 63) >= off) {incl += o;}
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+        if ((tid & 63) >= off) {incl += o;}
+      }
+      if ((tid & 63) == 63) {sh[260 + (tid >> 6)] = incl;}
     }
-    if ((tid & 63) == 63) {sh[260 + (tid >> 6)] = incl;}
     __syncthreads();
-    uint32_t before = 0;
-    for (int w = 0; w < (tid >> 6); w++) {before += sh[260 + w];}
-    incl += before;
-    if (k < incl && k >= incl - mine) {sh[256] = (uint32_t)tid; sh[257] = k - (incl - mine); sh[258] = mine;}   // exactly one thread
+    if (tid < 256) {
+      uint32_t before = 0;
+      for (int w = 0; w < (tid >> 6); w++) {before += sh[260 + w];}
+      incl += before;
+      if (k < incl && k >= incl - mine) {sh[256] = (uint32_t)tid; sh[257] = k - (incl - mine); sh[258] = mine;}   // exactly one thread
+    }
     __syncthreads();
     prefix |= (uint64_t)sh[256] << shift;
     mask |= 0xFFull << shift;
@@ -920,12 +1000,12 @@ __device__ inline double workgroup_median(const double * __restrict__ v, uint32_
     const double o = __shfl_xor(next, off, 64);
     next = o < next ? o : next;
   }
-  double * shd = reinterpret_cast<double *>(sh);             // 264 words: room for 4 counts and 4 doubles
-  if ((tid & 63) == 0) {sh[tid >> 6] = not_above; shd[4 + (tid >> 6)] = next;}
+  double * shd = reinterpret_cast<double *>(sh);             // 264 words: room for 16 counts and, behind them, 16 doubles
+  if ((tid & 63) == 0) {sh[tid >> 6] = not_above; shd[8 + (tid >> 6)] = next;}
   __syncthreads();
   uint32_t total = 0;
   double e0 = INFINITY;
-  for (int w = 0; w < T / 64; w++) {total += sh[w]; e0 = shd[4 + w] < e0 ? shd[4 + w] : e0;}
+  for (int w = 0; w < T / 64; w++) {total += sh[w]; e0 = shd[8 + w] < e0 ? shd[8 + w] : e0;}
   __syncthreads();
   if (total > n / 2u) {e0 = e1;}
   return (e0 + e1) / 2.;
@@ -1029,14 +1109,18 @@ __device__ inline void solve_update(const double (&q)[4], const double * D, cons
 // (the surface rows; count1 may be null).  weights: one double per row, rows of scan s from begin3[s] + begin1[s] (also the
 // selection's keys when a scan has more than kAlignKeysLds rows).
 //
-// align_scale_kernel, one workgroup per scan: ComputeErrors, the error of the scan, Scale, ComputeWeights.
-__global__ __launch_bounds__(kAlignThreads) void align_scale_kernel(
+// align_scale_kernel, one workgroup of 1024 threads per scan: ComputeErrors, the error of the scan, Scale, ComputeWeights, and
+// the two stopping tests that need nothing else (optimizer.hpp:97-108).  A scan of up to kAlignKeysLds rows keeps each
+// thread's errors in registers -- all their loads in flight at once, read once -- and the selection's keys in LDS.
+constexpr int kScaleThreads = 1024, kScaleItems = kAlignKeysLds / kScaleThreads;
+__global__ __launch_bounds__(kScaleThreads) void align_scale_kernel(
   AlignState * __restrict__ states, int iter,
   const double * __restrict__ r3, const uint32_t * __restrict__ begin3, const uint32_t * __restrict__ count3, uint32_t stride3,
   const double * __restrict__ r1, const uint32_t * __restrict__ begin1, const uint32_t * __restrict__ count1, uint32_t stride1,
-  double * __restrict__ weights, uint32_t * __restrict__ active)
+  double * __restrict__ weights, uint32_t * __restrict__ active, AlignOut * __restrict__ out)
 {
-  constexpr int T = kAlignThreads;
+  constexpr int T = kScaleThreads, E = kScaleItems;
+  static_assert(kAlignKeysLds % kScaleThreads == 0, "whole items per thread");
   const uint32_t s = blockIdx.x;
   const int tid = threadIdx.x;
   AlignState & st = states[s];
@@ -1045,14 +1129,14 @@ __global__ __launch_bounds__(kAlignThreads) void align_scale_kernel(
   __shared__ double part[T / 64];
   const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u, n = n3 + n1;
   if (n == 0u) {                                            // EmptyInput (optimization_result.hpp:46-50)
-    if (tid == 0) {st.iteration = iter; st.error = 0.; st.scale = 0.; st.code = kAlignEmpty; st.done = 1; atomicSub(active, 1u);}
+    if (tid == 0) {align_finish(st, out[s], iter, 0., 0., kAlignEmpty, active);}
     return;
   }
   const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
   double * w_out = weights + (size_t)b3 + b1;
-  // the values the two medians are taken of: in LDS when the scan's rows fit (the selection passes over them 16-32 times)
   __shared__ double keys_lds[kAlignKeysLds];
-  double * key = n <= (uint32_t)kAlignKeysLds ? keys_lds : w_out;
+  const bool small = n <= (uint32_t)kAlignKeysLds;
+  double * key = small ? keys_lds : w_out;                   // (a longer scan: the keys pass through the weights' place)
   auto row_error = [&](uint32_t i) {                         // ComputeErrors (optimizer.cpp:99-107)
       if (i < n3) {
         const double * r = r3 + 3 * ((size_t)b3 + i);
@@ -1061,18 +1145,57 @@ __global__ __launch_bounds__(kAlignThreads) void align_scale_kernel(
       const double r = r1[(size_t)b1 + (i - n3)];
       return r * r;
     };
+  double e_reg[E];
   double esum = 0.;
-  for (uint32_t i = tid; i < n; i += T) {const double e = row_error(i); key[i] = e; esum += e;}
+  if (small) {
+    double ra[E], rb[E], rc[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+      const uint32_t i = (uint32_t)tid + (uint32_t)k * T;
+      ra[k] = 0.; rb[k] = 0.; rc[k] = 0.;
+      if (i < n3) {
+        const double * r = r3 + 3 * ((size_t)b3 + i);
+        ra[k] = r[0]; rb[k] = r[1]; rc[k] = r[2];
+      } else if (i < n) {
+        ra[k] = r1[(size_t)b1 + (i - n3)];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+      const uint32_t i = (uint32_t)tid + (uint32_t)k * T;
+      e_reg[k] = i < n3 ? ra[k] * ra[k] + rb[k] * rb[k] + rc[k] * rc[k] : ra[k] * ra[k];
+      if (i < n) {key[i] = e_reg[k]; esum += e_reg[k];}
+    }
+  } else {
+    for (uint32_t i = tid; i < n; i += T) {const double e = row_error(i); key[i] = e; esum += e;}
+  }
   __syncthreads();
   // Scale (robust.cpp:36-50): b * median(|e - median(e)|)
   const double median = workgroup_median(key, n, sh);
-  for (uint32_t i = tid; i < n; i += T) {key[i] = fabs(key[i] - median);}
+  if (small) {
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+      const uint32_t i = (uint32_t)tid + (uint32_t)k * T;
+      if (i < n) {key[i] = fabs(e_reg[k] - median);}
+    }
+  } else {
+    for (uint32_t i = tid; i < n; i += T) {key[i] = fabs(key[i] - median);}
+  }
   __syncthreads();
   const double scale = 1.482602218505602 * workgroup_median(key, n, sh);
-  // ComputeWeights (optimizer.cpp:120-127)
-  for (uint32_t i = tid; i < n; i += T) {
-    const double en = row_error(i) / (scale + 1e-16);
-    w_out[i] = en < 1.345 * 1.345 ? 1. : 1.345 / sqrt(en);                // HuberDerivative, robust.cpp:61-68
+  // ComputeWeights (optimizer.cpp:120-127); HuberDerivative, robust.cpp:61-68
+  if (small) {
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+      const uint32_t i = (uint32_t)tid + (uint32_t)k * T;
+      const double en = e_reg[k] / (scale + 1e-16);
+      if (i < n) {w_out[i] = en < 1.345 * 1.345 ? 1. : 1.345 / sqrt(en);}
+    }
+  } else {
+    for (uint32_t i = tid; i < n; i += T) {
+      const double en = row_error(i) / (scale + 1e-16);
+      w_out[i] = en < 1.345 * 1.345 ? 1. : 1.345 / sqrt(en);
+    }
   }
   // the error of the scan (errors.sum()), fixed tree order
 #pragma unroll
@@ -1080,9 +1203,20 @@ __global__ __launch_bounds__(kAlignThreads) void align_scale_kernel(
   if ((tid & 63) == 0) {part[tid >> 6] = esum;}
   __syncthreads();
   if (tid == 0) {
-    double e = 0.;
-    for (int wv = 0; wv < T / 64; wv++) {e += part[wv];}
-    st.cur_error = e; st.cur_scale = scale;
+    double error = 0.;
+    for (int wv = 0; wv < T / 64; wv++) {error += part[wv];}
+    st.cur_error = error; st.cur_scale = scale;
+    // the two tests of optimizer.hpp:97-108, in its order; a scan stopped here costs the update kernel nothing
+    if (error > st.prev_error) {                             // LargerErrorThanPrevious
+      align_finish(st, out[s], iter, error, scale, kAlignLargerError, active);
+    } else {
+      st.prev_error = error;
+      if (scale > st.prev_scale) {                           // LargerScaleThanPrevious
+        align_finish(st, out[s], iter, error, scale, kAlignLargerScale, active);
+      } else {
+        st.prev_scale = scale;
+      }
+    }
   }
 }
 
@@ -1098,7 +1232,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   const uint32_t * __restrict__ count3, uint32_t stride3,
   const double * __restrict__ r1, const double * __restrict__ J1, const uint32_t * __restrict__ begin1,
   const uint32_t * __restrict__ count1, uint32_t stride1, const double * __restrict__ weights, double * __restrict__ partials,
-  uint32_t * __restrict__ tickets, uint32_t * __restrict__ active)
+  uint32_t * __restrict__ tickets, uint32_t * __restrict__ active, AlignOut * __restrict__ out)
 {
   constexpr int T = kAlignThreads, NS = 64, G = kAlignSlices;   // 28 (D) + 28 (A) upper triangles + 7 (b) (+ 1 unused)
   const uint32_t s = blockIdx.y, g = blockIdx.x;
@@ -1180,17 +1314,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   __syncthreads();
   if (tid != 0) {return;}
   tickets[s] = 0u;                                           // for the next iteration
-  const double error = st.cur_error, scale = st.cur_scale;
-  if (error > st.prev_error) {                               // LargerErrorThanPrevious
-    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerError; st.done = 1; atomicSub(active, 1u);
-    return;
-  }
-  st.prev_error = error;
-  if (scale > st.prev_scale) {                               // LargerScaleThanPrevious
-    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignLargerScale; st.done = 1; atomicSub(active, 1u);
-    return;
-  }
-  st.prev_scale = scale;
+  const double error = st.cur_error, scale = st.cur_scale;   // (both have passed align_scale_kernel's tests)
   double D[49], A[49], b[7];
   {
     int at = 0;
@@ -1213,9 +1337,9 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   refresh_pose(st);
   const double nq = sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]), nt = sqrt(dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2]);
   if (nq < 1e-3 && nt < 1e-3) {                              // CheckConvergence (optimizer.cpp:35-38)
-    st.iteration = iter; st.error = error; st.scale = scale; st.code = kAlignConverged; st.done = 1; atomicSub(active, 1u);
+    align_finish(st, out[s], iter, error, scale, kAlignConverged, active);
   } else if (iter == max_iter - 1) {                         // ReachedMaximumIteration
-    st.iteration = max_iter; st.error = error; st.scale = scale; st.code = kAlignMaxIteration; st.done = 1; atomicSub(active, 1u);
+    align_finish(st, out[s], max_iter, error, scale, kAlignMaxIteration, active);
   }
 }
 

@@ -273,11 +273,11 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
 {
   static_assert(sizeof(lfx::AlignState) % 8 == 0, "AlignState is an array of doubles' worth");
   if (n_clouds > 65535u) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "at most 65535 scans per alignment call");}   // (a launch's y extent)
-  const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds, pose_d = 12 * (size_t)n_clouds;
+  const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds;
   const size_t rows = pr.total3 + pr.total1;
   const size_t partial_d = (size_t)n_clouds * lfx::kAlignSlices * 64;
   const size_t nbr_d = (size_t)lfx::kNearestMax / 2 * rows;                   // the searches' results: 16 words per row
-  const size_t need = state_d + pose_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + nbr_d + (n_clouds + 1) / 2 + 9;
+  const size_t need = state_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + nbr_d + (n_clouds + 1) / 2 + 9;
   if (c->align_scratch.n < need) {
     c->align_scratch.release();
     if (c->align_scratch.alloc(need) != hipSuccess) {
@@ -287,7 +287,6 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   }
   double * w = c->align_scratch.p;
   lfx::AlignState * states = reinterpret_cast<lfx::AlignState *>(w); w += state_d;
-  double * d_initial = w; w += pose_d;
   double * r3 = w; w += 3 * pr.total3;
   double * J3 = w; w += 21 * pr.total3;
   double * r1 = w; w += pr.total1;
@@ -297,70 +296,92 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   uint32_t * nbr3 = reinterpret_cast<uint32_t *>(w), * nbr1 = nbr3 + (size_t)lfx::kNearestMax * pr.total3; w += nbr_d;
   uint32_t * d_tickets = reinterpret_cast<uint32_t *>(w); w += (n_clouds + 1) / 2;
   uint32_t * d_active = reinterpret_cast<uint32_t *>(w);
-  LFX_HIP(c, hipMemsetAsync(d_tickets, 0, sizeof(uint32_t) * n_clouds, st));
-  // small copies through pinned memory: [poses | states | active]
-  const size_t h_states_at = pose_d * 8, h_active_at = h_states_at + sizeof(lfx::AlignState) * n_clouds;
-  LFX_HIP(c, c->h_align.reserve(h_active_at + 16 + 20 * (size_t)n_clouds));
-  std::memcpy(c->h_align.p, initial_poses, pose_d * 8);
-  LFX_HIP(c, hipMemcpyAsync(d_initial, c->h_align.p, pose_d * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(lfx::align_begin_kernel, dim3((n_clouds + 63u) / 64u), dim3(64), 0, st, states, d_initial, n_clouds, d_active);
+  // Pinned host memory, read and written by the kernels themselves: [the caller's poses | a result record per scan].  No
+  // copy is queued in either direction; the thread that ends a scan's iterations writes its record.
+  const size_t pose_bytes = 96 * (size_t)n_clouds;
+  LFX_HIP(c, c->h_align.reserve(pose_bytes + sizeof(lfx::AlignOut) * (size_t)n_clouds));
+  std::memcpy(c->h_align.p, initial_poses, pose_bytes);
+  volatile lfx::AlignOut * out = reinterpret_cast<volatile lfx::AlignOut *>(c->h_align.p + pose_bytes);
+  void * d_pinned = nullptr;
+  LFX_HIP(c, hipHostGetDevicePointer(&d_pinned, c->h_align.p, 0));
+  const double * d_initial = static_cast<const double *>(d_pinned);
+  lfx::AlignOut * d_out = reinterpret_cast<lfx::AlignOut *>(static_cast<uint8_t *>(d_pinned) + pose_bytes);
+  hipLaunchKernelGGL(lfx::align_begin_kernel, dim3((n_clouds + 63u) / 64u), dim3(64), 0, st, states, d_initial, n_clouds, d_active,
+    d_tickets, d_out);
   const lfx::MapPose none{};
-  for (int iter = 0; iter < max_iter; iter++) {
-    if (pr.X) {
-      if (pr.longest3) {
-        hipLaunchKernelGGL(lfx::pair_rows_kernel, dim3((pr.longest3 + 127u) / 128u, n_clouds), dim3(128), 0, st, pr.X, pr.Y,
-          pr.begin3, pr.count3, r3, J3, states);
-      }
-    } else {
-      const bool both_grids = pr.edge_map->index.start && pr.surface_map->index.start;
-      if (both_grids) {
-        // the searches of both kinds in one launch, one wave per query; then the rows, one thread per query
-        const lfx::RowsOfKind e{pr.edge_map->index, reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3,
-          pr.rbegin3, nbr3};
-        const lfx::RowsOfKind f{pr.surface_map->index, reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1,
-          r1, J1, pr.rbegin1, nbr1};
-        if (pr.longest3 + pr.longest1) {
-          hipLaunchKernelGGL(lfx::map_search_kernel, dim3(pr.longest3 + pr.longest1, n_clouds), dim3(64), 0, st, e, f, pr.longest3,
-            pr.n_neighbors, states);
-          const uint32_t g3 = (pr.longest3 + lfx::kRowThreads - 1u) / lfx::kRowThreads, g1 = (pr.longest1 + lfx::kRowThreads - 1u) / lfx::kRowThreads;
-          hipLaunchKernelGGL(lfx::rows_from_neighbours_kernel, dim3(g3 + g1, n_clouds), dim3(lfx::kRowThreads), 0, st, e, f, g3,
-            pr.n_neighbors, states);
+  auto iteration = [&](int iter) {
+      if (pr.X) {
+        if (pr.longest3) {
+          hipLaunchKernelGGL(lfx::pair_rows_kernel, dim3((pr.longest3 + 127u) / 128u, n_clouds), dim3(128), 0, st, pr.X, pr.Y,
+            pr.begin3, pr.count3, r3, J3, states);
         }
       } else {
-        if (pr.longest3) {
-          launch_rows(false, pr.edge_map->index, none, pr.n_neighbors, pr.edge_points, pr.begin3, pr.count3, pr.stride3, n_clouds,
-            pr.longest3, r3, J3, states, st, pr.rbegin3);
-        }
-        if (pr.longest1) {
-          launch_rows(true, pr.surface_map->index, none, pr.n_neighbors, pr.surface_points, pr.begin1, pr.count1, pr.stride1, n_clouds,
-            pr.longest1, r1, J1, states, st, pr.rbegin1);
+        const bool both_grids = pr.edge_map->index.start && pr.surface_map->index.start;
+        if (both_grids) {
+          // the searches of both kinds in one launch, one wave per query; then the rows, one thread per query
+          const lfx::RowsOfKind e{pr.edge_map->index, reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3,
+            pr.rbegin3, nbr3};
+          const lfx::RowsOfKind f{pr.surface_map->index, reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1,
+            r1, J1, pr.rbegin1, nbr1};
+          if (pr.longest3 + pr.longest1) {
+            const uint32_t w3 = (pr.longest3 + lfx::kSearchWaves - 1u) / lfx::kSearchWaves, w1 = (pr.longest1 + lfx::kSearchWaves - 1u) / lfx::kSearchWaves;
+            hipLaunchKernelGGL(lfx::map_search_kernel, dim3(w3 + w1, n_clouds), dim3(64 * lfx::kSearchWaves), 0, st, e, f, w3,
+              pr.n_neighbors, states);
+            const uint32_t g3 = (pr.longest3 + lfx::kRowThreads - 1u) / lfx::kRowThreads, g1 = (pr.longest1 + lfx::kRowThreads - 1u) / lfx::kRowThreads;
+            hipLaunchKernelGGL(lfx::rows_from_neighbours_kernel, dim3(g3 + g1, n_clouds), dim3(lfx::kRowThreads), 0, st, e, f, g3,
+              pr.n_neighbors, states);
+          }
+        } else {
+          if (pr.longest3) {
+            launch_rows(false, pr.edge_map->index, none, pr.n_neighbors, pr.edge_points, pr.begin3, pr.count3, pr.stride3, n_clouds,
+              pr.longest3, r3, J3, states, st, pr.rbegin3);
+          }
+          if (pr.longest1) {
+            launch_rows(true, pr.surface_map->index, none, pr.n_neighbors, pr.surface_points, pr.begin1, pr.count1, pr.stride1, n_clouds,
+              pr.longest1, r1, J1, states, st, pr.rbegin1);
+          }
         }
       }
+      // (the step kernels only address rows)
+      const uint32_t * rb3 = pr.rbegin3 ? pr.rbegin3 : pr.begin3, * rb1 = pr.rbegin1 ? pr.rbegin1 : pr.begin1;
+      hipLaunchKernelGGL(lfx::align_scale_kernel, dim3(n_clouds), dim3(lfx::kScaleThreads), 0, st, states, iter, r3, rb3, pr.count3,
+        pr.stride3, r1, rb1, pr.count1, pr.stride1, d_weights, d_active, d_out);
+      hipLaunchKernelGGL(lfx::align_update_kernel, dim3(lfx::kAlignSlices, n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter,
+        max_iter, r3, J3, rb3, pr.count3, pr.stride3, r1, J1, rb1, pr.count1, pr.stride1, d_weights, d_partials, d_tickets,
+        d_active, d_out);
+    };
+  // As many iterations as the previous call needed are queued at once (a finished scan's kernels return at once, but a launch
+  // is a launch); only then does the host look -- at the records in its own memory -- and, where a scan still iterates,
+  // goes on one iteration at a time.
+  int launched = 0, target = std::min(max_iter, std::max(1, c->align_guess));
+  for (;;) {
+    for (; launched < target; launched++) {iteration(launched);}
+    LFX_HIP(c, hipGetLastError());
+    // the wait: on the records themselves first (the thread that ends a scan sets `done` behind a system-scope fence; a
+    // blocking wait on the stream wakes 30-50 us late, a third of what a whole scan's alignment takes), then until the stream
+    // has drained what was queued behind them
+    auto all_done = [&]() {
+        for (uint32_t s = 0; s < n_clouds; s++) {if (out[s].done == 0) {return false;}}
+        return true;
+      };
+    hipError_t q = hipErrorNotReady;
+    for (uint32_t spins = 0; q == hipErrorNotReady; spins++) {
+      if (all_done() || (spins & 63u) == 63u) {q = hipStreamQuery(st);}
+      if (spins > (1u << 24)) {q = hipStreamSynchronize(st);}         // (seconds: something else holds the stream)
     }
-    // (the step kernels only address rows)
-    const uint32_t * rb3 = pr.rbegin3 ? pr.rbegin3 : pr.begin3, * rb1 = pr.rbegin1 ? pr.rbegin1 : pr.begin1;
-    hipLaunchKernelGGL(lfx::align_scale_kernel, dim3(n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter, r3, rb3, pr.count3,
-      pr.stride3, r1, rb1, pr.count1, pr.stride1, d_weights, d_active);
-    hipLaunchKernelGGL(lfx::align_update_kernel, dim3(lfx::kAlignSlices, n_clouds), dim3(lfx::kAlignThreads), 0, st, states, iter,
-      max_iter, r3, J3, rb3, pr.count3, pr.stride3, r1, J1, rb1, pr.count1, pr.stride1, d_weights, d_partials, d_tickets,
-      d_active);
-    // the kernels of a finished scan return at once, but a launch is a launch: now and then ask whether any scan still iterates
-    if ((iter == 2 || iter == 4 || iter == 7 || iter == 11 || iter == 15) && iter + 1 < max_iter) {
-      uint32_t * active = reinterpret_cast<uint32_t *>(c->h_align.p + h_active_at);
-      LFX_HIP(c, hipMemcpyAsync(active, d_active, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      LFX_HIP(c, hipStreamSynchronize(st));
-      if (*active == 0) {break;}
-    }
+    LFX_HIP(c, q);
+    if (all_done()) {break;}
+    if (launched >= max_iter) {return fail(c, LFX_ERR_HIP, "the alignment did not finish within its iterations");}   // (cannot happen)
+    target = launched + 1;
   }
-  LFX_HIP(c, hipGetLastError());
-  const lfx::AlignState * h = reinterpret_cast<const lfx::AlignState *>(c->h_align.p + h_states_at);
-  LFX_HIP(c, hipMemcpyAsync(c->h_align.p + h_states_at, states, sizeof(lfx::AlignState) * n_clouds, hipMemcpyDeviceToHost, st));
-  LFX_HIP(c, hipStreamSynchronize(st));
+  int needed = 1;
   for (uint32_t s = 0; s < n_clouds; s++) {
-    for (int i = 0; i < 12; i++) {results[s].pose[i] = h[s].pose.m[i];}
-    results[s].error = h[s].error; results[s].error_scale = h[s].scale;
-    results[s].iteration = h[s].iteration; results[s].code = h[s].code;
+    for (int i = 0; i < 12; i++) {results[s].pose[i] = out[s].pose[i];}
+    results[s].error = out[s].error; results[s].error_scale = out[s].scale;
+    results[s].iteration = out[s].iteration; results[s].code = out[s].code;
+    needed = std::max(needed, std::min(out[s].iteration + 1, max_iter));
   }
+  c->align_guess = needed;
   return LFX_OK;
 }
 }  // namespace
@@ -469,35 +490,50 @@ int lfx_localize_batch(
   uint32_t * d_row3 = down_status + batch, * d_row1 = d_row3 + batch;
   const int rc = lfx_downsample_surface(c, surface_leaf, down, down_count, down_status, stream);
   if (rc != LFX_OK) {return rc;}
-  // where PCL gives the cloud back unfiltered (leaf too small for its extent) the rows are built from all surface points
-  hipLaunchKernelGGL(lfx::downsample_passthrough_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream),
-    reinterpret_cast<const float4 *>(c->surf_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoSurface, 4u,
-    reinterpret_cast<float4 *>(down), down_count, down_status);
-  // the longest edge cloud and the longest downsampled surface cloud size the launches (and choose between one query per
-  // thread and one per wave): two small copies, and the call is synchronous anyway
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // (the pinned block as run_align lays it out -- poses | states | counter | 20 spare bytes per scan --, reserved here so that
-  // it does not move later: the row starts go into the spare part, which run_align does not touch, and are still being
-  // read by the copy queued below when run_align writes the poses at the front)
-  const size_t spare_at = 96 * (size_t)batch + sizeof(lfx::AlignState) * (size_t)batch + 16;
-  LFX_HIP(c, c->h_align.reserve(spare_at + 20 * (size_t)batch));
-  uint32_t * info = reinterpret_cast<uint32_t *>(c->h_align.p), * down_n = info + 4 * (size_t)batch;
-  uint32_t * rows = reinterpret_cast<uint32_t *>(c->h_align.p + spare_at);
-  LFX_HIP(c, hipMemcpyAsync(info, c->scan_info.p, sizeof(uint32_t) * 4 * batch, hipMemcpyDeviceToHost, st));
-  LFX_HIP(c, hipMemcpyAsync(down_n, down_count, sizeof(uint32_t) * batch, hipMemcpyDeviceToHost, st));
+  // A few scans: nothing is asked of the device before the alignment.  The rows' scratch is sized by a bound (a scan has no
+  // more edge points, and no more surface points, than points: 400 bytes per input point), the rows of scan s start where
+  // its points do, and the launches are sized by the previous call's longest clouds (the kernels stride over what there is).
+  const bool by_bound = 400u * total <= ((size_t)512 << 20);
+  LFX_HIP(c, c->h_loc.reserve(8 * (size_t)batch));
+  volatile uint32_t * lengths = reinterpret_cast<volatile uint32_t *>(c->h_loc.p);
+  void * d_lengths = nullptr;
+  LFX_HIP(c, hipHostGetDevicePointer(&d_lengths, c->h_loc.p, 0));
+  // where PCL gives the cloud back unfiltered (leaf too small for its extent) the rows are built from all surface points
+  hipLaunchKernelGGL(lfx::downsample_passthrough_kernel, dim3(batch), dim3(256), 0, st,
+    reinterpret_cast<const float4 *>(c->surf_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoSurface, 4u,
+    reinterpret_cast<float4 *>(down), down_count, down_status, c->scan_info.p + lfx::kInfoEdge, static_cast<uint32_t *>(d_lengths));
+  auto remember = [&]() {
+      uint32_t e = 0, f = 0;
+      for (uint32_t s = 0; s < batch; s++) {e = std::max(e, (uint32_t)lengths[2 * s]); f = std::max(f, (uint32_t)lengths[2 * s + 1]);}
+      c->loc_guess[0] = e; c->loc_guess[1] = f;
+    };
+  if (by_bound) {
+    const uint32_t guess3 = c->loc_guess[0] ? c->loc_guess[0] + c->loc_guess[0] / 8u : 4096u;
+    const uint32_t guess1 = c->loc_guess[1] ? c->loc_guess[1] + c->loc_guess[1] / 8u : 2048u;
+    const int ra = align_clouds(c, edge_map, surface_map, n_neighbors, max_iter,
+      reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, guess3, total,
+      down, c->scan_begin.p, down_count, 1, guess1, total, batch, initial_poses, results, stream, nullptr, nullptr);
+    if (ra == LFX_OK) {remember();}
+    return ra;
+  }
+  // Many scans: the clouds' real lengths first (one wait), so that the rows are packed -- scan s's rows start at the number of
+  // edge (downsampled surface) points of the scans before it, 400 bytes per row of a few thousand rows per scan instead of
+  // per input point
   LFX_HIP(c, hipStreamSynchronize(st));
-  // The clouds of scan s start at its first input point; their ROWS are packed: scan s's rows start at the number of edge
-  // (downsampled surface) points of the scans before it, so that the scratch (272 bytes per row) is sized by the clouds'
-  // real lengths -- a few thousand rows per scan -- not by the 115 200 input points per scan they are spread over.
+  LFX_HIP(c, c->h_align.reserve(8 * (size_t)batch));
+  uint32_t * rows = reinterpret_cast<uint32_t *>(c->h_align.p);
   uint32_t longest_edge = 0, longest_surface = 0;
   size_t rows3 = 0, rows1 = 0;
   for (uint32_t s = 0; s < batch; s++) {
     rows[s] = (uint32_t)rows3; rows[batch + s] = (uint32_t)rows1;
-    rows3 += info[4 * s + lfx::kInfoEdge]; rows1 += down_n[s];
-    longest_edge = std::max(longest_edge, info[4 * s + lfx::kInfoEdge]);
-    longest_surface = std::max(longest_surface, down_n[s]);
+    rows3 += lengths[2 * s]; rows1 += lengths[2 * s + 1];
+    longest_edge = std::max(longest_edge, (uint32_t)lengths[2 * s]);
+    longest_surface = std::max(longest_surface, (uint32_t)lengths[2 * s + 1]);
   }
+  c->loc_guess[0] = longest_edge; c->loc_guess[1] = longest_surface;
   LFX_HIP(c, hipMemcpyAsync(d_row3, rows, sizeof(uint32_t) * 2 * batch, hipMemcpyHostToDevice, st));
+  LFX_HIP(c, hipStreamSynchronize(st));              // (run_align lays its own records over the pinned block)
   return align_clouds(c, edge_map, surface_map, n_neighbors, max_iter,
            reinterpret_cast<const float *>(c->edge_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoEdge, 4, longest_edge, rows3,
            down, c->scan_begin.p, down_count, 1, longest_surface, rows1, batch, initial_poses, results, stream, d_row3, d_row1);
@@ -537,7 +573,7 @@ int lfx_localize_host(
     const int rc = lfx_voxel_downsample(c, d_surface, d_words, d_words + 2, 1, 1, ns, surface_leaf, d_down, d_words + 3, d_words + 4, stream);
     if (rc != LFX_OK) {return rc;}
     hipLaunchKernelGGL(lfx::downsample_passthrough_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float4 *>(d_surface),
-      d_words, d_words + 2, 1u, reinterpret_cast<float4 *>(d_down), d_words + 3, d_words + 4);
+      d_words, d_words + 2, 1u, reinterpret_cast<float4 *>(d_down), d_words + 3, d_words + 4, d_words + 1, static_cast<uint32_t *>(nullptr));
     LFX_HIP(c, hipMemcpyAsync(h_words + 3, d_words + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     LFX_HIP(c, hipStreamSynchronize(st));
     n_down = h_words[3];
