@@ -24,7 +24,15 @@ int lfx_voxel_downsample(
     }
   }
   uint32_t * w = c->vox_scratch.p;
-  hipLaunchKernelGGL(lfx::voxel_downsample_kernel, dim3(n_clouds), dim3(lfx::kVoxThreads), 0, static_cast<hipStream_t>(stream),
+  // the small-cloud form's ranking table (96 KB), then its sorted points (144 KB) in LDS: more than a kernel gets without asking
+  constexpr size_t table_bytes = (size_t)lfx::kVoxItems * lfx::kVoxThreads * 3 * sizeof(float);
+  static_assert(table_bytes >= (size_t)lfx::kVoxItems * (lfx::kVoxThreads / 64) * 256 * sizeof(uint16_t), "the table fits where the points go");
+  if (!c->vox_lds_asked) {
+    LFX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lfx::voxel_downsample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (int)table_bytes));
+    c->vox_lds_asked = true;
+  }
+  hipLaunchKernelGGL(lfx::voxel_downsample_kernel, dim3(n_clouds), dim3(lfx::kVoxThreads), table_bytes, static_cast<hipStream_t>(stream),
     reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, leaf, w, w + total_points, w + 2 * total_points,
     w + 3 * total_points, reinterpret_cast<float4 *>(d_out), d_out_count, d_status);
   LFX_HIP(c, hipGetLastError());

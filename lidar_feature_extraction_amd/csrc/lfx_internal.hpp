@@ -136,6 +136,7 @@ struct lfx_ctx
   lfx_host::DevBuf<float> align_surface;           // lfx_localize_batch: the downsampled surface clouds (+ counts, status)
   lfx_host::PinnedBuf h_align;                     // the alignment's small copies to and from the host (poses, counts, states)
   lfx_host::PinnedBuf h_loc;                       // lfx_localize_batch: the clouds' lengths as the device saw them, [batch][2]
+  bool vox_lds_asked = false;                      // the voxel-grid kernel has been granted its 144 KB of dynamic LDS on this device
   int align_guess = 4;                             // iterations the previous alignment needed: so many are queued before the host looks
   uint32_t loc_guess[2] = {0u, 0u};                // longest edge / downsampled surface cloud of the previous lfx_localize_batch
 

@@ -16,7 +16,40 @@ namespace lfx
 // One workgroup per cloud: bounds -> cell index per point -> stable LSD radix sort of (cell, point) by 8-bit digits
 // (stable, so the points of a cell stay in input order: PCL leaves that order to an unstable sort, here it is defined)
 // -> cell heads -> one thread per cell sums its points in that order.  Scratch: two (key, value) arrays per point.
-constexpr int kVoxThreads = 1024;
+constexpr int kVoxThreads = 1024, kVoxItems = 12;
+
+// bounds of the cloud (per-wave minima and maxima in red[0..2][w], red[3..5][w]) -> geo: min cell x, y, z; multipliers of y, z;
+// radix passes; leaf too small
+__device__ inline void voxel_geometry(const float (*red)[kVoxThreads / 64], int W, float inv, int * geo)
+{
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; a++) {
+    lo[a] = red[a][0]; hi[a] = red[3 + a][0];
+    for (int w = 1; w < W; w++) {lo[a] = fminf(lo[a], red[a][w]); hi[a] = fmaxf(hi[a], red[3 + a][w]);}
+  }
+  const long long dx = (long long)((hi[0] - lo[0]) * inv) + 1, dy = (long long)((hi[1] - lo[1]) * inv) + 1,
+    dz = (long long)((hi[2] - lo[2]) * inv) + 1;
+  // PCL: "leaf size is too small for the input dataset" (also catches non-finite bounds); factor by factor, three extents of
+  // a few million cells overflow 64 bits
+  const long long lim = 2147483647LL;
+  int bad = !(dx >= 1 && dy >= 1 && dz >= 1 && dx <= lim && dy <= lim && dz <= lim && dx * dy <= lim && dx * dy * dz <= lim);
+  int min_b[3], div_b[3];
+  for (int a = 0; a < 3; a++) {
+    min_b[a] = (int)floorf(lo[a] * inv);
+    div_b[a] = (int)floorf(hi[a] * inv) - min_b[a] + 1;
+  }
+  long long cells = 0;
+  if (!bad && div_b[0] > 0 && div_b[1] > 0 && div_b[2] > 0 && (long long)div_b[0] * div_b[1] <= lim) {
+    cells = (long long)div_b[0] * div_b[1] * div_b[2];
+  }
+  if (!(cells > 0 && cells <= lim)) {bad = 1;}
+  const uint32_t maxkey = bad ? 0u : (uint32_t)(cells - 1);
+  geo[0] = min_b[0]; geo[1] = min_b[1]; geo[2] = min_b[2];
+  geo[3] = div_b[0]; geo[4] = div_b[0] * div_b[1];
+  geo[5] = maxkey == 0u ? 1 : (32 - __clz((int)maxkey) + 7) / 8;
+  geo[6] = bad;
+  }
+
 __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
   const float4 * __restrict__ pts, const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count,
   uint32_t count_stride, float leaf, uint32_t * __restrict__ key_a, uint32_t * __restrict__ key_b,
@@ -30,11 +63,176 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
   __shared__ int geo[8];                      // min cell x, y, z; multipliers of y, z; radix passes; leaf too small
   __shared__ uint32_t hist[256], base[256], wtot[W];
   __shared__ uint16_t wcnt[W][256];
+  extern __shared__ uint16_t table[];         // [tiles of the cloud][W][256], then the sorted points: the form for clouds of up to kVoxItems * T points
   if (n == 0) {
     if (tid == 0) {out_count[s] = 0; status[s] = 0;}
     return;
   }
   const float inv = 1.0f / leaf;              // inverse_leaf_size_
+  if (n <= (uint32_t)(kVoxItems * T)) {
+    // ---- A cloud of up to 12 288 points (a scan's surface cloud): the same steps with each thread's points and sort items in
+    // registers -- every pass over the cloud is ONE round trip to memory with all its loads in flight, where the general
+    // form below pays one per 1 024 points (its loops wait for each load: 110 round trips, 72 us for 10 000 points).
+    constexpr int VI = kVoxItems;
+    float4 p[VI];
+#pragma unroll
+    for (int t = 0; t < VI; t++) {
+      const uint32_t i = (uint32_t)t * T + tid;
+      p[t] = pts[b + (i < n ? i : 0u)];
+    }
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int t = 0; t < VI; t++) {
+      const uint32_t i = (uint32_t)t * T + tid;
+      if (i < n) {
+        mn[0] = fminf(mn[0], p[t].x); mn[1] = fminf(mn[1], p[t].y); mn[2] = fminf(mn[2], p[t].z);
+        mx[0] = fmaxf(mx[0], p[t].x); mx[1] = fmaxf(mx[1], p[t].y); mx[2] = fmaxf(mx[2], p[t].z);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      for (int o = 32; o > 0; o >>= 1) {
+        mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+        mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+      }
+      if (lane == 0) {red[a][wave] = mn[a]; red[3 + a][wave] = mx[a];}
+    }
+    __syncthreads();
+    if (tid == 0) {voxel_geometry(red, W, inv, geo);}
+    __syncthreads();
+    if (geo[6]) {
+      if (tid == 0) {out_count[s] = 0; status[s] = 1;}
+      return;
+    }
+    const float fb0 = (float)geo[0], fb1 = (float)geo[1], fb2 = (float)geo[2];
+    const int mul1 = geo[3], mul2 = geo[4], passes = geo[5];
+    uint32_t k[VI], v[VI];
+#pragma unroll
+    for (int t = 0; t < VI; t++) {
+      const int i0 = (int)(floorf(p[t].x * inv) - fb0), i1 = (int)(floorf(p[t].y * inv) - fb1), i2 = (int)(floorf(p[t].z * inv) - fb2);
+      k[t] = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+      v[t] = (uint32_t)t * T + tid;
+    }
+    uint32_t * ks = key_a, * kd = key_b, * vs = val_a, * vd = val_b;
+    for (int pass = 0; pass < passes; pass++) {
+      const int shift = 8 * pass;
+      if (pass > 0) {                                            // what the previous pass wrote, all of it at once
+#pragma unroll
+        for (int t = 0; t < VI; t++) {
+          const uint32_t i = (uint32_t)t * T + tid;
+          k[t] = ks[b + (i < n ? i : 0u)]; v[t] = vs[b + (i < n ? i : 0u)];
+        }
+      }
+      // every tile's ranking at once: table[(tile, wave)][digit] = points of that digit in that wave of that tile (the waves'
+      // ballots, as below), then ONE walk per digit over the (tile, wave) pairs in order turns the counts into the places
+      // where each group starts inside its digit and leaves the digit's total -- four barriers per pass where a barrier-
+      // ridden loop over the tiles took four per tile
+      const uint32_t n_tiles = (n + T - 1) / T;
+      for (uint32_t z = tid; z < n_tiles * W * 128u; z += T) {reinterpret_cast<uint32_t *>(table)[z] = 0u;}
+      __syncthreads();
+      uint32_t rank[VI], dig[VI];
+#pragma unroll
+      for (int t = 0; t < VI; t++) {
+        rank[t] = 0u; dig[t] = 256u;
+        if ((uint32_t)t * T >= n) {continue;}                  // (the same in every thread)
+        const bool valid = (uint32_t)t * T + tid < n;
+        const uint32_t d = valid ? (k[t] >> shift) & 255u : 256u;
+        uint64_t peers = ~0ull;
+#pragma unroll
+        for (int bit = 0; bit < 9; bit++) {
+          const bool set = (d >> bit) & 1u;
+          const uint64_t m = __ballot(set);
+          peers &= set ? m : ~m;
+        }
+        rank[t] = __popcll(peers & ((1ull << lane) - 1ull));
+        dig[t] = d;
+        if (valid && rank[t] == 0) {table[((uint32_t)t * W + wave) * 256u + d] = (uint16_t)__popcll(peers);}
+      }
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t acc = 0;
+        const uint32_t groups = n_tiles * W;
+#pragma unroll 8
+        for (uint32_t g = 0; g < groups; g++) {
+          const uint32_t c = table[g * 256u + tid];
+          table[g * 256u + tid] = (uint16_t)acc;
+          acc += c;
+        }
+        hist[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < 64) {                                           // exclusive scan of the 256 bins by one wave, four bins per lane
+        const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        uint32_t incl = h0 + h1 + h2 + h3;
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = __shfl_up(incl, d);
+          if ((int)tid >= d) {incl += t;}
+        }
+        const uint32_t ex = incl - (h0 + h1 + h2 + h3);
+        base[4 * tid] = ex; base[4 * tid + 1] = ex + h0; base[4 * tid + 2] = ex + h0 + h1; base[4 * tid + 3] = ex + h0 + h1 + h2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < VI; t++) {
+        if (dig[t] < 256u) {
+          const uint32_t pos = base[dig[t]] + table[((uint32_t)t * W + wave) * 256u + dig[t]] + rank[t];
+          kd[b + pos] = k[t];
+          vd[b + pos] = v[t];
+        }
+      }
+      __syncthreads();
+      uint32_t * t_ = ks; ks = kd; kd = t_;
+      t_ = vs; vs = vd; vd = t_;
+    }
+    // ---- the sorted keys with their predecessors, and the points in sorted order (two round trips)
+    uint32_t kp[VI];
+#pragma unroll
+    for (int t = 0; t < VI; t++) {
+      const uint32_t i = (uint32_t)t * T + tid, ii = i < n ? i : 0u;
+      k[t] = ks[b + ii]; kp[t] = ks[b + (ii ? ii - 1u : 0u)]; v[t] = vs[b + ii];
+    }
+#pragma unroll
+    for (int t = 0; t < VI; t++) {p[t] = pts[b + v[t]];}
+    // (the ranking table is done with: its place in LDS takes the points in sorted order, x y z planes)
+    float * sx_l = reinterpret_cast<float *>(table), * sy_l = sx_l + VI * T, * sz_l = sy_l + VI * T;
+#pragma unroll
+    for (int t = 0; t < VI; t++) {
+      const uint32_t i = (uint32_t)t * T + tid;
+      if (i < n) {sx_l[i] = p[t].x; sy_l[i] = p[t].y; sz_l[i] = p[t].z;}
+    }
+    // ---- cell heads
+    uint32_t cells_before = 0;
+#pragma unroll
+    for (int t = 0; t < VI; t++) {
+      if ((uint32_t)t * T >= n) {continue;}
+      const uint32_t i = (uint32_t)t * T + tid;
+      const bool head = i < n && (i == 0 || k[t] != kp[t]);
+      const uint64_t hm = __ballot(head);
+      if (lane == 0) {wtot[wave] = __popcll(hm);}
+      __syncthreads();
+      uint32_t before = cells_before, total = 0;
+      for (int w = 0; w < W; w++) {
+        if (w < (int)wave) {before += wtot[w];}
+        total += wtot[w];
+      }
+      if (head) {kd[b + before + __popcll(hm & ((1ull << lane) - 1ull))] = i;}
+      cells_before += total;
+      __syncthreads();
+    }
+    const uint32_t m = cells_before;
+    __syncthreads();
+    // ---- centroids: the points of a cell in input order (AccumulatorXYZ: float sums, then / count), out of LDS: a cell of
+    // a few hundred points near the sensor is a few hundred LDS reads for its thread, not as many trips to memory
+    for (uint32_t c = tid; c < m; c += T) {
+      const uint32_t a = kd[b + c], e = c + 1 < m ? kd[b + c + 1] : n;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      for (uint32_t j = a; j < e; j++) {sx += sx_l[j]; sy += sy_l[j]; sz += sz_l[j];}
+      const float cnt = (float)(e - a);
+      out[b + c] = make_float4(sx / cnt, sy / cnt, sz / cnt, 1.0f);
+    }
+    if (tid == 0) {out_count[s] = m; status[s] = 0;}
+    return;
+  }
   // ---- bounds (getMinMax3D)
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (uint32_t i = tid; i < n; i += T) {
@@ -51,34 +249,7 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
     if (lane == 0) {red[a][wave] = mn[a]; red[3 + a][wave] = mx[a];}
   }
   __syncthreads();
-  if (tid == 0) {
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; a++) {
-      lo[a] = red[a][0]; hi[a] = red[3 + a][0];
-      for (int w = 1; w < W; w++) {lo[a] = fminf(lo[a], red[a][w]); hi[a] = fmaxf(hi[a], red[3 + a][w]);}
-    }
-    const long long dx = (long long)((hi[0] - lo[0]) * inv) + 1, dy = (long long)((hi[1] - lo[1]) * inv) + 1,
-      dz = (long long)((hi[2] - lo[2]) * inv) + 1;
-    // PCL: "leaf size is too small for the input dataset" (also catches non-finite bounds); factor by factor, three extents of
-    // a few million cells overflow 64 bits
-    const long long lim = 2147483647LL;
-    int bad = !(dx >= 1 && dy >= 1 && dz >= 1 && dx <= lim && dy <= lim && dz <= lim && dx * dy <= lim && dx * dy * dz <= lim);
-    int min_b[3], div_b[3];
-    for (int a = 0; a < 3; a++) {
-      min_b[a] = (int)floorf(lo[a] * inv);
-      div_b[a] = (int)floorf(hi[a] * inv) - min_b[a] + 1;
-    }
-    long long cells = 0;
-    if (!bad && div_b[0] > 0 && div_b[1] > 0 && div_b[2] > 0 && (long long)div_b[0] * div_b[1] <= lim) {
-      cells = (long long)div_b[0] * div_b[1] * div_b[2];
-    }
-    if (!(cells > 0 && cells <= lim)) {bad = 1;}
-    const uint32_t maxkey = bad ? 0u : (uint32_t)(cells - 1);
-    geo[0] = min_b[0]; geo[1] = min_b[1]; geo[2] = min_b[2];
-    geo[3] = div_b[0]; geo[4] = div_b[0] * div_b[1];
-    geo[5] = maxkey == 0u ? 1 : (32 - __clz((int)maxkey) + 7) / 8;
-    geo[6] = bad;
-  }
+  if (tid == 0) {voxel_geometry(red, W, inv, geo);}
   __syncthreads();
   if (geo[6]) {
     if (tid == 0) {out_count[s] = 0; status[s] = 1;}

@@ -248,14 +248,8 @@ __device__ __forceinline__ void wave_sort_steps(double & d, uint32_t & orig, uin
 // (Measured against one query per thread -- lists in registers with batched insertion, or heaps in LDS: a thread inserts
 // for a few points in a hundred, but some thread of 64 does at nearly every point, so the wave paid the insertion at every
 // point; this form was 2-4x faster from one scan to 64 and level at 256, and it is the only one kept.)
-#ifdef LFX_SEARCH_STAMPS
-#define LFX_SS(...) __VA_ARGS__
-#else
-#define LFX_SS(...)
-#endif
 __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, uint32_t kk, double & ldist, uint32_t & lidx)
 {
-  LFX_SS(const unsigned long long ss_t0 = __builtin_amdgcn_s_memtime(); unsigned long long ss_t1 = 0; uint32_t ss_runs = 0, ss_steps = 0, ss_cand = 0, ss_single = 0, ss_bulk = 0, ss_pass = 0;)
   constexpr int KM = kNearestMax;
   const int lane = threadIdx.x & 63;
   GridCube cube;
@@ -270,9 +264,7 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
     double bar = wave_read(ldist, KM - 1);
     uint32_t bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
     auto run = [&](uint32_t a, uint32_t b) __attribute__((always_inline)) {
-        LFX_SS(ss_runs++; ss_cand += b - a;)
         for (uint32_t base = a; base < b; base += 64u * kGridUnroll) {
-          LFX_SS(ss_steps++;)
           float4 mpts[kGridUnroll];
 #pragma unroll
           for (int u = 0; u < kGridUnroll; u++) {
@@ -290,7 +282,6 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
             const uint32_t orig = __float_as_uint(mpt.w);
             uint64_t pass = __ballot(live && (d < bar || (d == bar && orig < bar_orig)));
             if (__popcll(pass) >= kBulkInsert) {
-              LFX_SS(ss_bulk++;)
               // many at once (the first points of a query, before there is a bar worth the name): sort the 64 of them, merge
               // their 16 smallest with the list -- the cost of about eight single insertions, whatever their number
               const bool mine = ((pass >> lane) & 1ull) != 0ull;
@@ -310,7 +301,6 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
               pass = 0;
             }
             while (pass) {
-              LFX_SS(ss_single++;)
               const int src = __ffsll((unsigned long long)pass) - 1;
               pass &= pass - 1;
               const double cd = wave_read(d, src);
@@ -349,7 +339,6 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
       const double gy = fmax(fmax(y0 - cube.uy, cube.uy - (y0 + 1.)) - 1e-7, 0.), gz = fmax(fmax(z0 - cube.uz, cube.uz - (z0 + 1.)) - 1e-7, 0.);
       const double far2 = (gy * gy + gz * gz) * (mi.h * mi.h);
       uint64_t todo = __ballot(has && a != b);
-      LFX_SS(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ss_t1 = __builtin_amdgcn_s_memtime(); ss_pass++;)
       while (todo) {
         double m = ((todo >> lane) & 1ull) ? far2 : INFINITY;
 #pragma unroll
@@ -369,10 +358,6 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
       }
     }
     if (cube.done(mi, wave_read(ldist, (int)kk - 1))) {
-      LFX_SS(const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-      if (lane == 0 && blockIdx.y == 0 && t2 - ss_t0 > 50000ull) {
-        printf("SS x=%u rho=%d table=%llu total=%llu passes=%u runs=%u steps=%u cand=%u single=%u bulk=%u\n", blockIdx.x, cube.rho, ss_t1 - ss_t0, t2 - ss_t0, ss_pass, ss_runs, ss_steps, ss_cand, ss_single, ss_bulk);
-      })
       return;
     }
     cube.grow(mi);
@@ -573,18 +558,21 @@ __global__ __launch_bounds__(64 * kSearchWaves) void map_search_kernel(
   RowsOfKind edge, RowsOfKind surface, uint32_t x_edge /* workgroups of edge queries */, uint32_t k, const AlignState * __restrict__ align)
 {
   const uint32_t s = blockIdx.y;
-  if (align[s].done) {return;}
   const bool surf = blockIdx.x >= x_edge;
   const RowsOfKind & R = surf ? surface : edge;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  // (everything the wave needs before its first point, asked for at once: a wave's time is a chain of round trips to memory)
+  const int32_t done = align[s].done;
+  const MapPose P = align[s].pose;
   // (the launch is sized from what the host knows of the clouds' lengths -- a bound, or what the previous call saw: the
   // workgroups of a kind stride over its queries)
   const uint32_t n = R.count[(size_t)s * R.count_stride], stride = (surf ? gridDim.x - x_edge : x_edge) * kSearchWaves;
   const uint32_t b = R.begin[s], rb = R.row_begin ? R.row_begin[s] : b;
+  if (done) {return;}
   const uint32_t kk = k < (uint32_t)kNearestMax ? k : (uint32_t)kNearestMax;
   for (uint32_t i = (surf ? blockIdx.x - x_edge : blockIdx.x) * kSearchWaves + wave; i < n; i += stride) {
     const float4 pf = R.pts[b + i];
-    const D3 q = to_map(align[s].pose, D3{(double)pf.x, (double)pf.y, (double)pf.z});
+    const D3 q = to_map(P, D3{(double)pf.x, (double)pf.y, (double)pf.z});
     double ld;
     uint32_t li;
     nearest_in_grid_wave(R.mi, q, kk, ld, li);
@@ -1220,12 +1208,18 @@ __global__ __launch_bounds__(kScaleThreads) void align_scale_kernel(
   }
 }
 
-// align_update_kernel, kAlignSlices workgroups per scan: each sums the rows of its slice for WeightedUpdate (optimizer.cpp:
-// 40-64) -- one 1 x 7 row of a Jacobian with its residual at a time: the three rows of an edge residual lie one after the
-// other (J3 is [n3][3][7]), the surface rows follow; four rows per thread in flight, this loop is a chain of small loads
-// whose latency is its whole cost -- and leaves its 63 sums in `partials`; the workgroup that finishes last adds the slices
-// up in slice order and does the rest of the iteration on one thread: the stopping tests, CalcUpdate, the pose.
-constexpr int kAlignSlices = 8;
+// align_update_kernel, kAlignSlices workgroups per scan: the sums of WeightedUpdate (optimizer.cpp:40-64) -- D = sum J^T J,
+// A = sum w J^T J, b = sum w J^T r over the 1 x 7 rows of the scan's Jacobians (the three rows of an edge residual lie one
+// after the other and share a weight; the surface rows follow) -- as ONE product on the f64 matrix unit: four rows at a
+// time, v_mfma_f64_16x16x4_f64 with the left operand [J | 0 | w J | 0]^T (16 x 4) and the right operand [J | r | 0] (4 x 16)
+// accumulates D in rows 0-6, A in rows 8-14 and b in column 7 of rows 8-14 of its 16 x 16 tile: no accumulator per pair of
+// columns in every thread, and no reduction across lanes (63 sums x 6 shuffle steps were half of this kernel's time).
+// The waves' tiles are added in wave order, the slices' in slice order by the workgroup that finishes last, which then
+// does the rest of the iteration on one thread: CalcUpdate, the pose, the last two stopping tests.
+// (Operand and result lanes of the f64 form: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C[row = (lane >> 4) + 4 reg][col = lane & 15], i.e. element reg * 64 + lane of a wave's result is C[16 row + col].)
+constexpr int kAlignSlices = 16, kAlignTile = 256;
+typedef double lfx_f64x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   AlignState * __restrict__ states, int iter, int max_iter,
   const double * __restrict__ r3, const double * __restrict__ J3, const uint32_t * __restrict__ begin3,
@@ -1234,69 +1228,61 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   const uint32_t * __restrict__ count1, uint32_t stride1, const double * __restrict__ weights, double * __restrict__ partials,
   uint32_t * __restrict__ tickets, uint32_t * __restrict__ active, AlignOut * __restrict__ out)
 {
-  constexpr int T = kAlignThreads, NS = 64, G = kAlignSlices;   // 28 (D) + 28 (A) upper triangles + 7 (b) (+ 1 unused)
+  constexpr int T = kAlignThreads, W = T / 64, NS = kAlignTile, G = kAlignSlices;
+  static_assert(T == NS, "one thread per element of the tile in the sums across waves and slices");
   const uint32_t s = blockIdx.y, g = blockIdx.x;
   const int tid = threadIdx.x;
   AlignState & st = states[s];
   if (st.done) {return;}
-  __shared__ double part[T / 64][NS];
+  __shared__ double part[W][NS];
   __shared__ double total[NS];
   __shared__ uint32_t last;
   const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u;
   const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
   const double * key = weights + (size_t)b3 + b1;
-  double acc[NS];
-#pragma unroll
-  for (int a = 0; a < NS; a++) {acc[a] = 0.;}
+  const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6), lane = (uint32_t)tid & 63u;
+  lfx_f64x4 acc = {0., 0., 0., 0.};
   {
-    const uint32_t m3 = 3u * n3, m_all = m3 + n1;
+    const uint32_t m3 = 3u * n3, m_all = m3 + n1, groups = (m_all + 3u) / 4u;
     const double * Je = J3 + 21 * (size_t)b3, * re = r3 + 3 * (size_t)b3;
     const double * Js = J1 + 7 * (size_t)b1, * rs = r1 + (size_t)b1;
-    constexpr int U = 4;
-    for (uint32_t base = g * T + tid; base < m_all; base += U * G * T) {
-      double row[U][7], rk[U], w[U];
+    const uint32_t k = lane >> 4, c = lane & 15u;
+    const bool plain = c < 7u, weighted = c >= 8u && c < 15u;
+    const uint32_t jc = plain ? c : (weighted ? c - 8u : 0u);          // the column of J this lane reads
+    // (the loads of U groups are issued before the first product: a loop of one round trip to memory per step otherwise)
+    constexpr int U = 12;
+    for (uint32_t g0 = g * W + wave; g0 < groups; g0 += U * G * W) {
+      double x[U], wv[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const uint32_t m = base + u * G * T;
+        const uint32_t m = 4u * (g0 + (uint32_t)u * G * W) + k;
         const bool live = m < m_all;
-        const uint32_t mm = live ? m : m_all - 1u;
+        const uint32_t mm = live ? m : 0u;
         const bool edge = mm < m3;
         const double * J = edge ? Je + 7 * (size_t)mm : Js + 7 * (size_t)(mm - m3);
-#pragma unroll
-        for (int a = 0; a < 7; a++) {row[u][a] = live ? J[a] : 0.;}
-        rk[u] = live ? (edge ? re[mm] : rs[mm - m3]) : 0.;
-        w[u] = live ? key[edge ? mm / 3u : n3 + (mm - m3)] : 0.;
+        const double * R = edge ? re + mm : rs + (mm - m3);
+        // (every lane loads -- a lane with nothing to fetch reads row 0 -- and what it read is masked afterwards: loads under
+        // a condition are waited for one by one)
+        x[u] = *(c == 7u ? R : J + jc);                               // J[m][c] | r[m] | J[m][c - 8]
+        wv[u] = key[edge ? mm / 3u : n3 + (mm - m3)];
+        x[u] = live && c != 15u ? x[u] : 0.;
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        int at = 0;
-#pragma unroll
-        for (int a = 0; a < 7; a++) {
-#pragma unroll
-          for (int c = a; c < 7; c++) {
-            const double jj = row[u][a] * row[u][c];
-            acc[at] += jj;
-            acc[28 + at] += w[u] * jj;
-            at++;
-          }
-          acc[56 + a] += w[u] * (row[u][a] * rk[u]);
-        }
+        const double a = plain ? x[u] : (weighted ? wv[u] * x[u] : 0.);
+        const double b = weighted ? 0. : x[u];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
     }
   }
-  // fixed-order tree: lanes of a wave, the waves, then (by the last workgroup) the slices
+  // fixed order: the waves of the workgroup, then (by the last workgroup) the slices
 #pragma unroll
-  for (int a = 0; a < NS; a++) {
-    double v = acc[a];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {v += __shfl_xor(v, off, 64);}
-    if ((tid & 63) == 0) {part[tid >> 6][a] = v;}
-  }
+  for (int r = 0; r < 4; r++) {part[wave][64 * r + lane] = acc[r];}
   __syncthreads();
   double * mine = partials + ((size_t)s * G + g) * NS;
-  if (tid < NS) {
+  {
     double v = 0.;
-    for (int wv = 0; wv < T / 64; wv++) {v += part[wv][tid];}
+    for (int wv = 0; wv < W; wv++) {v += part[wv][tid];}
     mine[tid] = v;
   }
   __threadfence();
@@ -1305,7 +1291,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   __syncthreads();
   if (last == 0u) {return;}
   __threadfence();
-  if (tid < NS) {
+  {
     const volatile double * all = partials + (size_t)s * G * NS;
     double v = 0.;
     for (int k = 0; k < G; k++) {v += all[(size_t)k * NS + tid];}
@@ -1316,16 +1302,12 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   tickets[s] = 0u;                                           // for the next iteration
   const double error = st.cur_error, scale = st.cur_scale;   // (both have passed align_scale_kernel's tests)
   double D[49], A[49], b[7];
-  {
-    int at = 0;
-    for (int a = 0; a < 7; a++) {
-      for (int c = a; c < 7; c++) {
-        D[7 * a + c] = total[at]; D[7 * c + a] = total[at];
-        A[7 * a + c] = total[28 + at]; A[7 * c + a] = total[28 + at];
-        at++;
-      }
-      b[a] = total[56 + a];
+  for (int a = 0; a < 7; a++) {                              // the upper triangles, mirrored
+    for (int c = a; c < 7; c++) {
+      D[7 * a + c] = total[16 * a + c]; D[7 * c + a] = total[16 * a + c];
+      A[7 * a + c] = total[16 * (8 + a) + c]; A[7 * c + a] = total[16 * (8 + a) + c];
     }
+    b[a] = total[16 * (8 + a) + 7];
   }
   double q[4] = {st.q[0], st.q[1], st.q[2], st.q[3]}, dq[4], dt[3];
   solve_update(q, D, A, b, dq, dt);

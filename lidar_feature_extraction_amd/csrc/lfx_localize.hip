@@ -275,7 +275,7 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   if (n_clouds > 65535u) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "at most 65535 scans per alignment call");}   // (a launch's y extent)
   const size_t state_d = sizeof(lfx::AlignState) / 8 * (size_t)n_clouds;
   const size_t rows = pr.total3 + pr.total1;
-  const size_t partial_d = (size_t)n_clouds * lfx::kAlignSlices * 64;
+  const size_t partial_d = (size_t)n_clouds * lfx::kAlignSlices * lfx::kAlignTile;
   const size_t nbr_d = (size_t)lfx::kNearestMax / 2 * rows;                   // the searches' results: 16 words per row
   const size_t need = state_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + nbr_d + (n_clouds + 1) / 2 + 9;
   if (c->align_scratch.n < need) {

@@ -217,6 +217,53 @@ def test_localize_batch_against_the_oracle(batch):
     fx.close()
 
 
+def test_localize_calls_in_a_row_and_both_ways_of_sizing_the_rows():
+    """lfx_localize_batch asks the device nothing before it aligns a few scans: launches sized by the previous call's clouds,
+    as many iterations queued as the previous call needed, rows laid out by a bound.  So: a call after a much smaller one
+    (short clouds, two iterations) must give what a fresh context gives; and a batch large enough for the other layout (the
+    clouds' lengths fetched first, rows packed) must give every scan what it gets alone -- bit for bit, the arithmetic of a
+    scan does not depend on its neighbours."""
+    import torch
+    from lidar_feature_extraction_amd import FeatureExtraction, concat, make_scan
+    rng = np.random.default_rng(77)
+    rings, cols, k = 32, 1024, 15
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    _, maps = _scene(rings, cols, [7590, 7591, 7592])
+    edge_map = np.ascontiguousarray(np.concatenate([m["edge_points"] for m in maps]), np.float32)
+    surf_map = np.ascontiguousarray(np.concatenate([m["surface_points"] for m in maps]), np.float32)
+    d_emap, d_smap = torch.from_numpy(edge_map).to(dev), torch.from_numpy(surf_map).to(dev)
+    full = [make_scan(rings, cols, seed=7600 + s) for s in range(8)]
+    small = full[0][:4 * cols].copy()                      # the first four columns' worth of points: a few features per ring
+    poses = np.stack([_pose(rng.normal(0, 0.004, 3), rng.normal(0, 0.03, 3)) for _ in range(8)])
+
+    def alone(fx, emap, smap, cloud, pose, max_iter=20):
+        d = torch.from_numpy(cloud.view(np.uint8).copy()).to(dev)
+        fx.extract_batch_device(d.data_ptr(), [len(cloud)], stream)
+        return fx.localize_batch(emap, smap, pose[None], k, max_iter, 1.0, stream)[0]
+
+    def same(a, b):
+        return a["pose"].tobytes() == b["pose"].tobytes() and (a["code"], a["iteration"], a["error"], a["error_scale"]) == (
+            b["code"], b["iteration"], b["error"], b["error_scale"])
+
+    batch = 44                                             # 44 x 32 768 points x 400 bytes: past the bound's budget of 512 MB
+    fx = FeatureExtraction(device=0, max_points_per_scan=rings * cols, max_batch=batch, max_points_per_ring=cols, max_rings=rings)
+    emap, smap = fx.make_map(d_emap.data_ptr(), len(edge_map), 1.0, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), 2.0, stream)
+    fresh = alone(fx, emap, smap, full[3], poses[3])
+    assert fresh["iteration"] >= 2
+    alone(fx, emap, smap, small, poses[0], max_iter=2)     # leaves short guesses behind
+    again = alone(fx, emap, smap, full[3], poses[3])
+    assert same(fresh, again), (fresh, again)
+    clouds = [full[s % 8] for s in range(batch)]
+    d = torch.from_numpy(concat(clouds).view(np.uint8).copy()).to(dev)
+    fx.extract_batch_device(d.data_ptr(), [len(c) for c in clouds], stream)
+    got = fx.localize_batch(emap, smap, np.stack([poses[s % 8] for s in range(batch)]), k, 20, 1.0, stream)
+    for s in (0, 3, 13, 43):
+        assert same(got[s], got[s % 8]), s
+        assert same(got[s], alone(fx, emap, smap, full[s % 8], poses[s % 8])), s
+    fx.close()
+
+
 def test_scan_to_map_align_on_caller_clouds_and_its_arguments():
     """The general entry: clouds the caller lays out (ragged, one scan without surface points), fewer iterations; argument
     checks."""
