@@ -1233,12 +1233,15 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   const uint32_t s = blockIdx.y, g = blockIdx.x;
   const int tid = threadIdx.x;
   AlignState & st = states[s];
-  if (st.done) {return;}
   __shared__ double part[W][NS];
   __shared__ double total[NS];
   __shared__ uint32_t last;
-  const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u;
-  const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
+  // (the scan's state and extents asked for together, whether or not there are rows of dimension 1: one round trip, not four)
+  const int32_t done = st.done;
+  const uint32_t * c1 = count1 ? count1 + (size_t)s * stride1 : count3, * s1 = count1 ? begin1 + s : begin3;
+  const uint32_t n3 = count3[(size_t)s * stride3], b3 = begin3[s], n1_ = *c1, b1_ = *s1;
+  if (done) {return;}
+  const uint32_t n1 = count1 ? n1_ : 0u, b1 = count1 ? b1_ : 0u;
   const double * key = weights + (size_t)b3 + b1;
   const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6), lane = (uint32_t)tid & 63u;
   lfx_f64x4 acc = {0., 0., 0., 0.};
