@@ -494,7 +494,7 @@ int lfx_localize_batch(
   // A few scans: nothing is asked of the device before the alignment.  The rows' scratch is sized by a bound (a scan has no
   // more edge points, and no more surface points, than points: 400 bytes per input point), the rows of scan s start where
   // its points do, and the launches are sized by the previous call's longest clouds (the kernels stride over what there is).
-  const bool by_bound = 400u * total <= ((size_t)512 << 20);
+  const bool by_bound = 400u * total <= ((size_t)192 << 20);      // (four 64 x 1800 scans; the scratch only ever grows)
   LFX_HIP(c, c->h_loc.reserve(8 * (size_t)batch));
   volatile uint32_t * lengths = reinterpret_cast<volatile uint32_t *>(c->h_loc.p);
   void * d_lengths = nullptr;

@@ -246,7 +246,7 @@ def test_localize_calls_in_a_row_and_both_ways_of_sizing_the_rows():
         return a["pose"].tobytes() == b["pose"].tobytes() and (a["code"], a["iteration"], a["error"], a["error_scale"]) == (
             b["code"], b["iteration"], b["error"], b["error_scale"])
 
-    batch = 44                                             # 44 x 32 768 points x 400 bytes: past the bound's budget of 512 MB
+    batch = 44                                             # 44 x 32 768 points x 400 bytes: past the bound's budget of 192 MB
     fx = FeatureExtraction(device=0, max_points_per_scan=rings * cols, max_batch=batch, max_points_per_ring=cols, max_rings=rings)
     emap, smap = fx.make_map(d_emap.data_ptr(), len(edge_map), 1.0, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), 2.0, stream)
     fresh = alone(fx, emap, smap, full[3], poses[3])
