@@ -394,7 +394,7 @@ def main():
                                      "frac": round(one["search_bytes_per_scan"] / (1e-3 * one["localize_ms_per_scan"]) / 1e9 / HBM_PEAK_GBS, 5),
                                      "bytes_per_scan": one["search_bytes_per_scan"],
                                      "note": "16 B x the map points of the 27 grid cells around every query x iterations, over the time of one scan's "
-                                             "Update: latency- and launch-bound (three launches and ~160 us per iteration), nowhere near a roof"},
+                                             "Update: latency-bound (four dependent kernels and ~105 us per iteration, each a chain of round trips to memory), nowhere near a roof"},
                         "note": "lfx_localize_batch after extraction (Downsample + Optimizer::Run of the reference localizer, localizer.hpp:71-80; "
                                 "clouds never leave the device); maps = the features of 16 scans along a track, grid cells of 1 m; "
                                 "parity with Eigen / nanoflann / PCL arithmetic unpinned (DESIGN.md 7)"}
