@@ -215,9 +215,13 @@ struct GridCube
 #endif
 constexpr int kGridUnroll = LFX_GRID_UNROLL;      // runs of 64 points loaded at once
 #ifndef LFX_BULK_INSERT
-#define LFX_BULK_INSERT 10
+#define LFX_BULK_INSERT 24
 #endif
 constexpr int kBulkInsert = LFX_BULK_INSERT;      // this many points passing the bar at once are merged in, not inserted one by one
+#ifndef LFX_MERGE_INSERT
+#define LFX_MERGE_INSERT 4
+#endif
+constexpr int kMergeInsert = LFX_MERGE_INSERT;    // this many (and fewer than kBulkInsert): placed by counting, in one step
 
 __device__ __forceinline__ double wave_read(double v, int lane)
 {
@@ -296,6 +300,38 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
               const bool cand_less = rd < ldist || (rd == ldist && ro < lorig);
               if (lane < KM) {ldist = cand_less ? rd : ldist; lorig = cand_less ? ro : lorig; lidx = cand_less ? ra : lidx;}
               wave_sort_steps(ldist, lorig, lidx, lane, 16, 16);             // (k = 16 within lanes 0..15: ascending)
+              bar = wave_read(ldist, KM - 1);
+              bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+              pass = 0;
+            }
+            if (__popcll(pass) >= kMergeInsert) {
+              // a few at once: every passing candidate is told to all lanes in turn (no lane-to-lane traffic), the lanes count
+              // for their list entry the candidates that come before it and for their candidate the list entries and the
+              // candidates that come before it -- its place in the merged order --, and two pushes (the entries, then the
+              // candidates: ds_permute hands a lane nothing written to it as 0) put the first 16 of the merged order in
+              // place.  One after the other the same insertions are a chain: each has to see the list the last one left.
+              const bool mine = ((pass >> lane) & 1ull) != 0ull;
+              uint32_t shift = 0u, before = 0u, among = 0u;
+              for (uint64_t it = pass; it; it &= it - 1ull) {
+                const int src = __ffsll((unsigned long long)it) - 1;
+                const double cd = wave_read(d, src);
+                const uint32_t corig = (uint32_t)__builtin_amdgcn_readlane((int)orig, src);
+                const bool entry_first = ldist < cd || (ldist == cd && lorig < corig);      // my list entry comes before it
+                const uint32_t n_first = (uint32_t)__popcll(__ballot(lane < KM && entry_first));
+                before = lane == src ? n_first : before;
+                shift += entry_first ? 0u : 1u;
+                among += (cd < d || (cd == d && corig < orig)) ? 1u : 0u;                 // it comes before my candidate
+              }
+              const uint32_t to_e = (uint32_t)lane + shift, to_c = before + among;
+              const int dst_e = 4 * (int)(lane < KM && to_e < (uint32_t)KM ? to_e : 63u);
+              const int dst_c = 4 * (int)(mine && to_c < (uint32_t)KM ? to_c : 63u);
+              const long long db = __double_as_longlong(d), lb = __double_as_longlong(ldist);
+              const uint32_t n_lo = (uint32_t)__builtin_amdgcn_ds_permute(dst_e, (int)(uint32_t)lb) | (uint32_t)__builtin_amdgcn_ds_permute(dst_c, (int)(uint32_t)db);
+              const uint32_t n_hi = (uint32_t)__builtin_amdgcn_ds_permute(dst_e, (int)(uint32_t)(lb >> 32)) |
+                (uint32_t)__builtin_amdgcn_ds_permute(dst_c, (int)(uint32_t)(db >> 32));
+              const uint32_t n_i = (uint32_t)__builtin_amdgcn_ds_permute(dst_e, (int)lidx) | (uint32_t)__builtin_amdgcn_ds_permute(dst_c, (int)at);
+              const uint32_t n_o = (uint32_t)__builtin_amdgcn_ds_permute(dst_e, (int)lorig) | (uint32_t)__builtin_amdgcn_ds_permute(dst_c, (int)orig);
+              if (lane < KM) {ldist = __longlong_as_double((long long)(((uint64_t)n_hi << 32) | n_lo)); lidx = n_i; lorig = n_o;}
               bar = wave_read(ldist, KM - 1);
               bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
               pass = 0;
