@@ -950,56 +950,55 @@ __global__ __launch_bounds__(128) void pair_rows_kernel(
 
 // k-th smallest (0-based) of the n non-negative doubles v[0..n): most-significant-byte-first radix selection over their bit
 // patterns (non-negative doubles order like their bits), a 256-bin histogram in LDS per byte.  Every thread of the
-// workgroup (256 threads) calls it and gets the value.  sh: 264 words of LDS.
+// workgroup calls it and gets the value.  sh: kSelectWords words of LDS, the first 256 ZERO on entry and zero again on
+// return.  Two barriers per byte: the counts by all threads | wave 0 reads the 256 bins (four per lane), clears them for
+// the next byte, finds the bin that holds rank k by a prefix sum along its lanes and publishes it | everyone reads that.
+constexpr int kSelectWords = 320;
 __device__ inline double workgroup_select(const double * __restrict__ v, uint32_t n, uint32_t k, uint32_t * sh)
 {
-  const int tid = threadIdx.x, T = blockDim.x;           // T >= 256: threads 0..255 are the bins
+  const int tid = threadIdx.x, T = blockDim.x;
   uint64_t prefix = 0, mask = 0;
   for (int shift = 56; shift >= 0; shift -= 8) {
-    if (tid < 256) {sh[tid] = 0u;}
-    __syncthreads();
     for (uint32_t i = tid; i < n; i += T) {
       const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
       if ((key & mask) == prefix) {atomicAdd(&sh[(uint32_t)(key >> shift) & 255u], 1u);}
     }
     __syncthreads();
-    // the bin that holds rank k: inclusive prefix sums of the 256 counts (lanes of a wave, then the four waves)
-    uint32_t mine = 0, incl = 0;
-    if (tid < 256) {
-      mine = sh[tid];
-      incl = mine;
+    if (tid < 64) {
+      const uint32_t h0 = sh[4 * tid], h1 = sh[4 * tid + 1], h2 = sh[4 * tid + 2], h3 = sh[4 * tid + 3];
+      sh[4 * tid] = 0u; sh[4 * tid + 1] = 0u; sh[4 * tid + 2] = 0u; sh[4 * tid + 3] = 0u;
+      uint32_t incl = h0 + h1 + h2 + h3;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-        if ((tid & 63) >= off) {incl += o;}
+        if (tid >= off) {incl += o;}
       }
-      if ((tid & 63) == 63) {sh[260 + (tid >> 6)] = incl;}
-    }
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t before = 0;
-      for (int w = 0; w < (tid >> 6); w++) {before += sh[260 + w];}
-      incl += before;
-      if (k < incl && k >= incl - mine) {sh[256] = (uint32_t)tid; sh[257] = k - (incl - mine); sh[258] = mine;}   // exactly one thread
+      const uint32_t c0 = incl - (h0 + h1 + h2 + h3), c1 = c0 + h0, c2 = c1 + h1, c3 = c2 + h2;
+      if (k >= c0 && k < incl) {                                // exactly one lane
+        const uint32_t which = k < c1 ? 0u : (k < c2 ? 1u : (k < c3 ? 2u : 3u));
+        sh[256] = 4u * (uint32_t)tid + which;
+        sh[257] = k - (which == 0u ? c0 : (which == 1u ? c1 : (which == 2u ? c2 : c3)));
+        sh[258] = which == 0u ? h0 : (which == 1u ? h1 : (which == 2u ? h2 : h3));
+      }
     }
     __syncthreads();
     prefix |= (uint64_t)sh[256] << shift;
     mask |= 0xFFull << shift;
     k = sh[257];
     const uint32_t left = sh[258];
-    __syncthreads();
     if (left == 1u && shift > 0) {
       // one value carries this prefix: it is the answer, and the passes over its remaining bytes are one pass to fetch it
       for (uint32_t i = tid; i < n; i += T) {
         const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
-        if ((key & mask) == prefix) {sh[256] = (uint32_t)key; sh[257] = (uint32_t)(key >> 32);}
+        if ((key & mask) == prefix) {sh[259] = (uint32_t)key; sh[260] = (uint32_t)(key >> 32);}
       }
       __syncthreads();
-      const uint64_t key = ((uint64_t)sh[257] << 32) | sh[256];
-      __syncthreads();
+      const uint64_t key = ((uint64_t)sh[260] << 32) | sh[259];
+      __syncthreads();                                          // (the next selection's wave 0 may publish at once)
       return __longlong_as_double((long long)key);
     }
   }
+  __syncthreads();                                              // (everyone has read the last byte's result)
   return __longlong_as_double((long long)prefix);
 }
 
@@ -1024,12 +1023,13 @@ __device__ inline double workgroup_median(const double * __restrict__ v, uint32_
     const double o = __shfl_xor(next, off, 64);
     next = o < next ? o : next;
   }
-  double * shd = reinterpret_cast<double *>(sh);             // 264 words: room for 16 counts and, behind them, 16 doubles
-  if ((tid & 63) == 0) {sh[tid >> 6] = not_above; shd[8 + (tid >> 6)] = next;}
+  uint32_t * cnt = sh + 264;                                    // (behind the selection's words: its bins stay zero)
+  double * shd = reinterpret_cast<double *>(sh + 280);
+  if ((tid & 63) == 0) {cnt[tid >> 6] = not_above; shd[tid >> 6] = next;}
   __syncthreads();
   uint32_t total = 0;
   double e0 = INFINITY;
-  for (int w = 0; w < T / 64; w++) {total += sh[w]; e0 = shd[8 + w] < e0 ? shd[8 + w] : e0;}
+  for (int w = 0; w < T / 64; w++) {total += cnt[w]; e0 = shd[w] < e0 ? shd[w] : e0;}
   __syncthreads();
   if (total > n / 2u) {e0 = e1;}
   return (e0 + e1) / 2.;
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(kScaleThreads) void align_scale_kernel(
   const int tid = threadIdx.x;
   AlignState & st = states[s];
   if (st.done) {return;}
-  __shared__ uint32_t sh[264];
+  __shared__ __attribute__((aligned(8))) uint32_t sh[kSelectWords];
   __shared__ double part[T / 64];
   const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u, n = n3 + n1;
   if (n == 0u) {                                            // EmptyInput (optimization_result.hpp:46-50)
@@ -1169,6 +1169,7 @@ __global__ __launch_bounds__(kScaleThreads) void align_scale_kernel(
       const double r = r1[(size_t)b1 + (i - n3)];
       return r * r;
     };
+  if (tid < 256) {sh[tid] = 0u;}                              // (the selection's bins; the barrier after the keys covers this)
   double e_reg[E];
   double esum = 0.;
   if (small) {
