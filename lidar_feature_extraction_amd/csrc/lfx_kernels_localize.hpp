@@ -36,6 +36,7 @@ struct AlignState
   double error, scale;                    // OptimizationResult
   double cur_error, cur_scale;            // this iteration's, from align_scale_kernel to align_update_kernel
   int32_t iteration, code, done, pad;
+  double prev_m[12];                      // the pose of the iteration before (the searches bound how far a query has moved)
 };
 
 // what the host reads when a scan has stopped iterating: written by the thread that stops it, straight into pinned host memory
@@ -252,7 +253,12 @@ __device__ __forceinline__ void wave_sort_steps(double & d, uint32_t & orig, uin
 // (Measured against one query per thread -- lists in registers with batched insertion, or heaps in LDS: a thread inserts
 // for a few points in a hundred, but some thread of 64 does at nearly every point, so the wave paid the insertion at every
 // point; this form was 2-4x faster from one scan to 64 and level at 256, and it is the only one kept.)
-__device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, uint32_t kk, double & ldist, uint32_t & lidx)
+// known, reach2 (optional): a squared distance within which at least KM map points are KNOWN to lie (the caller's bound;
+// infinity says nothing).  The list's bar then starts there instead of at infinity: nothing farther is ever looked at, so
+// the first candidates are not all sorted into the list only to be pushed out again, and rows beyond it are not read.
+// (A flag beside the value, not a NaN for "none": a wave-uniform double constant is what hipcc 7.2 gets wrong, see below.)
+__device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, uint32_t kk, double & ldist, uint32_t & lidx,
+  bool known = false, double reach2 = 0.)
 {
   constexpr int KM = kNearestMax;
   const int lane = threadIdx.x & 63;
@@ -265,8 +271,18 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
     // constant: hipcc 7.2 materialises a wave-uniform double constant with s_mov_b64 and a 64-bit literal, which gfx950
     // truncates to its low word -- infinity became 0.0 here)
     asm volatile("" : "+v"(ldist));
-    double bar = wave_read(ldist, KM - 1);
-    uint32_t bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+    const bool bounded = known && reach2 < ldist;              // (ldist is infinity here: a bound of infinity is none)
+    // the bar: the list's last entry once that is within the caller's bound, the bound (any point AT it passes) until then
+    auto set_bar = [&](double & bar_, uint32_t & bar_orig_) __attribute__((always_inline)) {
+        const double d_last = wave_read(ldist, KM - 1);
+        const uint32_t o_last = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+        const bool mine = !bounded || d_last <= reach2;
+        bar_ = mine ? d_last : reach2;
+        bar_orig_ = mine ? o_last : 0xFFFFFFFFu;
+      };
+    double bar;
+    uint32_t bar_orig;
+    set_bar(bar, bar_orig);
     auto run = [&](uint32_t a, uint32_t b) __attribute__((always_inline)) {
         for (uint32_t base = a; base < b; base += 64u * kGridUnroll) {
           float4 mpts[kGridUnroll];
@@ -300,8 +316,7 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
               const bool cand_less = rd < ldist || (rd == ldist && ro < lorig);
               if (lane < KM) {ldist = cand_less ? rd : ldist; lorig = cand_less ? ro : lorig; lidx = cand_less ? ra : lidx;}
               wave_sort_steps(ldist, lorig, lidx, lane, 16, 16);             // (k = 16 within lanes 0..15: ascending)
-              bar = wave_read(ldist, KM - 1);
-              bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+              set_bar(bar, bar_orig);
               pass = 0;
             }
             if (__popcll(pass) >= kMergeInsert) {
@@ -332,8 +347,7 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
               const uint32_t n_i = (uint32_t)__builtin_amdgcn_ds_permute(dst_e, (int)lidx) | (uint32_t)__builtin_amdgcn_ds_permute(dst_c, (int)at);
               const uint32_t n_o = (uint32_t)__builtin_amdgcn_ds_permute(dst_e, (int)lorig) | (uint32_t)__builtin_amdgcn_ds_permute(dst_c, (int)orig);
               if (lane < KM) {ldist = __longlong_as_double((long long)(((uint64_t)n_hi << 32) | n_lo)); lidx = n_i; lorig = n_o;}
-              bar = wave_read(ldist, KM - 1);
-              bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+              set_bar(bar, bar_orig);
               pass = 0;
             }
             while (pass) {
@@ -350,8 +364,7 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
               ldist = shifts ? up_d : (lands ? cd : ldist);
               lidx = shifts ? up_i : (lands ? cat : lidx);
               lorig = shifts ? up_o : (lands ? corig : lorig);
-              bar = wave_read(ldist, KM - 1);
-              bar_orig = (uint32_t)__builtin_amdgcn_readlane((int)lorig, KM - 1);
+              set_bar(bar, bar_orig);
             }
           }
         }
@@ -365,22 +378,41 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
       // half a metre that is most of the 9 rows.  Exact: a row is left out only if each of its points is farther than the
       // 16th nearest found so far.
       const int rz = lane / ny_c, ry = lane - rz * ny_c;
-      const bool has = lane < n_rows;
-      uint32_t a = 0u, b = 0u;
-      if (has) {
-        const size_t cell0 = ((size_t)(cube.zlo + rz) * mi.ny + (cube.ylo + ry)) * mi.nx;
-        a = mi.start[cell0 + cube.xlo]; b = mi.start[cell0 + cube.xhi + 1];
-      }
+      bool has = lane < n_rows;
       const double y0 = (double)(cube.ylo + ry), z0 = (double)(cube.zlo + rz);
       const double gy = fmax(fmax(y0 - cube.uy, cube.uy - (y0 + 1.)) - 1e-7, 0.), gz = fmax(fmax(z0 - cube.uz, cube.uz - (z0 + 1.)) - 1e-7, 0.);
       const double far2 = (gy * gy + gz * gz) * (mi.h * mi.h);
+      // With a bound from the caller, what is left of it after the row's gaps along y and z limits the cells of the row worth
+      // reading along x as well (cell c holds nothing within the bound unless c - ux and ux - (c + 1) are both at most the
+      // rest, in cells; 1e-6 cells of slack): the run's ends are fetched for those cells only.
+      int xa = cube.xlo, xb = cube.xhi;
+      if (bounded) {
+        const double left2 = reach2 - far2;
+        if (left2 < 0.) {
+          has = false;
+        } else {
+          const double rx = sqrt(left2) * mi.inv_h + 1e-6;
+          const double lo = fmin(fmax(ceil(cube.ux - 1. - rx), -1e9), 1e9), hi = fmin(fmax(floor(cube.ux + rx), -1e9), 1e9);
+          xa = max(xa, (int)lo); xb = min(xb, (int)hi);
+          has = has && xa <= xb;
+        }
+      }
+      uint32_t a = 0u, b = 0u;
+      if (has) {
+        const size_t cell0 = ((size_t)(cube.zlo + rz) * mi.ny + (cube.ylo + ry)) * mi.nx;
+        a = mi.start[cell0 + xa]; b = mi.start[cell0 + xb + 1];
+      }
       uint64_t todo = __ballot(has && a != b);
-      while (todo) {
-        double m = ((todo >> lane) & 1ull) ? far2 : INFINITY;
+      for (;;) {
+        const uint64_t within = todo & __ballot(!(far2 > bar));      // the rows the bar has not passed by
+        if (within == 0ull) {break;}
+        int pick = __ffsll((unsigned long long)within) - 1;
+        if (within & (within - 1ull)) {                               // more than one: the nearest of them
+          double m = ((within >> lane) & 1ull) ? far2 : INFINITY;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {const double o = __shfl_xor(m, off, 64); m = o < m ? o : m;}
-        if (m > bar) {break;}
-        const int pick = __ffsll((unsigned long long)(__ballot(far2 == m) & todo)) - 1;
+          for (int off = 32; off >= 1; off >>= 1) {const double o = __shfl_xor(m, off, 64); m = o < m ? o : m;}
+          pick = __ffsll((unsigned long long)(__ballot(far2 == m) & within)) - 1;
+        }
         todo &= ~(1ull << pick);
         run((uint32_t)__builtin_amdgcn_readlane((int)a, pick), (uint32_t)__builtin_amdgcn_readlane((int)b, pick));
       }
@@ -580,6 +612,7 @@ struct RowsOfKind
   double * residual, * jacobian;
   const uint32_t * row_begin;
   uint32_t * nbr;                          // [rows][kNearestMax]
+  double * reach;                          // [rows] the distance of each row's last neighbour at the previous iteration, squared
 };
 
 __device__ __forceinline__ D3 to_map(const MapPose & P, D3 p)
@@ -591,7 +624,8 @@ __device__ __forceinline__ D3 to_map(const MapPose & P, D3 p)
 constexpr int kSearchWaves = 4;          // queries per workgroup (nothing is shared between them: a workgroup of one wave each made
                                          // the dispatch of 4 500 workgroups the longest part of a single scan's search)
 __global__ __launch_bounds__(64 * kSearchWaves) void map_search_kernel(
-  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge /* workgroups of edge queries */, uint32_t k, const AlignState * __restrict__ align)
+  RowsOfKind edge, RowsOfKind surface, uint32_t x_edge /* workgroups of edge queries */, uint32_t k, const AlignState * __restrict__ align,
+  int iter)
 {
   const uint32_t s = blockIdx.y;
   const bool surf = blockIdx.x >= x_edge;
@@ -600,6 +634,9 @@ __global__ __launch_bounds__(64 * kSearchWaves) void map_search_kernel(
   // (everything the wave needs before its first point, asked for at once: a wave's time is a chain of round trips to memory)
   const int32_t done = align[s].done;
   const MapPose P = align[s].pose;
+  double prev[12];
+#pragma unroll
+  for (int a = 0; a < 12; a++) {prev[a] = align[s].prev_m[a];}
   // (the launch is sized from what the host knows of the clouds' lengths -- a bound, or what the previous call saw: the
   // workgroups of a kind stride over its queries)
   const uint32_t n = R.count[(size_t)s * R.count_stride], stride = (surf ? gridDim.x - x_edge : x_edge) * kSearchWaves;
@@ -608,11 +645,27 @@ __global__ __launch_bounds__(64 * kSearchWaves) void map_search_kernel(
   const uint32_t kk = k < (uint32_t)kNearestMax ? k : (uint32_t)kNearestMax;
   for (uint32_t i = (surf ? blockIdx.x - x_edge : blockIdx.x) * kSearchWaves + wave; i < n; i += stride) {
     const float4 pf = R.pts[b + i];
-    const D3 q = to_map(P, D3{(double)pf.x, (double)pf.y, (double)pf.z});
+    const bool again = iter > 0;
+    double was = 0.;
+    if (again) {was = R.reach[rb + i];}
+    const D3 p0{(double)pf.x, (double)pf.y, (double)pf.z};
+    const D3 q = to_map(P, p0);
+    // After the first iteration: the 16 points that were nearest then lay within sqrt(was) of where the query was; it has
+    // moved by |q - q_before| since, so 16 points lie within the sum of the two now (the triangle inequality; a part in
+    // 10^9 and 10^-12 on top for the roundings of this very estimate).  The search starts with that as its bar.
+    double reach2 = 0.;
+    if (again) {
+      const D3 qb{prev[0] * p0.x + prev[1] * p0.y + prev[2] * p0.z + prev[3], prev[4] * p0.x + prev[5] * p0.y + prev[6] * p0.z + prev[7],
+        prev[8] * p0.x + prev[9] * p0.y + prev[10] * p0.z + prev[11]};
+      const D3 dq = d3_sub(q, qb);
+      const double r = (sqrt(was) + sqrt(d3_dot(dq, dq))) * (1. + 1e-9) + 1e-12;
+      reach2 = r * r;
+    }
     double ld;
     uint32_t li;
-    nearest_in_grid_wave(R.mi, q, kk, ld, li);
+    nearest_in_grid_wave(R.mi, q, kk, ld, li, again, reach2);
     if (lane < (uint32_t)kNearestMax) {R.nbr[(size_t)(rb + i) * kNearestMax + lane] = li;}
+    if (lane == (uint32_t)kNearestMax - 1u) {R.reach[rb + i] = ld;}
   }
 }
 
@@ -904,6 +957,7 @@ __global__ void align_begin_kernel(AlignState * __restrict__ states, const doubl
   a.prev_error = 1.7976931348623157e308; a.prev_scale = 1.7976931348623157e308;   // std::numeric_limits<double>::max()
   a.error = 0.; a.scale = 0.; a.cur_error = 0.; a.cur_scale = 0.; a.iteration = 0; a.code = kAlignMaxIteration; a.done = 0; a.pad = 0;
   refresh_pose(a);
+  for (int i = 0; i < 12; i++) {a.prev_m[i] = a.pose.m[i];}
   states[s] = a;
 }
 
@@ -1319,22 +1373,26 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
 #pragma unroll
   for (int r = 0; r < 4; r++) {part[wave][64 * r + lane] = acc[r];}
   __syncthreads();
+  // The slices' hand-over without a fence: a fence at agent scope writes back and invalidates the whole L2 of its XCD, twice
+  // here.  Instead the slice's tile goes out in write-through stores at agent scope, the wave waits until they have left
+  // (vmcnt), the barrier collects the waves and one thread takes the ticket; the last workgroup reads the tiles with loads
+  // at agent scope, which do not look at its own L2's copy (cdna_hip_programming.md Guideline 16, as the bucketing kernel).
   double * mine = partials + ((size_t)s * G + g) * NS;
   {
     double v = 0.;
     for (int wv = 0; wv < W; wv++) {v += part[wv][tid];}
-    mine[tid] = v;
+    __hip_atomic_store(&mine[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) {last = atomicAdd(&tickets[s], 1u) == (uint32_t)G - 1u ? 1u : 0u;}
+  if (tid == 0) {last = __hip_atomic_fetch_add(&tickets[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)G - 1u ? 1u : 0u;}
   __syncthreads();
   if (last == 0u) {return;}
-  __threadfence();
   {
-    const volatile double * all = partials + (size_t)s * G * NS;
+    double * all = partials + (size_t)s * G * NS;
     double v = 0.;
-    for (int k = 0; k < G; k++) {v += all[(size_t)k * NS + tid];}
+#pragma unroll
+    for (int k = 0; k < G; k++) {v += __hip_atomic_load(&all[(size_t)k * NS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);}
     total[tid] = v;
   }
   __syncthreads();
@@ -1356,6 +1414,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_update_kernel(
   st.q[2] = q[0] * dq[2] + q[2] * dq[0] + q[3] * dq[1] - q[1] * dq[3];
   st.q[3] = q[0] * dq[3] + q[3] * dq[0] + q[1] * dq[2] - q[2] * dq[1];
   st.t[0] += dt[0]; st.t[1] += dt[1]; st.t[2] += dt[2];
+  for (int i = 0; i < 12; i++) {st.prev_m[i] = st.pose.m[i];}
   refresh_pose(st);
   const double nq = sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]), nt = sqrt(dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2]);
   if (nq < 1e-3 && nt < 1e-3) {                              // CheckConvergence (optimizer.cpp:35-38)

@@ -277,7 +277,8 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   const size_t rows = pr.total3 + pr.total1;
   const size_t partial_d = (size_t)n_clouds * lfx::kAlignSlices * lfx::kAlignTile;
   const size_t nbr_d = (size_t)lfx::kNearestMax / 2 * rows;                   // the searches' results: 16 words per row
-  const size_t need = state_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + nbr_d + (n_clouds + 1) / 2 + 9;
+  const size_t reach_d = rows;                                               // and how far each row's 16th neighbour was
+  const size_t need = state_d + 24 * pr.total3 + 8 * pr.total1 + rows + partial_d + nbr_d + reach_d + (n_clouds + 1) / 2 + 9;
   if (c->align_scratch.n < need) {
     c->align_scratch.release();
     if (c->align_scratch.alloc(need) != hipSuccess) {
@@ -294,6 +295,7 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
   double * d_weights = w; w += rows;
   double * d_partials = w; w += partial_d;
   uint32_t * nbr3 = reinterpret_cast<uint32_t *>(w), * nbr1 = nbr3 + (size_t)lfx::kNearestMax * pr.total3; w += nbr_d;
+  double * reach3 = w, * reach1 = w + pr.total3; w += reach_d;
   uint32_t * d_tickets = reinterpret_cast<uint32_t *>(w); w += (n_clouds + 1) / 2;
   uint32_t * d_active = reinterpret_cast<uint32_t *>(w);
   // Pinned host memory, read and written by the kernels themselves: [the caller's poses | a result record per scan].  No
@@ -320,13 +322,13 @@ int run_align(lfx_ctx * c, const AlignProblem & pr, uint32_t n_clouds, int max_i
         if (both_grids) {
           // the searches of both kinds in one launch, one wave per query; then the rows, one thread per query
           const lfx::RowsOfKind e{pr.edge_map->index, reinterpret_cast<const float4 *>(pr.edge_points), pr.begin3, pr.count3, pr.stride3, r3, J3,
-            pr.rbegin3, nbr3};
+            pr.rbegin3, nbr3, reach3};
           const lfx::RowsOfKind f{pr.surface_map->index, reinterpret_cast<const float4 *>(pr.surface_points), pr.begin1, pr.count1, pr.stride1,
-            r1, J1, pr.rbegin1, nbr1};
+            r1, J1, pr.rbegin1, nbr1, reach1};
           if (pr.longest3 + pr.longest1) {
             const uint32_t w3 = (pr.longest3 + lfx::kSearchWaves - 1u) / lfx::kSearchWaves, w1 = (pr.longest1 + lfx::kSearchWaves - 1u) / lfx::kSearchWaves;
             hipLaunchKernelGGL(lfx::map_search_kernel, dim3(w3 + w1, n_clouds), dim3(64 * lfx::kSearchWaves), 0, st, e, f, w3,
-              pr.n_neighbors, states);
+              pr.n_neighbors, states, iter);
             const uint32_t g3 = (pr.longest3 + lfx::kRowThreads - 1u) / lfx::kRowThreads, g1 = (pr.longest1 + lfx::kRowThreads - 1u) / lfx::kRowThreads;
             hipLaunchKernelGGL(lfx::rows_from_neighbours_kernel, dim3(g3 + g1, n_clouds), dim3(lfx::kRowThreads), 0, st, e, f, g3,
               pr.n_neighbors, states);
