@@ -1013,9 +1013,23 @@ __device__ inline double workgroup_select(const double * __restrict__ v, uint32_
   const int tid = threadIdx.x, T = blockDim.x;
   uint64_t prefix = 0, mask = 0;
   for (int shift = 56; shift >= 0; shift -= 8) {
-    for (uint32_t i = tid; i < n; i += T) {
-      const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
-      if ((key & mask) == prefix) {atomicAdd(&sh[(uint32_t)(key >> shift) & 255u], 1u);}
+    // (the counts: a wave whose lanes all hold the same byte adds their number in ONE atomic -- in the high bytes all the
+    // values of a scan share two or three bins, and four thousand atomics on one LDS address take their turns)
+    for (uint32_t i0 = 0; i0 < n; i0 += T) {
+      const uint32_t i = i0 + (uint32_t)tid;
+      const uint64_t key = (uint64_t)__double_as_longlong(v[i < n ? i : 0u]);
+      const bool match = i < n && (key & mask) == prefix;
+      const uint32_t digit = (uint32_t)(key >> shift) & 255u;
+      const uint64_t todo = __ballot(match);
+      if (todo) {
+        const int first = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)digit, first);
+        if (__ballot(match && digit == d) == todo) {            // one bin for the whole wave: the high bytes
+          if ((tid & 63) == first) {atomicAdd(&sh[d], (uint32_t)__popcll(todo));}
+        } else if (match) {
+          atomicAdd(&sh[digit], 1u);
+        }
+      }
     }
     __syncthreads();
     if (tid < 64) {
