@@ -5,11 +5,14 @@
 using namespace lfx_host;
 
 // ---------------------------------------------------------------------------- voxel-grid Downsample
-extern "C" {
-
-int lfx_voxel_downsample(
+namespace lfx_host
+{
+// lfx_voxel_downsample, with what lfx_localize_batch adds: a cloud PCL would hand back unfiltered is copied to the output
+// (status still says so), and the clouds' lengths go to pinned host memory for the next call's launch sizes
+int voxel_downsample(
   lfx_ctx * c, const float * d_points, const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride,
-  uint32_t n_clouds, size_t total_points, float leaf, float * d_out, uint32_t * d_out_count, uint32_t * d_status, void * stream)
+  uint32_t n_clouds, size_t total_points, float leaf, float * d_out, uint32_t * d_out_count, uint32_t * d_status, void * stream,
+  bool unfiltered, const uint32_t * d_other_count, uint32_t * lengths)
 {
   if (!c || !d_points || !d_begin || !d_count || !d_out || !d_out_count || !d_status || n_clouds == 0 || count_stride == 0) {
     return LFX_ERR_INVALID_ARGUMENT;
@@ -34,9 +37,20 @@ int lfx_voxel_downsample(
   }
   hipLaunchKernelGGL(lfx::voxel_downsample_kernel, dim3(n_clouds), dim3(lfx::kVoxThreads), table_bytes, static_cast<hipStream_t>(stream),
     reinterpret_cast<const float4 *>(d_points), d_begin, d_count, count_stride, leaf, w, w + total_points, w + 2 * total_points,
-    w + 3 * total_points, reinterpret_cast<float4 *>(d_out), d_out_count, d_status);
+    w + 3 * total_points, reinterpret_cast<float4 *>(d_out), d_out_count, d_status, unfiltered ? 1u : 0u, d_other_count, lengths);
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
+}
+}  // namespace lfx_host
+
+extern "C" {
+
+int lfx_voxel_downsample(
+  lfx_ctx * c, const float * d_points, const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride,
+  uint32_t n_clouds, size_t total_points, float leaf, float * d_out, uint32_t * d_out_count, uint32_t * d_status, void * stream)
+{
+  return voxel_downsample(c, d_points, d_begin, d_count, count_stride, n_clouds, total_points, leaf, d_out, d_out_count, d_status, stream,
+           false, nullptr, nullptr);
 }
 
 int lfx_downsample_surface(lfx_ctx * c, float leaf, float * d_out, uint32_t * d_out_count, uint32_t * d_status, void * stream)

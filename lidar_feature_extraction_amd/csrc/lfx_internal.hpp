@@ -195,4 +195,10 @@ inline int fail(lfx_ctx * ctx, int code, const std::string & msg)
   return code;
 }
 
+// lfx_downsample.hip: lfx_voxel_downsample with the extras of lfx_localize_batch
+int voxel_downsample(
+  lfx_ctx * c, const float * d_points, const uint32_t * d_begin, const uint32_t * d_count, uint32_t count_stride,
+  uint32_t n_clouds, size_t total_points, float leaf, float * d_out, uint32_t * d_out_count, uint32_t * d_status, void * stream,
+  bool unfiltered, const uint32_t * d_other_count, uint32_t * lengths);
+
 }  // namespace lfx_host

@@ -54,7 +54,10 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
   const float4 * __restrict__ pts, const uint32_t * __restrict__ begin, const uint32_t * __restrict__ count,
   uint32_t count_stride, float leaf, uint32_t * __restrict__ key_a, uint32_t * __restrict__ key_b,
   uint32_t * __restrict__ val_a, uint32_t * __restrict__ val_b, float4 * __restrict__ out,
-  uint32_t * __restrict__ out_count, uint32_t * __restrict__ status)
+  uint32_t * __restrict__ out_count, uint32_t * __restrict__ status,
+  uint32_t unfiltered /* PCL hands a cloud whose leaf is too small back as it is: copy it to `out` (status stays 1) */,
+  const uint32_t * __restrict__ other_count, uint32_t * __restrict__ lengths /* null, or [clouds][2] in pinned host memory:
+     other_count[s * count_stride] and this cloud's output length, for lfx_localize_batch's next call */)
 {
   constexpr int T = kVoxThreads, W = T / 64;
   const uint32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,8 +67,21 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
   __shared__ uint32_t hist[256], base[256], wtot[W];
   __shared__ uint16_t wcnt[W][256];
   extern __shared__ uint16_t table[];         // [tiles of the cloud][W][256], then the sorted points: the form for clouds of up to kVoxItems * T points
+  auto finish = [&](uint32_t n_out, uint32_t st) __attribute__((always_inline)) {      // every thread calls it, at the end
+      if (st == 1u && unfiltered) {
+        for (uint32_t i = tid; i < n; i += T) {
+          const float4 p = pts[b + i];
+          out[b + i] = make_float4(p.x, p.y, p.z, 1.f);
+        }
+        n_out = n;
+      }
+      if (tid == 0) {
+        out_count[s] = n_out; status[s] = st;
+        if (lengths) {lengths[2 * s] = other_count[(size_t)s * count_stride]; lengths[2 * s + 1] = n_out;}
+      }
+    };
   if (n == 0) {
-    if (tid == 0) {out_count[s] = 0; status[s] = 0;}
+    finish(0u, 0u);
     return;
   }
   const float inv = 1.0f / leaf;              // inverse_leaf_size_
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
     if (tid == 0) {voxel_geometry(red, W, inv, geo);}
     __syncthreads();
     if (geo[6]) {
-      if (tid == 0) {out_count[s] = 0; status[s] = 1;}
+      finish(0u, 1u);
       return;
     }
     const float fb0 = (float)geo[0], fb1 = (float)geo[1], fb2 = (float)geo[2];
@@ -200,37 +216,56 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
       const uint32_t i = (uint32_t)t * T + tid;
       if (i < n) {sx_l[i] = p[t].x; sy_l[i] = p[t].y; sz_l[i] = p[t].z;}
     }
-    // ---- cell heads
-    uint32_t cells_before = 0;
+    // ---- cell heads, every tile at once: the waves' head counts per (tile, wave), one wave's prefix over them, then each
+    // head's place; the places go to LDS when there are at most 2 047 cells (a scan's surface cloud has a few hundred)
+    uint64_t hm[VI];
 #pragma unroll
     for (int t = 0; t < VI; t++) {
-      if ((uint32_t)t * T >= n) {continue;}
       const uint32_t i = (uint32_t)t * T + tid;
       const bool head = i < n && (i == 0 || k[t] != kp[t]);
-      const uint64_t hm = __ballot(head);
-      if (lane == 0) {wtot[wave] = __popcll(hm);}
-      __syncthreads();
-      uint32_t before = cells_before, total = 0;
-      for (int w = 0; w < W; w++) {
-        if (w < (int)wave) {before += wtot[w];}
-        total += wtot[w];
-      }
-      if (head) {kd[b + before + __popcll(hm & ((1ull << lane) - 1ull))] = i;}
-      cells_before += total;
-      __syncthreads();
+      hm[t] = __ballot(head);
+      if (lane == 0) {hist[t * W + wave] = (uint32_t)__popcll(hm[t]);}
     }
-    const uint32_t m = cells_before;
+    __syncthreads();
+    static_assert(VI * W <= 256 && VI * W <= 4 * 64, "the head counts fit the bins' place and one wave's lanes, four each");
+    if (tid < 64) {
+      uint32_t c[4], sum = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {c[e] = 4 * tid + e < VI * W ? hist[4 * tid + e] : 0u; sum += c[e];}
+      uint32_t incl = sum;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((int)tid >= d) {incl += o;}
+      }
+      uint32_t ex = incl - sum;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {if (4 * tid + e < VI * W) {hist[4 * tid + e] = ex;} ex += c[e];}
+      if (tid == 63) {base[0] = incl;}
+    }
+    __syncthreads();
+    const uint32_t m = base[0];
+    uint32_t * heads_l = reinterpret_cast<uint32_t *>(&wcnt[0][0]);
+    const bool heads_in_lds = m < (uint32_t)(W * 256 / 2);
+#pragma unroll
+    for (int t = 0; t < VI; t++) {
+      const uint32_t i = (uint32_t)t * T + tid;
+      if ((hm[t] >> lane) & 1ull) {
+        const uint32_t at = hist[t * W + wave] + (uint32_t)__popcll(hm[t] & ((1ull << lane) - 1ull));
+        if (heads_in_lds) {heads_l[at] = i;} else {kd[b + at] = i;}
+      }
+    }
+    if (tid == 0) {if (heads_in_lds) {heads_l[m] = n;}}
     __syncthreads();
     // ---- centroids: the points of a cell in input order (AccumulatorXYZ: float sums, then / count), out of LDS: a cell of
     // a few hundred points near the sensor is a few hundred LDS reads for its thread, not as many trips to memory
     for (uint32_t c = tid; c < m; c += T) {
-      const uint32_t a = kd[b + c], e = c + 1 < m ? kd[b + c + 1] : n;
+      const uint32_t a = heads_in_lds ? heads_l[c] : kd[b + c], e = heads_in_lds ? heads_l[c + 1] : (c + 1 < m ? kd[b + c + 1] : n);
       float sx = 0.f, sy = 0.f, sz = 0.f;
       for (uint32_t j = a; j < e; j++) {sx += sx_l[j]; sy += sy_l[j]; sz += sz_l[j];}
       const float cnt = (float)(e - a);
       out[b + c] = make_float4(sx / cnt, sy / cnt, sz / cnt, 1.0f);
     }
-    if (tid == 0) {out_count[s] = m; status[s] = 0;}
+    finish(m, 0u);
     return;
   }
   // ---- bounds (getMinMax3D)
@@ -252,7 +287,7 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
   if (tid == 0) {voxel_geometry(red, W, inv, geo);}
   __syncthreads();
   if (geo[6]) {
-    if (tid == 0) {out_count[s] = 0; status[s] = 1;}
+    finish(0u, 1u);
     return;
   }
   const float fb0 = (float)geo[0], fb1 = (float)geo[1], fb2 = (float)geo[2];
@@ -352,7 +387,7 @@ __global__ __launch_bounds__(kVoxThreads) void voxel_downsample_kernel(
     const float cnt = (float)(e - a);
     out[b + c] = make_float4(sx / cnt, sy / cnt, sz / cnt, 1.0f);
   }
-  if (tid == 0) {out_count[s] = m; status[s] = 0;}
+  finish(m, 0u);
 }
 
 }  // namespace lfx

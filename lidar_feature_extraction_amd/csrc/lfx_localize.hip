@@ -490,8 +490,6 @@ int lfx_localize_batch(
   float * down = c->align_surface.p;
   uint32_t * down_count = reinterpret_cast<uint32_t *>(down + 4 * total), * down_status = down_count + batch;
   uint32_t * d_row3 = down_status + batch, * d_row1 = d_row3 + batch;
-  const int rc = lfx_downsample_surface(c, surface_leaf, down, down_count, down_status, stream);
-  if (rc != LFX_OK) {return rc;}
   hipStream_t st = static_cast<hipStream_t>(stream);
   // A few scans: nothing is asked of the device before the alignment.  The rows' scratch is sized by a bound (a scan has no
   // more edge points, and no more surface points, than points: 400 bytes per input point), the rows of scan s start where
@@ -501,10 +499,11 @@ int lfx_localize_batch(
   volatile uint32_t * lengths = reinterpret_cast<volatile uint32_t *>(c->h_loc.p);
   void * d_lengths = nullptr;
   LFX_HIP(c, hipHostGetDevicePointer(&d_lengths, c->h_loc.p, 0));
-  // where PCL gives the cloud back unfiltered (leaf too small for its extent) the rows are built from all surface points
-  hipLaunchKernelGGL(lfx::downsample_passthrough_kernel, dim3(batch), dim3(256), 0, st,
-    reinterpret_cast<const float4 *>(c->surf_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoSurface, 4u,
-    reinterpret_cast<float4 *>(down), down_count, down_status, c->scan_info.p + lfx::kInfoEdge, static_cast<uint32_t *>(d_lengths));
+  // Downsample of the surface clouds (where PCL gives a cloud back unfiltered -- leaf too small for its extent -- the rows are
+  // built from all its points: the kernel copies it), the clouds' lengths left in pinned memory on the way
+  const int rc = voxel_downsample(c, reinterpret_cast<const float *>(c->surf_pts.p), c->scan_begin.p, c->scan_info.p + lfx::kInfoSurface, 4,
+    batch, total, surface_leaf, down, down_count, down_status, stream, true, c->scan_info.p + lfx::kInfoEdge, static_cast<uint32_t *>(d_lengths));
+  if (rc != LFX_OK) {return rc;}
   auto remember = [&]() {
       uint32_t e = 0, f = 0;
       for (uint32_t s = 0; s < batch; s++) {e = std::max(e, (uint32_t)lengths[2 * s]); f = std::max(f, (uint32_t)lengths[2 * s + 1]);}

@@ -264,6 +264,33 @@ def test_localize_calls_in_a_row_and_both_ways_of_sizing_the_rows():
     fx.close()
 
 
+def test_localize_batch_with_a_leaf_too_small_for_the_cloud():
+    """PCL's VoxelGrid hands a cloud back unfiltered when the leaf is too small for its extent (downsample.hpp:37-51): the rows
+    are then built from every surface point.  lfx_localize_batch does that copy inside its Downsample launch."""
+    import torch
+    from lidar_feature_extraction_amd import FeatureExtraction, concat
+    rng = np.random.default_rng(5)
+    rings, cols, k, max_iter, leaf = 16, 900, 15, 3, 1e-7
+    clouds, want = _scene(rings, cols, [7700])
+    _, maps = _scene(rings, cols, [7790, 7791])
+    edge_map = np.ascontiguousarray(np.concatenate([m["edge_points"] for m in maps]), np.float32)
+    surf_map = np.ascontiguousarray(np.concatenate([m["surface_points"] for m in maps]), np.float32)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    fx = FeatureExtraction(device=0, max_points_per_scan=rings * cols, max_batch=1, max_points_per_ring=cols, max_rings=rings)
+    d = torch.from_numpy(concat(clouds).view(np.uint8).copy()).to(dev)
+    fx.extract_batch_device(d.data_ptr(), [len(c) for c in clouds], stream)
+    d_emap, d_smap = torch.from_numpy(edge_map).to(dev), torch.from_numpy(surf_map).to(dev)
+    emap, smap = fx.make_map(d_emap.data_ptr(), len(edge_map), 1.0, stream), fx.make_map(d_smap.data_ptr(), len(surf_map), 1.0, stream)
+    pose = _pose(rng.normal(0, 0.004, 3), rng.normal(0, 0.03, 3))
+    got = fx.localize_batch(emap, smap, pose[None], k, max_iter, leaf, stream)[0]
+    down = _downsample(want[0]["surface_points"], leaf)
+    assert len(down) == len(want[0]["surface_points"])                  # unfiltered
+    w = _oracle_scan(edge_map, surf_map, k, want[0]["edge_points"], down, pose, max_iter)
+    _same_result(got, w, "unfiltered", pose_tol=1e-6, rel=1e-5)
+    fx.close()
+
+
 def test_scan_to_map_align_on_caller_clouds_and_its_arguments():
     """The general entry: clouds the caller lays out (ragged, one scan without surface points), fewer iterations; argument
     checks."""
