@@ -674,12 +674,14 @@ __global__ __launch_bounds__(kRowThreads) void rows_from_neighbours_kernel(
   RowsOfKind edge, RowsOfKind surface, uint32_t x_edge /* workgroups of edge rows */, uint32_t k, const AlignState * __restrict__ align)
 {
   const uint32_t s = blockIdx.y;
-  if (align[s].done) {return;}
   const bool surf = blockIdx.x >= x_edge;
   const RowsOfKind & R = surf ? surface : edge;
+  // (the scan's state and extents asked for together, as in map_search_kernel)
+  const int32_t done = align[s].done;
+  const MapPose P = align[s].pose;
   const uint32_t n = R.count[(size_t)s * R.count_stride], stride = (surf ? gridDim.x - x_edge : x_edge) * kRowThreads;
   const uint32_t b = R.begin[s], rb = R.row_begin ? R.row_begin[s] : b;
-  const MapPose P = align[s].pose;
+  if (done) {return;}
   const uint32_t kk = k < (uint32_t)kNearestMax ? k : (uint32_t)kNearestMax;
   for (uint32_t i = (surf ? blockIdx.x - x_edge : blockIdx.x) * kRowThreads + threadIdx.x; i < n; i += stride) {
     const float4 pf = R.pts[b + i];
@@ -1216,15 +1218,18 @@ __global__ __launch_bounds__(kScaleThreads) void align_scale_kernel(
   const uint32_t s = blockIdx.x;
   const int tid = threadIdx.x;
   AlignState & st = states[s];
-  if (st.done) {return;}
   __shared__ __attribute__((aligned(8))) uint32_t sh[kSelectWords];
   __shared__ double part[T / 64];
-  const uint32_t n3 = count3[(size_t)s * stride3], n1 = count1 ? count1[(size_t)s * stride1] : 0u, n = n3 + n1;
+  // (the scan's state and extents asked for together, whether or not there are rows of dimension 1)
+  const int32_t done = st.done;
+  const uint32_t * c1 = count1 ? count1 + (size_t)s * stride1 : count3, * s1 = count1 ? begin1 + s : begin3;
+  const uint32_t n3 = count3[(size_t)s * stride3], b3 = begin3[s], n1_ = *c1, b1_ = *s1;
+  if (done) {return;}
+  const uint32_t n1 = count1 ? n1_ : 0u, b1 = count1 ? b1_ : 0u, n = n3 + n1;
   if (n == 0u) {                                            // EmptyInput (optimization_result.hpp:46-50)
     if (tid == 0) {align_finish(st, out[s], iter, 0., 0., kAlignEmpty, active);}
     return;
   }
-  const uint32_t b3 = begin3[s], b1 = count1 ? begin1[s] : 0u;
   double * w_out = weights + (size_t)b3 + b1;
   __shared__ double keys_lds[kAlignKeysLds];
   const bool small = n <= (uint32_t)kAlignKeysLds;
