@@ -264,6 +264,17 @@ __device__ __forceinline__ void nearest_in_grid_wave(const MapIndex & mi, D3 q, 
   const int lane = threadIdx.x & 63;
   GridCube cube;
   cube.begin(mi, q);
+  if (known && cube.rho == 1) {
+    // With a bound the cube can be made large enough at once for the search to END with it (GridCube::done: the 16th distance
+    // within the cube's inscribed sphere): the sphere of the bound has to fit, i.e. rho cells plus the query's distance to the
+    // nearest face of its own cell.  A query in thin surroundings otherwise walks the small cube first, finds too little and
+    // starts again.  Rows beyond the bound are never fetched, so the larger cube costs its row table only (up to 7 x 7 rows
+    // fit the wave's lanes; a bound that needs more starts small as before).
+    const double g0 = fmin(fmin(fmin(cube.ux - (double)cube.cx, (double)cube.cx + 1. - cube.ux), fmin(cube.uy - (double)cube.cy, (double)cube.cy + 1. - cube.uy)),
+        fmin(cube.uz - (double)cube.cz, (double)cube.cz + 1. - cube.uz));
+    const double need = ceil(sqrt(reach2) * mi.inv_h - fmax(g0, 0.) + 1e-6);
+    if (need >= 2. && need <= 3.) {cube.rho = (int)need; cube.clip(mi);}
+  }
   uint32_t lorig = 0u;
   for (;;) {
     ldist = INFINITY; lidx = 0u; lorig = 0xFFFFFFFFu;
