@@ -1020,14 +1020,32 @@ __global__ __launch_bounds__(128) void pair_rows_kernel(
 // workgroup calls it and gets the value.  sh: kSelectWords words of LDS, the first 256 ZERO on entry and zero again on
 // return.  Two barriers per byte: the counts by all threads | wave 0 reads the 256 bins (four per lane), clears them for
 // the next byte, finds the bin that holds rank k by a prefix sum along its lanes and publishes it | everyone reads that.
-constexpr int kSelectWords = 320;
+constexpr int kSelectWords = 576;         // 256 bins | 8 words of result | 48 words of the median's own | 256 "who counted here"
+
+// inclusive prefix sum along the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16 lanes, then the two
+// row broadcasts): eight VALU instructions where six ds_bpermute round trips through the LDS crossbar were ~700 cycles
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+  uint32_t t = x;
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);      // row_shr:1
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);      // row_shr:2
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xF, 0xF, true);      // row_shr:3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xE, true);      // row_shr:4, banks 1-3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xC, true);      // row_shr:8, banks 2-3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+  return t;
+}
+
 __device__ inline double workgroup_select(const double * __restrict__ v, uint32_t n, uint32_t k, uint32_t * sh)
 {
   const int tid = threadIdx.x, T = blockDim.x;
+  uint32_t * who = sh + 320;
   uint64_t prefix = 0, mask = 0;
   for (int shift = 56; shift >= 0; shift -= 8) {
     // (the counts: a wave whose lanes all hold the same byte adds their number in ONE atomic -- in the high bytes all the
-    // values of a scan share two or three bins, and four thousand atomics on one LDS address take their turns)
+    // values of a scan share two or three bins, and four thousand atomics on one LDS address take their turns.  Whoever
+    // counts in a bin leaves its value's place there: a bin that ends with one value names it without another pass)
     for (uint32_t i0 = 0; i0 < n; i0 += T) {
       const uint32_t i = i0 + (uint32_t)tid;
       const uint64_t key = (uint64_t)__double_as_longlong(v[i < n ? i : 0u]);
@@ -1038,9 +1056,10 @@ __device__ inline double workgroup_select(const double * __restrict__ v, uint32_
         const int first = __ffsll((unsigned long long)todo) - 1;
         const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)digit, first);
         if (__ballot(match && digit == d) == todo) {            // one bin for the whole wave: the high bytes
-          if ((tid & 63) == first) {atomicAdd(&sh[d], (uint32_t)__popcll(todo));}
+          if ((tid & 63) == first) {atomicAdd(&sh[d], (uint32_t)__popcll(todo)); who[d] = i;}
         } else if (match) {
           atomicAdd(&sh[digit], 1u);
+          who[digit] = i;
         }
       }
     }
@@ -1048,38 +1067,26 @@ __device__ inline double workgroup_select(const double * __restrict__ v, uint32_
     if (tid < 64) {
       const uint32_t h0 = sh[4 * tid], h1 = sh[4 * tid + 1], h2 = sh[4 * tid + 2], h3 = sh[4 * tid + 3];
       sh[4 * tid] = 0u; sh[4 * tid + 1] = 0u; sh[4 * tid + 2] = 0u; sh[4 * tid + 3] = 0u;
-      uint32_t incl = h0 + h1 + h2 + h3;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-        if (tid >= off) {incl += o;}
-      }
+      const uint32_t incl = wave_inclusive_sum(h0 + h1 + h2 + h3);
       const uint32_t c0 = incl - (h0 + h1 + h2 + h3), c1 = c0 + h0, c2 = c1 + h1, c3 = c2 + h2;
       if (k >= c0 && k < incl) {                                // exactly one lane
         const uint32_t which = k < c1 ? 0u : (k < c2 ? 1u : (k < c3 ? 2u : 3u));
-        sh[256] = 4u * (uint32_t)tid + which;
+        const uint32_t bin = 4u * (uint32_t)tid + which;
+        const uint64_t only = (uint64_t)__double_as_longlong(v[who[bin] < n ? who[bin] : 0u]);   // (the answer if the bin holds one value)
+        sh[256] = bin;
         sh[257] = k - (which == 0u ? c0 : (which == 1u ? c1 : (which == 2u ? c2 : c3)));
         sh[258] = which == 0u ? h0 : (which == 1u ? h1 : (which == 2u ? h2 : h3));
+        sh[259] = (uint32_t)only; sh[260] = (uint32_t)(only >> 32);
       }
     }
     __syncthreads();
     prefix |= (uint64_t)sh[256] << shift;
     mask |= 0xFFull << shift;
     k = sh[257];
-    const uint32_t left = sh[258];
-    if (left == 1u && shift > 0) {
-      // one value carries this prefix: it is the answer, and the passes over its remaining bytes are one pass to fetch it
-      for (uint32_t i = tid; i < n; i += T) {
-        const uint64_t key = (uint64_t)__double_as_longlong(v[i]);
-        if ((key & mask) == prefix) {sh[259] = (uint32_t)key; sh[260] = (uint32_t)(key >> 32);}
-      }
-      __syncthreads();
-      const uint64_t key = ((uint64_t)sh[260] << 32) | sh[259];
-      __syncthreads();                                          // (the next selection's wave 0 may publish at once)
-      return __longlong_as_double((long long)key);
+    if (sh[258] == 1u) {                                        // one value carries this prefix: it is the answer
+      return __longlong_as_double((long long)(((uint64_t)sh[260] << 32) | sh[259]));
     }
   }
-  __syncthreads();                                              // (everyone has read the last byte's result)
   return __longlong_as_double((long long)prefix);
 }
 
