@@ -471,7 +471,7 @@ int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_p
                               float *out);
 
 /* --- measurement ------------------------------------------------------------------------- */
-#define LFX_N_KERNELS 12  /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact, ring_unit_org (organised scans, one wave per unit: LFX_DEBUG_STREAM=0), ring_cut (transforms of rotated / reversed rings), ring_stream (organised scans: the waves walk their rings, the next unit's records in flight) */
+#define LFX_N_KERNELS 11  /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact (the last two: bucketing route only), ring_unit_org (organised scans, writes the clouds itself), ring_cut (transforms of rotated / reversed rings) */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);
 /* Record the events around every n-th batch only (default 1).  The event pairs between the kernels of a batch
  * cost ~7 % of the device-resident throughput at 64x1800x256; sampled, the durations stay live and the cost goes. */

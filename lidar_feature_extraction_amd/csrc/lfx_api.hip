@@ -15,7 +15,7 @@ std::string g_create_error;
 const char * kKernelNames[LFX_N_KERNELS] = {
   "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_unit_kernel",
   "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel", "ring_totals_kernel",
-  "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel", "ring_stream_kernel"};
+  "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -233,12 +233,10 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::ring_cut_kernel, dim3(batch), dim3(lfx::kCutThreads), 0, st,
         pts, c->scan_begin.p, c->max_rings, c->cap, c->xform.p, counters);
     }
-    const bool stream_wanted = c->walk_rings && c->unit_chunks == 5 && c->default_thresholds;
-    Timed t(c, stream_wanted ? 11 : 9, st);
-    bool stream_form = false;
+    Timed t(c, 9, st);
     const uint32_t groups = (c->max_rings + 3u) / 4u;
     void (*kern)(lfx::Params, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t *,
-      const lfx::UnitTables *, const uint32_t *) = nullptr;
+      const lfx::UnitTables *, const uint32_t *, uint32_t, uint32_t) = nullptr;
 #define LFX_PICK_ORG(DEFV, XFV) \
     (c->unit_chunks == 5 ? &lfx::ring_unit_org_kernel<5, DEFV, XFV> : c->unit_chunks == 4 ? &lfx::ring_unit_org_kernel<4, DEFV, XFV> : \
      c->unit_chunks == 3 ? &lfx::ring_unit_org_kernel<3, DEFV, XFV> : &lfx::ring_unit_org_kernel<6, DEFV, XFV>)
@@ -248,13 +246,15 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       kern = xf ? LFX_PICK_ORG(false, true) : LFX_PICK_ORG(false, false);
     }
 #undef LFX_PICK_ORG
-    // (the experiment is built for the bench's shape only: rings of up to 5 chunks, the reference's default thresholds)
-    if (c->walk_rings && c->unit_chunks == 5 && c->default_thresholds) {
-      kern = xf ? &lfx::ring_stream_kernel<5, true, true> : &lfx::ring_stream_kernel<5, true, false>;
-      stream_form = true;
+    // the tag of this launch's unit granules (unit_look_back): the launch's serial number, never 0; when it wraps the
+    // table is zeroed, so that no granule of 2^32 launches ago can pass for one of this launch
+    if (++c->unit_epoch == 0u) {
+      LFX_HIP(c, hipMemsetAsync(c->unit_state.p, 0, c->unit_state.n * 8, st));
+      c->unit_epoch = 1u;
     }
-    hipLaunchKernelGGL(kern, dim3(stream_form ? groups : groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-      c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p);
+    hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B * batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
+      c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p,
+      c->unit_epoch, batch);
   }
   // ---- the bucketing route, over the scans on the fall-back list
   if (c->single_pass) {
@@ -360,18 +360,22 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       short_tail ? fb_count : slow_count, short_tail ? c->fb_list.p : c->slow_list.p, c->max_rings);
   }
   {
-    Timed t(c, 7, st);
-    hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
-      c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
-      c->ring_ebase.p, c->ring_sbase.p, c->fast_path ? (uint32_t)c->dev.B : 1u, c->max_rings);
-  }
-  {
-    Timed t(c, 8, st);
+    // compaction of the bucketing route's per-unit records (the organised-scan kernel writes its clouds itself): over the
+    // fall-back list
     const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
-    hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
-      n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
-      c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-      c->surf_idx.p, c->max_rings);
+    {
+      Timed t(c, 7, st);
+      hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(fb_grid), dim3(lfx::kRings), 0, st,
+        c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
+        c->ring_ebase.p, c->ring_sbase.p, n_units, c->max_rings, fb_count, c->fb_list.p);
+    }
+    {
+      Timed t(c, 8, st);
+      hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, fb_grid), dim3(256), 0, st,
+        n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
+        c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
+        c->surf_idx.p, c->max_rings, fb_count, c->fb_list.p);
+    }
   }
   if (c->h_counters) {
     // for the next batches' decision about the order pre-pass; nobody waits for this copy
@@ -721,7 +725,6 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
   if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->fused_env = std::atoi(dbg) != 0 ? 1 : 0;}
-  if (const char * dbg = std::getenv("LFX_DEBUG_STREAM")) {c->walk_rings = std::atoi(dbg) != 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->short_tail_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_XFORM")) {c->xform_env = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
@@ -759,6 +762,10 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
+  // the organised-scan kernel's unit granules (unit_look_back): per scan max_rings * n_blocks, rounded up to whole sweeps
+  c->state_stride = ((c->max_rings * (uint32_t)(c->dev.B < 1 ? 1 : (c->dev.B > lfx::kUnitMaxBlocks ? lfx::kUnitMaxBlocks : c->dev.B)) + 383u) / 384u) * 384u;
+  ok(c->unit_state.alloc(nb * c->state_stride));
+  if (e == hipSuccess) {e = hipMemset(c->unit_state.p, 0, c->unit_state.n * 8);}
   if (e == hipSuccess) {
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 4 * lfx::kCounters, hipHostMallocDefault);
     if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * lfx::kCounters);}
@@ -766,7 +773,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (e == hipSuccess) {
     const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
-      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p};
+      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p,
+      c->edge_pts.p, c->surf_pts.p, c->edge_idx.p, c->surf_idx.p, c->unit_state.p, c->state_stride};
     e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
@@ -805,7 +813,7 @@ void lfx_destroy(lfx_ctx * c)
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
   c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
-  c->unit_tab.release();
+  c->unit_tab.release(); c->unit_state.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();

@@ -103,7 +103,6 @@ struct lfx_ctx
   // LFX_DEBUG_FUSED=0/1 pins it.
   bool fused_possible = false;
   int fused_env = -1;
-  bool walk_rings = false;                // the organised-scan kernel in its streaming form (ring_stream_kernel); LFX_DEBUG_STREAM=0: one wave per unit
   // Rings that arrive rotated / reversed (a driver that does not cut its scans at -pi, a clockwise sensor): while the
   // organised-scan kernel keeps giving scans up for their angle order alone, ring_cut_kernel finds every ring's
   // transform first and the kernel applies it in its loads (LFX_DEBUG_XFORM=0/1 pins it).
@@ -131,6 +130,8 @@ struct lfx_ctx
   lfx_host::DevBuf<double> curv_s;
   lfx_host::DevBuf<float4> edge_pts, surf_pts, rec_pts;
   lfx_host::DevBuf<lfx::UnitTables> unit_tab;      // the unit kernel's output pointers (one element)
+  lfx_host::DevBuf<uint64_t> unit_state;           // organised-scan kernel: one granule {launch tag, n_edge | n_surface << 16} per unit
+  uint32_t state_stride = 0, unit_epoch = 0;       // granules per scan; the tag of the last launch
   lfx_host::DevBuf<uint32_t> vox_scratch;          // lfx_voxel_downsample: sort keys / values, allocated on first use
   lfx_host::DevBuf<double> align_scratch;          // lfx_scan_to_map_align: states, rows, errors; allocated on first use
   lfx_host::DevBuf<float> align_surface;           // lfx_localize_batch: the downsampled surface clouds (+ counts, status)

@@ -133,5 +133,19 @@ __host__ __device__ inline size_t ring_base(uint32_t s, uint32_t ring, uint32_t 
   return ((size_t)s * max_rings + ring) * cap;
 }
 
+// inclusive prefix sum along the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16 lanes, then the two
+// row broadcasts): eight VALU instructions where six ds_bpermute round trips through the LDS crossbar were ~700 cycles
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+  uint32_t t = x;
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);      // row_shr:1
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);      // row_shr:2
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xF, 0xF, true);      // row_shr:3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xE, true);      // row_shr:4, banks 1-3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xC, true);      // row_shr:8, banks 2-3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+  return t;
+}
 
 }  // namespace lfx

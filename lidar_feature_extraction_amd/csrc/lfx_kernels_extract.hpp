@@ -1295,6 +1295,7 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
 // kept for the first kStampUnits units of scan LFX_STAMP_SCAN; read back with lfx_debug_read_stamps.  The product
 // build executes none of this.
 #ifdef LFX_STAMPS
+__device__ inline uint32_t xcc_id() {uint32_t v; asm volatile ("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15u;}
 #ifndef LFX_STAMP_SCAN
 #define LFX_STAMP_SCAN 128
 #endif
@@ -1307,12 +1308,20 @@ __device__ unsigned long long g_unit_stamps[kStampUnits * kStampSlots];
       if (lane == 0) {g_unit_stamps[(slot * B + j) * kStampSlots + (n)] = t_;} \
     } \
   } while (0)
+#define LFX_STAMP_VALUE(n, v) \
+  do { \
+    if (s == (uint32_t)LFX_STAMP_SCAN && (uint32_t)(slot * B + j) < (uint32_t)kStampUnits && lane == 0) { \
+      g_unit_stamps[(slot * B + j) * kStampSlots + (n)] = (v); \
+    } \
+  } while (0)
 #elif defined(LFX_MARKS)
 // Diagnostic assembly only (make marks): a comment line at every stage boundary, so that the instructions of the
 // listing can be counted per stage (tools/count_stage_instructions.py).
 #define LFX_STAMP(n) asm volatile ("; LFX_MARK " #n ::: "memory")
+#define LFX_STAMP_VALUE(n, v) do {} while (0)
 #else
 #define LFX_STAMP(n) do {} while (0)
+#define LFX_STAMP_VALUE(n, v) do {} while (0)
 #endif
 
 // Output tables of the unit kernel, read through one pointer: sixteen kernel-argument pointers held in
@@ -1328,7 +1337,125 @@ struct UnitTables
   uint32_t * unit_ne, * unit_ns, * unit_span;
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
+  // organised-scan kernel: the scan's dense clouds, written by the units themselves, and the table of unit counts their
+  // places come from (unit_look_back); state_stride = granules per scan
+  float4 * edge_pts, * surf_pts;
+  uint32_t * edge_idx, * surf_idx;
+  uint64_t * unit_state;
+  uint32_t state_stride;
 };
+
+// ------------------------------------------------------------------------------------------
+// Where a unit's feature points go: the scan's edge / surface clouds are dense, rings ascending and inside a ring angle
+// ascending (GetIndicesByValue / AppendXYZIR walk the ring's labels in order, algorithm.hpp:39-62, label.hpp:166-179;
+// feature_extraction.cpp:142-151 appends ring after ring), so unit (ring, block j) writes behind everything the units
+// before it in that order emit: lex = ring * B + j, and its places start at the sum of the counts of units 0 .. lex - 1
+// of the scan.  Those units run at the same time in other waves (all units of a scan are dispatched within a
+// microsecond), so the sum is taken INSIDE the launch, counts only, no data: every unit publishes ONE 8-byte granule
+// {tag = epoch of the launch, n_edge | n_surface << 16} as soon as its labels are final (a write-through store by one
+// lane: the data is the flag, cdna_hip_programming.md Guideline 16 form R2) and then reads the granules of its
+// predecessors with sc1 loads, 16 bytes = two granules per lane, re-reading what does not carry the tag yet.  Nobody
+// ever reads another unit's POINTS, so nothing has to have landed anywhere before a unit signals; what a unit pays is
+// the round trip of its sweep and the skew to the slowest of its predecessors, on a slot it holds meanwhile.
+// No reset between launches: the tag is the launch's serial number (the host zeroes the table when it wraps).
+// Progress: a unit waits only for units of lower lex, i.e. for workgroups of its own scan with a block index at most
+// B - 1 above its own (blockIdx.x = ring group * B + j: ring 4g+1's block 0 follows ring 4g's block B-1), so with
+// workgroups dispatched in index order the lowest unfinished one never waits for one that is not resident as long as
+// B workgroups fit the device (B <= 64; 1 536 fit); the spin is bounded all the same and a timeout marks the scan.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) uint64_t gu64_t;      // (global_ instructions: a generic pointer makes them flat_)
+
+__device__ __forceinline__ void unit_publish(uint64_t * row, uint32_t lex, uint32_t epoch, uint32_t n_edge, uint32_t n_surface)
+{
+  __hip_atomic_store((gu64_t *)row + lex, ((uint64_t)epoch << 32) | (n_surface << 16) | n_edge, __ATOMIC_RELAXED,
+    __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The first sweep of a unit's look-back, issued EARLY (before the unit's own counts exist: stage G starts with it) so that
+// its round trip runs under the parallel-beam test and the final labels: granules g = 128 m + 2 lane + h (m < 3, h < 2) of
+// the scan's row, two per 16-byte load; 384 units = one sweep.  Nothing waits here: the destinations are not to be
+// touched before unit_look_back's wait (tests/test_build_hazards.py checks the listing for that).
+struct LookBackSweep
+{
+  u32x4_t v0, v1, v2;
+};
+
+__device__ __forceinline__ void unit_sweep_issue(const uint64_t * row, uint32_t lex, int lane, LookBackSweep & w)
+{
+  const uint64_t * p = row + 2u * (uint32_t)lane;
+  w.v1 = u32x4_t{0u, 0u, 0u, 0u};
+  w.v2 = u32x4_t{0u, 0u, 0u, 0u};
+  // (loads the unit does not need are jumped over -- lex is wave-uniform)
+  asm volatile (
+    "global_load_dwordx4 %0, %3, off sc1\n\t"
+    "s_cmp_lt_u32 %4, 0x81\n\t"
+    "s_cbranch_scc1 1f\n\t"
+    "global_load_dwordx4 %1, %3, off offset:1024 sc1\n\t"
+    "s_cmp_lt_u32 %4, 0x101\n\t"
+    "s_cbranch_scc1 1f\n\t"
+    "global_load_dwordx4 %2, %3, off offset:2048 sc1\n"
+    "1:"
+    : "=&v"(w.v0), "+v"(w.v1), "+v"(w.v2) : "v"(p), "s"(lex) : "memory", "scc");
+}
+
+// Sum of the counts of units 0 .. lex - 1 of the scan whose granules start at `row`; false = gave up waiting.  `w`: the
+// sweep issued earlier (units 0 .. 383); `after`: vector-memory operations the wave has issued since (the publish), which
+// the wait lets stay in flight.  What the sweep did not find published yet is read again, only by the lanes that miss it.
+template<int AFTER>
+__device__ __forceinline__ bool unit_look_back(
+  const uint64_t * row, uint32_t lex, uint32_t epoch, int lane, LookBackSweep & w, uint32_t & before_e, uint32_t & before_s,
+  uint32_t & polls)
+{
+  uint32_t acc_e = 0, acc_s = 0;
+  bool ok = true;
+  polls = 0;
+  // (always: also the scan's first unit, which has nobody before it, has a load in flight into these registers)
+  asm volatile ("s_waitcnt vmcnt(%3)" : "+v"(w.v0), "+v"(w.v1), "+v"(w.v2) : "n"(AFTER) : "memory");
+  for (uint32_t g0 = 0; g0 < lex; g0 += 384u) {
+    const uint32_t rem = lex - g0;                   // predecessors from g0 on (wave-uniform)
+    const uint64_t * p = row + g0 + 2u * (uint32_t)lane;
+    if (g0 != 0u) {
+      // (more than 384 units in a scan: the later sweeps one after the other)
+      unit_sweep_issue(row + g0, rem, lane, w);
+      asm volatile ("s_waitcnt vmcnt(0)" : "+v"(w.v0), "+v"(w.v1), "+v"(w.v2) :: "memory");
+    }
+    uint32_t accp = 0;                               // per lane at most six counts of <= 511: no carry between the halves
+    uint32_t pend = 0;                               // bit t = 2 m + h: that granule is a predecessor's and not published yet
+    const uint32_t val[6] = {w.v0.x, w.v0.z, w.v1.x, w.v1.z, w.v2.x, w.v2.z}, tag[6] = {w.v0.y, w.v0.w, w.v1.y, w.v1.w, w.v2.y, w.v2.w};
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      const bool need = 128u * (uint32_t)(t >> 1) + 2u * (uint32_t)lane + (uint32_t)(t & 1) < rem;
+      const bool have = tag[t] == epoch;
+      accp += need && have ? val[t] : 0u;
+      pend |= need && !have ? 1u << t : 0u;
+    }
+    uint32_t spins = 0;
+    while (__ballot(pend != 0u) != 0ull) {
+      if (++spins > kSpinLimit) {ok = false; break;}
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+        if (__ballot((pend >> t) & 1u) != 0ull) {
+          if ((pend >> t) & 1u) {
+            const uint64_t g = __hip_atomic_load((const gu64_t *)p + 128 * (t >> 1) + (t & 1), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(g >> 32) == epoch) {
+              accp += (uint32_t)g;
+              pend &= ~(1u << t);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    acc_e += accp & 0xFFFFu;
+    acc_s += accp >> 16;
+    polls += spins;
+    if (!ok) {break;}
+  }
+  before_e = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(acc_e), 63);
+  before_s = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(acc_s), 63);
+  return ok;
+}
 
 // A scan the organised-scan kernel cannot take (ring pattern, point count, angle order, a skip condition, a unit that
 // does not fit a wave) is flagged once and appended to the fall-back list: the bucketing route then redoes it whole.
@@ -1357,6 +1484,7 @@ struct OrgScan
   uint32_t * __restrict__ ring_count_out;
   uint32_t R, r0, wave, drop_zero;
   const uint32_t * __restrict__ xform;    // [batch][256] ring transforms (XF instantiations only)
+  uint32_t epoch;                         // tag of this launch's unit granules (unit_look_back)
 };
 
 #ifndef LFX_ORG_FULL
@@ -1398,18 +1526,12 @@ __device__ inline UnitGeom unit_geometry(int N, int P, int B, int j, int b0, int
 // in registers.  Returns 0, or the reason the unit cannot be taken here (kDeferOrder / kDeferOther); feature records go
 // to positions [rec_lo, ...) (edges, ascending) and (..., rec_hi) (surfaces, descending) of the ring's record arrays,
 // their numbers to n_edge / n_surface.
-struct NoHooks
-{
-  __device__ __forceinline__ void after_range() const {}
-  __device__ __forceinline__ void before_outputs() const {}
-};
-
-template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF, class Hooks = NoHooks>
+template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF>
 __device__ __forceinline__ uint32_t unit_core(
   const Params & prm, UnitLds<CH> & U, const UnitGeom & G, uint32_t dbg_flags, uint32_t s, uint32_t slot, int j,
   const float (&x)[CH], const float (&y)[CH], const float (&z)[CH], const uint32_t (&src)[CH],
   const UnitTables * __restrict__ tab, bool second_pass, const OrgScan & og, size_t off,
-  uint32_t rec_lo, uint32_t rec_hi, uint32_t & n_edge, uint32_t & n_surface, const int lane, const Hooks & hooks = Hooks())
+  uint32_t rec_lo, uint32_t rec_hi, uint32_t & n_edge, uint32_t & n_surface, const int lane)
 {
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
   (void)B;
@@ -1459,7 +1581,6 @@ __device__ __forceinline__ uint32_t unit_core(
   }
   LFX_WAVE_SYNC();
   LFX_STAMP(3);
-  hooks.after_range();    // (ring_stream_kernel requests the next unit's records here ...)
   // ---- C. links (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the
   //         occlusion test (occlusion.hpp:44-57, 67-79)
   {
@@ -1745,8 +1866,12 @@ __device__ __forceinline__ uint32_t unit_core(
   }
 #endif
   LFX_STAMP(9);
-  hooks.before_outputs(); // (... and waits for them here, ahead of this unit's own stores)
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
+  // (ORG: the look-back's first sweep leaves here, its round trip runs under the rest of the stage)
+  const uint32_t lex = ORG ? slot * (uint32_t)B + (uint32_t)j : 0u;
+  uint64_t * const row = ORG ? tab->unit_state + (size_t)s * tab->state_stride : nullptr;
+  LookBackSweep sweep;
+  if constexpr (ORG) {unit_sweep_issue(row, lex, lane, sweep);}
   uint64_t pby[CH];
   {
     uint64_t pbu[CH];
@@ -1798,46 +1923,121 @@ __device__ __forceinline__ uint32_t unit_core(
   asm volatile ("" ::: "memory");          // the table entries are not to be fetched (and held) any earlier
   uint8_t * __restrict__ label_s = tab->label_s;
   double * __restrict__ curv_s = tab->curv_s;
-  float4 * __restrict__ rec_pts = tab->rec_pts;
-  uint32_t * __restrict__ rec_idx = tab->rec_idx;
+  // final label of position q = 64 k + lane (feature_extraction.cpp:133-138: the masks override the block labelling)
+  auto final_label = [&](int k, int q) -> uint32_t {
+    const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
+    uint32_t l = kDefault;
+    l = (wE & reach[k]) != 0u ? (uint32_t)kEdgeNeighbor : l;
+    l = (wS & reach[k]) != 0u ? (uint32_t)kSurfaceNeighbor : l;
+    l = (wS & (1u << 16)) != 0u ? (uint32_t)kSurface : l;
+    l = (wE & (1u << 16)) != 0u ? (uint32_t)kEdge : l;
+    const double ri = U.r[q];
+    uint32_t ov = lanes(occ[k]) ? (uint32_t)kOccluded : (uint32_t)kDefault;
+    ov = !(min_range <= ri && ri <= max_range) ? (uint32_t)kOutOfRange : ov;      // range.hpp:40-43
+    ov = lanes(pby[k]) ? (uint32_t)kParallelBeam : ov;
+    l = ov != kDefault ? ov : l;
+    return lanes(in_span(q, qo0, qo1)) ? l : (uint32_t)kDefault;
+  };
+  if constexpr (ORG) {
+    // The organised-scan kernel writes its feature points straight into the scan's dense clouds (unit_look_back above):
+    // first the labels of every chunk and with them the unit's two counts, which are published at once; then the label
+    // and curvature stores; then the sum over the units before this one; then the points.
+    uint32_t lab[CH];
 #pragma unroll
-  for (int k = 0; k < CH; k++) {
-    if (k < K) {
-      const int q = 64 * k + lane, i = g0 + q;
-      const bool own = lanes(in_span(q, qo0, qo1));
-      const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
-      uint8_t l = kDefault;
-      l = (wE & reach[k]) != 0u ? (uint8_t)kEdgeNeighbor : l;
-      l = (wS & reach[k]) != 0u ? (uint8_t)kSurfaceNeighbor : l;
-      l = (wS & (1u << 16)) != 0u ? (uint8_t)kSurface : l;
-      l = (wE & (1u << 16)) != 0u ? (uint8_t)kEdge : l;
-      const double ri = U.r[q];
-      uint32_t ov = lanes(occ[k]) ? (uint32_t)kOccluded : (uint32_t)kDefault;
-      ov = !(min_range <= ri && ri <= max_range) ? (uint32_t)kOutOfRange : ov;      // range.hpp:40-43
-      ov = lanes(pby[k]) ? (uint32_t)kParallelBeam : ov;
-      l = ov != kDefault ? (uint8_t)ov : l;
-      l = own ? l : (uint8_t)kDefault;
-      const double cv = U.c[q];
-      if (own) {
-        label_s[off + i] = l;
-        curv_s[off + i] = cv;
+    for (int k = 0; k < CH; k++) {
+      lab[k] = kDefault;
+      if (k < K) {
+        lab[k] = final_label(k, 64 * k + lane);
+        pe += __popcll(bal(lab[k] == kEdge));
+        ps += __popcll(bal(lab[k] == kSurface));
       }
-      const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
-      if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
-        // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-        const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
-        const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
-        const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
-        const size_t at = l == kEdge ? off + rec_lo + pe + be : off + rec_hi - 1 - (ps + bs);
-        rec_pts[at] = rec;
-        // ORG: position i of ring `slot` is point column * R + slot
-        rec_idx[at] = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
+    }
+    if (lane == 0) {unit_publish(row, lex, og.epoch, pe, ps);}
+    LFX_STAMP(11);
+    // the sum over the units before this one (the publish is the one operation the wait lets stay in flight).  The
+    // label and curvature stores come AFTER it: vector-memory operations complete in issue order, so a load issued behind
+    // them would wait for them to land (3 us under this kernel's own store traffic) before its data counted as back.
+    uint32_t before_e, before_s, polls;
+    const bool seen = unit_look_back<1>(row, lex, og.epoch, lane, sweep, before_e, before_s, polls);
+    LFX_STAMP(12);
+    LFX_STAMP_VALUE(15, polls | (xcc_id() << 16) | ((unsigned long long)blockIdx.x << 32));
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      if (k < K) {
+        const int q = 64 * k + lane, i = g0 + q;
+        if (lanes(in_span(q, qo0, qo1))) {
+          label_s[off + i] = (uint8_t)lab[k];
+          curv_s[off + i] = U.c[q];
+        }
       }
-      pe += __popcll(fe);
-      ps += __popcll(fs);
+    }
+    LFX_STAMP(13);
+    if (!seen) {
+      if (lane == 0) {atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kErrTimeout);}
+    } else if (LFX_STAGE_ON(1024u)) {
+      const size_t first = og.scan_begin[s];
+      float4 * __restrict__ const edge_pts = tab->edge_pts + first + before_e, * __restrict__ const surf_pts = tab->surf_pts + first + before_s;
+      uint32_t * __restrict__ const edge_idx = tab->edge_idx + first + before_e, * __restrict__ const surf_idx = tab->surf_idx + first + before_s;
+      uint32_t ne = 0, ns = 0;
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (k < K) {
+          const uint64_t fe = bal(lab[k] == kEdge), fs = bal(lab[k] == kSurface);
+          if ((fe | fs) != 0ull) {
+            const int q = 64 * k + lane, i = g0 + q;
+            if (lanes(fe | fs)) {
+              // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
+              const float4 rec = make_float4(x[k], y[k], z[k], (float)U.c[q]);
+              const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
+              const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
+              // position i of ring `slot` is point column * R + slot
+              const uint32_t idx = (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot;
+              const bool is_edge = lab[k] == kEdge;
+              const uint32_t at = is_edge ? ne + be : ns + bs;
+              (is_edge ? edge_pts : surf_pts)[at] = rec;
+              (is_edge ? edge_idx : surf_idx)[at] = idx;
+            }
+            ne += __popcll(fe);
+            ns += __popcll(fs);
+          }
+        }
+      }
+      // the last unit of the scan knows the totals
+      if (lex + 1u == og.R * (uint32_t)B && lane == 0) {
+        tab->scan_info[s * 4 + kInfoEdge] = before_e + pe;
+        tab->scan_info[s * 4 + kInfoSurface] = before_s + ps;
+      }
+    }
+  } else {
+    float4 * __restrict__ rec_pts = tab->rec_pts;
+    uint32_t * __restrict__ rec_idx = tab->rec_idx;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      if (k < K) {
+        const int q = 64 * k + lane, i = g0 + q;
+        const bool own = lanes(in_span(q, qo0, qo1));
+        const uint32_t l = final_label(k, q);
+        const double cv = U.c[q];
+        if (own) {
+          label_s[off + i] = (uint8_t)l;
+          curv_s[off + i] = cv;
+        }
+        const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
+        if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
+          // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
+          const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
+          const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
+          const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
+          const size_t at = l == kEdge ? off + rec_lo + pe + be : off + rec_hi - 1 - (ps + bs);
+          rec_pts[at] = rec;
+          rec_idx[at] = src[k];
+        }
+        pe += __popcll(fe);
+        ps += __popcll(fs);
+      }
     }
   }
-  LFX_STAMP(11);
+  LFX_STAMP(14);
   n_edge = pe;
   n_surface = ps;
   return 0u;
@@ -1863,7 +2063,7 @@ __device__ __forceinline__ void unit_body(
     const uint32_t C = n / og.R;
     N = (int)C;
     if (C * og.R != n || C == 0u || C > ring_cap) {
-      if (blockIdx.x == 0 && og.wave == 0 && lane == 0) {scan_falls_back(tab, s);}
+      if (og.r0 == 0u && j == 0 && og.wave == 0 && lane == 0) {scan_falls_back(tab, s);}
       return;
     }
   } else {
@@ -1878,7 +2078,12 @@ __device__ __forceinline__ void unit_body(
 #define LFX_DEFER(reason) \
   do { \
     if (ORG) { \
-      if (lane == 0) {scan_falls_back(tab, s, (reason) == kDeferOrder);} \
+      /* (the units behind this one in the scan's clouds must not wait for it: it counts as empty; what they write is */ \
+      /* redone with the whole scan by the bucketing route) */ \
+      if (lane == 0) { \
+        scan_falls_back(tab, s, (reason) == kDeferOrder); \
+        if (slot < og.R) {unit_publish(tab->unit_state + (size_t)s * tab->state_stride, slot * (uint32_t)B + (uint32_t)j, og.epoch, 0u, 0u);} \
+      } \
     } else if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
       defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
     } \
@@ -1994,10 +2199,12 @@ __device__ __forceinline__ void unit_body(
     if (why != 0u) {LFX_DEFER(why);}
   }
   if (lane == 0) {
-    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
-    tab->unit_ne[ui] = pe;
-    tab->unit_ns[ui] = ps;
-    tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
+    if (!ORG) {
+      const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
+      tab->unit_ne[ui] = pe;
+      tab->unit_ns[ui] = ps;
+      tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
+    }
     if (j == 0) {
       tab->ring_status[s * kRings + slot] = kOk;
       if (ORG) {
@@ -2032,7 +2239,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   UnitLds<CH> * U = &lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
-  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr};
+  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, 0u};
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
@@ -2079,21 +2286,44 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
 }
 
 // The organised-scan kernel (unit_body<ORG>): workgroup = block j of the four adjacent rings 4g .. 4g+3 of scan
-// blockIdx.y, one ring per wave.  blockIdx.x = j * groups + g: workgroups dispatched together take neighbouring ring
-// groups of the same block, i.e. neighbouring 128-byte lines of the same columns -- whole DRAM pages between them.
+// s, one ring per wave; workgroup x = g * B + j of the scan: a unit only ever waits for units of its scan in workgroups
+// at most B - 1 above its own (unit_look_back).
 template<int CH, bool DEF, bool XF>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform)
+  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform, uint32_t epoch, uint32_t batch)
 {
   __shared__ UnitLds<CH> lds[kUnitWaves];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t groups = (max_rings + 3u) >> 2;
-  const uint32_t g = blockIdx.x % groups;
-  const int j = (int)(blockIdx.x / groups);
-  const uint32_t s = blockIdx.y;
-  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform};
+  // Which scan, which workgroup of it.  The units of a scan wait for each other (unit_look_back), so they are kept on ONE
+  // XCD: workgroups are dealt to the eight XCDs round-robin by their index (MI355X_MICROARCH.md, Workgroup dispatch),
+  // each XCD walking its share in order at its own pace -- with a scan spread over all eight, every wave would wait for
+  // the XCD that happens to lag (measured: 8 us of a wave's 29).  Index L -> XCD L mod 8, place k = L / 8 in that XCD's
+  // sequence; the sequence takes scans xcd, xcd + 8, ... whole, one after the other.  (A speed matter only: if the
+  // dealing is ever different the waits are longer, not wrong.)  The last batch mod 8 scans are dealt plainly.
+  const uint32_t per_scan = ((max_rings + 3u) >> 2) * (uint32_t)prm.B;
+  uint32_t s, x;
+#ifdef LFX_ORG_PLAIN_MAP
+  s = blockIdx.x / per_scan;
+  x = blockIdx.x % per_scan;
+#else
+  {
+    const uint32_t whole = batch & ~7u;
+    if (blockIdx.x < whole * per_scan) {
+      const uint32_t k = blockIdx.x >> 3;
+      s = 8u * (k / per_scan) + (blockIdx.x & 7u);
+      x = k % per_scan;
+    } else {
+      const uint32_t r = blockIdx.x - whole * per_scan;
+      s = whole + r / per_scan;
+      x = r % per_scan;
+    }
+  }
+#endif
+  const uint32_t g = x / (uint32_t)prm.B;
+  const int j = (int)(x % (uint32_t)prm.B);
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, epoch};
   const uint32_t slot = 4u * g + wave;
   if (DEF || prm.P == 5) {
     unit_body<5, CH, DEF, true, LFX_ORG_FULL, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
@@ -2107,280 +2337,9 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   }
 }
 
-// ==========================================================================================
-// The streaming form of the organised-scan kernel: workgroup = the four ADJACENT rings 4g .. 4g+3 of scan blockIdx.y,
-// one ring per wave, and the waves WALK their ring block by block (feature_extraction.cpp:120-157 is one such walk per
-// ring).  While unit j is computed the 32-byte records of unit j+1 are already in flight: they are requested early in
-// unit j (lane = (column, ring of the group) as in ring_unit_org_kernel: every 128-byte line once) by LDS-DMA
-// (global_load_lds_dwordx3: x, y, z straight into a landing zone in LDS, no registers held meanwhile) and waited for
-// just before unit j's own stores, so that a wave's memory phases no longer run in series with its arithmetic
-// (31 % of a wave's life was parked in s_waitcnt); and the per-wave prologue -- scan shape, tables, skip
-// tests -- is paid once per ring instead of once per block.  One workgroup barrier per unit (the landed tile is read by
-// all four waves); that every wave has taken its part of the previous tile out of the landing zone before the next one
-// is requested into it is a counter in LDS, not a second barrier.  Feature records are packed per RING (edges ascending
-// from the ring's first position, surfaces descending from its last): one dense run of each kind for the compaction
-// instead of one per unit.
-constexpr int stream_waves_per_simd(int ch) {return ch <= 4 ? 5 : (ch == 5 ? 4 : 3);}      // (LDS: 4 workgroups per CU at 5 chunks, 3 at 6)
-
-// The landing zone: x, y and z planes; piece (m, w) = columns 64 m + 16 w .. + 15 of the four rings, requested by wave w,
-// lane l's record in element l.  (LDS-DMA puts lane l's data at M0 + instruction offset + 16 l for the dwordx3 and dwordx4
-// forms and at + 4 l for the dword form -- tools/probes/lds_dma_layout.hip --, so three dword transfers per piece land
-// in 12 bytes per record where one dwordx3 transfer would take 16: 15 KB instead of 20 per workgroup, the difference
-// between three and four workgroups per CU.)
-template<int CH>
-struct TileZone
-{
-  __attribute__((aligned(16))) float v[3][CH * kUnitWaves][64];
-};
-
-// Request the tile of unit geometry g0 (4 rings x the unit's span): CH pieces of 16 columns per wave.  The DMA is inline
-// asm (the compiler's own LDS-DMA would make every later LDS read wait for it); the ring words come by ordinary loads.
-template<int CH, bool XF>
-__device__ __forceinline__ void tile_request(
-  const OrgScan & og, const uint8_t * base, int N, int g0, uint32_t xf, uint32_t rload, uint32_t cq,
-  const TileZone<CH> & zone, uint32_t (&rw)[CH])
-{
-#pragma unroll
-  for (int m = 0; m < CH; m++) {
-    const int q = 64 * m + 16 * (int)og.wave + (int)cq;
-    int i = g0 + q;
-    i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);       // beyond the ring / the span: any valid record (masked out when taken)
-    const uint32_t col = XF ? ring_column(xf, (uint32_t)i, (uint32_t)N) : (uint32_t)i;
-    const uint8_t * p = base + (col * og.R + rload) * 32u;                // a scan is < 2^27 points (host check)
-    const int piece = m * kUnitWaves + (int)og.wave;
-    // (the instruction offset moves the LDS address with the global one: the y and z destinations are given less it)
-    const uint32_t dx = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(&zone.v[0][piece][0]));
-    const uint32_t dy = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(&zone.v[1][piece][0]) - 4u);
-    const uint32_t dz = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(&zone.v[2][piece][0]) - 8u);
-    uint32_t keep;
-    asm volatile (
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
-      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:4\n\t"
-      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:8\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep) : "v"(p), "s"(dx), "s"(dy), "s"(dz) : "memory");
-    rw[m] = *reinterpret_cast<const uint32_t *>(p + 20);
-  }
-}
-
-// The pattern test of a landed tile (this wave's own pieces): every record inside the ring must carry the ring id its
-// place implies (and, with the zero-point filter on, must not be a (0, 0, 0) record: convert.py:162-163,192 would have
-// dropped it).
-template<int CH>
-__device__ __forceinline__ uint64_t tile_check(
-  const OrgScan & og, const UnitGeom & G, uint32_t rr, uint32_t cq, int lane, const TileZone<CH> & zone, const uint32_t (&rw)[CH])
-{
-  uint64_t wrong = 0;
-#pragma unroll
-  for (int m = 0; m < CH; m++) {
-    const int q = 64 * m + 16 * (int)og.wave + (int)cq;
-    uint64_t bad = bal((rw[m] & 0xFFFFu) != rr);
-    if (og.drop_zero) {
-      const int piece = m * kUnitWaves + (int)og.wave;
-      bad |= bal(zone.v[0][piece][lane] == 0.f) & bal(zone.v[1][piece][lane] == 0.f) & bal(zone.v[2][piece][lane] == 0.f);
-    }
-    wrong |= bad & in_span(q, G.qlo, G.qhi);
-  }
-  return wrong & bal(rr < og.R);
-}
-
-template<int CH, bool XF>
-struct TileHooks
-{
-  const OrgScan & og;
-  const UnitGeom & Gn;
-  const TileZone<CH> & zone;
-  volatile uint32_t * ctl;             // [0], [1] a wave gave the scan up (by unit parity), [2] parts of tiles taken out of the zone so far
-  const uint8_t * base;
-  uint32_t (&rw)[CH];
-  uint64_t & wrong;
-  int N, lane;
-  uint32_t xf, rload, rr, cq, taken_needed, give_up_at;
-  bool more;
-  __device__ __forceinline__ void after_range() const
-  {
-    if (!more) {return;}
-    // every wave has taken its ring's part of the current tile (it does so first thing in a unit); the wait is bounded
-    // (a few milliseconds): should a wave never get there the scan is given up rather than the GPU hung
-    uint32_t spins = 0;
-    while ((uint32_t)__builtin_amdgcn_readfirstlane(ctl[2]) < taken_needed) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 17)) {
-        if (lane == 0) {ctl[give_up_at] = 1u;}
-        return;
-      }
-    }
-    tile_request<CH, XF>(og, base, N, Gn.g0, xf, rload, cq, zone, rw);
-  }
-  __device__ __forceinline__ void before_outputs() const
-  {
-    if (!more) {return;}
-    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-    wrong = tile_check<CH>(og, Gn, rr, cq, lane, zone, rw);
-  }
-};
-
-template<int PT, int CH, bool DEF, bool XF>
-__device__ __forceinline__ void stream_body(
-  const Params & prm, UnitLds<CH> * __restrict__ slabs, TileZone<CH> & zone, volatile uint32_t * ctl, uint32_t ring_cap,
-  uint32_t max_rings, uint32_t dbg_flags, uint32_t s, const UnitTables * __restrict__ tab, const OrgScan & og)
-{
-  const int lane_id = threadIdx.x & 63;
-  UnitLds<CH> & U = slabs[og.wave];
-  const int P = PT > 0 ? PT : prm.P, B = prm.B;
-  const uint32_t slot = og.r0 + og.wave;
-  // the scan must be R rings x C columns, C within the ring capacity, and long enough for its blocks: the same for every
-  // wave of every workgroup of the scan, which therefore leave together
-  const uint32_t scan_first = og.scan_begin[s];
-  const uint32_t n = og.scan_begin[s + 1] - scan_first;
-  const uint32_t C = n / og.R;
-  const int N = (int)C;
-  if (C * og.R != n || C == 0u || C > ring_cap || N < 2 * P + 1 || N - 2 * P < B) {
-    if (og.r0 == 0u && og.wave == 0u && lane_id == 0) {scan_falls_back(tab, s);}
-    return;
-  }
-  const size_t off = ring_base(s, slot, max_rings, ring_cap);
-  const uint8_t * const base = og.pts + (size_t)scan_first * 32u;
-  // A wave that has to give the scan up says so in LDS; the workgroup leaves behind its next barrier.  Two words, by unit
-  // parity: what is written during unit j is read behind the barrier that opens unit j + 1 and nowhere else, so that the
-  // four waves always take the same decision (a wave still on its way from the barrier to the test of unit j must not
-  // see what a faster one writes during unit j).
-#define LFX_GIVE_UP(order_only, unit) \
-  do { \
-    if (lane == 0) { \
-      scan_falls_back(tab, s, (order_only)); \
-      ctl[((unit) + 1) & 1] = 1u; \
-    } \
-  } while (0)
-#define LFX_UNIT_GEOMETRY(G, jj) \
-  UnitGeom G; \
-  { \
-    const int bj_ = block_boundary(N, P, B, (jj) + (lane & 1));      /* even lanes j, odd lanes j + 1 */ \
-    G = unit_geometry(N, P, B, (jj), __builtin_amdgcn_readlane(bj_, 0), __builtin_amdgcn_readlane(bj_, 1), 0); \
-  }
-  uint32_t rw[CH];
-  UnitGeom G;
-  {
-    const int lane = lane_id;
-    const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
-    const uint32_t rr = og.r0 + sub;
-    const uint32_t rload = rr < og.R ? rr : og.R - 1u;          // a group beyond the last ring loads nothing new
-    const uint32_t xf = XF ? og.xform[s * kRings + rload] : 0u;
-    LFX_UNIT_GEOMETRY(G0, 0);
-    G = G0;
-    if (G.b1 - G.b0 < 2 || G.span > 64 * CH) {          // (wave-uniform and the same in the four waves)
-      if (og.wave == 0u && lane == 0) {scan_falls_back(tab, s);}
-      return;
-    }
-    tile_request<CH, XF>(og, base, N, G.g0, xf, rload, cq, zone, rw);
-    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tile_check<CH>(og, G, rr, cq, lane, zone, rw) != 0ull) {LFX_GIVE_UP(false, -1);}
-  }
-  uint32_t ring_ne = 0, ring_ns = 0;
-  bool gave_up = false;
-  for (int j = 0; j < B; j++) {
-    // (the lane index is made opaque per unit: everything derived from it -- LDS addresses, window shifts, span tests of
-    // every chunk -- is otherwise hoisted out of the loop and held in registers across it)
-    int lane = lane_id;
-    asm volatile ("" : "+v"(lane));
-    __syncthreads();                                     // the tile of unit j has landed, for every wave
-    if (__builtin_amdgcn_readfirstlane(ctl[j & 1]) != 0u) {return;}
-    const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
-    const uint32_t rr = og.r0 + sub;
-    const uint32_t rload = rr < og.R ? rr : og.R - 1u;
-    const uint32_t xf = XF ? og.xform[s * kRings + rload] : 0u;
-    const bool more = j + 1 < B;
-    LFX_UNIT_GEOMETRY(Gn, more ? j + 1 : j);
-    if (more && (Gn.b1 - Gn.b0 < 2 || Gn.span > 64 * CH)) {
-      if (og.wave == 0u && lane == 0) {scan_falls_back(tab, s);}
-      return;
-    }
-    uint64_t wrong = 0;
-    const TileHooks<CH, XF> hooks{og, Gn, zone, ctl, base, rw, wrong, N, lane, xf, rload, rr, cq, (uint32_t)kUnitWaves * (uint32_t)(j + 1),
-      (uint32_t)(j + 1) & 1u, more};
-    uint32_t why = 0u;
-    if (slot < og.R) {
-      // this ring's part of the tile: position q = 64 k + lane is record (lane & 15) * 4 + wave of piece (k, lane >> 4)
-      float x[CH], y[CH], z[CH];
-      uint32_t src[CH];
-      {
-        uint32_t * zb = &U.bits[0][0];
-        zb[lane] = 0u;
-        if (lane + 64 < kUnitBitArrays * UnitLds<CH>::kBitWords) {zb[lane + 64] = 0u;}
-      }
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        const int q = 64 * k + lane;
-        const int piece = k * kUnitWaves + (lane >> 4), e = (lane & 15) * 4 + (int)og.wave;
-        const float xr = zone.v[0][piece][e], yr = zone.v[1][piece][e];
-        z[k] = zone.v[2][piece][e];
-        const bool in = lanes(in_span(q, G.qlo, G.qhi));
-        x[k] = in ? xr : 0.f;
-        y[k] = in ? yr : 0.f;
-        U.pxy[q] = make_float2(x[k], y[k]);
-        src[k] = 0u;
-      }
-      LFX_WAVE_SYNC();
-      if (lane == 0) {atomicAdd(const_cast<uint32_t *>(ctl + 2), 1u);}
-      uint32_t pe = 0, ps = 0;
-      why = unit_core<PT, CH, DEF, true, false, XF>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, false, og, off,
-        ring_ne, (uint32_t)N - ring_ns, pe, ps, lane, hooks);
-      ring_ne += pe;
-      ring_ns += ps;
-    } else {                                             // (ring count not a multiple of four: this wave only loads)
-      if (lane == 0) {atomicAdd(const_cast<uint32_t *>(ctl + 2), 1u);}
-      hooks.after_range();
-      hooks.before_outputs();
-    }
-    if (why != 0u) {LFX_GIVE_UP(why == (uint32_t)kDeferOrder, j); gave_up = true;}
-    if (!more) {break;}
-    if (why == 0u && wrong != 0ull) {LFX_GIVE_UP(false, j);}
-    G = Gn;
-  }
-#undef LFX_UNIT_GEOMETRY
-#undef LFX_GIVE_UP
-  if (slot >= og.R || gave_up) {return;}
-  // the ring's records are ONE unit for the compaction: [0, N) with all its edges and surfaces
-  if (lane_id < B) {
-    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + lane_id;
-    tab->unit_ne[ui] = lane_id == 0 ? ring_ne : 0u;
-    tab->unit_ns[ui] = lane_id == 0 ? ring_ns : 0u;
-    tab->unit_span[ui] = lane_id == 0 ? ((uint32_t)N << 16) : 0u;
-  }
-  if (lane_id == 0) {
-    tab->ring_status[s * kRings + slot] = kOk;
-    // what the bucketing kernel would have counted (it overwrites both if the scan falls back after all)
-    og.ring_count_out[s * kRings + slot] = (uint32_t)N;
-    if (slot == 0) {
-      tab->scan_info[s * 4 + kInfoRings] = og.R;
-      atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kScanFused);
-    }
-  }
-}
-
-template<int CH, bool DEF, bool XF>
-__global__ __launch_bounds__(64 * kUnitWaves, stream_waves_per_simd(CH)) void ring_stream_kernel(
-  Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
-  const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform)
-{
-  __shared__ UnitLds<CH> lds[kUnitWaves];
-  __shared__ TileZone<CH> zone;
-  __shared__ uint32_t ctl[4];
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (threadIdx.x < 4) {ctl[threadIdx.x] = 0u;}
-  __syncthreads();
-  const uint32_t s = blockIdx.y;
-  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * blockIdx.x, wave, drop_zero, xform};
-  if (DEF || prm.P == 5) {
-    stream_body<5, CH, DEF, XF>(prm, lds, zone, ctl, ring_cap, max_rings, dbg_flags, s, tab, og);
-  } else if (prm.P == 2) {
-    stream_body<2, CH, false, XF>(prm, lds, zone, ctl, ring_cap, max_rings, dbg_flags, s, tab, og);
-  } else {
-    stream_body<0, CH, false, XF>(prm, lds, zone, ctl, ring_cap, max_rings, dbg_flags, s, tab, og);
-  }
-}
+// (The streaming form of this kernel -- waves walking their ring with the next unit's records arriving by LDS-DMA -- was
+// built, measured slower and taken out again: git show 1488a09:lidar_feature_extraction_amd/csrc/lfx_kernels_extract.hpp,
+// ring_stream_kernel; DESIGN.md 4 "Round 3".)
 
 // The ring transforms of an organised stream whose rings do not arrive in angle order: a driver that starts its scans
 // at another azimuth delivers every ring as a ROTATION of its sorted order, a clockwise sensor as its REVERSE (or
@@ -2809,41 +2768,49 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Compaction, step 1: per scan, ring totals and their exclusive prefix (rings ascending).
+// Compaction of the bucketing route (the organised-scan kernel writes its clouds itself, unit_look_back): both kernels
+// walk the scans on the fall-back list -- every scan of the batch when the organised-scan kernel is not in use --,
+// list entries blockIdx, + gridDim, ... (a length the host can only guess).
+// Step 1: per scan, ring totals and their exclusive prefix (rings ascending).
 __global__ __launch_bounds__(kRings) void ring_totals_kernel(
   uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
   const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
   uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf, uint32_t * __restrict__ ring_ebase,
-  uint32_t * __restrict__ ring_sbase, uint32_t n_units, uint32_t max_rings)
+  uint32_t * __restrict__ ring_sbase, uint32_t n_units, uint32_t max_rings,
+  const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
 {
-  const uint32_t s = blockIdx.x, slot = threadIdx.x;
-  uint32_t e = 0, f = 0;
-  if (slot < max_rings && ring_count[s * kRings + slot] != 0u) {
-    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
-    for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ui + j]; f += unit_ns[ui + j];}
-  }
+  const uint32_t slot = threadIdx.x, n_list = *fb_count;
   __shared__ uint32_t pe[kRings], pf[kRings];
-  pe[slot] = e;
-  pf[slot] = f;
-  __syncthreads();
-  for (uint32_t d = 1; d < kRings; d <<= 1) {
-    const uint32_t a = slot >= d ? pe[slot - d] : 0u, b = slot >= d ? pf[slot - d] : 0u;
+  for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
+    const uint32_t s = fb_list[it];
+    uint32_t e = 0, f = 0;
+    if (slot < max_rings && ring_count[s * kRings + slot] != 0u) {
+      const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+      for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ui + j]; f += unit_ns[ui + j];}
+    }
+    pe[slot] = e;
+    pf[slot] = f;
     __syncthreads();
-    pe[slot] += a;
-    pf[slot] += b;
+    for (uint32_t d = 1; d < kRings; d <<= 1) {
+      const uint32_t a = slot >= d ? pe[slot - d] : 0u, b = slot >= d ? pf[slot - d] : 0u;
+      __syncthreads();
+      pe[slot] += a;
+      pf[slot] += b;
+      __syncthreads();
+    }
+    ring_nedge[s * kRings + slot] = e;
+    ring_nsurf[s * kRings + slot] = f;
+    ring_ebase[s * kRings + slot] = pe[slot] - e;
+    ring_sbase[s * kRings + slot] = pf[slot] - f;
+    if (slot == kRings - 1) {
+      scan_info[s * 4 + kInfoEdge] = pe[slot];
+      scan_info[s * 4 + kInfoSurface] = pf[slot];
+    }
     __syncthreads();
-  }
-  ring_nedge[s * kRings + slot] = e;
-  ring_nsurf[s * kRings + slot] = f;
-  ring_ebase[s * kRings + slot] = pe[slot] - e;
-  ring_sbase[s * kRings + slot] = pf[slot] - f;
-  if (slot == kRings - 1) {
-    scan_info[s * 4 + kInfoEdge] = pe[slot];
-    scan_info[s * 4 + kInfoSurface] = pf[slot];
   }
 }
 
-// Compaction, step 2: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
+// Step 2: copy the feature records into the scan's edge / surface clouds: rings ascending, inside a
 // ring angle ascending (units ascending; a slow-path ring is one unit).  One wave per ring; the ring's records
 // are taken as ONE sequence over its units, four per lane in flight, so that the copy waits for memory once per
 // 256 records instead of once per unit.
@@ -2854,71 +2821,75 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ unit_span,
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
-  uint32_t max_rings)
+  uint32_t max_rings, const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
 {
-  const uint32_t s = blockIdx.y, lane = threadIdx.x & 63;
+  const uint32_t lane = threadIdx.x & 63, n_list = *fb_count;
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (slot >= max_rings || ring_count[s * kRings + slot] == 0u) {return;}
-  const size_t b = scan_begin[s];
-  const size_t off = ring_base(s, slot, max_rings, cap);
-  const size_t eb = b + ring_ebase[s * kRings + slot], fb = b + ring_sbase[s * kRings + slot];
-  const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
-  uint32_t ne_k = 0, ns_k = 0, span_k = 0;               // lane j holds unit j's entries (n_units <= 64)
-  if (lane < n_units) {
-    ne_k = unit_ne[ui + lane];
-    ns_k = unit_ns[ui + lane];
-    span_k = unit_span[ui + lane];
-  }
-  uint32_t total = ne_k + ns_k;
-  for (int o = 32; o > 0; o >>= 1) {total += __shfl_xor(total, o);}
-  for (uint32_t t0 = 0; t0 < total; t0 += 256) {
-    size_t src[4], dst[4];
-    bool edge[4], valid[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      valid[i] = t0 + 64 * i + lane < total;
-      edge[i] = false;
-      src[i] = off;
-      dst[i] = b;
+  if (slot >= max_rings) {return;}
+  for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
+    const uint32_t s = fb_list[it];
+    if (ring_count[s * kRings + slot] == 0u) {continue;}
+    const size_t b = scan_begin[s];
+    const size_t off = ring_base(s, slot, max_rings, cap);
+    const size_t eb = b + ring_ebase[s * kRings + slot], fb = b + ring_sbase[s * kRings + slot];
+    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+    uint32_t ne_k = 0, ns_k = 0, span_k = 0;               // lane j holds unit j's entries (n_units <= 64)
+    if (lane < n_units) {
+      ne_k = unit_ne[ui + lane];
+      ns_k = unit_ns[ui + lane];
+      span_k = unit_span[ui + lane];
     }
-    uint32_t cum = 0, ecum = 0, scum = 0;
-    for (uint32_t u = 0; u < n_units; u++) {               // the units' counts are wave-uniform
-      const uint32_t ne = __builtin_amdgcn_readlane(ne_k, u), ns = __builtin_amdgcn_readlane(ns_k, u);
-      const uint32_t span = __builtin_amdgcn_readlane(span_k, u);
-      const size_t first = off + (span & 0xFFFFu), last = off + (span >> 16);
-#pragma unroll
+    uint32_t total = ne_k + ns_k;
+    for (int o = 32; o > 0; o >>= 1) {total += __shfl_xor(total, o);}
+    for (uint32_t t0 = 0; t0 < total; t0 += 256) {
+      size_t src[4], dst[4];
+      bool edge[4], valid[4];
+  #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const uint32_t q = t0 + 64 * i + lane - cum;       // index inside unit u (wraps when the record lies before it)
-        if (q < ne + ns) {
-          edge[i] = q < ne;
-          src[i] = edge[i] ? first + q : last - 1 - (q - ne);
-          dst[i] = edge[i] ? eb + ecum + q : fb + scum + (q - ne);
+        valid[i] = t0 + 64 * i + lane < total;
+        edge[i] = false;
+        src[i] = off;
+        dst[i] = b;
+      }
+      uint32_t cum = 0, ecum = 0, scum = 0;
+      for (uint32_t u = 0; u < n_units; u++) {               // the units' counts are wave-uniform
+        const uint32_t ne = __builtin_amdgcn_readlane(ne_k, u), ns = __builtin_amdgcn_readlane(ns_k, u);
+        const uint32_t span = __builtin_amdgcn_readlane(span_k, u);
+        const size_t first = off + (span & 0xFFFFu), last = off + (span >> 16);
+  #pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t q = t0 + 64 * i + lane - cum;       // index inside unit u (wraps when the record lies before it)
+          if (q < ne + ns) {
+            edge[i] = q < ne;
+            src[i] = edge[i] ? first + q : last - 1 - (q - ne);
+            dst[i] = edge[i] ? eb + ecum + q : fb + scum + (q - ne);
+          }
+        }
+        cum += ne + ns;
+        ecum += ne;
+        scum += ns;
+      }
+      float4 rp[4];
+      uint32_t ri[4];
+  #pragma unroll
+      for (int i = 0; i < 4; i++) {
+        rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ri[i] = 0;
+        if (valid[i]) {
+          rp[i] = rec_pts[src[i]];
+          ri[i] = rec_idx[src[i]];
         }
       }
-      cum += ne + ns;
-      ecum += ne;
-      scum += ns;
-    }
-    float4 rp[4];
-    uint32_t ri[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      ri[i] = 0;
-      if (valid[i]) {
-        rp[i] = rec_pts[src[i]];
-        ri[i] = rec_idx[src[i]];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (valid[i]) {
-        if (edge[i]) {
-          edge_pts[dst[i]] = rp[i];
-          edge_idx[dst[i]] = ri[i];
-        } else {
-          surf_pts[dst[i]] = rp[i];
-          surf_idx[dst[i]] = ri[i];
+  #pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (valid[i]) {
+          if (edge[i]) {
+            edge_pts[dst[i]] = rp[i];
+            edge_idx[dst[i]] = ri[i];
+          } else {
+            surf_pts[dst[i]] = rp[i];
+            surf_idx[dst[i]] = ri[i];
+          }
         }
       }
     }

@@ -1022,21 +1022,6 @@ __global__ __launch_bounds__(128) void pair_rows_kernel(
 // the next byte, finds the bin that holds rank k by a prefix sum along its lanes and publishes it | everyone reads that.
 constexpr int kSelectWords = 576;         // 256 bins | 8 words of result | 48 words of the median's own | 256 "who counted here"
 
-// inclusive prefix sum along the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16 lanes, then the two
-// row broadcasts): eight VALU instructions where six ds_bpermute round trips through the LDS crossbar were ~700 cycles
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
-{
-  uint32_t t = x;
-  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);      // row_shr:1
-  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);      // row_shr:2
-  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xF, 0xF, true);      // row_shr:3
-  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xE, true);      // row_shr:4, banks 1-3
-  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xC, true);      // row_shr:8, banks 2-3
-  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
-  t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
-  return t;
-}
-
 __device__ inline double workgroup_select(const double * __restrict__ v, uint32_t n, uint32_t k, uint32_t * sh)
 {
   const int tid = threadIdx.x, T = blockDim.x;

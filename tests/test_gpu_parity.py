@@ -476,11 +476,11 @@ def test_every_unit_kernel_variant(chunks):
     f.close()
 
 
-def test_streaming_form_of_the_organised_kernel(monkeypatch):
-    """LFX_DEBUG_STREAM=1: ring_stream_kernel (the waves walk their rings block by block, the next unit's records arriving by
-    LDS-DMA meanwhile) instead of one wave per unit.  Slower as measured, kept as the record of the experiment:
-    it must stay correct.  Scans in order, a scan that breaks the pattern half-way (falls back), rotated rings."""
-    monkeypatch.setenv("LFX_DEBUG_STREAM", "1")
+def test_organised_kernel_gives_a_scan_up_half_way():
+    """The organised-scan kernel writes its feature points straight into the scan's clouds, every unit behind the counts
+    its predecessors publish (unit_look_back).  A scan that breaks the pattern in a late unit has by then written part of
+    its clouds: the unit that gives up publishes an empty count (nobody may wait for it), the scan is redone whole by the
+    bucketing route, whose compaction overwrites what was there.  Scans in order, one such scan, rotated rings."""
     f = FeatureExtraction(device=0, max_points_per_scan=64 * 1800, max_batch=4, max_points_per_ring=1800, max_rings=64)
     clouds = [make_scan(64, 1800, seed=880 + i) for i in range(4)]
     clouds[2] = clouds[2].copy()
