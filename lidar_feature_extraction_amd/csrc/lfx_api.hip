@@ -147,7 +147,7 @@ uint32_t ring_threads_for(uint32_t cap)
   return cap > 1024 ? 512u : 256u;
 }
 
-// Launch the five kernels for `batch` scans whose records lie back to back at d_points.
+// Launch the kernels for `batch` scans whose records lie back to back at d_points.
 int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uint32_t batch, hipStream_t st)
 {
   if (!d_points || !n_points || batch == 0) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "empty batch");}
@@ -233,10 +233,9 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::ring_cut_kernel, dim3(batch), dim3(lfx::kCutThreads), 0, st,
         pts, c->scan_begin.p, c->max_rings, c->cap, c->xform.p, counters);
     }
-    Timed t(c, 9, st);
     const uint32_t groups = (c->max_rings + 3u) / 4u;
     void (*kern)(lfx::Params, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t *,
-      const lfx::UnitTables *, const uint32_t *, uint32_t, uint32_t) = nullptr;
+      const lfx::UnitTables *, const uint32_t *) = nullptr;
 #define LFX_PICK_ORG(DEFV, XFV) \
     (c->unit_chunks == 5 ? &lfx::ring_unit_org_kernel<5, DEFV, XFV> : c->unit_chunks == 4 ? &lfx::ring_unit_org_kernel<4, DEFV, XFV> : \
      c->unit_chunks == 3 ? &lfx::ring_unit_org_kernel<3, DEFV, XFV> : &lfx::ring_unit_org_kernel<6, DEFV, XFV>)
@@ -246,15 +245,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       kern = xf ? LFX_PICK_ORG(false, true) : LFX_PICK_ORG(false, false);
     }
 #undef LFX_PICK_ORG
-    // the tag of this launch's unit granules (unit_look_back): the launch's serial number, never 0; when it wraps the
-    // table is zeroed, so that no granule of 2^32 launches ago can pass for one of this launch
-    if (++c->unit_epoch == 0u) {
-      LFX_HIP(c, hipMemsetAsync(c->unit_state.p, 0, c->unit_state.n * 8, st));
-      c->unit_epoch = 1u;
+    {
+      Timed t(c, 9, st);
+      hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
+        c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p);
     }
-    hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B * batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-      c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p,
-      c->unit_epoch, batch);
   }
   // ---- the bucketing route, over the scans on the fall-back list
   if (c->single_pass) {
@@ -360,21 +355,20 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       short_tail ? fb_count : slow_count, short_tail ? c->fb_list.p : c->slow_list.p, c->max_rings);
   }
   {
-    // compaction of the bucketing route's per-unit records (the organised-scan kernel writes its clouds itself): over the
-    // fall-back list
+    // compaction: every scan of the batch, whoever labelled it
     const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
     {
       Timed t(c, 7, st);
-      hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(fb_grid), dim3(lfx::kRings), 0, st,
+      hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
         c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
-        c->ring_ebase.p, c->ring_sbase.p, n_units, c->max_rings, fb_count, c->fb_list.p);
+        c->ring_ebase.p, c->ring_sbase.p, n_units, c->max_rings, nullptr, nullptr, 0u, batch, 0u);
     }
     {
       Timed t(c, 8, st);
-      hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, fb_grid), dim3(256), 0, st,
+      hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
         n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
         c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-        c->surf_idx.p, c->max_rings, fb_count, c->fb_list.p);
+        c->surf_idx.p, c->max_rings, nullptr, nullptr, 0u, batch, nullptr);
     }
   }
   if (c->h_counters) {
@@ -762,10 +756,6 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
-  // the organised-scan kernel's unit granules (unit_look_back): per scan max_rings * n_blocks, rounded up to whole sweeps
-  c->state_stride = ((c->max_rings * (uint32_t)(c->dev.B < 1 ? 1 : (c->dev.B > lfx::kUnitMaxBlocks ? lfx::kUnitMaxBlocks : c->dev.B)) + 383u) / 384u) * 384u;
-  ok(c->unit_state.alloc(nb * c->state_stride));
-  if (e == hipSuccess) {e = hipMemset(c->unit_state.p, 0, c->unit_state.n * 8);}
   if (e == hipSuccess) {
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 4 * lfx::kCounters, hipHostMallocDefault);
     if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * lfx::kCounters);}
@@ -773,8 +763,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (e == hipSuccess) {
     const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
-      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p,
-      c->edge_pts.p, c->surf_pts.p, c->edge_idx.p, c->surf_idx.p, c->unit_state.p, c->state_stride};
+      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p};
     e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
@@ -813,7 +802,7 @@ void lfx_destroy(lfx_ctx * c)
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
   c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
-  c->unit_tab.release(); c->unit_state.release();
+  c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();

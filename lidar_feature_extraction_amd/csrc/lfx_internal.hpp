@@ -130,8 +130,6 @@ struct lfx_ctx
   lfx_host::DevBuf<double> curv_s;
   lfx_host::DevBuf<float4> edge_pts, surf_pts, rec_pts;
   lfx_host::DevBuf<lfx::UnitTables> unit_tab;      // the unit kernel's output pointers (one element)
-  lfx_host::DevBuf<uint64_t> unit_state;           // organised-scan kernel: one granule {launch tag, n_edge | n_surface << 16} per unit
-  uint32_t state_stride = 0, unit_epoch = 0;       // granules per scan; the tag of the last launch
   lfx_host::DevBuf<uint32_t> vox_scratch;          // lfx_voxel_downsample: sort keys / values, allocated on first use
   lfx_host::DevBuf<double> align_scratch;          // lfx_scan_to_map_align: states, rows, errors; allocated on first use
   lfx_host::DevBuf<float> align_surface;           // lfx_localize_batch: the downsampled surface clouds (+ counts, status)

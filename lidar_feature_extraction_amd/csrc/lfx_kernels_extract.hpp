@@ -1295,7 +1295,6 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
 // kept for the first kStampUnits units of scan LFX_STAMP_SCAN; read back with lfx_debug_read_stamps.  The product
 // build executes none of this.
 #ifdef LFX_STAMPS
-__device__ inline uint32_t xcc_id() {uint32_t v; asm volatile ("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15u;}
 #ifndef LFX_STAMP_SCAN
 #define LFX_STAMP_SCAN 128
 #endif
@@ -1308,20 +1307,12 @@ __device__ unsigned long long g_unit_stamps[kStampUnits * kStampSlots];
       if (lane == 0) {g_unit_stamps[(slot * B + j) * kStampSlots + (n)] = t_;} \
     } \
   } while (0)
-#define LFX_STAMP_VALUE(n, v) \
-  do { \
-    if (s == (uint32_t)LFX_STAMP_SCAN && (uint32_t)(slot * B + j) < (uint32_t)kStampUnits && lane == 0) { \
-      g_unit_stamps[(slot * B + j) * kStampSlots + (n)] = (v); \
-    } \
-  } while (0)
 #elif defined(LFX_MARKS)
 // Diagnostic assembly only (make marks): a comment line at every stage boundary, so that the instructions of the
 // listing can be counted per stage (tools/count_stage_instructions.py).
 #define LFX_STAMP(n) asm volatile ("; LFX_MARK " #n ::: "memory")
-#define LFX_STAMP_VALUE(n, v) do {} while (0)
 #else
 #define LFX_STAMP(n) do {} while (0)
-#define LFX_STAMP_VALUE(n, v) do {} while (0)
 #endif
 
 // Output tables of the unit kernel, read through one pointer: sixteen kernel-argument pointers held in
@@ -1337,125 +1328,7 @@ struct UnitTables
   uint32_t * unit_ne, * unit_ns, * unit_span;
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
-  // organised-scan kernel: the scan's dense clouds, written by the units themselves, and the table of unit counts their
-  // places come from (unit_look_back); state_stride = granules per scan
-  float4 * edge_pts, * surf_pts;
-  uint32_t * edge_idx, * surf_idx;
-  uint64_t * unit_state;
-  uint32_t state_stride;
 };
-
-// ------------------------------------------------------------------------------------------
-// Where a unit's feature points go: the scan's edge / surface clouds are dense, rings ascending and inside a ring angle
-// ascending (GetIndicesByValue / AppendXYZIR walk the ring's labels in order, algorithm.hpp:39-62, label.hpp:166-179;
-// feature_extraction.cpp:142-151 appends ring after ring), so unit (ring, block j) writes behind everything the units
-// before it in that order emit: lex = ring * B + j, and its places start at the sum of the counts of units 0 .. lex - 1
-// of the scan.  Those units run at the same time in other waves (all units of a scan are dispatched within a
-// microsecond), so the sum is taken INSIDE the launch, counts only, no data: every unit publishes ONE 8-byte granule
-// {tag = epoch of the launch, n_edge | n_surface << 16} as soon as its labels are final (a write-through store by one
-// lane: the data is the flag, cdna_hip_programming.md Guideline 16 form R2) and then reads the granules of its
-// predecessors with sc1 loads, 16 bytes = two granules per lane, re-reading what does not carry the tag yet.  Nobody
-// ever reads another unit's POINTS, so nothing has to have landed anywhere before a unit signals; what a unit pays is
-// the round trip of its sweep and the skew to the slowest of its predecessors, on a slot it holds meanwhile.
-// No reset between launches: the tag is the launch's serial number (the host zeroes the table when it wraps).
-// Progress: a unit waits only for units of lower lex, i.e. for workgroups of its own scan with a block index at most
-// B - 1 above its own (blockIdx.x = ring group * B + j: ring 4g+1's block 0 follows ring 4g's block B-1), so with
-// workgroups dispatched in index order the lowest unfinished one never waits for one that is not resident as long as
-// B workgroups fit the device (B <= 64; 1 536 fit); the spin is bounded all the same and a timeout marks the scan.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) uint64_t gu64_t;      // (global_ instructions: a generic pointer makes them flat_)
-
-__device__ __forceinline__ void unit_publish(uint64_t * row, uint32_t lex, uint32_t epoch, uint32_t n_edge, uint32_t n_surface)
-{
-  __hip_atomic_store((gu64_t *)row + lex, ((uint64_t)epoch << 32) | (n_surface << 16) | n_edge, __ATOMIC_RELAXED,
-    __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The first sweep of a unit's look-back, issued EARLY (before the unit's own counts exist: stage G starts with it) so that
-// its round trip runs under the parallel-beam test and the final labels: granules g = 128 m + 2 lane + h (m < 3, h < 2) of
-// the scan's row, two per 16-byte load; 384 units = one sweep.  Nothing waits here: the destinations are not to be
-// touched before unit_look_back's wait (tests/test_build_hazards.py checks the listing for that).
-struct LookBackSweep
-{
-  u32x4_t v0, v1, v2;
-};
-
-__device__ __forceinline__ void unit_sweep_issue(const uint64_t * row, uint32_t lex, int lane, LookBackSweep & w)
-{
-  const uint64_t * p = row + 2u * (uint32_t)lane;
-  w.v1 = u32x4_t{0u, 0u, 0u, 0u};
-  w.v2 = u32x4_t{0u, 0u, 0u, 0u};
-  // (loads the unit does not need are jumped over -- lex is wave-uniform)
-  asm volatile (
-    "global_load_dwordx4 %0, %3, off sc1\n\t"
-    "s_cmp_lt_u32 %4, 0x81\n\t"
-    "s_cbranch_scc1 1f\n\t"
-    "global_load_dwordx4 %1, %3, off offset:1024 sc1\n\t"
-    "s_cmp_lt_u32 %4, 0x101\n\t"
-    "s_cbranch_scc1 1f\n\t"
-    "global_load_dwordx4 %2, %3, off offset:2048 sc1\n"
-    "1:"
-    : "=&v"(w.v0), "+v"(w.v1), "+v"(w.v2) : "v"(p), "s"(lex) : "memory", "scc");
-}
-
-// Sum of the counts of units 0 .. lex - 1 of the scan whose granules start at `row`; false = gave up waiting.  `w`: the
-// sweep issued earlier (units 0 .. 383); `after`: vector-memory operations the wave has issued since (the publish), which
-// the wait lets stay in flight.  What the sweep did not find published yet is read again, only by the lanes that miss it.
-template<int AFTER>
-__device__ __forceinline__ bool unit_look_back(
-  const uint64_t * row, uint32_t lex, uint32_t epoch, int lane, LookBackSweep & w, uint32_t & before_e, uint32_t & before_s,
-  uint32_t & polls)
-{
-  uint32_t acc_e = 0, acc_s = 0;
-  bool ok = true;
-  polls = 0;
-  // (always: also the scan's first unit, which has nobody before it, has a load in flight into these registers)
-  asm volatile ("s_waitcnt vmcnt(%3)" : "+v"(w.v0), "+v"(w.v1), "+v"(w.v2) : "n"(AFTER) : "memory");
-  for (uint32_t g0 = 0; g0 < lex; g0 += 384u) {
-    const uint32_t rem = lex - g0;                   // predecessors from g0 on (wave-uniform)
-    const uint64_t * p = row + g0 + 2u * (uint32_t)lane;
-    if (g0 != 0u) {
-      // (more than 384 units in a scan: the later sweeps one after the other)
-      unit_sweep_issue(row + g0, rem, lane, w);
-      asm volatile ("s_waitcnt vmcnt(0)" : "+v"(w.v0), "+v"(w.v1), "+v"(w.v2) :: "memory");
-    }
-    uint32_t accp = 0;                               // per lane at most six counts of <= 511: no carry between the halves
-    uint32_t pend = 0;                               // bit t = 2 m + h: that granule is a predecessor's and not published yet
-    const uint32_t val[6] = {w.v0.x, w.v0.z, w.v1.x, w.v1.z, w.v2.x, w.v2.z}, tag[6] = {w.v0.y, w.v0.w, w.v1.y, w.v1.w, w.v2.y, w.v2.w};
-#pragma unroll
-    for (int t = 0; t < 6; t++) {
-      const bool need = 128u * (uint32_t)(t >> 1) + 2u * (uint32_t)lane + (uint32_t)(t & 1) < rem;
-      const bool have = tag[t] == epoch;
-      accp += need && have ? val[t] : 0u;
-      pend |= need && !have ? 1u << t : 0u;
-    }
-    uint32_t spins = 0;
-    while (__ballot(pend != 0u) != 0ull) {
-      if (++spins > kSpinLimit) {ok = false; break;}
-#pragma unroll
-      for (int t = 0; t < 6; t++) {
-        if (__ballot((pend >> t) & 1u) != 0ull) {
-          if ((pend >> t) & 1u) {
-            const uint64_t g = __hip_atomic_load((const gu64_t *)p + 128 * (t >> 1) + (t & 1), __ATOMIC_RELAXED,
-                __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(g >> 32) == epoch) {
-              accp += (uint32_t)g;
-              pend &= ~(1u << t);
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    acc_e += accp & 0xFFFFu;
-    acc_s += accp >> 16;
-    polls += spins;
-    if (!ok) {break;}
-  }
-  before_e = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(acc_e), 63);
-  before_s = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(acc_s), 63);
-  return ok;
-}
 
 // A scan the organised-scan kernel cannot take (ring pattern, point count, angle order, a skip condition, a unit that
 // does not fit a wave) is flagged once and appended to the fall-back list: the bucketing route then redoes it whole.
@@ -1484,7 +1357,6 @@ struct OrgScan
   uint32_t * __restrict__ ring_count_out;
   uint32_t R, r0, wave, drop_zero;
   const uint32_t * __restrict__ xform;    // [batch][256] ring transforms (XF instantiations only)
-  uint32_t epoch;                         // tag of this launch's unit granules (unit_look_back)
 };
 
 #ifndef LFX_ORG_FULL
@@ -1867,11 +1739,6 @@ __device__ __forceinline__ uint32_t unit_core(
 #endif
   LFX_STAMP(9);
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
-  // (ORG: the look-back's first sweep leaves here, its round trip runs under the rest of the stage)
-  const uint32_t lex = ORG ? slot * (uint32_t)B + (uint32_t)j : 0u;
-  uint64_t * const row = ORG ? tab->unit_state + (size_t)s * tab->state_stride : nullptr;
-  LookBackSweep sweep;
-  if constexpr (ORG) {unit_sweep_issue(row, lex, lane, sweep);}
   uint64_t pby[CH];
   {
     uint64_t pbu[CH];
@@ -1938,106 +1805,35 @@ __device__ __forceinline__ uint32_t unit_core(
     l = ov != kDefault ? ov : l;
     return lanes(in_span(q, qo0, qo1)) ? l : (uint32_t)kDefault;
   };
-  if constexpr (ORG) {
-    // The organised-scan kernel writes its feature points straight into the scan's dense clouds (unit_look_back above):
-    // first the labels of every chunk and with them the unit's two counts, which are published at once; then the label
-    // and curvature stores; then the sum over the units before this one; then the points.
-    uint32_t lab[CH];
+  float4 * __restrict__ rec_pts = tab->rec_pts;
+  uint32_t * __restrict__ rec_idx = tab->rec_idx;
 #pragma unroll
-    for (int k = 0; k < CH; k++) {
-      lab[k] = kDefault;
-      if (k < K) {
-        lab[k] = final_label(k, 64 * k + lane);
-        pe += __popcll(bal(lab[k] == kEdge));
-        ps += __popcll(bal(lab[k] == kSurface));
+  for (int k = 0; k < CH; k++) {
+    if (k < K) {
+      const int q = 64 * k + lane, i = g0 + q;
+      const bool own = lanes(in_span(q, qo0, qo1));
+      const uint32_t l = final_label(k, q);
+      const double cv = U.c[q];
+      if (own) {
+        label_s[off + i] = (uint8_t)l;
+        curv_s[off + i] = cv;
       }
-    }
-    if (lane == 0) {unit_publish(row, lex, og.epoch, pe, ps);}
-    LFX_STAMP(11);
-    // the sum over the units before this one (the publish is the one operation the wait lets stay in flight).  The
-    // label and curvature stores come AFTER it: vector-memory operations complete in issue order, so a load issued behind
-    // them would wait for them to land (3 us under this kernel's own store traffic) before its data counted as back.
-    uint32_t before_e, before_s, polls;
-    const bool seen = unit_look_back<1>(row, lex, og.epoch, lane, sweep, before_e, before_s, polls);
-    LFX_STAMP(12);
-    LFX_STAMP_VALUE(15, polls | (xcc_id() << 16) | ((unsigned long long)blockIdx.x << 32));
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-      if (k < K) {
-        const int q = 64 * k + lane, i = g0 + q;
-        if (lanes(in_span(q, qo0, qo1))) {
-          label_s[off + i] = (uint8_t)lab[k];
-          curv_s[off + i] = U.c[q];
-        }
+      const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
+      if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
+        // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
+        const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
+        const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
+        const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
+        const size_t at = l == kEdge ? off + rec_lo + pe + be : off + rec_hi - 1 - (ps + bs);
+        rec_pts[at] = rec;
+        // ORG: position i of ring `slot` is point column * R + slot
+        rec_idx[at] = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
       }
-    }
-    LFX_STAMP(13);
-    if (!seen) {
-      if (lane == 0) {atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kErrTimeout);}
-    } else if (LFX_STAGE_ON(1024u)) {
-      const size_t first = og.scan_begin[s];
-      float4 * __restrict__ const edge_pts = tab->edge_pts + first + before_e, * __restrict__ const surf_pts = tab->surf_pts + first + before_s;
-      uint32_t * __restrict__ const edge_idx = tab->edge_idx + first + before_e, * __restrict__ const surf_idx = tab->surf_idx + first + before_s;
-      uint32_t ne = 0, ns = 0;
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        if (k < K) {
-          const uint64_t fe = bal(lab[k] == kEdge), fs = bal(lab[k] == kSurface);
-          if ((fe | fs) != 0ull) {
-            const int q = 64 * k + lane, i = g0 + q;
-            if (lanes(fe | fs)) {
-              // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-              const float4 rec = make_float4(x[k], y[k], z[k], (float)U.c[q]);
-              const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
-              const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
-              // position i of ring `slot` is point column * R + slot
-              const uint32_t idx = (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot;
-              const bool is_edge = lab[k] == kEdge;
-              const uint32_t at = is_edge ? ne + be : ns + bs;
-              (is_edge ? edge_pts : surf_pts)[at] = rec;
-              (is_edge ? edge_idx : surf_idx)[at] = idx;
-            }
-            ne += __popcll(fe);
-            ns += __popcll(fs);
-          }
-        }
-      }
-      // the last unit of the scan knows the totals
-      if (lex + 1u == og.R * (uint32_t)B && lane == 0) {
-        tab->scan_info[s * 4 + kInfoEdge] = before_e + pe;
-        tab->scan_info[s * 4 + kInfoSurface] = before_s + ps;
-      }
-    }
-  } else {
-    float4 * __restrict__ rec_pts = tab->rec_pts;
-    uint32_t * __restrict__ rec_idx = tab->rec_idx;
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-      if (k < K) {
-        const int q = 64 * k + lane, i = g0 + q;
-        const bool own = lanes(in_span(q, qo0, qo1));
-        const uint32_t l = final_label(k, q);
-        const double cv = U.c[q];
-        if (own) {
-          label_s[off + i] = (uint8_t)l;
-          curv_s[off + i] = cv;
-        }
-        const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
-        if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
-          // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-          const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
-          const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
-          const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
-          const size_t at = l == kEdge ? off + rec_lo + pe + be : off + rec_hi - 1 - (ps + bs);
-          rec_pts[at] = rec;
-          rec_idx[at] = src[k];
-        }
-        pe += __popcll(fe);
-        ps += __popcll(fs);
-      }
+      pe += __popcll(fe);
+      ps += __popcll(fs);
     }
   }
-  LFX_STAMP(14);
+  LFX_STAMP(11);
   n_edge = pe;
   n_surface = ps;
   return 0u;
@@ -2078,12 +1874,7 @@ __device__ __forceinline__ void unit_body(
 #define LFX_DEFER(reason) \
   do { \
     if (ORG) { \
-      /* (the units behind this one in the scan's clouds must not wait for it: it counts as empty; what they write is */ \
-      /* redone with the whole scan by the bucketing route) */ \
-      if (lane == 0) { \
-        scan_falls_back(tab, s, (reason) == kDeferOrder); \
-        if (slot < og.R) {unit_publish(tab->unit_state + (size_t)s * tab->state_stride, slot * (uint32_t)B + (uint32_t)j, og.epoch, 0u, 0u);} \
-      } \
+      if (lane == 0) {scan_falls_back(tab, s, (reason) == kDeferOrder);} \
     } else if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
       defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
     } \
@@ -2199,12 +1990,10 @@ __device__ __forceinline__ void unit_body(
     if (why != 0u) {LFX_DEFER(why);}
   }
   if (lane == 0) {
-    if (!ORG) {
-      const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
-      tab->unit_ne[ui] = pe;
-      tab->unit_ns[ui] = ps;
-      tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
-    }
+    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
+    tab->unit_ne[ui] = pe;
+    tab->unit_ns[ui] = ps;
+    tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
     if (j == 0) {
       tab->ring_status[s * kRings + slot] = kOk;
       if (ORG) {
@@ -2239,7 +2028,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   UnitLds<CH> * U = &lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
-  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, 0u};
+  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr};
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
@@ -2286,44 +2075,22 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
 }
 
 // The organised-scan kernel (unit_body<ORG>): workgroup = block j of the four adjacent rings 4g .. 4g+3 of scan
-// s, one ring per wave; workgroup x = g * B + j of the scan: a unit only ever waits for units of its scan in workgroups
-// at most B - 1 above its own (unit_look_back).
+// blockIdx.y, one ring per wave.  blockIdx.x = j * groups + g: workgroups dispatched together take neighbouring ring
+// groups of the same block, i.e. neighbouring 128-byte lines of the same columns -- whole DRAM pages between them.
+// (Every scan on ONE XCD, so that the six units of a ring share an L2: measured, no difference -- profiles/r04_slices.)
 template<int CH, bool DEF, bool XF>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform, uint32_t epoch, uint32_t batch)
+  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform)
 {
   __shared__ UnitLds<CH> lds[kUnitWaves];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // Which scan, which workgroup of it.  The units of a scan wait for each other (unit_look_back), so they are kept on ONE
-  // XCD: workgroups are dealt to the eight XCDs round-robin by their index (MI355X_MICROARCH.md, Workgroup dispatch),
-  // each XCD walking its share in order at its own pace -- with a scan spread over all eight, every wave would wait for
-  // the XCD that happens to lag (measured: 8 us of a wave's 29).  Index L -> XCD L mod 8, place k = L / 8 in that XCD's
-  // sequence; the sequence takes scans xcd, xcd + 8, ... whole, one after the other.  (A speed matter only: if the
-  // dealing is ever different the waits are longer, not wrong.)  The last batch mod 8 scans are dealt plainly.
-  const uint32_t per_scan = ((max_rings + 3u) >> 2) * (uint32_t)prm.B;
-  uint32_t s, x;
-#ifdef LFX_ORG_PLAIN_MAP
-  s = blockIdx.x / per_scan;
-  x = blockIdx.x % per_scan;
-#else
-  {
-    const uint32_t whole = batch & ~7u;
-    if (blockIdx.x < whole * per_scan) {
-      const uint32_t k = blockIdx.x >> 3;
-      s = 8u * (k / per_scan) + (blockIdx.x & 7u);
-      x = k % per_scan;
-    } else {
-      const uint32_t r = blockIdx.x - whole * per_scan;
-      s = whole + r / per_scan;
-      x = r % per_scan;
-    }
-  }
-#endif
-  const uint32_t g = x / (uint32_t)prm.B;
-  const int j = (int)(x % (uint32_t)prm.B);
-  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, epoch};
+  const uint32_t groups = (max_rings + 3u) >> 2;
+  const uint32_t g = blockIdx.x % groups;
+  const int j = (int)(blockIdx.x / groups);
+  const uint32_t s = blockIdx.y;
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform};
   const uint32_t slot = 4u * g + wave;
   if (DEF || prm.P == 5) {
     unit_body<5, CH, DEF, true, LFX_ORG_FULL, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
@@ -2768,21 +2535,24 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Compaction of the bucketing route (the organised-scan kernel writes its clouds itself, unit_look_back): both kernels
-// walk the scans on the fall-back list -- every scan of the batch when the organised-scan kernel is not in use --,
-// list entries blockIdx, + gridDim, ... (a length the host can only guess).
+// Compaction: per-unit records -> the scan's dense edge / surface clouds.  Both kernels walk either a range of scans
+// (fb_list == nullptr: scans s_base + blockIdx, + gridDim, ... below s_base + n_scans) or the scans on the fall-back list
+// (what the bucketing route redid, of a length the host can only guess).  A range that is a slice of the batch the
+// organised-scan kernel has just finished skips the scans that kernel gave up (skip_given_up / scan_info given).
 // Step 1: per scan, ring totals and their exclusive prefix (rings ascending).
 __global__ __launch_bounds__(kRings) void ring_totals_kernel(
   uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
   const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
   uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf, uint32_t * __restrict__ ring_ebase,
   uint32_t * __restrict__ ring_sbase, uint32_t n_units, uint32_t max_rings,
-  const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
+  const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list, uint32_t s_base, uint32_t n_scans,
+  uint32_t skip_given_up)
 {
-  const uint32_t slot = threadIdx.x, n_list = *fb_count;
+  const uint32_t slot = threadIdx.x, n_list = fb_list ? *fb_count : n_scans;
   __shared__ uint32_t pe[kRings], pf[kRings];
   for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-    const uint32_t s = fb_list[it];
+    const uint32_t s = fb_list ? fb_list[it] : s_base + it;
+    if (skip_given_up && (scan_info[s * 4 + kInfoError] & kScanFellBack)) {continue;}      // (the same for the whole workgroup: see feature_compact_kernel)
     uint32_t e = 0, f = 0;
     if (slot < max_rings && ring_count[s * kRings + slot] != 0u) {
       const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
@@ -2821,13 +2591,16 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ unit_span,
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
-  uint32_t max_rings, const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
+  uint32_t max_rings, const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list, uint32_t s_base,
+  uint32_t n_scans, const uint32_t * __restrict__ scan_info)
 {
-  const uint32_t lane = threadIdx.x & 63, n_list = *fb_count;
+  const uint32_t lane = threadIdx.x & 63, n_list = fb_list ? *fb_count : n_scans;
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (slot >= max_rings) {return;}
   for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
-    const uint32_t s = fb_list[it];
+    const uint32_t s = fb_list ? fb_list[it] : s_base + it;
+    // (a scan of the range that the organised-scan kernel gave up: its tables are half-written, the bucketing route redoes it)
+    if (scan_info && (scan_info[s * 4 + kInfoError] & kScanFellBack)) {continue;}
     if (ring_count[s * kRings + slot] == 0u) {continue;}
     const size_t b = scan_begin[s];
     const size_t off = ring_base(s, slot, max_rings, cap);
