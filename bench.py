@@ -57,8 +57,12 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (--steps steps between two fences) is run this many times; value = the median")
     ap.add_argument("--gather-dst", default="0", help="destination rank of the per-step gather: a rank, or 'rotate' (step k -> rank k mod N)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the rendezvous traffic (communicator id, agreements, barriers, the maximum "
+                         "over ranks); gloo where the ranks share a GPU (rehearsal: a real RCCL communicator refuses that)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip BASELINE.json's other configurations (the \"configs\" list of the line)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
     ap.add_argument("--force-gather", action="store_true", help="run the pack + gather step even with one rank (rehearsal)")
     ap.add_argument("--streams", type=int, default=1,
@@ -75,6 +79,69 @@ def kernels_sha256():
     return h.hexdigest()
 
 
+WORKLOADS = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800): "vlp16-16x1800 (BASELINE.json configs[1])",
+             (16, 900): "plumbing-16x900 (BASELINE.json configs[0])", (128, 2048): "os1-128x2048 (BASELINE.json configs[3])"}
+
+
+def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, repeats=3):
+    """One of BASELINE.json's other configurations, measured inside the same run as the headline (a few steps, the same
+    fences, HIP-event kernel durations, one scan checked against the oracle): so that every number DESIGN.md quotes for them
+    has a driver-observed line behind it.  Single GPU, one stream, inputs resident in HBM."""
+    from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, concat
+    from oracle import binding as oracle
+    n_unique = min(8, batch)
+    clouds = [make_scan(rings, cols, seed=1234 + j, vfov_deg=22.5 if rings >= 128 else 15.0) for j in range(n_unique)]
+    if drop_zero_fraction > 0.0:
+        for j, c in enumerate(clouds):
+            gone = np.random.Generator(np.random.PCG64(99 + j)).uniform(0.0, 1.0, len(c)) < drop_zero_fraction
+            for f in ("x", "y", "z"):
+                c[f][gone] = 0.0
+    valid = [((c["x"] != 0) | (c["y"] != 0) | (c["z"] != 0)) if drop_zero_fraction > 0.0 else np.ones(len(c), bool) for c in clouds]
+    tiled = [clouds[j % n_unique] for j in range(batch)]
+    d_points = torch.from_numpy(concat(tiled).view(np.uint8)).to(dev)
+    n_list = np.array([len(c) for c in tiled], np.uint32)
+    fx = FeatureExtraction(HyperParameters(), device=dev.index, max_points_per_scan=max(len(c) for c in clouds), max_batch=batch,
+                           max_points_per_ring=max(cols, 64), max_rings=rings, drop_zero_points=drop_zero_fraction > 0.0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
+    torch.cuda.synchronize()
+    fx.set_profiling(True, every=1)
+    dts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
+    per_launch_us = {k: 1e3 * ms / max(cnt, 1) for k, (ms, cnt) in fx.kernel_times().items()}
+    fx.set_profiling(False)
+    dominant = max(per_launch_us, key=per_launch_us.get)
+    feats, parity = [], None
+    for j in range(n_unique):
+        g = fx.download(j, stream)
+        feats.append(len(g.edge_index) + len(g.surface_index))
+        if j == 0:
+            keep = np.nonzero(valid[0])[0]
+            w = oracle.extract(np.ascontiguousarray(clouds[0][keep]), canonical_ties=False)
+            parity = bool(np.array_equal(g.labels[keep], w["labels"]) and g.curvature[keep].tobytes() == w["curvature"].tobytes()
+                          and np.array_equal(g.edge_index, keep[w["edge_index"]].astype(np.uint32))
+                          and np.array_equal(g.surface_index, keep[w["surface_index"]].astype(np.uint32)))
+    algo = 25 * sum(int(valid[j % n_unique].sum()) for j in range(batch)) + 16 * sum(feats[j % n_unique] for j in range(batch))
+    fx.close()
+    del d_points
+    torch.cuda.empty_cache()
+    name = WORKLOADS.get((rings, cols), "%dx%d" % (rings, cols))
+    if drop_zero_fraction > 0.0:
+        name += ", %.0f %% of the returns written as (0, 0, 0) and filtered (convert.py:162-163)" % (100 * drop_zero_fraction)
+    return {"workload": name, "scans_per_step": batch, "steps": steps, "value": round(batch * steps / dt, 2), "unit": "scans/s",
+            "ms_per_step": round(1e3 * dt / steps, 4), "dominant_kernel": dominant,
+            "frac": round(algo / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+            "whole_path_frac": round(algo / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items() if v > 0}, "parity_spot_check": parity}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -89,7 +156,12 @@ def main():
     if world > 1 or a.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    # where the tensors of the rendezvous traffic live: on the device for nccl (= RCCL), on the host for gloo
+    ddev = dev if a.dist_backend == "nccl" else torch.device("cpu")
 
     if not os.path.exists(os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx.so")):
         import __graft_entry__
@@ -143,7 +215,7 @@ def main():
         # rank drops the gather together and the line says so ("sharding"): a measurement of the sharded extraction without
         # its exchange is worth more than none.
         gather, gather_error = None, None
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        idt = torch.zeros(128, dtype=torch.uint8, device=ddev)
         # every rank first checks that it CAN enter the collective initialisation (the RCCL library opens and has the
         # entry points: making an id proves both) and the ranks agree on that before anyone calls ncclCommInitRank --
         # a rank that failed earlier would otherwise leave the others waiting inside it
@@ -154,7 +226,7 @@ def main():
         except Exception as e:             # noqa: BLE001
             gather_error = "rank %d: %s" % (rank, e)
         if world > 1:
-            cannot = torch.tensor([0 if gather_error is None else 1], dtype=torch.int32, device=dev)
+            cannot = torch.tensor([0 if gather_error is None else 1], dtype=torch.int32, device=ddev)
             dist.all_reduce(cannot, op=dist.ReduceOp.MAX)
             if int(cannot.item()) and gather_error is None:
                 gather_error = "another rank cannot open its RCCL library"
@@ -169,7 +241,7 @@ def main():
             except Exception as e:         # noqa: BLE001
                 gather_error = "rank %d: %s" % (rank, e)
         if world > 1:
-            failed = torch.tensor([0 if gather_error is None else 1], dtype=torch.int32, device=dev)
+            failed = torch.tensor([0 if gather_error is None else 1], dtype=torch.int32, device=ddev)
             dist.all_reduce(failed, op=dist.ReduceOp.MAX)
             if int(failed.item()) and gather_error is None:
                 gather_error = "another rank could not create its communicator"
@@ -220,13 +292,23 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=ddev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         dts.append(dt)
     dt = float(np.median(dts))
     scans_total = a.batch * a.steps * world
     value = scans_total / dt
+    # which side set the rate of an N > 1 step: the time this rank's side stream spent inside the gathers (the exchange and
+    # its waits for the peers), per step, maximum over the ranks -- beside the kernels' own durations in "roofline"
+    gather_ms_per_step = None
+    if use_gather:
+        g_ms, g_n = gather.gather_ms()
+        gather_ms_per_step = g_ms / max(g_n, 1)
+        if world > 1:
+            t = torch.tensor([gather_ms_per_step], dtype=torch.float64, device=ddev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gather_ms_per_step = float(t.item())
 
     kt = {}
     for f in fxs:
@@ -399,11 +481,24 @@ def main():
                                 "clouds never leave the device); maps = the features of 16 scans along a track, grid cells of 1 m; "
                                 "parity with Eigen / nanoflann / PCL arithmetic unpinned (DESIGN.md 7)"}
 
+    # ---- BASELINE.json's other single-GPU configurations and the stream the reference's own pipeline produces (invalid
+    #      returns as (0, 0, 0) records, filtered), a few steps each, in the same run
+    configs = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.no_side_configs and (a.rings, a.cols, a.batch) == (64, 1800, 1024):
+        for f in fxs:
+            f.close()
+        fxs = []
+        del d_points
+        torch.cuda.empty_cache()
+        configs = []
+        for args in ((16, 900, 1024, 20, 3), (16, 1800, 1024, 20, 3), (128, 2048, 32, 40, 5), (64, 1800, 1024, 8, 2, 0.05)):
+            try:
+                configs.append(side_config(dev, *args))
+            except Exception as e:         # noqa: BLE001  (a side measurement must not cost the line its headline)
+                configs.append({"workload": "%dx%d" % args[:2], "error": "%s: %s" % (type(e).__name__, e)})
+
     if rank == 0:
-        workload = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800): "vlp16-16x1800 (BASELINE.json configs[1])",
-                    (16, 900): "plumbing-16x900 (BASELINE.json configs[0])",
-                    (128, 2048): "os1-128x2048 (BASELINE.json configs[3]%s)" % (", batch = 32" if a.batch == 32 else "")}.get(
-                        (a.rings, a.cols), "%dx%d" % (a.rings, a.cols))
+        workload = WORKLOADS.get((a.rings, a.cols), "%dx%d" % (a.rings, a.cols)) + (", batch = 32" if (a.rings, a.batch) == (128, 32) else "")
         out = {
             "metric": "scans/sec (%d-ring x %d synthetic scans, extraction hot path, inputs resident in HBM)" % (a.rings, a.cols),
             "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -420,7 +515,13 @@ def main():
                        "sharding": "scan i -> gpu i mod N" + ((", RCCL gather of clouds to rank %s per step" % ("k mod N of step k" if a.gather_dst == "rotate" else a.gather_dst)) if use_gather else "") +
                                    (" (gather unavailable: %s)" % gather_error if gather_error else "")},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
+            "configs": configs,
         }
+        if world > 1:
+            out["cpu_baseline_from"] = "the N=1 line of the same bench (the host baseline is timed on rank 0 at N=1 only)"
+            out["roofline"]["note"] = "rank 0's kernels (every rank runs the same launches on its own scans)"
+        if gather_ms_per_step is not None:
+            out["gather_ms_per_step"] = round(gather_ms_per_step, 4)
         print(json.dumps(out))
         sys.stdout.flush()
     if use_gather:

@@ -73,6 +73,9 @@ typedef struct lfx_point_field {
 } lfx_point_field;
 
 typedef struct lfx_config {
+  uint32_t struct_size;           /* sizeof(lfx_config) as the CALLER was compiled with it: fields beyond it (added to the end
+                                   * of this struct by a later header) read as zero, so that a caller built against an
+                                   * older header keeps working.  0 is refused (an uninitialised struct).               */
   uint32_t max_points_per_scan;   /* capacity of one scan                                   */
   uint32_t max_batch;             /* scans per lfx_extract_batch* call                      */
   uint32_t max_points_per_ring;   /* 0 = LFX_MAX_RING_POINTS; rounded up to a multiple of 64.  The sensor's real
@@ -469,6 +472,23 @@ int lfx_label_to_color(uint8_t label, uint8_t rgb[3]);
  * returned.  points: the scan's records (layout as given to lfx_create); out: n_points * 4 floats. */
 int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_points, const uint8_t *labels,
                               float *out);
+
+/* --- the route selection, as a function ---------------------------------------------------- */
+/* Which kernels a batch is given depends on what the batches before it reported about the stream (organised scans are read
+ * in place, anything else is bucketed first; rotated / reversed rings get their transforms found first; see
+ * INTEGRATION.md 3).  This is that decision with nothing around it -- no context, no device: `report` = the counters a
+ * batch leaves behind ([0] rings deferred by the first unit pass, [1] repaired after it, [2] sent to the workgroup-per-ring
+ * kernel, [3] repaired before it, [4] scans on the fall-back list, [5] whether the organised-scan kernel ran, [6] scans in
+ * the batch, [7] scans given up for the angle order of their rings alone, [8] rings found rotated / reversed, [9] whether
+ * the transforms were looked for), `report_rings` = rings of that batch (0 = no report yet), `state` in and out = {rings
+ * transformed, every scan bucketed, batches until the organised route is tried again, order repair first}, `choice` out =
+ * {organised-scan kernel first, with ring transforms, fall-back list entries launched for, two-launch tail, order repair
+ * before the first unit pass, rings the second unit pass is launched for}.  tests/test_route_choice.py drives it. */
+#define LFX_ROUTE_REPORT_WORDS 12
+#define LFX_ROUTE_STATE_WORDS 4
+#define LFX_ROUTE_CHOICE_WORDS 6
+int lfx_route_choice(const uint32_t report[LFX_ROUTE_REPORT_WORDS], uint32_t report_rings, uint32_t state[LFX_ROUTE_STATE_WORDS],
+                     int organised_possible, uint32_t batch, uint32_t max_rings, uint32_t choice[LFX_ROUTE_CHOICE_WORDS]);
 
 /* --- measurement ------------------------------------------------------------------------- */
 #define LFX_N_KERNELS 11  /* ring_histogram, ring_scan (two-pass bucketing only), ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract, ring_totals, feature_compact (the last two: bucketing route only), ring_unit_org (organised scans, writes the clouds itself), ring_cut (transforms of rotated / reversed rings) */

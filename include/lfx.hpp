@@ -72,6 +72,7 @@ public:
     std::uint32_t max_rings = 0, std::uint32_t outputs = LFX_OUT_ALL)
   {
     lfx_config cfg{};
+    cfg.struct_size = sizeof(cfg);
     cfg.max_points_per_scan = max_points_per_scan;
     cfg.max_batch = 1;
     cfg.max_points_per_ring = max_points_per_ring;

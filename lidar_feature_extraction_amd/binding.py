@@ -46,7 +46,7 @@ INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64 = range(1, 9)
 
 
 class Config(C.Structure):
-    _fields_ = [("max_points_per_scan", C.c_uint32), ("max_batch", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("max_points_per_scan", C.c_uint32), ("max_batch", C.c_uint32),
                 ("max_points_per_ring", C.c_uint32), ("max_rings", C.c_uint32), ("drop_zero_points", C.c_uint32),
                 ("layout", Layout), ("outputs", C.c_uint32), ("stream_hint", C.c_uint32)]
 
@@ -88,6 +88,7 @@ EXPORTS = [
     "lfx_localize_batch", "lfx_localize_host",
     "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
+    "lfx_route_choice",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
 

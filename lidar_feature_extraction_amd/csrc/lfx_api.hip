@@ -3,6 +3,8 @@
 // lfx_wire.hip; the RCCL gather: lfx_gather.hip; Downsample: lfx_downsample.hip; the localizer: lfx_localize.hip.)
 // There is no CPU implementation of the path here: without a gfx950 device every entry point fails.
 #include "lfx_internal.hpp"
+
+#include <cstddef>
 #include "lfx_kernels_extract.hpp"
 
 using namespace lfx_host;
@@ -147,6 +149,76 @@ uint32_t ring_threads_for(uint32_t cap)
   return cap > 1024 ? 512u : 256u;
 }
 
+// Which route a batch takes, from what earlier batches reported (RouteState::report = the counters block of the last
+// batch whose report has landed) and the state the choices before left behind.  No device, no context: the function the
+// table-driven test drives (lfx_route_choice, tests/test_route_choice.py).
+//   fused       the organised-scan kernel runs first; the bucketing kernels then take the fall-back list only
+//   xform       ... after ring_cut_kernel has found every ring's rotation / reversal
+//   fb_grid     list entries the bucketing kernels are launched for (they loop where the list turns out longer)
+//   short_tail  bucketing route = bucketing + the workgroup-per-ring kernel (two near-empty launches instead of five)
+//   pre_order   order repair ahead of the first unit pass;  redo_cap  rings the second unit pass is launched for
+RouteChoice choose_route(RouteState & st, const RoutePins & pin, bool organised_possible, uint32_t batch, uint32_t max_rings)
+{
+  RouteChoice ch;
+  const uint32_t * rep = st.report;
+  bool fused = organised_possible;
+  ch.fb_grid = batch;
+  if (fused) {
+    const uint32_t was_fused = rep[lfx::kCntFusedRan], fell = rep[lfx::kCntFallback], of = rep[lfx::kCntBatch];
+    const uint32_t order_fell = rep[lfx::kCntOrderFell], cut_ran = rep[lfx::kCntCutRan], turned = rep[lfx::kCntTurned];
+    if (was_fused && of) {
+      // most of what fell back did so for the angle order of its rings alone: find the rings' transforms first from now
+      // on; back to plain loads once (almost) no ring needs one any more
+      if (!cut_ran && 4u * order_fell > of && 2u * order_fell > fell) {st.use_xform = true;}
+      if (cut_ran && 50u * turned < of * max_rings) {st.use_xform = false;}
+    }
+    if (pin.xform >= 0) {st.use_xform = pin.xform != 0;}
+    if (pin.fused >= 0) {
+      fused = pin.fused != 0;
+    } else {
+      if (was_fused && of) {
+        // (a report from before the transforms were switched on says nothing about the route with them)
+        const bool mostly_not = 4u * fell > of && !(st.use_xform && !cut_ran);
+        if (mostly_not && !st.bucket_all) {st.retry_in = 16;}
+        st.bucket_all = mostly_not;
+      }
+      if (st.bucket_all) {
+        fused = false;
+        if (st.retry_in == 0 || --st.retry_in == 0) {fused = true; st.retry_in = 16;}     // the stream may have changed
+      }
+    }
+    if (fused) {
+      const uint32_t guess = (was_fused ? 2u * fell : 0u) + 8u;
+      ch.fb_grid = guess < batch && !st.bucket_all ? guess : batch;      // (a retry on a stream that has been falling back: expect all of it)
+      // a stream that has not been falling back: its odd scan out (if one turns up) is redone by the workgroup-per-ring
+      // kernel straight from the bucketed arrays -- two near-empty launches per batch instead of five
+      ch.short_tail = was_fused && of && fell == 0 && pin.pre_order < 0 && pin.redo_cap == 0;
+      if (pin.short_tail >= 0) {ch.short_tail = pin.short_tail != 0;}
+    }
+  }
+  ch.fused = fused;
+  ch.xform = fused && st.use_xform;
+  // more than a twentieth of the rings of an earlier batch needed their order repaired: expect the same now
+  ch.pre_order = st.pre_order;
+  if (pin.pre_order >= 0) {
+    ch.pre_order = pin.pre_order != 0;
+  } else if (st.report_rings) {
+    ch.pre_order = 20u * (rep[lfx::kCntRedo] + rep[lfx::kCntPreFixed]) > st.report_rings;
+  }
+  st.pre_order = ch.pre_order;
+  // The second pass is launched for as many rings as earlier batches had repaired after their first pass, twice
+  // over and at least 256 (a launch that covers every unit of a large batch costs ~20 us to find nothing to do);
+  // the order kernel hands what does not fit to the workgroup-per-ring kernel.
+  ch.redo_cap = batch * max_rings;
+  if (pin.redo_cap) {
+    ch.redo_cap = pin.redo_cap;
+  } else if (st.report_rings) {
+    const uint32_t want = 2u * rep[lfx::kCntRedo] + 256u;
+    ch.redo_cap = want < ch.redo_cap ? want : ch.redo_cap;
+  }
+  return ch;
+}
+
 // Launch the kernels for `batch` scans whose records lie back to back at d_points.
 int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uint32_t batch, hipStream_t st)
 {
@@ -181,53 +253,25 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0 &&
     (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
   // ---- which route: the organised-scan kernel first (scans it cannot take fall back inside this call), or
-  //      bucketing for every scan.  What earlier batches reported arrives in pinned memory unasked.
-  bool fused = c->fused_possible && canon && chunks != 0;
-  uint32_t fb_grid = batch;                            // list entries the bucketing kernels are launched for
-  bool short_tail = false;                             // bucketing route = bucketing + the workgroup-per-ring kernel only
-  if (fused) {
-    const uint32_t was_fused = c->h_counters[lfx::kCntFusedRan], fell = c->h_counters[lfx::kCntFallback],
-      of = c->h_counters[lfx::kCntBatch];
-    const uint32_t order_fell = c->h_counters[lfx::kCntOrderFell], cut_ran = c->h_counters[lfx::kCntCutRan],
-      turned = c->h_counters[lfx::kCntTurned];
-    if (was_fused && of) {
-      // most of what fell back did so for the angle order of its rings alone: find the rings' transforms first from now
-      // on; back to plain loads once (almost) no ring needs one any more
-      if (!cut_ran && 4u * order_fell > of && 2u * order_fell > fell) {c->use_xform = true;}
-      if (cut_ran && 50u * turned < of * c->max_rings) {c->use_xform = false;}
-    }
-    if (c->xform_env >= 0) {c->use_xform = c->xform_env != 0;}
-    if (c->fused_env >= 0) {
-      fused = c->fused_env != 0;
-    } else {
-      if (was_fused && of) {
-        // (a report from before the transforms were switched on says nothing about the route with them)
-        const bool mostly_not = 4u * fell > of && !(c->use_xform && !cut_ran);
-        if (mostly_not && !c->bucket_all) {c->retry_in = 16;}
-        c->bucket_all = mostly_not;
-      }
-      if (c->bucket_all) {
-        fused = false;
-        if (c->retry_in == 0 || --c->retry_in == 0) {fused = true; c->retry_in = 16;}     // the stream may have changed
-      }
-    }
-    if (fused) {
-      const uint32_t guess = (was_fused ? 2u * fell : 0u) + 8u;
-      fb_grid = guess < batch && !c->bucket_all ? guess : batch;      // (a retry on a stream that has been falling back: expect all of it)
-      // a stream that has not been falling back: its odd scan out (if one turns up) is redone by the workgroup-per-ring
-      // kernel straight from the bucketed arrays -- two near-empty launches per batch instead of five
-      short_tail = was_fused && of && fell == 0 && c->pre_order_env < 0 && c->redo_cap_env == 0;
-      if (c->short_tail_env >= 0) {short_tail = c->short_tail_env != 0;}
-    }
+  //      bucketing for every scan: choose_route() over what earlier batches reported.  The report arrives in pinned
+  //      memory unasked; it is read only once the copy that brought it is known to be complete (with two scans in flight the
+  //      previous batch's copy may still be writing), otherwise the report before it stands.
+  if (c->report_pending && hipEventQuery(c->report_landed) == hipSuccess) {
+    std::memcpy(c->route.report, c->h_counters, sizeof(c->route.report));
+    c->route.report_rings = c->report_rings_pending;
+    c->report_pending = false;
   }
+  const RouteChoice choice = choose_route(c->route, c->route_pins, c->fused_possible && canon && chunks != 0, batch, c->max_rings);
+  const bool fused = choice.fused, short_tail = choice.short_tail;
+  const uint32_t fb_grid = choice.fb_grid;             // list entries the bucketing kernels are launched for
   hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
     c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
     c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
     fused ? 0u : 1u, c->xform.p);
   if (chunks == 0) {return LFX_OK;}
-  c->last_used_xform = fused && c->use_xform;
+  c->last_used_xform = fused && choice.xform;
   if (fused) {
-    const bool xf = c->use_xform;
+    const bool xf = choice.xform;
     if (xf) {
       Timed t(c, 10, st);
       hipLaunchKernelGGL(lfx::ring_cut_kernel, dim3(batch), dim3(lfx::kCutThreads), 0, st,
@@ -286,12 +330,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   // the near-empty launches of the bucketing route are kept small while the organised-scan kernel takes the stream
   const uint32_t list_grid = fused ? (c->slow_grid < 4u * fb_grid ? c->slow_grid : 4u * fb_grid) : c->slow_grid;
   if (c->fast_path && !short_tail) {
-    if (c->pre_order_env >= 0) {
-      c->pre_order = c->pre_order_env != 0;
-    } else if (c->h_counters && c->h_rings_seen) {
-      // more than a twentieth of the rings of an earlier batch needed their order repaired: expect the same now
-      c->pre_order = 20u * (c->h_counters[lfx::kCntRedo] + c->h_counters[lfx::kCntPreFixed]) > c->h_rings_seen;
-    }
+    c->pre_order = choice.pre_order;
     if (c->pre_order) {
       Timed t(c, 4, st);
       hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(fused ? list_grid : 4 * c->slow_grid), dim3(512), c->order_lds, st,
@@ -314,16 +353,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
         c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
         defer_count, c->defer_list.p, fb_count, c->fb_list.p, 0u);
     }
-    // The second pass is launched for as many rings as earlier batches had repaired after their first pass, twice
-    // over and at least 256 (a launch that covers every unit of a large batch costs ~20 us to find nothing to do);
-    // the order kernel hands what does not fit to the workgroup-per-ring kernel.
-    uint32_t redo_cap = batch * c->max_rings;
-    if (c->redo_cap_env) {
-      redo_cap = c->redo_cap_env;
-    } else if (c->h_counters && c->h_rings_seen) {
-      const uint32_t want = 2u * c->h_counters[lfx::kCntRedo] + 256u;
-      redo_cap = want < redo_cap ? want : redo_cap;
-    }
+    const uint32_t redo_cap = choice.redo_cap;
     {
       // rings out of angle order: repaired in place, then a second pass of the unit kernel over them
       Timed t(c, 4, st);
@@ -372,9 +402,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     }
   }
   if (c->h_counters) {
-    // for the next batches' decision about the order pre-pass; nobody waits for this copy
+    // what this batch reports, for the next batches' choice of route; nobody waits for this copy
     LFX_HIP(c, hipMemcpyAsync(c->h_counters, counters, 4 * lfx::kCounters, hipMemcpyDeviceToHost, st));
-    c->h_rings_seen = batch * c->max_rings;
+    LFX_HIP(c, hipEventRecord(c->report_landed, st));
+    c->report_pending = true;
+    c->report_rings_pending = batch * c->max_rings;
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -588,6 +620,22 @@ int lfx_ring_message(int ring_status, uint32_t n_points, const lfx_params * p, c
   }
 }
 
+int lfx_route_choice(const uint32_t report[LFX_ROUTE_REPORT_WORDS], uint32_t report_rings, uint32_t state[LFX_ROUTE_STATE_WORDS],
+                     int organised_possible, uint32_t batch, uint32_t max_rings, uint32_t choice[LFX_ROUTE_CHOICE_WORDS])
+{
+  static_assert(LFX_ROUTE_REPORT_WORDS == lfx::kCounters, "the report is the counters block");
+  if (!report || !state || !choice) {return LFX_ERR_INVALID_ARGUMENT;}
+  RouteState st;
+  std::memcpy(st.report, report, sizeof(st.report));
+  st.report_rings = report_rings;
+  st.use_xform = state[0] != 0; st.bucket_all = state[1] != 0; st.retry_in = state[2]; st.pre_order = state[3] != 0;
+  const RouteChoice ch = choose_route(st, RoutePins(), organised_possible != 0, batch, max_rings);
+  state[0] = st.use_xform; state[1] = st.bucket_all; state[2] = st.retry_in; state[3] = st.pre_order;
+  choice[0] = ch.fused; choice[1] = ch.xform; choice[2] = ch.fb_grid; choice[3] = ch.short_tail; choice[4] = ch.pre_order;
+  choice[5] = ch.redo_cap;
+  return LFX_OK;
+}
+
 const char * lfx_kernel_name(int k) {return (k >= 0 && k < LFX_N_KERNELS) ? kKernelNames[k] : "";}
 
 const char * lfx_last_error(const lfx_ctx * ctx) {return ctx ? ctx->err.c_str() : g_create_error.c_str();}
@@ -632,13 +680,22 @@ int lfx_layout_from_fields(
   return LFX_OK;
 }
 
-int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const lfx_config * config)
+int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const lfx_config * caller_config)
 {
   if (!out) {return LFX_ERR_INVALID_ARGUMENT;}
   *out = nullptr;
   std::string why;
   if (validate_params(params, why) != LFX_OK) {g_create_error = why; return LFX_ERR_INVALID_ARGUMENT;}
-  if (!config || config->max_points_per_scan == 0 || config->max_batch == 0) {
+  // the caller's struct may be shorter (built against an older header) or longer (a newer one) than this library's: only
+  // the bytes both know are read, the rest of ours are zero
+  if (!caller_config || caller_config->struct_size < offsetof(lfx_config, max_batch) + sizeof(uint32_t)) {
+    g_create_error = "config->struct_size must be sizeof(lfx_config)";
+    return LFX_ERR_INVALID_ARGUMENT;
+  }
+  lfx_config own{};
+  std::memcpy(&own, caller_config, caller_config->struct_size < sizeof(own) ? caller_config->struct_size : sizeof(own));
+  const lfx_config * config = &own;
+  if (config->max_points_per_scan == 0 || config->max_batch == 0) {
     g_create_error = "config must give max_points_per_scan and max_batch";
     return LFX_ERR_INVALID_ARGUMENT;
   }
@@ -682,8 +739,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   }
   c->drop_zero = config->drop_zero_points ? 1u : 0u;
   // what the caller knows about its stream: the state the route selection would otherwise reach after a batch or two
-  if (config->stream_hint == LFX_STREAM_TURNED_RINGS) {c->use_xform = true;}
-  if (config->stream_hint == LFX_STREAM_NO_GRID) {c->bucket_all = true; c->retry_in = 16;}
+  if (config->stream_hint == LFX_STREAM_TURNED_RINGS) {c->route.use_xform = true;}
+  if (config->stream_hint == LFX_STREAM_NO_GRID) {c->route.bucket_all = true; c->route.retry_in = 16;}
   if (config->stream_hint > LFX_STREAM_NO_GRID) {
     g_create_error = "stream_hint must be LFX_STREAM_UNKNOWN, LFX_STREAM_TURNED_RINGS or LFX_STREAM_NO_GRID";
     delete c;
@@ -718,12 +775,12 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   // the organised-scan kernel needs to know the sensor's ring count (max_rings given) and reads PointXYZIR records
   c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
-  if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->fused_env = std::atoi(dbg) != 0 ? 1 : 0;}
-  if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->short_tail_env = std::atoi(dbg) != 0 ? 1 : 0;}
-  if (const char * dbg = std::getenv("LFX_DEBUG_XFORM")) {c->xform_env = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->route_pins.fused = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->route_pins.short_tail = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_XFORM")) {c->route_pins.xform = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
-  if (const char * dbg = std::getenv("LFX_DEBUG_REDO_CAP")) {c->redo_cap_env = (uint32_t)std::atoi(dbg);}
-  if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->pre_order_env = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_REDO_CAP")) {c->route_pins.redo_cap = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->route_pins.pre_order = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_FLAGS")) {c->unit_flags = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
@@ -760,6 +817,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 4 * lfx::kCounters, hipHostMallocDefault);
     if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * lfx::kCounters);}
   }
+  if (e == hipSuccess) {e = hipEventCreateWithFlags(&c->report_landed, hipEventDisableTiming);}
   if (e == hipSuccess) {
     const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
@@ -804,6 +862,7 @@ void lfx_destroy(lfx_ctx * c)
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
+  if (c->report_landed) {(void)hipEventDestroy(c->report_landed);}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
   c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release(); c->h_align.release(); c->h_loc.release();

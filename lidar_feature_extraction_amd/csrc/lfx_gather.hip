@@ -28,13 +28,17 @@ Rccl * rccl()
 {
   static Rccl r;
   if (r.lib || !r.why.empty()) {return &r;}
-  // LFX_RCCL_LIB: another library with the same nine entry points (tests/shim/rccl_shim.cpp lets several processes that
-  // share ONE GPU run the N > 1 exchange, which a real RCCL communicator refuses); else the copy already in the process
-  // (PyTorch ships one under the same SONAME) or the ROCm installation's
+  // the copy already in the process (PyTorch ships one under the same SONAME) or the ROCm installation's
+#ifdef LFX_TEST_HOOKS
+  // Test build only (liblfx_testhooks.so, `make testhooks`; the shipped library has no such door): LFX_RCCL_LIB names
+  // another library with the same nine entry points -- tests/shim/rccl_shim.cpp lets several processes that share ONE
+  // GPU run the N > 1 exchange, which a real RCCL communicator refuses.
   if (const char * named = std::getenv("LFX_RCCL_LIB")) {
     r.lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
     if (!r.lib) {r.why = std::string("cannot open LFX_RCCL_LIB: ") + dlerror(); return &r;}
+    std::fprintf(stderr, "liblfx (test hooks): nccl* entry points taken from %s\n", named);
   }
+#endif
   for (const char * name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     if (r.lib) {break;}
     r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);

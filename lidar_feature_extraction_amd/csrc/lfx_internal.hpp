@@ -75,6 +75,28 @@ struct PinnedBuf
 
 }  // namespace lfx_host
 
+// The route selection of run_batch (lfx_api.hip, choose_route): what it remembers between batches, the switches that pin
+// its choices (tests), what it decides for one batch.
+struct RouteState
+{
+  uint32_t report[lfx::kCounters] = {};  // the counters block of the last batch whose report has landed (lfx_kernels_common.hpp)
+  uint32_t report_rings = 0;             // rings of that batch (0 = no report yet)
+  bool use_xform = false;                // rings arrive rotated / reversed: ring_cut_kernel ahead of the organised-scan kernel
+  bool bucket_all = false;               // the stream is not organised: bucketing route for every scan
+  uint32_t retry_in = 0;                 // ... and the organised-scan kernel is tried again in so many batches
+  bool pre_order = false;                // order repair BEFORE the first unit pass (a stream that keeps arriving out of order)
+};
+struct RoutePins                         // LFX_DEBUG_FUSED / _XFORM / _SHORT_TAIL / _PRE_ORDER (0 / 1; -1 = not pinned), _REDO_CAP (0 = not)
+{
+  int fused = -1, xform = -1, short_tail = -1, pre_order = -1;
+  uint32_t redo_cap = 0;
+};
+struct RouteChoice
+{
+  bool fused = false, xform = false, short_tail = false, pre_order = false;
+  uint32_t fb_grid = 0, redo_cap = 0;
+};
+
 struct lfx_ctx
 {
   int device = 0;
@@ -90,30 +112,19 @@ struct lfx_ctx
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
   bool single_pass = true;               // look-back bucketing; LFX_DEBUG_TWO_PASS selects histogram + scan + scatter
-  // Order repair BEFORE the unit kernel (ring_order_kernel over every ring), switched on while the stream keeps
-  // arriving rotated / reversed: decided from the counters of earlier batches, which arrive in pinned host
-  // memory without anyone waiting for them.  LFX_DEBUG_PRE_ORDER=0/1 pins it.
-  int pre_order_env = -1;
-  bool pre_order = false;
-  uint32_t * h_counters = nullptr;       // pinned [lfx::kCounters]: deferred, repaired after the first pass, slow, repaired before it,
-                                         // scans on the fall-back list, organised-scan kernel ran, scans of that batch
-  // The organised-scan kernel (lfx_kernels.hpp, unit_body<ORG>) reads a driver's column-major scan directly; scans that are
-  // not of that form fall back to the bucketing route inside the same call.  While most scans of a stream fall back the
-  // kernel is not launched at all (decided from the counters of earlier batches; every 16th batch tries again).
-  // LFX_DEBUG_FUSED=0/1 pins it.
+  // What a batch reports about its stream (the counters block behind ring_flags) is copied to pinned memory at the end of
+  // the batch, nobody waiting; the next batches' route is chosen from the last report that has LANDED (report_landed).
+  uint32_t * h_counters = nullptr;       // pinned [lfx::kCounters]
+  hipEvent_t report_landed = nullptr;
+  bool report_pending = false;
+  uint32_t report_rings_pending = 0;
+  RouteState route;
+  RoutePins route_pins;
+  bool pre_order = false;                // this batch's choice (run_batch)
+  // The organised-scan kernel (lfx_kernels_extract.hpp, unit_body<ORG>) reads a driver's column-major scan directly; scans
+  // that are not of that form fall back to the bucketing route inside the same call (choose_route decides per batch).
   bool fused_possible = false;
-  int fused_env = -1;
-  // Rings that arrive rotated / reversed (a driver that does not cut its scans at -pi, a clockwise sensor): while the
-  // organised-scan kernel keeps giving scans up for their angle order alone, ring_cut_kernel finds every ring's
-  // transform first and the kernel applies it in its loads (LFX_DEBUG_XFORM=0/1 pins it).
-  int xform_env = -1;
-  bool use_xform = false;
-  bool last_used_xform = false;          // the last batch's organised-scan kernel ran with the transforms
-  int short_tail_env = -1;               // LFX_DEBUG_SHORT_TAIL=0/1 pins the two-launch tail of the bucketing route (tests)
-  bool bucket_all = false;               // the stream is not organised: bucketing route for every scan
-  uint32_t retry_in = 0;
-  uint32_t redo_cap_env = 0;             // LFX_DEBUG_REDO_CAP: rings the second unit pass is launched for (tests)
-  uint32_t h_rings_seen = 0;             // rings of the batch those counters belong to
+  bool last_used_xform = false;          // the last batch's organised-scan kernel ran with the ring transforms
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
 

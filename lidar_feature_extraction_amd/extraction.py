@@ -107,8 +107,8 @@ class FeatureExtraction:
         self._step = lay.point_step or 32
         # outputs: B.OUT_* mask of what ExtractFeatures / extract_batch bring back (0 = everything); the two clouds always do
         # stream_hint: B.STREAM_* (what the caller knows about the order its driver publishes in; spares the first batch a slower route)
-        cfg = B.Config(max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay, int(outputs),
-                       int(stream_hint))
+        cfg = B.Config(C.sizeof(B.Config), max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay,
+                       int(outputs), int(stream_hint))
         self._pinned = []
         cp = self.params.to_c()
         rc = self._L.lfx_create(C.byref(self._ctx), device, C.byref(cp), C.byref(cfg))

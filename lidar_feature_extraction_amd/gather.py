@@ -107,6 +107,8 @@ class CloudGather:
         else:
             self.recv = [(None, None, None)] * 2
         self.step = 0
+        self.received = 0              # gathers this rank has been the destination of: alternates the two receive sets
+        self.spans = []                # (start, end) events on the side stream around every gather (gather_ms)
 
     def close(self):
         self.rccl.close()
@@ -130,21 +132,37 @@ class CloudGather:
 
     def _finish(self, p):
         edge, surface, offsets, batch = p
-        ea, sa, oa = self.recv[self.step % 2]
         dst = self.step % self.world if self.rotate else self.dst
         self.last_dst = dst
         self.step += 1
+        # (the receive set alternates with the gathers this rank RECEIVES: with an even world size and a rotating
+        # destination a rank is the destination of steps of one parity only)
+        ea, sa, oa = self.recv[self.received % 2] if self.rank == dst else (None, None, None)
+        if self.rank == dst:
+            self.received += 1
+        t0 = torch.cuda.Event(enable_timing=True)
+        t0.record(self.side)
         counts = self.rccl.payload(dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
                                    ea.data_ptr() if ea is not None else 0, sa.data_ptr() if sa is not None else 0,
                                    oa.data_ptr() if oa is not None else 0, self.cap, self.side.cuda_stream)
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=True)
         ev.record(self.side)
+        self.spans.append((t0, ev))
         for t in (edge, surface, offsets):
             self.buffer_free[t.data_ptr()] = ev
         self.done = ev
         if self.rank != dst:
             return None
         return split_gathered(ea, sa, oa, counts, batch)
+
+    def gather_ms(self, reset=True):
+        """(sum, count) of the side stream's time inside the gathers completed so far (payload exchange incl. its waits for
+        the peers), in milliseconds; the side stream must be idle (flush())."""
+        total = sum(a.elapsed_time(b) for a, b in self.spans)
+        n = len(self.spans)
+        if reset:
+            self.spans = []
+        return total, n
 
     def flush(self):
         prev, self.pending = self.pending, None

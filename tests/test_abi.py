@@ -48,14 +48,26 @@ def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     ctx = C.c_void_p()
     p = LB.Params()
     lib.lfx_default_params(C.byref(p))
-    cfg = LB.Config(1000, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0))
+    cfg = LB.Config(C.sizeof(LB.Config), 1000, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0))
     p.padding = 0                            # hyper_parameter.hpp:45 asserts padding > 0
     assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg)) == -1
     p.padding = 99
     assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg)) == -1
     lib.lfx_default_params(C.byref(p))
-    cfg0 = LB.Config(0, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0))
+    cfg0 = LB.Config(C.sizeof(LB.Config), 0, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0))
     assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg0)) == -1
+    # struct_size: an uninitialised struct (0) and one too short to hold the two capacities are refused by name; a caller
+    # built against an OLDER header (a shorter struct: here without outputs and stream_hint) is taken -- what it does not
+    # know reads as zero -- and gets as far as the device check
+    for size in (0, 8):
+        bad = LB.Config(size, 1000, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0))
+        assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(bad)) == -1
+        assert b"struct_size" in lib.lfx_last_error(None)
+    older = LB.Config(C.sizeof(LB.Config) - 8, 1000, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0), 0xFFFFFFFF, 0xFFFFFFFF)      # garbage behind its end
+    rc = lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(older))
+    assert rc in (0, -2) and b"stream_hint" not in lib.lfx_last_error(None), (rc, lib.lfx_last_error(None))
+    if rc == 0:
+        lib.lfx_destroy(ctx)
     assert lib.lfx_status_string(5).decode().startswith("two adjacent points")
     assert lib.lfx_kernel_name(3) == b"ring_unit_kernel"
 
@@ -111,7 +123,7 @@ def test_no_cpu_fallback_without_a_device(lib):
     ctx = C.c_void_p()
     p = LB.Params()
     lib.lfx_default_params(C.byref(p))
-    cfg = LB.Config(1000, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0))
+    cfg = LB.Config(C.sizeof(LB.Config), 1000, 1, 0, 0, 0, LB.Layout(0, 0, 0, 0, 0))
     assert lib.lfx_create(C.byref(ctx), 0, C.byref(p), C.byref(cfg)) == -2          # LFX_ERR_NO_DEVICE
     assert b"no CPU path" in lib.lfx_last_error(None)
     from lidar_feature_extraction_amd import FeatureExtraction

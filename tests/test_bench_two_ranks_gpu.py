@@ -1,0 +1,57 @@
+"""bench.py's own N > 1 flow, EXECUTED before the driver's one shot at it on an 8-GPU node: two fresh processes, ranks 0 and
+1 of a world of 2, both on GPU 0 (a box of this pool has one) -- process group, communicator id from rank 0, the two
+agreements, `CloudGather` one step behind on its side stream, the fence with its flush and barrier, the maximum over
+the ranks, the one JSON line.  Two things differ from the driver's launch, both forced by the shared GPU: the rendezvous
+traffic goes over gloo (`--dist-backend gloo`; the driver's default is nccl = RCCL) and the library's nccl* entry points
+come from tests/shim (the test-hooks build of the library: a real RCCL communicator refuses two ranks on one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_DIR = os.path.join(ROOT, "tests", "shim")
+
+
+def _shim():
+    so = os.path.join(SHIM_DIR, "_build", "librccl_shim.so")
+    src = os.path.join(SHIM_DIR, "rccl_shim.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", SHIM_DIR])
+    return so
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("dst", ["0", "rotate"])
+def test_bench_runs_with_two_ranks(dst):
+    world = 2
+    base = dict(os.environ, WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                LFX_RCCL_LIB=_shim(), LFX_LIB_PATH=os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx_testhooks.so"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--batch", "8", "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--no-cpu-baseline", "--dist-backend", "gloo", "--gather-dst", dst]
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=420) for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d exit %s:\n%s" % (r, p.returncode, outs[r][1].decode(errors="replace")[-3000:])
+    lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line: %r" % (outs[0][0][-500:],)
+    assert not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")], "only rank 0 prints the line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak"
+    assert "RCCL gather of clouds to rank" in d["config"]["sharding"] and "unavailable" not in d["config"]["sharding"], d["config"]["sharding"]
+    assert ("k mod N" in d["config"]["sharding"]) == (dst == "rotate")
+    assert d["parity_spot_check"] is True
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["gather_ms_per_step"] > 0
+    assert d["cpu_baseline"] is None and "N=1" in d["cpu_baseline_from"]
+    # whole-job aggregate: both ranks' scans over the slowest rank's time
+    assert abs(d["value"] - world * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3

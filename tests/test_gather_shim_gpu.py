@@ -30,7 +30,8 @@ def test_two_ranks_exchange_through_the_library(tmp_path):
     from lidar_feature_extraction_amd.gather import reassemble, split_gathered
     from oracle import binding as OB
     world = 2
-    env = dict(os.environ, LFX_RCCL_LIB=_shim())
+    # (the door for another nccl* implementation exists in the test-hooks build of the library only)
+    env = dict(os.environ, LFX_RCCL_LIB=_shim(), LFX_LIB_PATH=os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx_testhooks.so"))
     procs = [subprocess.Popen([sys.executable, os.path.join(SHIM_DIR, "gather_worker.py"), str(r), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=240)[0].decode(errors="replace") for p in procs]

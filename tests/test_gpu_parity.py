@@ -2,6 +2,7 @@
 the same seeded inputs, plus the reference's own unit-test vectors run through the device stages.
 All marked gpu; run on the MI355X box with `pytest -m gpu`."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -215,10 +216,23 @@ def test_stream_of_turned_rings_stays_on_the_organised_route(kind):
     f.close()
 
 
-def test_organised_scan_kernel_more_fall_backs_than_expected():
+@pytest.mark.parametrize("tail", [None, "short"])
+def test_organised_scan_kernel_more_fall_backs_than_expected(tail):
     """The bucketing route is launched for as many scans as earlier batches sent to it (plus a few); scans beyond
     that are still bucketed, and their rings are handed to the workgroup-per-ring kernel.  32 rotated scans arrive
-    at a context that has seen nothing (room for 8), then again (room for all), then 32 organised ones."""
+    at a context that has seen nothing (room for 8), then again (room for all), then 32 organised ones.
+    "short": the same with the two-launch tail pinned (the form the route has while nothing has been falling back, i.e.
+    exactly when a guess is too small): every list-driven kernel has to cope with a list four times its grid."""
+    if tail == "short":
+        os.environ["LFX_DEBUG_FUSED"], os.environ["LFX_DEBUG_SHORT_TAIL"] = "1", "1"
+    try:
+        _more_fall_backs_than_expected()
+    finally:
+        os.environ.pop("LFX_DEBUG_FUSED", None)
+        os.environ.pop("LFX_DEBUG_SHORT_TAIL", None)
+
+
+def _more_fall_backs_than_expected():
     R, Ccols, nb = 8, 600, 32
     rot = [make_scan(R, Ccols, seed=700 + i, start_col=37 + 11 * i) for i in range(nb)]
     srt = [make_scan(R, Ccols, seed=800 + i) for i in range(nb)]
