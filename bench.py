@@ -106,7 +106,6 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
     for _ in range(warmup):
         fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
     torch.cuda.synchronize()
-    fx.set_profiling(True, every=1)
     dts = []
     for _ in range(repeats):
         t0 = time.perf_counter()
@@ -115,6 +114,11 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
     dt = float(np.median(dts))
+    # the kernels' own durations from a pass of their own (the event pairs cost a small step a fifth of its time)
+    fx.set_profiling(True, every=1)
+    for _ in range(max(2, steps // 4)):
+        fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
+    torch.cuda.synchronize()
     per_launch_us = {k: 1e3 * ms / max(cnt, 1) for k, (ms, cnt) in fx.kernel_times().items()}
     fx.set_profiling(False)
     dominant = max(per_launch_us, key=per_launch_us.get)

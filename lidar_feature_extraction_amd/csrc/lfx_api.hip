@@ -15,9 +15,8 @@ namespace
 std::string g_create_error;
 
 const char * kKernelNames[LFX_N_KERNELS] = {
-  "ring_histogram_kernel", "ring_scan_kernel", "ring_scatter_kernel", "ring_unit_kernel",
-  "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel", "ring_totals_kernel",
-  "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel"};
+  "ring_scatter_kernel", "ring_unit_kernel", "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel",
+  "ring_totals_kernel", "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -266,14 +265,14 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   const uint32_t fb_grid = choice.fb_grid;             // list entries the bucketing kernels are launched for
   hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
     c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
-    c->single_pass ? batch * c->max_chunks : 0u, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
+    batch * c->max_chunks, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
     fused ? 0u : 1u, c->xform.p);
   if (chunks == 0) {return LFX_OK;}
   c->last_used_xform = fused && choice.xform;
   if (fused) {
     const bool xf = choice.xform;
     if (xf) {
-      Timed t(c, 10, st);
+      Timed t(c, 8, st);
       hipLaunchKernelGGL(lfx::ring_cut_kernel, dim3(batch), dim3(lfx::kCutThreads), 0, st,
         pts, c->scan_begin.p, c->max_rings, c->cap, c->xform.p, counters);
     }
@@ -290,56 +289,36 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     }
 #undef LFX_PICK_ORG
     {
-      Timed t(c, 9, st);
+      Timed t(c, 7, st);
       hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
         c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p);
     }
   }
   // ---- the bucketing route, over the scans on the fall-back list
-  if (c->single_pass) {
-    Timed t(c, 2, st);
-    auto kern = &lfx::ring_scatter_kernel<false, true>;
-    if (canon) {kern = &lfx::ring_scatter_kernel<true, true>;}
+  {
+    Timed t(c, 0, st);
+    auto kern = &lfx::ring_scatter_kernel<false>;
+    if (canon) {kern = &lfx::ring_scatter_kernel<true>;}
     if (fb_grid == batch) {                            // a row per scan: the form without the loop over list entries
-      kern = canon ? &lfx::ring_scatter_kernel<true, true, true> : &lfx::ring_scatter_kernel<false, true, true>;
+      kern = canon ? &lfx::ring_scatter_kernel<true, true> : &lfx::ring_scatter_kernel<false, true>;
     }
     hipLaunchKernelGGL(kern, dim3(chunks, fb_grid), dim3(lfx::kChunkThreads), 0, st,
       pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
       c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p);
-  } else {
-    // (two-pass bucketing, LFX_DEBUG_TWO_PASS: never together with the organised-scan kernel, so the list is every scan in order)
-    {
-      Timed t(c, 0, st);
-      hipLaunchKernelGGL(lfx::ring_histogram_kernel, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
-        pts, c->layout, c->scan_begin.p, c->chunk_hist.p, c->scan_info.p, c->max_chunks, c->max_rings, c->drop_zero);
-    }
-    {
-      Timed t(c, 1, st);
-      hipLaunchKernelGGL(lfx::ring_scan_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
-        c->scan_begin.p, c->chunk_hist.p, c->chunk_base.p, c->ring_count.p, c->scan_info.p, c->max_chunks);
-    }
-    {
-      Timed t(c, 2, st);
-      auto kern = &lfx::ring_scatter_kernel<false, false>;
-      if (canon) {kern = &lfx::ring_scatter_kernel<true, false>;}
-      hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(lfx::kChunkThreads), 0, st,
-        pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
-        c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p);
-    }
   }
   // the near-empty launches of the bucketing route are kept small while the organised-scan kernel takes the stream
   const uint32_t list_grid = fused ? (c->slow_grid < 4u * fb_grid ? c->slow_grid : 4u * fb_grid) : c->slow_grid;
   if (c->fast_path && !short_tail) {
     c->pre_order = choice.pre_order;
     if (c->pre_order) {
-      Timed t(c, 4, st);
+      Timed t(c, 2, st);
       hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(fused ? list_grid : 4 * c->slow_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
         c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 1u, counters + lfx::kCntPreFixed, 0u,
         fb_count, c->fb_list.p, 0u);
     }
     {
-      Timed t(c, 3, st);
+      Timed t(c, 1, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
       // the looping form only where the list's length is a guess (behind the organised-scan kernel)
 #define LFX_PICK_UNIT(DEFV, LOOPV) \
@@ -356,14 +335,14 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     const uint32_t redo_cap = choice.redo_cap;
     {
       // rings out of angle order: repaired in place, then a second pass of the unit kernel over them
-      Timed t(c, 4, st);
+      Timed t(c, 2, st);
       hipLaunchKernelGGL(lfx::ring_order_kernel, dim3(list_grid), dim3(512), c->order_lds, st,
         c->cap, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->ring_flags.p, defer_count,
         c->defer_list.p, redo_count, c->redo_list.p, slow_count, c->slow_list.p, 0u, counters + lfx::kCntPreFixed, redo_cap,
         fb_count, c->fb_list.p, 0xFFFFFFFFu /* the first unit pass covers the whole list (it loops where it has to) */);
     }
     {
-      Timed t(c, 5, st);
+      Timed t(c, 3, st);
       const uint32_t units = redo_cap * (uint32_t)c->dev.B;
       auto kern = &lfx::ring_unit_kernel<true, 6, false>;
       if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<true, 5, false>;}
@@ -376,7 +355,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     }
   }
   {
-    Timed t(c, 6, st);
+    Timed t(c, 4, st);
     const dim3 grid = c->fast_path ? dim3(list_grid) : dim3(c->max_rings, batch);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
       c->dev, c->cap, c->stage_flags, short_tail ? 2u : (c->fast_path ? 1u : 0u), pts, c->layout, c->scan_begin.p,
@@ -385,25 +364,27 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       short_tail ? fb_count : slow_count, short_tail ? c->fb_list.p : c->slow_list.p, c->max_rings);
   }
   {
-    // compaction: every scan of the batch, whoever labelled it
+    // compaction: every scan of the batch, whoever labelled it.  Small batches: the compaction kernel finds every ring's
+    // place itself (a launch costs more than the sums it saves; at 65 536 rings the same was measured at +75 us)
     const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
-    {
-      Timed t(c, 7, st);
+    const bool self_totals = (uint64_t)batch * c->max_rings <= 8192u && c->totals_env != 1;
+    if (!self_totals) {
+      Timed t(c, 5, st);
       hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
         c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
-        c->ring_ebase.p, c->ring_sbase.p, n_units, c->max_rings, nullptr, nullptr, 0u, batch, 0u);
+        c->ring_ebase.p, c->ring_sbase.p, n_units, c->max_rings);
     }
     {
-      Timed t(c, 8, st);
+      Timed t(c, 6, st);
       hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
-        n_units, c->cap, c->scan_begin.p, c->ring_count.p, c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
+        n_units, c->cap, c->scan_begin.p, c->ring_count.p, self_totals ? nullptr : c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
         c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-        c->surf_idx.p, c->max_rings, nullptr, nullptr, 0u, batch, nullptr);
+        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters);
     }
   }
   if (c->h_counters) {
-    // what this batch reports, for the next batches' choice of route; nobody waits for this copy
-    LFX_HIP(c, hipMemcpyAsync(c->h_counters, counters, 4 * lfx::kCounters, hipMemcpyDeviceToHost, st));
+    // what this batch reports, for the next batches' choice of route, has been written to pinned memory by the last kernel;
+    // nobody waits for it
     LFX_HIP(c, hipEventRecord(c->report_landed, st));
     c->report_pending = true;
     c->report_rings_pending = batch * c->max_rings;
@@ -486,7 +467,7 @@ int fetch_finish(lfx_ctx * c, const FetchPlan & plan, HostScan * hosts, lfx_scan
       return fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)");
     }
     if (hdr[lfx::kInfoError] & lfx::kErrTimeout) {
-      return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
+      return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (the workgroups of a scan were not dispatched in index order)");
     }
     HostScan & h = hosts[k];
     h.ring_id.clear(); h.ring_count.clear(); h.ring_offset.clear(); h.ring_status.clear();
@@ -771,11 +752,11 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   }
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
-  c->single_pass = std::getenv("LFX_DEBUG_TWO_PASS") == nullptr;
   // the organised-scan kernel needs to know the sensor's ring count (max_rings given) and reads PointXYZIR records
-  c->fused_possible = c->fast_path && c->single_pass && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
+  c->fused_possible = c->fast_path && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
   if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->route_pins.fused = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = std::getenv("LFX_DEBUG_TOTALS_KERNEL")) {c->totals_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->route_pins.short_tail = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = std::getenv("LFX_DEBUG_XFORM")) {c->route_pins.xform = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
@@ -798,7 +779,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   const size_t nb = c->max_batch, tc = c->total_cap, tables = nb * lfx::kRings, chunk_tab = nb * c->max_chunks * lfx::kRings;
   auto ok = [&](hipError_t r) {if (e == hipSuccess) {e = r;}};
   ok(c->scan_begin.alloc(nb + 1)); ok(c->scan_info.alloc(nb * 4));
-  ok(c->chunk_hist.alloc(chunk_tab)); ok(c->chunk_base.alloc(chunk_tab));
+  ok(c->chunk_base.alloc(chunk_tab));
   ok(c->ring_count.alloc(tables)); ok(c->chunk_flags.alloc(nb * c->max_chunks));
   ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
   ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
@@ -855,7 +836,7 @@ void lfx_destroy(lfx_ctx * c)
   if (c->stream) {(void)hipStreamSynchronize(c->stream);}
   for (auto & sp : c->spans) {(void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);}
   for (auto & ev : c->free_events) {(void)hipEventDestroy(ev);}
-  c->scan_begin.release(); c->scan_info.release(); c->chunk_hist.release(); c->chunk_base.release();
+  c->scan_begin.release(); c->scan_info.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
   c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
@@ -923,7 +904,7 @@ int lfx_batch_status(lfx_ctx * c, void * stream, uint32_t * first_bad)
       if (first_bad) {*first_bad = s;}
       return (e & lfx::kErrRingId) ?
              fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)") :
-             fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (set LFX_DEBUG_TWO_PASS=1)");
+             fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (the workgroups of a scan were not dispatched in index order)");
     }
   }
   return LFX_OK;

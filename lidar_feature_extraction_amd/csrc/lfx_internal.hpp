@@ -111,7 +111,6 @@ struct lfx_ctx
   uint32_t unit_chunks = 6;              // chunks of 64 positions per unit wave (3..6), from the configured ring length
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
-  bool single_pass = true;               // look-back bucketing; LFX_DEBUG_TWO_PASS selects histogram + scan + scatter
   // What a batch reports about its stream (the counters block behind ring_flags) is copied to pinned memory at the end of
   // the batch, nobody waiting; the next batches' route is chosen from the last report that has LANDED (report_landed).
   uint32_t * h_counters = nullptr;       // pinned [lfx::kCounters]
@@ -125,6 +124,7 @@ struct lfx_ctx
   // that are not of that form fall back to the bucketing route inside the same call (choose_route decides per batch).
   bool fused_possible = false;
   bool last_used_xform = false;          // the last batch's organised-scan kernel ran with the ring transforms
+  int totals_env = -1;                   // LFX_DEBUG_TOTALS_KERNEL=1: ring_totals_kernel also for small batches (A/B)
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
 
@@ -133,7 +133,6 @@ struct lfx_ctx
     ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list, xform,
     sidx, rec_idx, edge_idx,
     surf_idx, d_sidx;
-  lfx_host::DevBuf<uint16_t> chunk_hist;
   lfx_host::DevBuf<uint8_t> ring_status, label_s, staging, d_label;
   lfx_host::DevBuf<double> d_curv;
   lfx_host::DevBuf<float2> sxy;

@@ -31,71 +31,19 @@ __global__ __launch_bounds__(256) void batch_reset_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Two-pass bucketing only (LFX_DEBUG_TWO_PASS): ring histogram per chunk.
-__global__ __launch_bounds__(kChunkThreads) void ring_histogram_kernel(
-  const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
-  uint16_t * __restrict__ chunk_hist, uint32_t * __restrict__ scan_info, uint32_t max_chunks, uint32_t max_rings,
-  uint32_t drop_zero)
-{
-  const uint32_t s = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
-  if (chunk * kChunkPoints >= n) {return;}
-  __shared__ uint32_t h[kRings];
-  if (tid < kRings) {h[tid] = 0;}
-  __syncthreads();
-  bool bad = false;
-#pragma unroll
-  for (int i = 0; i < kChunkSlots; i++) {
-    const uint32_t e = chunk * kChunkPoints + i * kChunkThreads + tid;
-    if (e < n) {
-      const uint8_t * p = pts + (size_t)(b + e) * L.step;
-      const uint32_t ring = load_ring(p + L.oring, L.rtype, L.be);
-      const bool zero = drop_zero && load_f32(p + L.ox, L.be) == 0.f && load_f32(p + L.oy, L.be) == 0.f &&
-        load_f32(p + L.oz, L.be) == 0.f;
-      if (ring >= max_rings) {bad = true;} else if (!zero) {atomicAdd(&h[ring], 1u);}
-    }
-  }
-  __syncthreads();
-  if (tid < kRings) {chunk_hist[((size_t)s * max_chunks + chunk) * kRings + tid] = (uint16_t)h[tid];}
-  if (bad) {atomicOr(&scan_info[s * 4 + kInfoError], 1u);}
-}
-
-// ------------------------------------------------------------------------------------------
-// Two-pass bucketing only: per scan, prefix the chunk histograms per ring.
-__global__ __launch_bounds__(kRings) void ring_scan_kernel(
-  const uint32_t * __restrict__ scan_begin, const uint16_t * __restrict__ chunk_hist,
-  uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ ring_count, uint32_t * __restrict__ scan_info,
-  uint32_t max_chunks)
-{
-  const uint32_t s = blockIdx.x, r = threadIdx.x;
-  const uint32_t n = scan_begin[s + 1] - scan_begin[s];
-  const uint32_t nchunks = (n + kChunkPoints - 1) / kChunkPoints;
-  uint32_t acc = 0;
-  for (uint32_t c = 0; c < nchunks; c++) {
-    const size_t k = ((size_t)s * max_chunks + c) * kRings + r;
-    const uint32_t v = chunk_hist[k];
-    chunk_base[k] = acc;
-    acc += v;
-  }
-  ring_count[s * kRings + r] = acc;
-  const uint32_t occupied = __syncthreads_count(acc != 0u);
-  if (r == 0) {scan_info[s * 4 + kInfoRings] = occupied;}
-}
-
 constexpr uint32_t kSpinLimit = 200000;   // ~50 ms of s_sleep polls before a look-back gives up
 
 // Ring bucketing: stable scatter of (x, y | z | original index) into ring-major arrays.
-// LOOKBACK (default): the only pass over the input.  A chunk publishes its per-ring counts, waits
+// The only pass over the input.  A chunk publishes its per-ring counts, waits
 // for the counts of the scan's earlier chunks (lower block index: already dispatched) and sums
 // them -- no separate histogram pass.  Release / acquire at agent scope as
 // cdna_hip_programming.md Guideline 16 prescribes; the spin is bounded and a timeout marks the
-// scan as failed instead of hanging.  Without LOOKBACK the prefixes come from ring_scan_kernel.  The rank of a point
+// scan as failed instead of hanging.  The rank of a point
 // among the points of its ring inside the chunk comes from wave ballots (one per key bit), so the
 // order of arrival is kept.  The chunk is first laid out ring-major in LDS; the stores to HBM then
 // walk that layout, so a wave writes runs of consecutive positions (one run per ring) instead of
 // 64 scattered dwords.
-template<bool CANON, bool LOOKBACK>
+template<bool CANON>
 __device__ __forceinline__ void scatter_chunk(
   uint32_t s, const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
@@ -153,14 +101,14 @@ __device__ __forceinline__ void scatter_chunk(
         ring = load_ring(p + L.oring, L.rtype, L.be);
       }
       key[i] = ring < max_rings ? ring : kRings;
-      if (LOOKBACK && ring >= max_rings) {bad_ring = true;}
+      if (ring >= max_rings) {bad_ring = true;}
       // the upstream converter's filter (point_type_converter/convert.py:162-163,192): all-zero points
       // are not part of the scan
       if (drop_zero && x[i] == 0.f && y[i] == 0.f && z[i] == 0.f) {key[i] = kRings;}
     }
   }
   const size_t row = (size_t)s * max_chunks;
-  if (LOOKBACK) {
+  {
     // the per-ring counts are all the later chunks need: count with LDS atomics and publish them
     // before the ranking work, with write-through (sc1) stores, drain, then ONE lane sets the flag.
     // No L2 write-back fence: a release fence would flush every dirty line of the XCD's L2, i.e. the
@@ -207,7 +155,7 @@ __device__ __forceinline__ void scatter_chunk(
     cstart[tid] = acc;
   }
   uint32_t before = 0;                     // points of ring `tid` in the scan's earlier chunks
-  if (LOOKBACK) {
+  {
     bool timeout = false;
     for (uint32_t p = tid; p < chunk; p += kChunkThreads) {
       uint32_t spins = 0;
@@ -261,8 +209,6 @@ __device__ __forceinline__ void scatter_chunk(
       const uint32_t occupied = __syncthreads_count(tid < kRings && before + mine != 0u);
       if (tid == 0) {scan_info[s * 4 + kInfoRings] = occupied;}
     }
-  } else {
-    before = tid < kRings ? chunk_base[(row + chunk) * kRings + tid] : 0u;
   }
   {
     // exclusive scan of the 256 ring counts: shuffles inside each wave, one exchange of the four wave
@@ -273,7 +219,7 @@ __device__ __forceinline__ void scatter_chunk(
       const uint32_t t = __shfl_up(incl, d);
       if (lane >= (uint32_t)d) {incl += t;}
     }
-    __syncthreads();                      // every thread has read its cstart[] entry (LOOKBACK) by now
+    __syncthreads();                      // every thread has read its cstart[] entry by now
     if (lane == 63 && wave < kRings / 64) {gfill[wave] = incl;} // wave totals, parked in gfill[0..3] for a moment
     __syncthreads();
     uint32_t base = 0;
@@ -328,7 +274,7 @@ __device__ __forceinline__ void scatter_chunk(
 // ONE = true: the grid has a row per scan of the batch (every scan may be on the list: a stream that is not organised), so a
 // workgroup has one entry at most and no loop -- the loop costs the kernel 40 registers, a handful of spills and, measured
 // on a ragged stream, a third of its speed.
-template<bool CANON, bool LOOKBACK, bool ONE = false>
+template<bool CANON, bool ONE = false>
 __global__ __launch_bounds__(kChunkThreads, ONE ? 1 : 4) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
@@ -339,13 +285,13 @@ __global__ __launch_bounds__(kChunkThreads, ONE ? 1 : 4) void ring_scatter_kerne
   const uint32_t n_list = *fb_count;
   if (ONE) {
     if (blockIdx.y < n_list) {
-      scatter_chunk<CANON, LOOKBACK>(fb_list[blockIdx.y], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
+      scatter_chunk<CANON>(fb_list[blockIdx.y], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
         sidx, max_chunks, max_rings, cap, drop_zero);
     }
     return;
   }
   for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
-    scatter_chunk<CANON, LOOKBACK>(fb_list[it], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
+    scatter_chunk<CANON>(fb_list[it], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
       sidx, max_chunks, max_rings, cap, drop_zero);
     __syncthreads();                        // the LDS blocks are reused by the next entry
   }
@@ -2078,8 +2024,13 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
 // blockIdx.y, one ring per wave.  blockIdx.x = j * groups + g: workgroups dispatched together take neighbouring ring
 // groups of the same block, i.e. neighbouring 128-byte lines of the same columns -- whole DRAM pages between them.
 // (Every scan on ONE XCD, so that the six units of a ring share an L2: measured, no difference -- profiles/r04_slices.)
+#ifdef LFX_ORG_SGPRS       // (A/B: what the scalar-register budget of 8 workgroups per CU would cost this kernel)
+#define LFX_ORG_ATTR __attribute__((amdgpu_num_sgpr(LFX_ORG_SGPRS)))
+#else
+#define LFX_ORG_ATTR
+#endif
 template<int CH, bool DEF, bool XF>
-__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_org_kernel(
+__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) LFX_ORG_ATTR void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
   const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform)
@@ -2535,48 +2486,41 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Compaction: per-unit records -> the scan's dense edge / surface clouds.  Both kernels walk either a range of scans
-// (fb_list == nullptr: scans s_base + blockIdx, + gridDim, ... below s_base + n_scans) or the scans on the fall-back list
-// (what the bucketing route redid, of a length the host can only guess).  A range that is a slice of the batch the
-// organised-scan kernel has just finished skips the scans that kernel gave up (skip_given_up / scan_info given).
+// Compaction: per-unit records -> the scan's dense edge / surface clouds, one workgroup (row of workgroups) per scan.
 // Step 1: per scan, ring totals and their exclusive prefix (rings ascending).
 __global__ __launch_bounds__(kRings) void ring_totals_kernel(
   uint32_t * __restrict__ scan_info, const uint32_t * __restrict__ ring_count,
   const uint32_t * __restrict__ unit_ne, const uint32_t * __restrict__ unit_ns,
   uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf, uint32_t * __restrict__ ring_ebase,
-  uint32_t * __restrict__ ring_sbase, uint32_t n_units, uint32_t max_rings,
-  const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list, uint32_t s_base, uint32_t n_scans,
-  uint32_t skip_given_up)
+  uint32_t * __restrict__ ring_sbase, uint32_t n_units, uint32_t max_rings)
 {
-  const uint32_t slot = threadIdx.x, n_list = fb_list ? *fb_count : n_scans;
-  __shared__ uint32_t pe[kRings], pf[kRings];
-  for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-    const uint32_t s = fb_list ? fb_list[it] : s_base + it;
-    if (skip_given_up && (scan_info[s * 4 + kInfoError] & kScanFellBack)) {continue;}      // (the same for the whole workgroup: see feature_compact_kernel)
+  const uint32_t slot = threadIdx.x, s = blockIdx.x;
+  const uint32_t lane = slot & 63u, wave = slot >> 6;
+  __shared__ uint32_t we[kRings / 64], wf[kRings / 64];
+  {
     uint32_t e = 0, f = 0;
     if (slot < max_rings && ring_count[s * kRings + slot] != 0u) {
       const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
       for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ui + j]; f += unit_ns[ui + j];}
     }
-    pe[slot] = e;
-    pf[slot] = f;
+    // prefix over the 256 ring ids: along the lanes of each wave (DPP), then the four wave totals through LDS
+    uint32_t ie = wave_inclusive_sum(e), jf = wave_inclusive_sum(f);
+    if (lane == 63u) {we[wave] = ie; wf[wave] = jf;}
     __syncthreads();
-    for (uint32_t d = 1; d < kRings; d <<= 1) {
-      const uint32_t a = slot >= d ? pe[slot - d] : 0u, b = slot >= d ? pf[slot - d] : 0u;
-      __syncthreads();
-      pe[slot] += a;
-      pf[slot] += b;
-      __syncthreads();
+    uint32_t tote = 0, totf = 0;
+    for (uint32_t w = 0; w < kRings / 64; w++) {
+      if (w < wave) {ie += we[w]; jf += wf[w];}
+      tote += we[w];
+      totf += wf[w];
     }
     ring_nedge[s * kRings + slot] = e;
     ring_nsurf[s * kRings + slot] = f;
-    ring_ebase[s * kRings + slot] = pe[slot] - e;
-    ring_sbase[s * kRings + slot] = pf[slot] - f;
+    ring_ebase[s * kRings + slot] = ie - e;
+    ring_sbase[s * kRings + slot] = jf - f;
     if (slot == kRings - 1) {
-      scan_info[s * 4 + kInfoEdge] = pe[slot];
-      scan_info[s * 4 + kInfoSurface] = pf[slot];
+      scan_info[s * 4 + kInfoEdge] = tote;
+      scan_info[s * 4 + kInfoSurface] = totf;
     }
-    __syncthreads();
   }
 }
 
@@ -2591,21 +2535,50 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ unit_span,
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
-  uint32_t max_rings, const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list, uint32_t s_base,
-  uint32_t n_scans, const uint32_t * __restrict__ scan_info)
+  uint32_t max_rings, uint32_t * __restrict__ totals_out /* scan_info, where ring_ebase == nullptr */,
+  const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory, or nullptr */)
 {
-  const uint32_t lane = threadIdx.x & 63, n_list = fb_list ? *fb_count : n_scans;
+  const uint32_t lane = threadIdx.x & 63, s = blockIdx.y;
+  // the batch's last kernel also hands what the batch reports about its stream to the host (the next batches' route is
+  // chosen from it, lfx_api.hip choose_route): a dozen words written straight into pinned memory -- as a copy of its own
+  // it would put another engine's work between this batch's kernels and the next one's
+  if (report && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kCounters) {report[threadIdx.x] = counters[threadIdx.x];}
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (slot >= max_rings) {return;}
-  for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
-    const uint32_t s = fb_list ? fb_list[it] : s_base + it;
-    // (a scan of the range that the organised-scan kernel gave up: its tables are half-written, the bucketing route redoes it)
-    if (scan_info && (scan_info[s * 4 + kInfoError] & kScanFellBack)) {continue;}
-    if (ring_count[s * kRings + slot] == 0u) {continue;}
+  {
     const size_t b = scan_begin[s];
-    const size_t off = ring_base(s, slot, max_rings, cap);
-    const size_t eb = b + ring_ebase[s * kRings + slot], fb = b + ring_sbase[s * kRings + slot];
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+    size_t eb, fb;
+    if (ring_ebase) {
+      eb = b + ring_ebase[s * kRings + slot];
+      fb = b + ring_sbase[s * kRings + slot];
+    } else {
+      // small batches (no ring_totals_kernel launch: a launch costs more than the sums): the ring's place from the unit
+      // tables themselves -- lane r, r + 64, ... sums the units of ring r < slot; the last ring's wave also writes the totals
+      uint32_t e = 0, f = 0;
+      for (uint32_t r = lane; r < slot; r += 64) {
+        if (ring_count[s * kRings + r] != 0u) {
+          const size_t ur = ((size_t)s * kRings + r) * kUnitMaxBlocks;
+          for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ur + j]; f += unit_ns[ur + j];}
+        }
+      }
+      e = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(e), 63);
+      f = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(f), 63);
+      eb = b + e;
+      fb = b + f;
+      if (slot == max_rings - 1u) {
+        uint32_t oe = 0, of = 0;
+        if (ring_count[s * kRings + slot] != 0u && lane < n_units) {oe = unit_ne[ui + lane]; of = unit_ns[ui + lane];}
+        oe = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(oe), 63);
+        of = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(of), 63);
+        if (lane == 0) {
+          totals_out[s * 4 + kInfoEdge] = e + oe;
+          totals_out[s * 4 + kInfoSurface] = f + of;
+        }
+      }
+    }
+    if (ring_count[s * kRings + slot] == 0u) {return;}
+    const size_t off = ring_base(s, slot, max_rings, cap);
     uint32_t ne_k = 0, ns_k = 0, span_k = 0;               // lane j holds unit j's entries (n_units <= 64)
     if (lane < n_units) {
       ne_k = unit_ne[ui + lane];

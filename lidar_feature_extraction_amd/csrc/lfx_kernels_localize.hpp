@@ -527,17 +527,25 @@ __device__ __forceinline__ void row_from_neighbours(
         for (int r = 0; r < KM; r++) {g[r] -= sdot * v[r];}
       }
     }
+    // A neighbourhood without a plane (the k points coincide or lie on a line through ... anything that leaves R a zero
+    // pivot): Eigen's householderQr().solve() divides by it all the same and hands back whatever comes out, which cannot
+    // be reproduced here (its arithmetic is not in the image).  Such a row is given weight 0 instead -- the ZERO row
+    // (residual 0, u = 0: it adds nothing to any of the optimizer's sums), which is also how a caller tells: every other
+    // surface row has |u| = 1.
+    const double r0 = fabs(X[0][0]), r1 = fabs(X[1][1]), r2 = fabs(X[2][2]);
+    const double rmax = fmax(r0, fmax(r1, r2));
+    const bool no_plane = !(fmin(r0, fmin(r1, r2)) > 1e-9 * rmax);
     double w[3];
     w[2] = g[2] / X[2][2];
     w[1] = (g[1] - X[1][2] * w[2]) / X[1][1];
     w[0] = (g[0] - X[0][1] * w[1] - X[0][2] * w[2]) / X[0][0];
     const double norm = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-    const double u[3] = {w[0] / norm, w[1] / norm, w[2] / norm};
+    const double u[3] = {no_plane ? 0. : w[0] / norm, no_plane ? 0. : w[1] / norm, no_plane ? 0. : w[2] / norm};
     double * J = J_out;
 #pragma unroll
     for (int cc = 0; cc < 4; cc++) {J[cc] = u[0] * d[cc] + u[1] * d[4 + cc] + u[2] * d[8 + cc];}   // MakeJacobianRow, surface.hpp:85-93
     J[4] = u[0]; J[5] = u[1]; J[6] = u[2];
-    R_out[0] = (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;                         // SignedPointPlaneDistance
+    R_out[0] = no_plane ? 0. : (w[0] * q.x + w[1] * q.y + w[2] * q.z + 1.0) / norm;         // SignedPointPlaneDistance
   }
 }
 

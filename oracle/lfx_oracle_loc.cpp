@@ -152,7 +152,9 @@ void Jacobi3(const double * C, double ev[3], double V[9])
 }
 
 // least squares A x = b by Householder QR (math.hpp:36-40: A.householderQr().solve(b)); A rows x cols row-major, rows >= cols
-void SolveLinear(std::vector<double> A, int rows, int cols, std::vector<double> b, double * x)
+// Returns false where R has a (numerically) zero pivot: no solution worth the name; Eigen divides by it all the same, what
+// comes out cannot be known here (its arithmetic is not in the image).
+bool SolveLinear(std::vector<double> A, int rows, int cols, std::vector<double> b, double * x)
 {
   for (int c = 0; c < cols; c++) {
     double norm = 0.;
@@ -177,11 +179,17 @@ void SolveLinear(std::vector<double> A, int rows, int cols, std::vector<double> 
     s = 2. * s / vv;
     for (int r = c; r < rows; r++) {b[r] -= s * v[r];}
   }
+  double rmax = 0., rmin = std::numeric_limits<double>::infinity();
+  for (int c = 0; c < cols; c++) {
+    rmax = std::max(rmax, std::fabs(A[c * cols + c]));
+    rmin = std::min(rmin, std::fabs(A[c * cols + c]));
+  }
   for (int c = cols - 1; c >= 0; c--) {
     double s = b[c];
     for (int cc = c + 1; cc < cols; cc++) {s -= A[c * cols + cc] * x[cc];}
     x[c] = s / A[c * cols + c];
   }
+  return rmin > 1e-9 * rmax;
 }
 
 // ---- the optimizer (optimizer.hpp / src/optimizer.cpp) ---------------------------------------------------------------
@@ -517,12 +525,19 @@ void orc_loc_surface_residuals(const float * map, int n_map, const double * pose
     Nearest(map, n_map, on_map, k, idx);
     for (int j = 0; j < k; j++) {for (int a = 0; a < 3; a++) {X[3 * j + a] = (double)map[4 * idx[j] + a];}}
     double wv[3];
-    SolveLinear(X, k, 3, g, wv);                                         // EstimatePlaneCoefficients, surface.hpp:78-83
+    const bool plane = SolveLinear(X, k, 3, g, wv);                      // EstimatePlaneCoefficients, surface.hpp:78-83
+    double * J = jacobian + 7 * i;
+    if (!plane) {
+      // the k neighbours coincide or lie on one line: the zero row (weight 0 in every sum of the optimizer; see
+      // scan_to_map_row in lfx_kernels_localize.hpp).  What Eigen returns here is not available.
+      for (int c = 0; c < 7; c++) {J[c] = 0.;}
+      residual[i] = 0.;
+      continue;
+    }
     const double norm = std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
     const double u[3] = {wv[0] / norm, wv[1] / norm, wv[2] / norm};
     double d[12];
     DRpDq(w, v, p, d);
-    double * J = jacobian + 7 * i;
     for (int c = 0; c < 4; c++) {J[c] = u[0] * d[c] + u[1] * d[4 + c] + u[2] * d[8 + c];}
     for (int c = 0; c < 3; c++) {J[4 + c] = u[c];}
     residual[i] = (wv[0] * on_map.x + wv[1] * on_map.y + wv[2] * on_map.z + 1.0) / norm;   // SignedPointPlaneDistance

@@ -69,7 +69,7 @@ def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     if rc == 0:
         lib.lfx_destroy(ctx)
     assert lib.lfx_status_string(5).decode().startswith("two adjacent points")
-    assert lib.lfx_kernel_name(3) == b"ring_unit_kernel"
+    assert lib.lfx_kernel_name(1) == b"ring_unit_kernel"
 
 
 def test_label_to_color_table(lib, refvec):

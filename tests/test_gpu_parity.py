@@ -510,7 +510,7 @@ def test_organised_kernel_gives_a_scan_up_half_way():
     f.close()
 
 
-@pytest.mark.parametrize("env", ["LFX_DEBUG_TWO_PASS", "LFX_DEBUG_NO_FAST_PATH", "LFX_DEBUG_GENERIC_THRESHOLDS"])
+@pytest.mark.parametrize("env", ["LFX_DEBUG_NO_FAST_PATH", "LFX_DEBUG_GENERIC_THRESHOLDS"])
 def test_fallback_paths_give_the_same_results(env):
     """The two-pass ring bucketing (histogram + scan + scatter) and the workgroup-per-ring kernel for
     every ring are kept as fallbacks of the look-back bucketing / wave-per-unit kernel; with the reference's

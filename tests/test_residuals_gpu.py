@@ -136,3 +136,49 @@ def test_reference_vectors_through_the_device():
     torch.cuda.synchronize()
     assert np.abs(d_res.cpu().numpy()[1]).max() < 1e-12
     fx.close()
+
+
+def test_surface_neighbourhoods_without_a_plane_get_the_zero_row():
+    """surface.hpp:78-83 solves X w = -1 by `householderQr().solve` whatever the rank of X.  Where the k nearest map
+    points coincide, or lie on one line, R has a zero pivot; what Eigen returns then cannot be known here (its arithmetic is
+    not in the image), so the row is given weight 0: residual 0 and u = 0, on the device and in the oracle alike -- it adds
+    nothing to any sum of the optimizer, and a caller can tell it (every other surface row has |u| = 1).  Three queries:
+    beside 20 coincident map points, beside 20 points on a line along (1, 1, 0), beside a proper patch of a plane."""
+    import torch
+    from lidar_feature_extraction_amd import FeatureExtraction
+    from oracle import binding as OB
+    L = OB.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    k = 15
+    same = np.tile(np.array([[10.0, 0.0, 1.0, 1.0]], np.float32), (20, 1))
+    t = np.arange(20, dtype=np.float32)
+    line = np.stack([-10 + 0.25 * t, 5 + 0.25 * t, np.full(20, 2.0, np.float32), np.ones(20, np.float32)], 1)
+    patch = np.zeros((40, 4), np.float32)
+    patch[:, :2] = rng.uniform(-1, 1, (40, 2))
+    patch[:, 2] = 0.3 * patch[:, 0] - 7.0
+    surf_map = np.ascontiguousarray(np.concatenate([same, line, patch]), np.float32)
+    pts = np.array([[10.2, 0.1, 1.1, 1], [-8.0, 7.1, 2.2, 1], [0.1, 0.2, -6.5, 1]], np.float32)
+    pose = np.hstack([np.eye(3), np.zeros((3, 1))])
+    fx = FeatureExtraction(device=0, max_points_per_scan=1024, max_batch=1)
+    d_map, d_pts = torch.from_numpy(surf_map).to(dev), torch.from_numpy(pts).to(dev)
+    for cell in (0.0, 1.0):                    # without and with the grid index
+        m = fx.make_map(d_map.data_ptr(), len(surf_map), cell)
+        d_b = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_n = torch.tensor([3], dtype=torch.int32, device=dev)
+        d_res = torch.full((3,), 7.0, dtype=torch.float64, device=dev)
+        d_jac = torch.full((3, 7), 7.0, dtype=torch.float64, device=dev)
+        fx.scan_to_map_residuals(1, m, pose, k, d_pts.data_ptr(), d_b.data_ptr(), d_n.data_ptr(), 1, 1, 3, d_res.data_ptr(), d_jac.data_ptr(), 0)
+        torch.cuda.synchronize()
+        res, jac = d_res.cpu().numpy(), d_jac.cpu().numpy()
+        wres, wjac = np.zeros(3), np.zeros((3, 7))
+        L.orc_loc_surface_residuals(OB.ptr(surf_map, PF), len(surf_map), OB.ptr(pose, PD), k, OB.ptr(pts, PF), 3, OB.ptr(wres, PD), OB.ptr(wjac, PD))
+        for i in (0, 1):
+            assert res[i] == 0.0 and not jac[i].any(), (cell, i, res[i], jac[i])
+            assert wres[i] == 0.0 and not wjac[i].any()
+        assert abs(np.linalg.norm(jac[2, 4:]) - 1.0) < 1e-12 and np.isfinite(res[2])
+        assert np.allclose(res[2], wres[2], rtol=1e-9, atol=1e-12) and np.allclose(jac[2], wjac[2], rtol=1e-9, atol=1e-12)
+        # the plane z = 0.3 x - 7: the query's signed distance to it
+        want = abs(0.3 * pts[2, 0] - pts[2, 2] - 7.0) / np.sqrt(1 + 0.09)
+        assert abs(abs(res[2]) - want) < 1e-5
+    fx.close()
