@@ -1086,13 +1086,27 @@ __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)
   for (int i = 0; i < NW; i++) {
     asm volatile ("ds_read_b64 %0, %1 offset:%2" : "=v"(w[i]) : "v"(addr), "n"(8 * i));
   }
-  double z = 0.;
-  double & w0 = w[0], & w1 = NW > 1 ? w[NW > 1 ? 1 : 0] : z, & w2 = NW > 2 ? w[NW > 2 ? 2 : 0] : z, & w3 = NW > 3 ? w[NW > 3 ? 3 : 0] : z,
-    & w4 = NW > 4 ? w[NW > 4 ? 4 : 0] : z, & w5 = NW > 5 ? w[NW > 5 ? 5 : 0] : z, & w6 = NW > 6 ? w[NW > 6 ? 6 : 0] : z,
-    & w7 = NW > 7 ? w[NW > 7 ? 7 : 0] : z, & w8 = NW > 8 ? w[NW > 8 ? 8 : 0] : z, & w9 = NW > 9 ? w[NW > 9 ? 9 : 0] : z,
-    & w10 = NW > 10 ? w[NW > 10 ? 10 : 0] : z;
-  asm volatile ("s_waitcnt lgkmcnt(0)"
-    : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7), "+v"(w8), "+v"(w9), "+v"(w10));
+  // (the wait names exactly the NW destinations: operands that stand for nothing would each cost a register pair and a
+  // v_mov to fill it -- nine of them per two-wide window, 135 vector instructions per wave, until round 4)
+  if constexpr (NW == 2) {
+    asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]));
+  } else if constexpr (NW == 5) {
+    asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]));
+  } else if constexpr (NW == 11) {
+    asm volatile ("s_waitcnt lgkmcnt(0)"
+      : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]));
+  } else {
+    static_assert(NW == 1 || NW == 3 || NW == 7 || NW == 9, "add the wait for this window width");
+    if constexpr (NW == 1) {asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]));}
+    if constexpr (NW == 3) {asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));}
+    if constexpr (NW == 7) {
+      asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]));
+    }
+    if constexpr (NW == 9) {
+      asm volatile ("s_waitcnt lgkmcnt(0)"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]));
+    }
+  }
 }
 
 // Lane predicate <-> wave-uniform mask.  `bal` is meant for ONE comparison (it then is the
