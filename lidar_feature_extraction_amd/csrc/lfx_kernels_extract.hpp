@@ -1560,12 +1560,15 @@ __device__ __forceinline__ uint32_t unit_core(
           double w[2 * (PT > 0 ? PT : 0) + 1];
           lds_window_f64(&U.c[qc - PT], w);
           const double ci = w[PT];
+          // bit 16 - d <-> c[q - d] <= c[q] (left neighbour: the lower index wins a tie), bit 16 + d <-> c[q + d] < c[q].
+          // The bits are shifted in from the top one down, one compare and one add-with-carry each (m + m + bit): written
+          // as a select of a bit constant per compare, the same mask cost a move, a select and an or per neighbour
 #pragma unroll
-          for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {
-            const double cl = w[PT - d], cr = w[PT + d];
-            m |= (cl <= ci) ? (1u << (16 - d)) : 0u;        // left neighbour: lower index wins a tie
-            m |= (cr < ci) ? (1u << (16 + d)) : 0u;
-          }
+          for (int d = (PT > 0 ? PT : 1); d >= 1; d--) {m = m + m + (uint32_t)(w[PT + d] < ci);}
+          m = m + m;                                        // (bit 16, the position itself: nobody reads it)
+#pragma unroll
+          for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {m = m + m + (uint32_t)(w[PT - d] <= ci);}
+          m <<= 16 - (PT > 0 ? PT : 1);
         } else {
           const double ci = U.c[qc];
           for (int d = 1; d <= P; d++) {
