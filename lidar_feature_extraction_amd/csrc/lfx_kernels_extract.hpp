@@ -1724,13 +1724,14 @@ __device__ __forceinline__ uint32_t unit_core(
         const float thr = pb_ratio_f * rf;
         const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
         const uint64_t guard = ratio_ok ? (bal(rf > 0.f) & bal(rf < 1e30f)) : 0ull;
-        const uint64_t y1 = bal(a1 > hi_t) & guard, n1 = bal(a1 < lo_t) & guard;
-        const uint64_t y2 = bal(a2 > hi_t) & guard, n2 = bal(a2 < lo_t) & guard;
-        const uint64_t u1 = ~(y1 | n1), u2 = ~(y2 | n2);
+        // decided yes: both sides clearly above the threshold; decided no: one side clearly below it; anything else (and
+        // everything outside the guard) takes the exact division below
+        const uint64_t yy = bal(a1 > hi_t) & bal(a2 > hi_t) & guard;
+        const uint64_t nn = (bal(a1 < lo_t) | bal(a2 < lo_t)) & guard;
         // i in [1, N-1) and owned
         const uint64_t valid = in_span(q, 1 - g0, N - 1 - g0) & in_span(q, qo0, qo1);
-        pby[k] = y1 & ~n1 & y2 & ~n2 & valid;
-        pbu[k] = ((u1 & ~n2) | (u2 & ~n1)) & valid;
+        pby[k] = yy & valid;
+        pbu[k] = valid & ~(yy | nn);
         any_uns |= pbu[k];
       }
     }
