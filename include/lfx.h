@@ -205,6 +205,15 @@ const char *lfx_status_string(int ring_status);
  * neighbor.hpp:72-73, math.cpp:41.  Empty for LFX_RING_OK, LFX_RING_SPARSE (RemoveSparseRings drops the ring silently,
  * ring.cpp:46-59) and LFX_RING_TOO_LARGE (no counterpart).  Returns the length written (snprintf semantics). */
 int lfx_ring_message(int ring_status, uint32_t n_points, const lfx_params *params, char *buf, size_t len);
+/* Optional log callback: where the node logs, the library calls back.  For every ring a host-API call (lfx_extract,
+ * lfx_extract_batch, lfx_extract_wait) finds abandoned on std::invalid_argument it calls `cb(LFX_LOG_WARN, text, user)` with
+ * the text of lfx_ring_message -- the node's RCLCPP_WARN(e.what()), feature_extraction.cpp:154-156, once per ring as there
+ * (a ring RemoveSparseRings drops makes no sound, ring.cpp:46-59; LFX_RING_TOO_LARGE, which has no counterpart, is reported
+ * with the library's own text).  Called on the caller's thread, inside the call that brought the results; cb = NULL
+ * switches it off (the default).  Nothing is ever printed by the library itself. */
+#define LFX_LOG_WARN 1
+typedef void (*lfx_log_fn)(int level, const char *message, void *user);
+int lfx_set_log_callback(lfx_ctx *ctx, lfx_log_fn cb, void *user);
 /* RangeMessage* of range_message.hpp:37-83, the texts of the reference's bounds errors ("i (which is 39) >= max (which
  * is 30)"): kind 0 LargerThanOrEqualTo, 1 SmallerThanOrEqualTo, 2 LargerThan, 3 SmallerThan.  Returns the length, -1
  * for an unknown kind. */

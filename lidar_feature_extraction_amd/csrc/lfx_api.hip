@@ -484,6 +484,20 @@ int fetch_finish(lfx_ctx * c, const FetchPlan & plan, HostScan * hosts, lfx_scan
     if (dense > n || (dense != n && !c->drop_zero)) {
       return fail(c, LFX_ERR_HIP, "internal: ring counts do not add up to the scan");
     }
+    if (c->log_cb) {
+      // what the node logs per abandoned ring (feature_extraction.cpp:154-156)
+      for (uint32_t r = 0; r < nr; r++) {
+        const int stat = h.ring_status[r];
+        if (stat == LFX_RING_OK || stat == LFX_RING_SPARSE) {continue;}
+        char text[160];
+        if (stat == LFX_RING_TOO_LARGE) {
+          std::snprintf(text, sizeof(text), "ring %u holds %u points, more than max_points_per_ring (%u)", (unsigned)h.ring_id[r], h.ring_count[r], c->cap);
+        } else {
+          lfx_ring_message(stat, h.ring_count[r], &c->params, text, sizeof(text));
+        }
+        c->log_cb(LFX_LOG_WARN, text, c->log_user);
+      }
+    }
     lfx_scan_result & o = out[k];
     o.n_points = n;
     o.n_sorted = dense;             // = n less the points the zero filter dropped
@@ -599,6 +613,14 @@ int lfx_ring_message(int ring_status, uint32_t n_points, const lfx_params * p, c
     default:
       return std::snprintf(buf, len, "%s", "");
   }
+}
+
+int lfx_set_log_callback(lfx_ctx * c, lfx_log_fn cb, void * user)
+{
+  if (!c) {return LFX_ERR_INVALID_ARGUMENT;}
+  c->log_cb = cb;
+  c->log_user = user;
+  return LFX_OK;
 }
 
 int lfx_route_choice(const uint32_t report[LFX_ROUTE_REPORT_WORDS], uint32_t report_rings, uint32_t state[LFX_ROUTE_STATE_WORDS],

@@ -127,6 +127,8 @@ struct lfx_ctx
   int totals_env = -1;                   // LFX_DEBUG_TOTALS_KERNEL=1: ring_totals_kernel also for small batches (A/B)
   bool fast_path = true;                 // wave-per-unit kernel first, workgroup-per-ring kernel for what it defers
   std::string err;
+  lfx_log_fn log_cb = nullptr;           // lfx_set_log_callback
+  void * log_user = nullptr;
 
   // device scratch
   lfx_host::DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,

@@ -4,10 +4,14 @@
 // the structure does not: the reference walks rings and blocks sequentially on one CPU thread
 // and decides edge/surface points by argsort + greedy suppression.  Per batch of scans:
 //
-//   ring_scatter_kernel     the ONE pass over the input: stable counting sort of the points by ring
+//   ring_unit_org_kernel    the path of an ORGANISED scan (a driver's column-major R x C grid, rings in angle order): a
+//                           workgroup = one block of four adjacent rings, one ring per wave, reads the 32-byte records
+//                           in place (four lanes share a 128-byte line) and does everything ring_unit_kernel does;
+//                           ring_cut_kernel first finds the rings' rotation / reversal where a stream needs it
+//   ring_scatter_kernel     any other scan: the ONE pass over the input, a stable counting sort of the points by ring
 //                           (MakePointIndices, ring.hpp:114-125) into ring-major arrays, the prefix
 //                           over earlier chunks obtained by look-back inside the launch
-//   ring_unit_kernel        fast path: one WAVE per (ring, block): angle-order check, range,
+//   ring_unit_kernel        one WAVE per (ring, block) of a bucketed scan: angle-order check, range,
 //                           curvature, links, block labelling, occlusion / out-of-range /
 //                           parallel-beam masks, per-unit feature records; no workgroup barrier;
 //                           point sets as ballot words in LDS bit arrays (one read + v_alignbit per
@@ -19,8 +23,8 @@
 //                           while a stream keeps arriving rotated, ahead of it over every ring
 //   ring_extract_kernel     slow path for what neither pass takes (skip conditions, blocks that do not
 //                           fit a wave, exactly tied directions): one workgroup per ring in LDS
-//   ring_totals_kernel, feature_compact_kernel   per-unit records -> the scan's edge / surface clouds
-//   (ring_histogram_kernel, ring_scan_kernel: two-pass bucketing kept as a fallback)
+//   ring_totals_kernel, feature_compact_kernel   per-unit records -> the scan's edge / surface clouds (small batches: the
+//                           second alone)
 //
 // Labelling without a sort.  The reference's per-block pass (label.hpp:72-95,113-134) visits
 // points in curvature order and lets every pick suppress what its link-aware +-P fill reaches

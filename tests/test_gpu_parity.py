@@ -354,6 +354,24 @@ def test_ring_skip_conditions(fx):
     st = dict(zip(got.ring_id.tolist(), got.ring_status.tolist()))
     assert st[1] == 1 and st[9] == 1 and st[2] == 2 and st[3] == 3 and st[7] == 5 and st[0] == 0
     assert st[4] != 0 and st[5] != 0
+    # the log callback: one warning per abandoned ring with the text of the reference's exception -- what the node hands to
+    # RCLCPP_WARN (feature_extraction.cpp:154-156); the two sparse rings are dropped without a sound (ring.cpp:46-59)
+    import ctypes as C
+    heard = []
+    FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
+    cb = FN(lambda level, text, user: heard.append((level, text.decode())))
+    L = LB.load()
+    L.lfx_set_log_callback.argtypes = [C.c_void_p, FN, C.c_void_p]
+    assert L.lfx_set_log_callback(fx._ctx, cb, None) == 0
+    fx.ExtractFeatures(c)
+    assert L.lfx_set_log_callback(fx._ctx, FN(0), None) == 0
+    fx.ExtractFeatures(c)                                         # switched off again: nothing more is heard
+    assert len(heard) == 5 and all(level == 1 for level, _ in heard), heard
+    texts = sorted(t for _, t in heard)
+    assert "All input values are zero. Angle cannot be calculated" in texts                        # ring 7, math.cpp:41
+    assert "Input array size 9 cannot be smaller than weight size 11" in texts                     # ring 2, convolution.cpp:40-41
+    assert "end_index - start_index (which is 4) cannot be smaller than n_blocks (which is 6" in texts     # ring 3, index_range.cpp:36-38
+    assert sum(t.startswith("The input point size (which is ") for t in texts) == 2                # rings 4 and 5, neighbor.hpp:72-73
 
 
 def test_one_zero_norm_point_breaks_links_only(fx):
