@@ -1769,8 +1769,21 @@ __device__ __forceinline__ uint32_t unit_core(
     l = ov != kDefault ? ov : l;
     return lanes(in_span(q, qo0, qo1)) ? l : (uint32_t)kDefault;
   };
-  float4 * __restrict__ rec_pts = tab->rec_pts;
-  uint32_t * __restrict__ rec_idx = tab->rec_idx;
+  // The stores: a wave-uniform 64-bit part (table entry + the ring's start + the unit's first position, in scalar
+  // registers) and a small unsigned lane part, through pointers declared global -- so that the store instructions take the
+  // base from a scalar pair and a 32-bit offset per lane (a generic pointer with a signed 64-bit index made every store a
+  // flat_ instruction behind a sign extension and three 64-bit adds per lane).  (off + g0 may lie a halo before the
+  // ring's start: the lanes there own nothing and store nothing.)
+  typedef __attribute__((address_space(1))) uint8_t g_u8_t;
+  typedef __attribute__((address_space(1))) double g_f64_t;
+  typedef __attribute__((address_space(1))) uint32_t g_u32_t;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) f32x4_t g_f32x4_t;
+  g_u8_t * const label_u = (g_u8_t *)label_s + ((ptrdiff_t)off + g0);
+  g_f64_t * const curv_u = (g_f64_t *)curv_s + ((ptrdiff_t)off + g0);
+  g_f32x4_t * const rec_u = (g_f32x4_t *)tab->rec_pts + (off + rec_lo);
+  g_u32_t * const idx_u = (g_u32_t *)tab->rec_idx + (off + rec_lo);
+  const uint32_t rec_n = rec_hi - rec_lo;          // edges from the front of the unit's positions, surfaces from their back
 #pragma unroll
   for (int k = 0; k < CH; k++) {
     if (k < K) {
@@ -1779,19 +1792,19 @@ __device__ __forceinline__ uint32_t unit_core(
       const uint32_t l = final_label(k, q);
       const double cv = U.c[q];
       if (own) {
-        label_s[off + i] = (uint8_t)l;
-        curv_s[off + i] = cv;
+        label_u[(uint32_t)q] = (uint8_t)l;
+        curv_u[(uint32_t)q] = cv;
       }
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
       if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-        const float4 rec = make_float4(x[k], y[k], z[k], (float)cv);
+        const f32x4_t rec = {x[k], y[k], z[k], (float)cv};
         const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
         const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
-        const size_t at = l == kEdge ? off + rec_lo + pe + be : off + rec_hi - 1 - (ps + bs);
-        rec_pts[at] = rec;
+        const uint32_t at = l == kEdge ? pe + be : rec_n - 1u - (ps + bs);
+        rec_u[at] = rec;
         // ORG: position i of ring `slot` is point column * R + slot
-        rec_idx[at] = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
+        idx_u[at] = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
       }
       pe += __popcll(fe);
       ps += __popcll(fs);
