@@ -1416,12 +1416,14 @@ __device__ __forceinline__ uint32_t unit_core(
   // ---- C. links (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the
   //         occlusion test (occlusion.hpp:44-57, 67-79)
   {
-    uint64_t lky[CH], uns[CH];
-    uint64_t zero_pair = 0, any_uns = 0;
+    // (one walk over the chunks: a chunk's links are final -- the undecided ones settled by the exact division at once --
+    // before its jumps are taken from the same two ranges; two walks read every range twice)
+    uint64_t zero_pair = 0;
+    uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
+    WordVec vlk, vjl, vjr;
     const float cbf = prm.cos_bound_f;
 #pragma unroll
     for (int k = 0; k < CH; k++) {
-      lky[k] = 0; uns[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
         const uint64_t pair = in_span(q, qlo, qhi - 1);
@@ -1432,7 +1434,7 @@ __device__ __forceinline__ uint32_t unit_core(
         // cos_bound <= cos <= 1 (neighbor.hpp:44-48 via the cosine bound): classified in f32 first.
         // |dot| <= r0*r1, so the f32 cosine is within ~4 ulp(1) = 5e-7 of the exact one; a value more
         // than 2^-19 (1.9e-6) away from both ends decides the test, anything closer (or not finite)
-        // takes the exact f64 division below.
+        // takes the exact f64 division.
         const float2 nb = U.pxy[q + 1];
         const float dotf = x[k] * nb.x + y[k] * nb.y;
         const float denf = (float)rk * (float)rn;
@@ -1440,48 +1442,29 @@ __device__ __forceinline__ uint32_t unit_core(
         const uint64_t yes = bal(cosf > cbf + 0x1p-19f) & bal(cosf < 1.0f - 0x1p-19f);
         const uint64_t no = bal(cosf < cbf - 0x1p-19f) | bal(cosf > 1.0f + 0x1p-19f);
         const uint64_t fin = bal(fabsf(cosf) < 4.0f);
-        lky[k] = yes & ~no & fin & pair;
-        uns[k] = (~(yes | no) | ~fin) & pair;
-        any_uns |= uns[k];
-      }
-    }
-    if (any_uns != 0ull) {
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        if (k < K && uns[k] != 0ull) {
-          const int q = 64 * k + lane;
-          const double rn = U.r[q + 1];
-          const float2 nb = U.pxy[q + 1];
+        uint64_t lk = yes & ~no & fin & pair;
+        const uint64_t undecided = (~(yes | no) | ~fin) & pair;
+        if (undecided != 0ull) {
           const double dot = (double)x[k] * (double)nb.x + (double)y[k] * (double)nb.y;
-          const double cosang = dot / (U.r[q] * rn);                     // math.cpp:44-45
-          lky[k] |= uns[k] & bal(cosang >= prm.cos_bound) & bal(cosang <= 1.0);   // acos(cos) < threshold; NaN -> false
+          const double cosang = dot / (rk * rn);                         // math.cpp:44-45
+          lk |= undecided & bal(cosang >= prm.cos_bound) & bal(cosang <= 1.0);    // acos(cos) < threshold; NaN -> false
         }
-      }
-    }
-    if (zero_pair != 0ull) {return (uint32_t)kDeferOther;}
-    uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
-    WordVec vlk, vjl, vjr;
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-      if (k < K) {
-        const int q = 64 * k + lane;
-        vlk.set(k, lky[k]);
+        vlk.set(k, lk);
         const int qm = q > 0 ? q - 1 : 0;
-        double rw2[2];
-        lds_window_f64(&U.r[q], rw2);
-        const double rq = rw2[0] + dist_diff;
+        const double rq = rk + dist_diff;
         // far side to the right of a linked pair (q, q+1), i in [0, N-P-1)
-        const uint64_t jl = lky[k] & in_span(q, 0, N - P - 1 - g0) & bal(rw2[1] > rq);
+        const uint64_t jl = lk & in_span(q, 0, N - P - 1 - g0) & bal(rn > rq);
         // far side to the left of a linked pair (q-1, q), i in [P+1, N-1]
-        const uint64_t lk_prev = (lky[k] << 1) | prev_top;
+        const uint64_t lk_prev = (lk << 1) | prev_top;
         const uint64_t jr = lk_prev & in_span(q, P + 1 - g0, qhi) & bal(U.r[qm] > rq);
-        prev_top = lky[k] >> 63;
+        prev_top = lk >> 63;
         if (LFX_STAGE_ON(256u)) {
           vjl.set(k, jl);
           vjr.set(k, jr);
         }
       }
     }
+    if (zero_pair != 0ull) {return (uint32_t)kDeferOther;}
     put_words(U, kBitLK, vlk, lane);
     if (LFX_STAGE_ON(256u)) {
       put_words(U, kBitJL, vjl, lane);
