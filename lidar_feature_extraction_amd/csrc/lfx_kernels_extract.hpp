@@ -1380,44 +1380,26 @@ __device__ __forceinline__ uint32_t unit_core(
   const UnitWin W0{(uint32_t)(lane + 48) >> 5, (uint32_t)(lane + 16) & 31u};   // window around q
   const UnitWin W1{(uint32_t)(lane + 49) >> 5, (uint32_t)(lane + 17) & 31u};   // window around q + 1
   LFX_STAMP(2);
-  // ---- B. angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, else
-  //         slow path; range (math.hpp:36-39)
-  const int pair_end = qo1 < qhi - 1 ? qo1 : qhi - 1;                  // owned pairs (q, q+1): q in [qo0, pair_end)
-  uint64_t bad = 0;
+  // ---- B. range (math.hpp:36-39)
 #pragma unroll
   for (int k = 0; k < CH; k++) {
     if (k < K) {
       const int q = 64 * k + lane;
-      const float2 nb = U.pxy[q + 1];
-      const float xn = nb.x, yn = nb.y;
-      uint64_t spec;
-      const uint64_t less = polar_less_masks(x[k], y[k], xn, yn, spec);
-      bad |= in_span(q, qo0, pair_end) & (spec | ~less);
       const double xd = (double)x[k], yd = (double)y[k];
       U.r[q] = sqrt_sum_of_squares(xd * xd + yd * yd);     // (kept in the slab only: registers are what the straight-line form is short of)
     }
   }
-  if (bad != 0ull) {
-    // re-evaluate with the full predicate: a special case is not necessarily out of order
-    bool really = false;
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-      if (k < K) {
-        const int q = 64 * k + lane;
-        const bool pair = q >= qo0 && q < pair_end;
-        const float2 nb = U.pxy[q + 1];
-        if (pair && !polar_less(x[k], y[k], nb.x, nb.y)) {really = true;}
-      }
-    }
-    if (__ballot(really) != 0ull) {return (uint32_t)(second_pass ? kDeferOther : kDeferOrder);}
-  }
   LFX_WAVE_SYNC();
   LFX_STAMP(3);
-  // ---- C. links (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the
-  //         occlusion test (occlusion.hpp:44-57, 67-79)
+  // ---- C. angle order of the owned pairs (ring.hpp:54-112): strictly increasing as bucketed, else slow path; links
+  //         (neighbor.hpp:44-48): bit q <-> pair (q, q+1); with them the range jumps of the occlusion test
+  //         (occlusion.hpp:44-57, 67-79)
   {
-    // (one walk over the chunks: a chunk's links are final -- the undecided ones settled by the exact division at once --
-    // before its jumps are taken from the same two ranges; two walks read every range twice)
+    // (one walk over the chunks, one read of the neighbour's x, y for the order test and the link's dot product; a
+    // chunk's links are final -- the undecided ones settled by the exact division at once -- before its jumps are taken
+    // from the same two ranges)
+    const int pair_end = qo1 < qhi - 1 ? qo1 : qhi - 1;                // owned pairs (q, q+1): q in [qo0, pair_end)
+    uint64_t bad = 0;
     uint64_t zero_pair = 0;
     uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
     WordVec vlk, vjl, vjr;
@@ -1436,6 +1418,11 @@ __device__ __forceinline__ uint32_t unit_core(
         // than 2^-19 (1.9e-6) away from both ends decides the test, anything closer (or not finite)
         // takes the exact f64 division.
         const float2 nb = U.pxy[q + 1];
+        {
+          uint64_t spec;
+          const uint64_t less = polar_less_masks(x[k], y[k], nb.x, nb.y, spec);
+          bad |= in_span(q, qo0, pair_end) & (spec | ~less);
+        }
         const float dotf = x[k] * nb.x + y[k] * nb.y;
         const float denf = (float)rk * (float)rn;
         const float cosf = dotf * __builtin_amdgcn_rcpf(denf);
@@ -1463,6 +1450,20 @@ __device__ __forceinline__ uint32_t unit_core(
           vjr.set(k, jr);
         }
       }
+    }
+    if (bad != 0ull) {
+      // re-evaluate with the full predicate: a special case is not necessarily out of order
+      bool really = false;
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (k < K) {
+          const int q = 64 * k + lane;
+          const bool pair = q >= qo0 && q < pair_end;
+          const float2 nb = U.pxy[q + 1];
+          if (pair && !polar_less(x[k], y[k], nb.x, nb.y)) {really = true;}
+        }
+      }
+      if (__ballot(really) != 0ull) {return (uint32_t)(second_pass ? kDeferOther : kDeferOrder);}
     }
     if (zero_pair != 0ull) {return (uint32_t)kDeferOther;}
     put_words(U, kBitLK, vlk, lane);
@@ -1684,71 +1685,55 @@ __device__ __forceinline__ uint32_t unit_core(
   }
 #endif
   LFX_STAMP(9);
-  // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
-  uint64_t pby[CH];
-  {
-    uint64_t pbu[CH];
-    uint64_t any_uns = 0;
-    // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
-    // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
-    // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
-    // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
-    const bool ratio_ok = pb_ratio_f >= 0x1p-9f;
-#pragma unroll
-    for (int k = 0; k < CH; k++) {
-      pby[k] = 0; pbu[k] = 0;
-      if (k < K && LFX_STAGE_ON(512u)) {
-        const int q = 64 * k + lane;
-        const int qm = q > 0 ? q - 1 : 0;
-        double rw2[2];
-        lds_window_f64(&U.r[q], rw2);
-        const float rf = (float)rw2[0], rmf = (float)U.r[qm], rpf = (float)rw2[1];
-        const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
-        const float thr = pb_ratio_f * rf;
-        const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
-        const uint64_t guard = ratio_ok ? (bal(rf > 0.f) & bal(rf < 1e30f)) : 0ull;
-        // decided yes: both sides clearly above the threshold; decided no: one side clearly below it; anything else (and
-        // everything outside the guard) takes the exact division below
-        const uint64_t yy = bal(a1 > hi_t) & bal(a2 > hi_t) & guard;
-        const uint64_t nn = (bal(a1 < lo_t) | bal(a2 < lo_t)) & guard;
-        // i in [1, N-1) and owned
-        const uint64_t valid = in_span(q, 1 - g0, N - 1 - g0) & in_span(q, qo0, qo1);
-        pby[k] = yy & valid;
-        pbu[k] = valid & ~(yy | nn);
-        any_uns |= pbu[k];
-      }
-    }
-    if (any_uns != 0ull) {
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        if (k < K && pbu[k] != 0ull) {
-          const int q = 64 * k + lane;
-          const int qm = q > 0 ? q - 1 : 0;
-          const double ri = U.r[q];
-          const float ratio1 = (float)(fabs(U.r[qm] - ri) / ri);
-          const float ratio2 = (float)(fabs(U.r[q + 1] - ri) / ri);
-          pby[k] |= pbu[k] & bal((double)ratio1 > pb_ratio) & bal((double)ratio2 > pb_ratio);
-        }
-      }
-    }
-  }
-  LFX_STAMP(10);
+  // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs: one walk over the chunks --
+  //         the parallel-beam test (settled by the exact division at once where the f32 test leaves it open), the range
+  //         test and the label from ONE read of the point's range and its two neighbours'
+  // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
+  // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
+  // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
+  // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
+  const bool ratio_ok = pb_ratio_f >= 0x1p-9f;
   uint32_t pe = 0, ps = 0;
   asm volatile ("" ::: "memory");          // the table entries are not to be fetched (and held) any earlier
   uint8_t * __restrict__ label_s = tab->label_s;
   double * __restrict__ curv_s = tab->curv_s;
   // final label of position q = 64 k + lane (feature_extraction.cpp:133-138: the masks override the block labelling)
   auto final_label = [&](int k, int q) -> uint32_t {
+    uint64_t pb = 0;
+    const int qm = q > 0 ? q - 1 : 0;
+    double rw2[2];
+    lds_window_f64(&U.r[q], rw2);
+    const double ri = rw2[0];
+    if (LFX_STAGE_ON(512u)) {
+      const double rm = U.r[qm];
+      const float rf = (float)ri, rmf = (float)rm, rpf = (float)rw2[1];
+      const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
+      const float thr = pb_ratio_f * rf;
+      const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
+      const uint64_t guard = ratio_ok ? (bal(rf > 0.f) & bal(rf < 1e30f)) : 0ull;
+      // decided yes: both sides clearly above the threshold; decided no: one side clearly below it; anything else (and
+      // everything outside the guard) takes the exact division
+      const uint64_t yy = bal(a1 > hi_t) & bal(a2 > hi_t) & guard;
+      const uint64_t nn = (bal(a1 < lo_t) | bal(a2 < lo_t)) & guard;
+      // i in [1, N-1) and owned
+      const uint64_t valid = in_span(q, 1 - g0, N - 1 - g0) & in_span(q, qo0, qo1);
+      pb = yy & valid;
+      const uint64_t undecided = valid & ~(yy | nn);
+      if (undecided != 0ull) {
+        const float ratio1 = (float)(fabs(rm - ri) / ri);
+        const float ratio2 = (float)(fabs(rw2[1] - ri) / ri);
+        pb |= undecided & bal((double)ratio1 > pb_ratio) & bal((double)ratio2 > pb_ratio);
+      }
+    }
     const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
     uint32_t l = kDefault;
     l = (wE & reach[k]) != 0u ? (uint32_t)kEdgeNeighbor : l;
     l = (wS & reach[k]) != 0u ? (uint32_t)kSurfaceNeighbor : l;
     l = (wS & (1u << 16)) != 0u ? (uint32_t)kSurface : l;
     l = (wE & (1u << 16)) != 0u ? (uint32_t)kEdge : l;
-    const double ri = U.r[q];
     uint32_t ov = lanes(occ[k]) ? (uint32_t)kOccluded : (uint32_t)kDefault;
     ov = !(min_range <= ri && ri <= max_range) ? (uint32_t)kOutOfRange : ov;      // range.hpp:40-43
-    ov = lanes(pby[k]) ? (uint32_t)kParallelBeam : ov;
+    ov = lanes(pb) ? (uint32_t)kParallelBeam : ov;
     l = ov != kDefault ? ov : l;
     return lanes(in_span(q, qo0, qo1)) ? l : (uint32_t)kDefault;
   };
@@ -1793,7 +1778,7 @@ __device__ __forceinline__ uint32_t unit_core(
       ps += __popcll(fs);
     }
   }
-  LFX_STAMP(11);
+  LFX_STAMP(10);
   n_edge = pe;
   n_surface = ps;
   return 0u;

@@ -1,7 +1,7 @@
 """Static instruction counts per stage of a unit kernel, from the marked listing (`make -C lidar_feature_extraction_amd/csrc marks`):
     python tools/count_stage_instructions.py [kernel-name-substring]
-Stages are the LFX_STAMP points of unit_body (0 entry, 1 geometry, 2 loads, 3 order check + range, 4 links + jumps,
-5 occlusion + reach, 6 curvature, 7 order masks, 8 edge pass, 9 surface pass, 10 parallel beam, 11 labels + records).
+Stages are the LFX_STAMP points of unit_body (0 entry, 1 geometry, 2 loads, 3 range, 4 order check + links + jumps,
+5 occlusion + reach, 6 curvature, 7 order masks, 8 edge pass, 9 surface pass, 10 parallel beam + labels + records).
 Counts are of the listing (every chunk of an unrolled stage once, a loop body once), not of executed instructions."""
 import collections
 import os

@@ -12,8 +12,8 @@ import torch
 from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, concat
 from lidar_feature_extraction_amd import binding as B
 
-NAMES = ["entry->checks", "boundaries", "A load", "B order+range", "C links+jumps", "D occlusion+reach",
-         "E curvature", "F order masks", "F edge pass", "F surface pass", "G parallel beam", "G labels+records"]
+NAMES = ["entry->checks", "boundaries", "A load", "B range", "C order+links+jumps", "D occlusion+reach",
+         "E curvature", "F order masks", "F edge pass", "F surface pass", "G parallel beam+labels+records"]
 batch, rings, cols = 256, 64, 1800
 clouds = [make_scan(rings, cols, seed=1234 + i) for i in range(8)]
 tiled = [clouds[i % 8] for i in range(batch)]
@@ -30,11 +30,11 @@ total = 384 * 16
 buf = (C.c_ulonglong * total)()
 assert L.lfx_debug_read_stamps(buf, total) == total
 t = np.frombuffer(buf, dtype=np.uint64).reshape(384, 16).astype(np.int64)
-ok = t[:, 11] > t[:, 0]
+ok = t[:, 10] > t[:, 0]
 t = t[ok]
 print("units stamped:", len(t))
-life = t[:, 11] - t[:, 0]
-print("lifetime (stamp 0 -> 11): median %d  p10 %d  p90 %d shader cycles" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
-for k in range(11):
+life = t[:, 10] - t[:, 0]
+print("lifetime (stamp 0 -> 10): median %d  p10 %d  p90 %d shader cycles" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
+for k in range(10):
     dt = t[:, k + 1] - t[:, k]
     print("%-22s median %6d  (%4.1f %%)" % (NAMES[k + 1], np.median(dt), 100.0 * np.median(dt) / np.median(life)))
