@@ -1529,12 +1529,14 @@ __device__ __forceinline__ uint32_t unit_core(
   LFX_STAMP(6);
   // ---- F. block labelling (label.hpp:61-139): edge pass, then surface pass over what is still Default
   uint32_t lt[CH];
+  uint64_t ecand[CH];           // the edge pass's candidates (label.hpp:80-82), taken here where the curvature is in a register
   {
     // order masks, see order_masks(); the slab has no pad here: neighbours are read at clamped
     // positions, and what a clamped read yields is masked by `reach` (zero outside the block)
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       lt[k] = 0;
+      ecand[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
         int qc = q < P ? P : q;
@@ -1553,8 +1555,11 @@ __device__ __forceinline__ uint32_t unit_core(
 #pragma unroll
           for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {m = m + m + (uint32_t)(w[PT - d] <= ci);}
           m <<= 16 - (PT > 0 ? PT : 1);
+          // (the slab is 0 outside the block, also where the window's centre was clamped, and the threshold is > 0)
+          ecand[k] = bal(ci >= edge_thr);
         } else {
           const double ci = U.c[qc];
+          ecand[k] = bal(ci >= edge_thr);
           for (int d = 1; d <= P; d++) {
             const double cl = U.c[qc - d], cr = U.c[qc + d];
             m |= (cl <= ci) ? (1u << (16 - d)) : 0u;
@@ -1581,13 +1586,12 @@ __device__ __forceinline__ uint32_t unit_core(
       A[k] = 0; SEL[k] = 0; Hp[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
-        const double c0 = U.c[q < span ? q : span - 1];
         uint64_t cd;
         if (edge) {
-          // label.hpp:80-82; the slab is 0 outside the block and the threshold is > 0 (validated)
-          cd = bal(c0 >= edge_thr);
+          cd = ecand[k];
         } else {
           // label.hpp:119-121: in the block and still Default, i.e. not reached by an edge pick
+          const double c0 = U.c[q < span ? q : span - 1];
           cd = in_span(q, qb0, qb1) & bal(c0 <= surf_thr) & ~bal((get_win(U, kBitSelE, k, W0) & reach[k]) != 0u);
         }
         A[k] = cd;
