@@ -11,8 +11,12 @@ already resident in HBM.  Workload at every N: HDL-64E-shaped 64-ring x 1800-col
          --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU; scan i of the stream goes to rank i mod N (weak scaling: `--batch`
-scans per step on every rank) and every step ends with the RCCL gather of the labelled clouds to
-rank 0 (lidar_feature_extraction_amd/gather.py), inside the timed region.
+scans per step on every rank) and every step ends with the RCCL gather of the step's labelled clouds
+to ONE rank (lidar_feature_extraction_amd/gather.py), inside the timed region.  Which rank rotates
+(step k -> rank k mod N, two gathers in flight) by default: a sender reaches a destination over a
+single xGMI link (~77 GB/s each way) and produces 117 GB/s of clouds, so a fixed destination
+(`--gather-dst 0`) binds every sender at 66 % of the kernel rate; consecutive steps towards
+different ranks use different links.
 
 Rank 0 prints ONE JSON line; "roofline" prices the dominant kernel against the HBM roof with the
 path's ALGORITHMIC bytes (25*N_pts + 16*(N_edge+N_surface) per scan), its duration
@@ -56,7 +60,13 @@ def parse():
     ap.add_argument("--shuffle", action="store_true", help="records in arbitrary order (the reference's documented input contract)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (--steps steps between two fences) is run this many times; value = the median")
-    ap.add_argument("--gather-dst", default="0", help="destination rank of the per-step gather: a rank, or 'rotate' (step k -> rank k mod N)")
+    ap.add_argument("--gather-dst", default="rotate",
+                    help="destination rank of the per-step gather: 'rotate' (step k's clouds land whole on rank k mod N: consecutive "
+                         "steps use different xGMI links) or a fixed rank (every sender is then bound by its ONE link to that rank: "
+                         "~77 GB/s each way = 512 k scans/s per GPU, 66 %% of the kernel rate, whatever N)")
+    ap.add_argument("--gather-lanes", type=int, default=0,
+                    help="gathers in flight (a communicator and a side stream each; step k on lane k mod L): 0 = 2 with a rotating "
+                         "destination (the steps' exchanges overlap on their different links), 1 with a fixed one")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the rendezvous traffic (communicator id, agreements, barriers, the maximum "
                          "over ranks); gloo where the ranks share a GPU (rehearsal: a real RCCL communicator refuses that)")
@@ -210,23 +220,25 @@ def main():
         feat_cap = int(a.batch * n_pts * 0.35) + 1024
         # x, y, z only (12 bytes per point): what the node publishes (pcl::PointXYZ clouds,
         # feature_extraction.cpp:163-166) and a quarter less to push through rank 0's links
+        n_lanes = a.gather_lanes if a.gather_lanes > 0 else (2 if a.gather_dst == "rotate" else 1)
+        # one set more than there are gathers in flight: while those read their sets, the next step packs into a free one
         bufs = [(torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
                  torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
-                 torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(2)]
+                 torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(n_lanes + 1)]
         # RCCL through the library's own entry points (lfx_comm_*, lfx_gather_*); torch.distributed only carries the
         # 128-byte communicator id from rank 0 to the others
         # If the communicator cannot be made on some rank (the RCCL library does not open, the id does not arrive), every
         # rank drops the gather together and the line says so ("sharding"): a measurement of the sharded extraction without
         # its exchange is worth more than none.
         gather, gather_error = None, None
-        idt = torch.zeros(128, dtype=torch.uint8, device=ddev)
+        idt = torch.zeros(128 * n_lanes, dtype=torch.uint8, device=ddev)
         # every rank first checks that it CAN enter the collective initialisation (the RCCL library opens and has the
         # entry points: making an id proves both) and the ranks agree on that before anyone calls ncclCommInitRank --
         # a rank that failed earlier would otherwise leave the others waiting inside it
         try:
-            my_id = RcclGather.unique_id()
+            my_ids = b"".join(RcclGather.unique_id() for _ in range(n_lanes))
             if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+                idt.copy_(torch.frombuffer(bytearray(my_ids), dtype=torch.uint8))
         except Exception as e:             # noqa: BLE001
             gather_error = "rank %d: %s" % (rank, e)
         if world > 1:
@@ -239,7 +251,8 @@ def main():
             gather_error = "no communicator id from rank 0"
         if gather_error is None:
             try:
-                gather = CloudGather(fx, rank, world, bytes(idt.cpu().numpy().tobytes()),
+                all_ids = bytes(idt.cpu().numpy().tobytes())
+                gather = CloudGather(fx, rank, world, [all_ids[128 * k:128 * (k + 1)] for k in range(n_lanes)],
                                      dst="rotate" if a.gather_dst == "rotate" else int(a.gather_dst), device=dev,
                                      capacity_points=feat_cap * world, batch=a.batch)
             except Exception as e:         # noqa: BLE001
@@ -262,7 +275,7 @@ def main():
             k = 0                      # the gather runs on torch's current stream
         fxs[k].extract_batch_device(d_points.data_ptr(), n_list, streams[k].cuda_stream)
         if use_gather:
-            edge_buf, surf_buf, offs = bufs[step_no[0] % 2]
+            edge_buf, surf_buf, offs = bufs[step_no[0] % len(bufs)]
             gather.wait_buffer(edge_buf)       # the gather that last read this set must be done
             fxs[k].pack_xyz12(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
             gather.submit(edge_buf, surf_buf, offs, a.batch)
@@ -516,7 +529,7 @@ def main():
                                       ((", %.0f %% of the returns %s" % (100 * a.drop_fraction, "written as (0, 0, 0) and filtered" if a.drop_zero else "missing"))
                                        if a.drop_fraction > 0 else ""),
                        "streams": 1 if use_gather else n_streams,
-                       "sharding": "scan i -> gpu i mod N" + ((", RCCL gather of clouds to rank %s per step" % ("k mod N of step k" if a.gather_dst == "rotate" else a.gather_dst)) if use_gather else "") +
+                       "sharding": "scan i -> gpu i mod N" + ((", RCCL gather of clouds to rank %s per step, %d in flight" % ("k mod N of step k" if a.gather_dst == "rotate" else a.gather_dst, n_lanes)) if use_gather else "") +
                                    (" (gather unavailable: %s)" % gather_error if gather_error else "")},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
             "configs": configs,

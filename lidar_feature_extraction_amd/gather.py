@@ -81,12 +81,19 @@ def split_gathered(edge_all, surface_all, offsets_all, counts, batch):
 
 
 class CloudGather:
-    """One-step-deep pipeline of the gather on a side stream (GPU tensors, RCCL through the C ABI).
+    """One-step-deep pipeline of the gather on side streams (GPU tensors, RCCL through the C ABI).
 
-    submit(edge, surface, offsets, batch) registers this step's packed clouds (they must stay untouched until the
-    NEXT submit returns: use two sets of buffers; `wait_buffer` orders their reuse), queues the all-gather of their
-    totals, and completes the previous step's gather, returning on rank dst the list split_gathered builds (views of
-    the receive buffers, valid once `done` has passed; None elsewhere).  flush() completes the last one."""
+    submit(edge, surface, offsets, batch) registers this step's packed clouds (they must stay untouched until their gather
+    is done: use `lanes` + 1 sets of buffers; `wait_buffer` orders their reuse), queues the all-gather of their
+    totals, and completes the previous step's gather, returning on its destination rank the list split_gathered builds
+    (views of the receive buffers, valid once `done` has passed; None elsewhere).  flush() completes the last one.
+
+    Lanes.  A sender reaches a destination over ONE xGMI link (≈ 77 GB/s each way), and a GPU that extracts 780 k scans/s
+    produces 117 GB/s of clouds: towards a fixed destination every sender is bound by that one link (66 % of the kernel
+    rate, whatever the number of GPUs), and the destination's seven links together take in 0.54 TB/s.  With a rotating
+    destination (step k -> rank k mod N) consecutive steps travel over DIFFERENT links -- if they are allowed to overlap:
+    `unique_id` may be a list of communicator ids, one lane (communicator + side stream) each; step k's exchange runs on
+    lane k mod len(ids), so that step k - 1's payload is still on its way while step k's leaves."""
 
     def __init__(self, fx, rank, world, unique_id, dst=0, device=None, capacity_points=0, batch=1, floats_per_point=3):
         # dst = "rotate": step k's clouds go to rank k mod world (every rank then needs receive buffers): no single
@@ -94,8 +101,9 @@ class CloudGather:
         self.rotate = dst == "rotate"
         self.dst, self.rank, self.world = (0 if self.rotate else int(dst)), rank, world
         self.fpp, self.batch, self.cap = floats_per_point, batch, int(capacity_points)
-        self.rccl = RcclGather(fx, rank, world, unique_id)
-        self.side = torch.cuda.Stream(device=device)
+        ids = [unique_id] if isinstance(unique_id, (bytes, bytearray)) else list(unique_id)
+        self.lanes = [(RcclGather(fx, rank, world, uid), torch.cuda.Stream(device=device)) for uid in ids]
+        self.rccl, self.side = self.lanes[0]       # (the first lane under its old names: single-lane callers, stats)
         self.pending = None
         self.buffer_free = {}          # data_ptr of a send buffer -> event recorded after the gather that read it
         self.done = None               # event after the last completed gather's receives
@@ -108,10 +116,11 @@ class CloudGather:
             self.recv = [(None, None, None)] * 2
         self.step = 0
         self.received = 0              # gathers this rank has been the destination of: alternates the two receive sets
-        self.spans = []                # (start, end) events on the side stream around every gather (gather_ms)
+        self.spans = []                # (start, end) events on the side streams around every gather (gather_ms)
 
     def close(self):
-        self.rccl.close()
+        for rccl, _ in self.lanes:
+            rccl.close()
 
     def wait_buffer(self, tensor):
         """Make the caller's current stream wait until the last gather reading `tensor` is done."""
@@ -122,16 +131,18 @@ class CloudGather:
     def submit(self, edge, surface, offsets, batch):
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
+        rccl, side = self.lanes[(self.step + (1 if self.pending is not None else 0)) % len(self.lanes)]     # this step's lane
         prev, self.pending = self.pending, (edge, surface, offsets, batch)
-        # the previous step's payload goes first: its totals landed long ago, and the side stream then does not sit on
+        # the previous step's payload goes first: its totals landed long ago, and its side stream then does not sit on
         # this step's `ready` before moving data that has been waiting since the step before
         out = self._finish(prev) if prev is not None else None
-        self.side.wait_event(ready)
-        self.rccl.counts(offsets.data_ptr(), batch, self.side.cuda_stream)
+        side.wait_event(ready)
+        rccl.counts(offsets.data_ptr(), batch, side.cuda_stream)
         return out
 
     def _finish(self, p):
         edge, surface, offsets, batch = p
+        rccl, side = self.lanes[self.step % len(self.lanes)]          # the lane its totals were queued on
         dst = self.step % self.world if self.rotate else self.dst
         self.last_dst = dst
         self.step += 1
@@ -141,12 +152,12 @@ class CloudGather:
         if self.rank == dst:
             self.received += 1
         t0 = torch.cuda.Event(enable_timing=True)
-        t0.record(self.side)
-        counts = self.rccl.payload(dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
-                                   ea.data_ptr() if ea is not None else 0, sa.data_ptr() if sa is not None else 0,
-                                   oa.data_ptr() if oa is not None else 0, self.cap, self.side.cuda_stream)
+        t0.record(side)
+        counts = rccl.payload(dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
+                              ea.data_ptr() if ea is not None else 0, sa.data_ptr() if sa is not None else 0,
+                              oa.data_ptr() if oa is not None else 0, self.cap, side.cuda_stream)
         ev = torch.cuda.Event(enable_timing=True)
-        ev.record(self.side)
+        ev.record(side)
         self.spans.append((t0, ev))
         for t in (edge, surface, offsets):
             self.buffer_free[t.data_ptr()] = ev
@@ -156,8 +167,8 @@ class CloudGather:
         return split_gathered(ea, sa, oa, counts, batch)
 
     def gather_ms(self, reset=True):
-        """(sum, count) of the side stream's time inside the gathers completed so far (payload exchange incl. its waits for
-        the peers), in milliseconds; the side stream must be idle (flush())."""
+        """(sum, count) of the side streams' time inside the gathers completed so far (payload exchange incl. its waits for
+        the peers), in milliseconds; the side streams must be idle (flush())."""
         total = sum(a.elapsed_time(b) for a, b in self.spans)
         n = len(self.spans)
         if reset:
@@ -167,7 +178,8 @@ class CloudGather:
     def flush(self):
         prev, self.pending = self.pending, None
         out = self._finish(prev) if prev is not None else None
-        self.side.synchronize()
+        for _, side in self.lanes:
+            side.synchronize()
         return out
 
 

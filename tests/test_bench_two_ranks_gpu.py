@@ -50,6 +50,7 @@ def test_bench_runs_with_two_ranks(dst):
     assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak"
     assert "RCCL gather of clouds to rank" in d["config"]["sharding"] and "unavailable" not in d["config"]["sharding"], d["config"]["sharding"]
     assert ("k mod N" in d["config"]["sharding"]) == (dst == "rotate")
+    assert ("2 in flight" if dst == "rotate" else "1 in flight") in d["config"]["sharding"]      # the rotating form runs two lanes
     assert d["parity_spot_check"] is True
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["gather_ms_per_step"] > 0
     assert d["cpu_baseline"] is None and "N=1" in d["cpu_baseline_from"]

@@ -7,20 +7,23 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_extract_pack_gather_reassemble_one_rank():
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_extract_pack_gather_reassemble_one_rank(lanes):
+    """lanes = 2: two communicators, two side streams, step k's exchange on lane k mod 2 (what bench.py runs with a rotating
+    destination), three sets of send buffers: every step's clouds must still arrive whole and in order."""
     import torch
     from lidar_feature_extraction_amd import FeatureExtraction, make_scan, concat
     from lidar_feature_extraction_amd.gather import CloudGather, RcclGather, reassemble
     from oracle import binding as OB
-    rings, cols, batch, steps = 16, 900, 3, 3
+    rings, cols, batch, steps = 16, 900, 3, 5
     dev = torch.device("cuda", 0)
     fx = FeatureExtraction(device=0, max_points_per_scan=rings * cols, max_batch=batch, max_points_per_ring=cols, max_rings=rings)
-    uid = RcclGather.unique_id()
+    uid = [RcclGather.unique_id() for _ in range(lanes)]
     cap = batch * rings * cols
-    g = CloudGather(fx, 0, 1, uid, dst=0, device=dev, capacity_points=cap, batch=batch)
+    g = CloudGather(fx, 0, 1, uid if lanes > 1 else uid[0], dst="rotate" if lanes > 1 else 0, device=dev, capacity_points=cap, batch=batch)
     stream = torch.cuda.current_stream().cuda_stream
     bufs = [(torch.zeros((cap, 3), dtype=torch.float32, device=dev), torch.zeros((cap, 3), dtype=torch.float32, device=dev),
-             torch.zeros(2 * (batch + 1), dtype=torch.int32, device=dev)) for _ in range(2)]
+             torch.zeros(2 * (batch + 1), dtype=torch.int32, device=dev)) for _ in range(lanes + 1)]
     scans, outs, keep = [], [], []
     for step in range(steps):
         clouds = [make_scan(rings, cols, seed=5000 + step * batch + k, start_col=(17 * k if step == 1 else 0)) for k in range(batch)]
@@ -28,7 +31,7 @@ def test_extract_pack_gather_reassemble_one_rank():
         d = torch.from_numpy(concat(clouds).view(np.uint8).copy()).to(dev)
         keep.append(d)
         fx.extract_batch_device(d.data_ptr(), [len(c) for c in clouds], stream)
-        e, s, o = bufs[step % 2]
+        e, s, o = bufs[step % len(bufs)]
         g.wait_buffer(e)
         fx.pack_xyz12(e.data_ptr(), s.data_ptr(), o.data_ptr(), cap, stream)
         out = g.submit(e, s, o, batch)
