@@ -458,6 +458,29 @@ def test_device_resident_path_with_torch(fx):
         assert_scan_equal(fx.download(i, stream), OB.extract(c, canonical_ties=False), "device%d" % i)
 
 
+def test_large_batch_compaction_with_the_totals_kernel():
+    """A batch of more than 8 192 rings (600 scans x 16 rings) compacts with ring_totals_kernel ahead of
+    feature_compact_kernel -- bench.py's form; the other tests' batches are small enough for the compaction kernel to find
+    the rings' places itself.  Every scan's clouds must be what the same scan gives alone."""
+    import torch
+    unique = [make_scan(16, 900, seed=4100 + i) for i in range(6)]
+    clouds = [unique[i % 6] for i in range(600)]
+    f = FeatureExtraction(device=0, max_points_per_scan=16 * 900, max_batch=600, max_points_per_ring=900, max_rings=16)
+    dev = torch.from_numpy(synth.concat(clouds).view(np.uint8).copy()).to("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):                                   # (the second call runs on what the first one reported)
+        f.extract_batch_device(dev.data_ptr(), [len(c) for c in clouds], stream)
+    torch.cuda.synchronize()
+    want = [OB.extract(c, canonical_ties=False) for c in unique]
+    for i in (0, 1, 5, 299, 598, 599):
+        assert_scan_equal(f.download(i, stream), want[i % 6], "scan %d of 600" % i)
+    for i in range(0, 600, 7):
+        g = f.download(i, stream)
+        assert np.array_equal(g.edge_index, want[i % 6]["edge_index"].astype(np.uint32)), i
+        assert np.array_equal(g.surface_points[:, :3], want[i % 6]["surface_points"][:, :3]), i
+    f.close()
+
+
 def test_large_random_parameters(fx):
     """Other paddings / block counts / thresholds, incl. the largest supported padding."""
     rng = np.random.default_rng(11)
@@ -528,11 +551,12 @@ def test_organised_kernel_gives_a_scan_up_half_way():
     f.close()
 
 
-@pytest.mark.parametrize("env", ["LFX_DEBUG_NO_FAST_PATH", "LFX_DEBUG_GENERIC_THRESHOLDS"])
+@pytest.mark.parametrize("env", ["LFX_DEBUG_NO_FAST_PATH", "LFX_DEBUG_GENERIC_THRESHOLDS", "LFX_DEBUG_TOTALS_KERNEL"])
 def test_fallback_paths_give_the_same_results(env):
-    """The two-pass ring bucketing (histogram + scan + scatter) and the workgroup-per-ring kernel for
-    every ring are kept as fallbacks of the look-back bucketing / wave-per-unit kernel; with the reference's
-    default thresholds the unit kernel runs a variant that has them as literals, here switched off."""
+    """The workgroup-per-ring kernel for every ring is kept as the fallback of the wave-per-unit kernel; with the
+    reference's default thresholds the unit kernel runs a variant that has them as literals, here switched off; batches of
+    more than 8 192 rings compact with ring_totals_kernel ahead of feature_compact_kernel (small ones without it), here
+    forced for a small batch.  Same results."""
     import os
     clouds = [make_scan(16, 1200, seed=70), make_scan(16, 1200, seed=71, drop_fraction=0.1), make_scan(8, 700, seed=72, shuffle=True)]
     os.environ[env] = "1"
