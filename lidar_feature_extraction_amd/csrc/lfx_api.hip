@@ -266,7 +266,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
     c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
     batch * c->max_chunks, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
-    fused ? 0u : 1u, c->xform.p);
+    fused ? 0u : 1u, c->xform.p, c->ring_nedge.p, c->ring_nsurf.p);
   if (chunks == 0) {return LFX_OK;}
   c->last_used_xform = fused && choice.xform;
   if (fused) {
@@ -367,7 +367,9 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     // compaction: every scan of the batch, whoever labelled it.  Small batches: the compaction kernel finds every ring's
     // place itself (a launch costs more than the sums it saves; at 65 536 rings the same was measured at +75 us)
     const uint32_t n_units = c->fast_path ? (uint32_t)c->dev.B : 1u;
-    const bool self_totals = (uint64_t)batch * c->max_rings <= 8192u && c->totals_env != 1;
+    // On the organised route the rings' totals are there already (its units added them up): no totals launch whatever the
+    // batch; a scan that route gave up is summed from its unit tables inside the compaction kernel.
+    const bool self_totals = (fused || (uint64_t)batch * c->max_rings <= 8192u) && c->totals_env != 1;
     if (!self_totals) {
       Timed t(c, 5, st);
       hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
@@ -379,7 +381,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
         n_units, c->cap, c->scan_begin.p, c->ring_count.p, self_totals ? nullptr : c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
         c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters);
+        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->ring_nedge.p, c->ring_nsurf.p);
     }
   }
   if (c->h_counters) {
@@ -824,7 +826,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (e == hipSuccess) {
     const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
-      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p};
+      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p, c->ring_nedge.p, c->ring_nsurf.p};
     e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}

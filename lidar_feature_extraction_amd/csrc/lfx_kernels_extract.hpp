@@ -16,11 +16,12 @@ __global__ __launch_bounds__(256) void batch_reset_kernel(
   uint32_t * __restrict__ chunk_flags, uint32_t n_flags, uint32_t * __restrict__ ring_flags, uint32_t n_rflags,
   uint32_t * __restrict__ counters /* [kCounters] */, uint32_t * __restrict__ fb_list, uint32_t batch,
   uint32_t all_fall_back /* 1: every scan takes the bucketing route (the organised-scan kernel is not launched) */,
-  uint32_t * __restrict__ xform /* [batch][256] ring transforms: identity unless ring_cut_kernel runs */)
+  uint32_t * __restrict__ xform /* [batch][256] ring transforms: identity unless ring_cut_kernel runs */,
+  uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf /* [batch][256]: the organised-scan kernel adds to them */)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t k = i; k < n_info; k += stride) {scan_info[k] = 0;}
-  for (uint32_t k = i; k < n_count; k += stride) {ring_count[k] = 0;}
+  for (uint32_t k = i; k < n_count; k += stride) {ring_count[k] = 0; ring_nedge[k] = 0; ring_nsurf[k] = 0;}
   for (uint32_t k = i; k < n_flags; k += stride) {chunk_flags[k] = 0;}
   for (uint32_t k = i; k < n_rflags; k += stride) {ring_flags[k] = 0; xform[k] = 0;}
   if (all_fall_back) {
@@ -1288,6 +1289,7 @@ struct UnitTables
   uint32_t * unit_ne, * unit_ns, * unit_span;
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
+  uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
 };
 
 // A scan the organised-scan kernel cannot take (ring pattern, point count, angle order, a skip condition, a unit that
@@ -1943,6 +1945,12 @@ __device__ __forceinline__ void unit_body(
     tab->unit_ne[ui] = pe;
     tab->unit_ns[ui] = ps;
     tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
+    if (ORG) {
+      // the ring's totals, for the compaction (no kernel of their own on this route): two adds nobody waits for.  If the
+      // scan falls back after all, the compaction takes the bucketing route's unit tables instead (feature_compact_kernel).
+      (void)__hip_atomic_fetch_add(tab->ring_nedge + s * kRings + slot, pe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      (void)__hip_atomic_fetch_add(tab->ring_nsurf + s * kRings + slot, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (j == 0) {
       tab->ring_status[s * kRings + slot] = kOk;
       if (ORG) {
@@ -2538,8 +2546,9 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ unit_span,
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
-  uint32_t max_rings, uint32_t * __restrict__ totals_out /* scan_info, where ring_ebase == nullptr */,
-  const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory, or nullptr */)
+  uint32_t max_rings, uint32_t * __restrict__ totals_out /* scan_info: read for the route, written where ring_ebase == nullptr */,
+  const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory, or nullptr */,
+  const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf)
 {
   const uint32_t lane = threadIdx.x & 63, s = blockIdx.y;
   // the batch's last kernel also hands what the batch reports about its stream to the host (the next batches' route is
@@ -2556,11 +2565,17 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       eb = b + ring_ebase[s * kRings + slot];
       fb = b + ring_sbase[s * kRings + slot];
     } else {
-      // small batches (no ring_totals_kernel launch: a launch costs more than the sums): the ring's place from the unit
-      // tables themselves -- lane r, r + 64, ... sums the units of ring r < slot; the last ring's wave also writes the totals
+      // No ring_totals_kernel ahead of this one.  A scan the organised-scan kernel took: its units added their counts to
+      // their rings' totals (unit_body), lane r, r + 64, ... takes ring r < slot.  Any other scan (a scan that kernel gave up,
+      // redone by the bucketing route; a small batch on the bucketing route): the same sums from the unit tables
+      // themselves.  The last ring's wave also writes the scan's totals.
+      const bool by_ring = scan_is_organised(totals_out[s * 4 + kInfoError]);
       uint32_t e = 0, f = 0;
       for (uint32_t r = lane; r < slot; r += 64) {
-        if (ring_count[s * kRings + r] != 0u) {
+        if (by_ring) {
+          e += ring_nedge[s * kRings + r];
+          f += ring_nsurf[s * kRings + r];
+        } else if (ring_count[s * kRings + r] != 0u) {
           const size_t ur = ((size_t)s * kRings + r) * kUnitMaxBlocks;
           for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ur + j]; f += unit_ns[ur + j];}
         }
@@ -2571,7 +2586,11 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       fb = b + f;
       if (slot == max_rings - 1u) {
         uint32_t oe = 0, of = 0;
-        if (ring_count[s * kRings + slot] != 0u && lane < n_units) {oe = unit_ne[ui + lane]; of = unit_ns[ui + lane];}
+        if (by_ring) {
+          if (lane == 0) {oe = ring_nedge[s * kRings + slot]; of = ring_nsurf[s * kRings + slot];}
+        } else if (ring_count[s * kRings + slot] != 0u && lane < n_units) {
+          oe = unit_ne[ui + lane]; of = unit_ns[ui + lane];
+        }
         oe = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(oe), 63);
         of = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(of), 63);
         if (lane == 0) {
