@@ -252,9 +252,9 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0 &&
     (reinterpret_cast<uintptr_t>(pts) & 15u) == 0;
   // ---- which route: the organised-scan kernel first (scans it cannot take fall back inside this call), or
-  //      bucketing for every scan: choose_route() over what earlier batches reported.  The report arrives in pinned
-  //      memory unasked; it is read only once the copy that brought it is known to be complete (with two scans in flight the
-  //      previous batch's copy may still be writing), otherwise the report before it stands.
+  //      bucketing for every scan: choose_route() over what earlier batches reported.  A batch's last kernel writes its
+  //      report into pinned memory unasked; it is read only once the event behind that kernel has passed (with two scans in
+  //      flight the previous batch may still be running), otherwise the report before it stands.
   if (c->report_pending && hipEventQuery(c->report_landed) == hipSuccess) {
     std::memcpy(c->route.report, c->h_counters, sizeof(c->route.report));
     c->route.report_rings = c->report_rings_pending;

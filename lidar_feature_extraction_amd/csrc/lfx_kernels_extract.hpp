@@ -2546,7 +2546,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ unit_span,
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
-  uint32_t max_rings, uint32_t * __restrict__ totals_out /* scan_info: read for the route, written where ring_ebase == nullptr */,
+  uint32_t max_rings, uint32_t * __restrict__ scan_info /* read for the scan's route; its totals written here where ring_ebase == nullptr */,
   const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory, or nullptr */,
   const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf)
 {
@@ -2569,7 +2569,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       // their rings' totals (unit_body), lane r, r + 64, ... takes ring r < slot.  Any other scan (a scan that kernel gave up,
       // redone by the bucketing route; a small batch on the bucketing route): the same sums from the unit tables
       // themselves.  The last ring's wave also writes the scan's totals.
-      const bool by_ring = scan_is_organised(totals_out[s * 4 + kInfoError]);
+      const bool by_ring = scan_is_organised(scan_info[s * 4 + kInfoError]);
       uint32_t e = 0, f = 0;
       for (uint32_t r = lane; r < slot; r += 64) {
         if (by_ring) {
@@ -2594,8 +2594,8 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         oe = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(oe), 63);
         of = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(of), 63);
         if (lane == 0) {
-          totals_out[s * 4 + kInfoEdge] = e + oe;
-          totals_out[s * 4 + kInfoSurface] = f + of;
+          scan_info[s * 4 + kInfoEdge] = e + oe;
+          scan_info[s * 4 + kInfoSurface] = f + of;
         }
       }
     }
