@@ -1072,7 +1072,7 @@ constexpr int unit_waves_per_simd(int ch) {return ch >= 6 ? 6 : (ch == 5 ? LFX_U
 template<int NW>
 __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)[NW])
 {
-  static_assert(NW <= 11, "extend the wait's operand list");
+  static_assert(NW <= 16, "extend the wait's operand list");
 #ifdef LFX_WHATIF_NOLDS
   {
     double seed = (double)(int)(threadIdx.x + 1u);
@@ -1096,6 +1096,14 @@ __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)
   } else if constexpr (NW == 11) {
     asm volatile ("s_waitcnt lgkmcnt(0)"
       : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]));
+  } else if constexpr (NW == 15) {
+    asm volatile ("s_waitcnt lgkmcnt(0)"
+      : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
+        "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]));
+  } else if constexpr (NW == 16) {
+    asm volatile ("s_waitcnt lgkmcnt(0)"
+      : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
+        "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
   } else {
     static_assert(NW == 1 || NW == 3 || NW == 7 || NW == 9, "add the wait for this window width");
     if constexpr (NW == 1) {asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]));}
@@ -1230,12 +1238,12 @@ __device__ __forceinline__ double sqrt_sum_of_squares(double a)
 // Branch-free form of polar_less for the common case, as masks: `spec` = one of the predicate's
 // special cases may apply (equal points, a zero point, a point on the x axis) and the full predicate
 // has to be evaluated instead.
-__device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float by, uint64_t & spec)
+__device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float by, uint64_t & spec, const float tiny = 1e-18f)
 {
   // a SUPERSET of the special cases is enough (the caller re-evaluates flagged pairs with the full
   // predicate): |y| < 1e-18 covers y == 0 and every point whose squared length rounds (or flushes) to
   // zero in f32, which needs |x|, |y| < 1.1e-19
-  spec = (bal(ax == bx) & bal(ay == by)) | bal(fabsf(ay) < 1e-18f) | bal(fabsf(by) < 1e-18f);
+  spec = (bal(ax == bx) & bal(ay == by)) | bal(fabsf(ay) < tiny) | bal(fabsf(by) < tiny);
   const float det = ax * by - ay * bx;
   const uint64_t same = bal(ay * by > 0.f);
   return (same & bal(det > 0.f)) | (~same & bal(ay < 0.f));
@@ -1381,6 +1389,11 @@ __device__ __forceinline__ uint32_t unit_core(
   (void)o0; (void)o1;
   const UnitWin W0{(uint32_t)(lane + 48) >> 5, (uint32_t)(lane + 16) & 31u};   // window around q
   const UnitWin W1{(uint32_t)(lane + 49) >> 5, (uint32_t)(lane + 17) & 31u};   // window around q + 1
+  // The masks that override the block labelling (feature_extraction.cpp:133-138), three bits per chunk in one register:
+  // they are known long before the labels (stages C and D, where the ranges and the jumps are at hand), and as wave-
+  // uniform masks they would hold 3 x CH scalar pairs through the pick rounds
+  constexpr uint32_t kOvrOccluded = 1u, kOvrRange = 2u, kOvrBeam = 4u;
+  uint32_t ovr = 0;
   LFX_STAMP(2);
   // ---- B. range (math.hpp:36-39)
 #pragma unroll
@@ -1406,30 +1419,48 @@ __device__ __forceinline__ uint32_t unit_core(
     uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
     WordVec vlk, vjl, vjr;
     const float cbf = prm.cos_bound_f;
+    // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
+    // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
+    // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
+    // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
+    const bool ratio_ok = pb_ratio_f >= 0x1p-9f;
+    // The constants of this walk, held in vector registers: a comparison into a scalar pair takes no literal, and a
+    // 64-bit one never, so every use of a literal was one or two scalar moves -- sixteen per chunk; the scalar unit is as
+    // busy as the vector unit here and its registers are all taken, the vector file has a few to spare in this stage.
+    double c_dd = dist_diff, c_min = min_range, c_max = max_range;
+    float c_one_lo = 1.0f - 0x1p-19f, c_one_hi = 1.0f + 0x1p-19f, c_tiny = 1e-18f, c_big = 1e30f, c_zero = 0.f;
+    asm volatile ("" : "+v"(c_dd), "+v"(c_min), "+v"(c_max), "+v"(c_one_lo), "+v"(c_one_hi), "+v"(c_tiny), "+v"(c_big), "+v"(c_zero));
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       if (k < K) {
         const int q = 64 * k + lane;
         const uint64_t pair = in_span(q, qlo, qhi - 1);
-        double rw2[2];
-        lds_window_f64(&U.r[q], rw2);
-        const double rk = rw2[0], rn = rw2[1];
+        // the neighbour's x, y and the three ranges r[q - 1], r[q], r[q + 1] behind ONE wait (position 0 has no left
+        // neighbour: its window starts at itself)
+        const float2 nb = U.pxy[q + 1];
+        double rw3[3];
+        lds_window_f64(&U.r[k == 0 ? (q > 0 ? q - 1 : 0) : q - 1], rw3);
+        double rk = rw3[1], rn = rw3[2];
+        const double rm = rw3[0];                  // (r[0] for position 0, as the clamped read gave)
+        if (k == 0) {
+          rk = q == 0 ? rw3[0] : rk;
+          rn = q == 0 ? rw3[1] : rn;
+        }
         zero_pair |= pair & in_span(q, qo0, qo1) & bal(rk == 0.) & bal(rn == 0.);       // math.cpp:40-42 throws
         // cos_bound <= cos <= 1 (neighbor.hpp:44-48 via the cosine bound): classified in f32 first.
         // |dot| <= r0*r1, so the f32 cosine is within ~4 ulp(1) = 5e-7 of the exact one; a value more
         // than 2^-19 (1.9e-6) away from both ends decides the test, anything closer (or not finite)
         // takes the exact f64 division.
-        const float2 nb = U.pxy[q + 1];
         {
           uint64_t spec;
-          const uint64_t less = polar_less_masks(x[k], y[k], nb.x, nb.y, spec);
+          const uint64_t less = polar_less_masks(x[k], y[k], nb.x, nb.y, spec, c_tiny);
           bad |= in_span(q, qo0, pair_end) & (spec | ~less);
         }
         const float dotf = x[k] * nb.x + y[k] * nb.y;
         const float denf = (float)rk * (float)rn;
         const float cosf = dotf * __builtin_amdgcn_rcpf(denf);
-        const uint64_t yes = bal(cosf > cbf + 0x1p-19f) & bal(cosf < 1.0f - 0x1p-19f);
-        const uint64_t no = bal(cosf < cbf - 0x1p-19f) | bal(cosf > 1.0f + 0x1p-19f);
+        const uint64_t yes = bal(cosf > cbf + 0x1p-19f) & bal(cosf < c_one_lo);
+        const uint64_t no = bal(cosf < cbf - 0x1p-19f) | bal(cosf > c_one_hi);
         const uint64_t fin = bal(fabsf(cosf) < 4.0f);
         uint64_t lk = yes & ~no & fin & pair;
         const uint64_t undecided = (~(yes | no) | ~fin) & pair;
@@ -1439,18 +1470,42 @@ __device__ __forceinline__ uint32_t unit_core(
           lk |= undecided & bal(cosang >= prm.cos_bound) & bal(cosang <= 1.0);    // acos(cos) < threshold; NaN -> false
         }
         vlk.set(k, lk);
-        const int qm = q > 0 ? q - 1 : 0;
-        const double rq = rk + dist_diff;
+        const double rq = rk + c_dd;
         // far side to the right of a linked pair (q, q+1), i in [0, N-P-1)
         const uint64_t jl = lk & in_span(q, 0, N - P - 1 - g0) & bal(rn > rq);
         // far side to the left of a linked pair (q-1, q), i in [P+1, N-1]
         const uint64_t lk_prev = (lk << 1) | prev_top;
-        const uint64_t jr = lk_prev & in_span(q, P + 1 - g0, qhi) & bal(U.r[qm] > rq);
+        const uint64_t jr = lk_prev & in_span(q, P + 1 - g0, qhi) & bal(rm > rq);
         prev_top = lk >> 63;
         if (LFX_STAGE_ON(256u)) {
           vjl.set(k, jl);
           vjr.set(k, jr);
         }
+        // the range test (range.hpp:40-43) and the parallel-beam test of position q, from the same three ranges; the
+        // latter settled by the exact division at once where the f32 test leaves it open
+        uint64_t pb = 0;
+        if (LFX_STAGE_ON(512u)) {
+          const float rf = (float)rk, rmf = (float)rm, rpf = (float)rn;
+          const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
+          const float thr = pb_ratio_f * rf;
+          const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
+          const uint64_t guard = ratio_ok ? (bal(rf > c_zero) & bal(rf < c_big)) : 0ull;
+          // decided yes: both sides clearly above the threshold; decided no: one side clearly below it; anything else (and
+          // everything outside the guard) takes the exact division
+          const uint64_t yy = bal(a1 > hi_t) & bal(a2 > hi_t) & guard;
+          const uint64_t nn = (bal(a1 < lo_t) | bal(a2 < lo_t)) & guard;
+          // i in [1, N-1) and owned
+          const uint64_t valid = in_span(q, 1 - g0, N - 1 - g0) & in_span(q, qo0, qo1);
+          pb = yy & valid;
+          const uint64_t undecided = valid & ~(yy | nn);
+          if (undecided != 0ull) {
+            const float ratio1 = (float)(fabs(rm - rk) / rk);
+            const float ratio2 = (float)(fabs(rn - rk) / rk);
+            pb |= undecided & bal((double)ratio1 > pb_ratio) & bal((double)ratio2 > pb_ratio);
+          }
+        }
+        const uint64_t oor = ~(bal(c_min <= rk) & bal(rk <= c_max));                  // (a NaN range is out of range)
+        ovr |= (lanes(oor) ? (uint32_t)kOvrRange << (3 * k) : 0u) | (lanes(pb) ? (uint32_t)kOvrBeam << (3 * k) : 0u);
       }
     }
     if (bad != 0ull) {
@@ -1476,12 +1531,10 @@ __device__ __forceinline__ uint32_t unit_core(
   }
   LFX_STAMP(4);
   // ---- D. occlusion fills (occlusion.hpp:37-91) and the reach of a pick inside the block (fill.hpp:101-117)
-  uint64_t occ[CH];             // occluded positions (the first of the masks that override the block labelling, feature_extraction.cpp:135-138)
   uint32_t reach[CH];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
     reach[k] = 0;
-    occ[k] = 0;
     if (k < K) {
       const int q = 64 * k + lane;
       const uint32_t lw = get_win(U, kBitLK, k, W0);
@@ -1492,7 +1545,7 @@ __device__ __forceinline__ uint32_t unit_core(
       const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
       const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
       if (LFX_STAGE_ON(256u)) {
-        occ[k] = bal(((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u);
+        ovr |= ((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u ? kOvrOccluded << (3 * k) : 0u;
       }
       // inside the block the links are cut at its ends (label.hpp:157-159): clamp the runs
       const int Lb = Lr < q - qb0 ? Lr : q - qb0;
@@ -1503,8 +1556,35 @@ __device__ __forceinline__ uint32_t unit_core(
   LFX_WAVE_SYNC();        // the x / y slab is dead from here on: the curvature slab takes its place
   LFX_STAMP(5);
   // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
+  // ROWS: for the two window stages (E and the order masks of F) a lane takes CH CONSECUTIVE positions, CH * lane + d,
+  // instead of one position per chunk: the windows of its positions overlap, so it reads 2 PT + CH values where the chunk
+  // form reads CH x (2 PT + 1) -- 15 against 55 LDS reads per stage, and the LDS pipe is the kernel's busiest resource.
+  // (Lane stride CH doubles: conflict-free for odd CH.)  Only the first and the last lane would read outside the slab;
+  // their window is moved inside, and what they then compute is thrown away: with PT <= CH <= PT + 1 all their positions
+  // lie outside any block (a block keeps PT + 1 positions away from either end of the span).
+  constexpr bool kRows = PT > 0 && (CH == PT || CH == PT + 1);
+  constexpr int kRowWin = kRows ? 2 * PT + CH : 1;
+  const int p0 = CH * lane;
+  int row_base = p0 - PT;
+  row_base = row_base < 0 ? 0 : row_base;
+  row_base = row_base > 64 * CH - kRowWin ? 64 * CH - kRowWin : row_base;
+  if constexpr (kRows) {
+    double w[kRowWin];
+    lds_window_f64(&U.r[row_base], w);
 #pragma unroll
-  for (int k = 0; k < CH; k++) {
+    for (int d = 0; d < CH; d++) {
+      double sum = 0.;                                                     // math.hpp:46-52: left to right from 0
+#pragma unroll
+      for (int t = 0; t <= 2 * PT; t++) {
+        const double v = w[d + t];
+        sum += (t == PT) ? v * (-2. * PT) : v;                             // r * 1.0 == r exactly
+      }
+      const int width = qb1 - qb0;
+      U.c[p0 + d] = (uint32_t)(p0 + d - qb0) < (uint32_t)(width > 0 ? width : 0) ? sum * sum : 0.;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (kRows ? 0 : CH); k++) {
     if (k < K) {
       const int q = 64 * k + lane;
       int qq = q < P ? P : q;                                            // keep the window inside the slab
@@ -1530,15 +1610,45 @@ __device__ __forceinline__ uint32_t unit_core(
   LFX_WAVE_SYNC();
   LFX_STAMP(6);
   // ---- F. block labelling (label.hpp:61-139): edge pass, then surface pass over what is still Default
+  // lt: the order masks, and on top of them the position's candidacy where the curvature is in a register: bit 31
+  // c >= edge threshold (label.hpp:80-82), bit 30 c <= surface threshold (label.hpp:119-121)
+  // (a run-time P may need every bit for the order: the candidates then are wave masks of their own)
   uint32_t lt[CH];
-  uint64_t ecand[CH];           // the edge pass's candidates (label.hpp:80-82), taken here where the curvature is in a register
-  {
+  uint64_t ecand[CH], scand[CH];
+  constexpr uint32_t kEdgeCand = 1u << ((PT > 0 ? PT : 1) + 18), kSurfCand = 1u << ((PT > 0 ? PT : 1) + 17);     // (just above the order bits)
+  if constexpr (kRows) {
+    // (the range slab is dead since stage E: its first half passes the masks from the lanes that made them to the lanes
+    // of the chunk form, which everything after this works in)
+    u32_alias_t * const pass_on = reinterpret_cast<u32_alias_t *>(U.r);
+    const uint32_t keep = row_base == p0 - PT ? ~0u : 0u;       // (a moved window: positions outside any block, no candidates)
+    double w[kRowWin];
+    lds_window_f64(&U.c[row_base], w);
+    // (forcing the bits in as the carry of an add, one vector instruction per compare and fewer instructions by a third,
+    // ran 8 % SLOWER in the whole kernel than the selects the compiler builds the word from: measured, round 4)
+#pragma unroll
+    for (int d = 0; d < CH; d++) {
+      const double ci = w[d + PT];
+      uint32_t m = 0;
+#pragma unroll
+      for (int t = PT; t >= 1; t--) {m = m + m + (uint32_t)(w[d + PT + t] < ci);}
+      m = m + m;
+#pragma unroll
+      for (int t = 1; t <= PT; t++) {m = m + m + (uint32_t)(w[d + PT - t] <= ci);}
+      m <<= 16 - PT;
+      m |= ci >= edge_thr ? kEdgeCand : 0u;
+      m |= ci <= surf_thr ? kSurfCand : 0u;
+      pass_on[p0 + d] = m & keep;
+    }
+    LFX_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < CH; k++) {lt[k] = k < K ? pass_on[64 * k + lane] : 0u;}
+  } else {
     // order masks, see order_masks(); the slab has no pad here: neighbours are read at clamped
     // positions, and what a clamped read yields is masked by `reach` (zero outside the block)
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       lt[k] = 0;
-      ecand[k] = 0;
+      ecand[k] = 0; scand[k] = 0;
       if (k < K) {
         const int q = 64 * k + lane;
         int qc = q < P ? P : q;
@@ -1558,15 +1668,17 @@ __device__ __forceinline__ uint32_t unit_core(
           for (int d = 1; d <= (PT > 0 ? PT : 1); d++) {m = m + m + (uint32_t)(w[PT - d] <= ci);}
           m <<= 16 - (PT > 0 ? PT : 1);
           // (the slab is 0 outside the block, also where the window's centre was clamped, and the threshold is > 0)
-          ecand[k] = bal(ci >= edge_thr);
+          m |= ci >= edge_thr ? kEdgeCand : 0u;
+          m |= ci <= surf_thr ? kSurfCand : 0u;
         } else {
           const double ci = U.c[qc];
-          ecand[k] = bal(ci >= edge_thr);
           for (int d = 1; d <= P; d++) {
             const double cl = U.c[qc - d], cr = U.c[qc + d];
             m |= (cl <= ci) ? (1u << (16 - d)) : 0u;
             m |= (cr < ci) ? (1u << (16 + d)) : 0u;
           }
+          ecand[k] = bal(ci >= edge_thr);
+          scand[k] = bal(ci <= surf_thr);
         }
         lt[k] = m;
       }
@@ -1590,11 +1702,11 @@ __device__ __forceinline__ uint32_t unit_core(
         const int q = 64 * k + lane;
         uint64_t cd;
         if (edge) {
-          cd = ecand[k];
+          cd = PT > 0 ? bal((lt[k] & kEdgeCand) != 0u) : ecand[k];
         } else {
           // label.hpp:119-121: in the block and still Default, i.e. not reached by an edge pick
-          const double c0 = U.c[q < span ? q : span - 1];
-          cd = in_span(q, qb0, qb1) & bal(c0 <= surf_thr) & ~bal((get_win(U, kBitSelE, k, W0) & reach[k]) != 0u);
+          const uint64_t low = PT > 0 ? bal((lt[k] & kSurfCand) != 0u) : scand[k];
+          cd = in_span(q, qb0, qb1) & low & ~bal((get_win(U, kBitSelE, k, W0) & reach[k]) != 0u);
         }
         A[k] = cd;
         va.set(k, cd);
@@ -1691,56 +1803,24 @@ __device__ __forceinline__ uint32_t unit_core(
   }
 #endif
   LFX_STAMP(9);
-  // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs: one walk over the chunks --
-  //         the parallel-beam test (settled by the exact division at once where the f32 test leaves it open), the range
-  //         test and the label from ONE read of the point's range and its two neighbours'
-  // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
-  // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
-  // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
-  // band of 2^-12 around the threshold is safe for any ratio >= 2^-9 (smaller ratios: exact path).
-  const bool ratio_ok = pb_ratio_f >= 0x1p-9f;
+  // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
   uint32_t pe = 0, ps = 0;
   asm volatile ("" ::: "memory");          // the table entries are not to be fetched (and held) any earlier
   uint8_t * __restrict__ label_s = tab->label_s;
   double * __restrict__ curv_s = tab->curv_s;
   // final label of position q = 64 k + lane (feature_extraction.cpp:133-138: the masks override the block labelling)
   auto final_label = [&](int k, int q) -> uint32_t {
-    uint64_t pb = 0;
-    const int qm = q > 0 ? q - 1 : 0;
-    double rw2[2];
-    lds_window_f64(&U.r[q], rw2);
-    const double ri = rw2[0];
-    if (LFX_STAGE_ON(512u)) {
-      const double rm = U.r[qm];
-      const float rf = (float)ri, rmf = (float)rm, rpf = (float)rw2[1];
-      const float a1 = fabsf(rmf - rf), a2 = fabsf(rpf - rf);
-      const float thr = pb_ratio_f * rf;
-      const float hi_t = thr * (1.0f + 0x1p-12f), lo_t = thr * (1.0f - 0x1p-12f);
-      const uint64_t guard = ratio_ok ? (bal(rf > 0.f) & bal(rf < 1e30f)) : 0ull;
-      // decided yes: both sides clearly above the threshold; decided no: one side clearly below it; anything else (and
-      // everything outside the guard) takes the exact division
-      const uint64_t yy = bal(a1 > hi_t) & bal(a2 > hi_t) & guard;
-      const uint64_t nn = (bal(a1 < lo_t) | bal(a2 < lo_t)) & guard;
-      // i in [1, N-1) and owned
-      const uint64_t valid = in_span(q, 1 - g0, N - 1 - g0) & in_span(q, qo0, qo1);
-      pb = yy & valid;
-      const uint64_t undecided = valid & ~(yy | nn);
-      if (undecided != 0ull) {
-        const float ratio1 = (float)(fabs(rm - ri) / ri);
-        const float ratio2 = (float)(fabs(rw2[1] - ri) / ri);
-        pb |= undecided & bal((double)ratio1 > pb_ratio) & bal((double)ratio2 > pb_ratio);
-      }
-    }
     const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
     uint32_t l = kDefault;
     l = (wE & reach[k]) != 0u ? (uint32_t)kEdgeNeighbor : l;
     l = (wS & reach[k]) != 0u ? (uint32_t)kSurfaceNeighbor : l;
     l = (wS & (1u << 16)) != 0u ? (uint32_t)kSurface : l;
     l = (wE & (1u << 16)) != 0u ? (uint32_t)kEdge : l;
-    uint32_t ov = lanes(occ[k]) ? (uint32_t)kOccluded : (uint32_t)kDefault;
-    ov = !(min_range <= ri && ri <= max_range) ? (uint32_t)kOutOfRange : ov;      // range.hpp:40-43
-    ov = lanes(pb) ? (uint32_t)kParallelBeam : ov;
-    l = ov != kDefault ? ov : l;
+    // occluded, then out of range, then parallel beam: the last one set wins -- a table of eight nibbles by the three bits
+    constexpr uint32_t kOverride = (uint32_t)kOccluded << 4 | (uint32_t)kOutOfRange << 8 | (uint32_t)kOutOfRange << 12 |
+      (uint32_t)kParallelBeam << 16 | (uint32_t)kParallelBeam << 20 | (uint32_t)kParallelBeam << 24 | (uint32_t)kParallelBeam << 28;
+    const uint32_t t = (ovr >> (3 * k)) & 7u;
+    l = t != 0u ? (kOverride >> (4u * t)) & 15u : l;
     return lanes(in_span(q, qo0, qo1)) ? l : (uint32_t)kDefault;
   };
   // The stores: a wave-uniform 64-bit part (table entry + the ring's start + the unit's first position, in scalar
