@@ -90,7 +90,8 @@ def kernels_sha256():
 
 
 WORKLOADS = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800): "vlp16-16x1800 (BASELINE.json configs[1])",
-             (16, 900): "plumbing-16x900 (BASELINE.json configs[0])", (128, 2048): "os1-128x2048 (BASELINE.json configs[3])"}
+             (16, 900): "plumbing-16x900 (BASELINE.json configs[0])", (128, 2048): "os1-128x2048 (BASELINE.json configs[3])",
+             (64, 3600): "64x3600 (a 0.1-degree sensor: units of 612 positions, the 12-chunk form of the unit kernels; not a BASELINE.json configuration)"}
 
 
 def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, repeats=3):
@@ -508,7 +509,8 @@ def main():
         del d_points
         torch.cuda.empty_cache()
         configs = []
-        for args in ((16, 900, 1024, 20, 3), (16, 1800, 1024, 20, 3), (128, 2048, 32, 40, 5), (64, 1800, 1024, 8, 2, 0.05)):
+        for args in ((16, 900, 1024, 20, 3), (16, 1800, 1024, 20, 3), (128, 2048, 32, 40, 5), (64, 1800, 1024, 8, 2, 0.05),
+                     (64, 3600, 256, 8, 2)):
             try:
                 configs.append(side_config(dev, *args))
             except Exception as e:         # noqa: BLE001  (a side measurement must not cost the line its headline)

@@ -281,7 +281,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       const lfx::UnitTables *, const uint32_t *) = nullptr;
 #define LFX_PICK_ORG(DEFV, XFV) \
     (c->unit_chunks == 5 ? &lfx::ring_unit_org_kernel<5, DEFV, XFV> : c->unit_chunks == 4 ? &lfx::ring_unit_org_kernel<4, DEFV, XFV> : \
-     c->unit_chunks == 3 ? &lfx::ring_unit_org_kernel<3, DEFV, XFV> : &lfx::ring_unit_org_kernel<6, DEFV, XFV>)
+     c->unit_chunks == 3 ? &lfx::ring_unit_org_kernel<3, DEFV, XFV> : c->unit_chunks == 6 ? &lfx::ring_unit_org_kernel<6, DEFV, XFV> : \
+     &lfx::ring_unit_org_kernel<lfx::kUnitMaxChunks, DEFV, XFV>)
     if (c->default_thresholds) {
       kern = xf ? LFX_PICK_ORG(true, true) : LFX_PICK_ORG(true, false);
     } else {
@@ -323,7 +324,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       // the looping form only where the list's length is a guess (behind the organised-scan kernel)
 #define LFX_PICK_UNIT(DEFV, LOOPV) \
       (c->unit_chunks == 5 ? &lfx::ring_unit_kernel<false, 5, DEFV, LOOPV> : c->unit_chunks == 4 ? &lfx::ring_unit_kernel<false, 4, DEFV, LOOPV> : \
-       c->unit_chunks == 3 ? &lfx::ring_unit_kernel<false, 3, DEFV, LOOPV> : &lfx::ring_unit_kernel<false, 6, DEFV, LOOPV>)
+       c->unit_chunks == 3 ? &lfx::ring_unit_kernel<false, 3, DEFV, LOOPV> : c->unit_chunks == 6 ? &lfx::ring_unit_kernel<false, 6, DEFV, LOOPV> : \
+       &lfx::ring_unit_kernel<false, lfx::kUnitMaxChunks, DEFV, LOOPV>)
       auto kern = c->default_thresholds ? (fused ? LFX_PICK_UNIT(true, true) : LFX_PICK_UNIT(true, false)) :
         (fused ? LFX_PICK_UNIT(false, true) : LFX_PICK_UNIT(false, false));
 #undef LFX_PICK_UNIT
@@ -344,7 +346,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 3, st);
       const uint32_t units = redo_cap * (uint32_t)c->dev.B;
-      auto kern = &lfx::ring_unit_kernel<true, 6, false>;
+      auto kern = &lfx::ring_unit_kernel<true, lfx::kUnitMaxChunks, false>;
+      if (c->unit_chunks == 6) {kern = &lfx::ring_unit_kernel<true, 6, false>;}
       if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<true, 5, false>;}
       if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<true, 4, false>;}
       if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<true, 3, false>;}
@@ -770,9 +773,11 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     const int P = c->dev.P, B = c->dev.B, N = (int)ring_cap;
     const int span = (N - 2 * P + B - 1) / B + 1 + 3 * P + 2;
     const int ch = (span + 63) / 64;
-    c->unit_chunks = (uint32_t)(ch < 3 ? 3 : (ch > 6 ? 6 : ch));
+    // (3 .. 6 chunks, or the long form for anything above -- blocks of up to 768 positions; longer ones are the
+    // workgroup-per-ring kernel's)
+    c->unit_chunks = (uint32_t)(ch < 3 ? 3 : (ch > 6 ? lfx::kUnitMaxChunks : ch));
     if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_CHUNKS")) {c->unit_chunks = (uint32_t)std::atoi(dbg);}
-    if (c->unit_chunks < 3 || c->unit_chunks > 6) {c->unit_chunks = 6;}
+    if (c->unit_chunks < 3 || c->unit_chunks > 6) {c->unit_chunks = (uint32_t)lfx::kUnitMaxChunks;}
   }
   if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
   c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;

@@ -1045,14 +1045,18 @@ struct UnitLds
   uint32_t pad_[kPadDwords ? kPadDwords : 32];
 };
 static_assert(sizeof(UnitLds<5>) % 128 == 32 && sizeof(UnitLds<3>) % 128 == 32 && sizeof(UnitLds<4>) % 128 == 32 &&
-  sizeof(UnitLds<6>) % 128 == 32, "slab stride");
+  sizeof(UnitLds<6>) % 128 == 32 && sizeof(UnitLds<12>) % 128 == 32, "slab stride");
 #ifndef LFX_UNIT_WAVES_CH5
 #define LFX_UNIT_WAVES_CH5 7
 #endif
 #ifndef LFX_LIBRARY_SQRT
 #define LFX_LIBRARY_SQRT 0
 #endif
-constexpr int unit_waves_per_simd(int ch) {return ch >= 6 ? 6 : (ch == 5 ? LFX_UNIT_WAVES_CH5 : 8);}
+#ifndef LFX_COS_BAND
+#define LFX_COS_BAND 0x1p-19f
+#endif
+constexpr int kUnitMaxChunks = 12;        // the long form: blocks of up to 768 positions (rings of up to ~4 500 points in 6 blocks)
+constexpr int unit_waves_per_simd(int ch) {return ch > 6 ? 3 : (ch == 6 ? 6 : (ch == 5 ? LFX_UNIT_WAVES_CH5 : 8));}
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
 // lane's LDS read above another lane's LDS write of the same wave.
@@ -1174,10 +1178,11 @@ struct WordVec
     break;
     switch (k) {
       LFX_WRITELANE(1) LFX_WRITELANE(2) LFX_WRITELANE(3) LFX_WRITELANE(4) LFX_WRITELANE(5) LFX_WRITELANE(6)
+      LFX_WRITELANE(7) LFX_WRITELANE(8) LFX_WRITELANE(9) LFX_WRITELANE(10) LFX_WRITELANE(11) LFX_WRITELANE(12)
       default: break;
     }
 #undef LFX_WRITELANE
-    static_assert(kWaveChunks <= 6, "one case per chunk");
+    static_assert(kUnitMaxChunks <= 12, "one case per chunk");
   }
 };
 
@@ -1393,7 +1398,9 @@ __device__ __forceinline__ uint32_t unit_core(
   // they are known long before the labels (stages C and D, where the ranges and the jumps are at hand), and as wave-
   // uniform masks they would hold 3 x CH scalar pairs through the pick rounds
   constexpr uint32_t kOvrOccluded = 1u, kOvrRange = 2u, kOvrBeam = 4u;
-  uint32_t ovr = 0;
+  uint32_t ovr[(CH + 9) / 10];                  // (ten chunks to a register)
+#pragma unroll
+  for (int t = 0; t < (CH + 9) / 10; t++) {ovr[t] = 0;}
   LFX_STAMP(2);
   // ---- B. range (math.hpp:36-39)
 #pragma unroll
@@ -1428,7 +1435,7 @@ __device__ __forceinline__ uint32_t unit_core(
     // 64-bit one never, so every use of a literal was one or two scalar moves -- sixteen per chunk; the scalar unit is as
     // busy as the vector unit here and its registers are all taken, the vector file has a few to spare in this stage.
     double c_dd = dist_diff, c_min = min_range, c_max = max_range;
-    float c_one_lo = 1.0f - 0x1p-19f, c_one_hi = 1.0f + 0x1p-19f, c_tiny = 1e-18f, c_big = 1e30f, c_zero = 0.f;
+    float c_one_lo = 1.0f - LFX_COS_BAND, c_one_hi = 1.0f + LFX_COS_BAND, c_tiny = 1e-18f, c_big = 1e30f, c_zero = 0.f;
     asm volatile ("" : "+v"(c_dd), "+v"(c_min), "+v"(c_max), "+v"(c_one_lo), "+v"(c_one_hi), "+v"(c_tiny), "+v"(c_big), "+v"(c_zero));
 #pragma unroll
     for (int k = 0; k < CH; k++) {
@@ -1459,8 +1466,8 @@ __device__ __forceinline__ uint32_t unit_core(
         const float dotf = x[k] * nb.x + y[k] * nb.y;
         const float denf = (float)rk * (float)rn;
         const float cosf = dotf * __builtin_amdgcn_rcpf(denf);
-        const uint64_t yes = bal(cosf > cbf + 0x1p-19f) & bal(cosf < c_one_lo);
-        const uint64_t no = bal(cosf < cbf - 0x1p-19f) | bal(cosf > c_one_hi);
+        const uint64_t yes = bal(cosf > cbf + LFX_COS_BAND) & bal(cosf < c_one_lo);
+        const uint64_t no = bal(cosf < cbf - LFX_COS_BAND) | bal(cosf > c_one_hi);
         const uint64_t fin = bal(fabsf(cosf) < 4.0f);
         uint64_t lk = yes & ~no & fin & pair;
         const uint64_t undecided = (~(yes | no) | ~fin) & pair;
@@ -1505,7 +1512,7 @@ __device__ __forceinline__ uint32_t unit_core(
           }
         }
         const uint64_t oor = ~(bal(c_min <= rk) & bal(rk <= c_max));                  // (a NaN range is out of range)
-        ovr |= (lanes(oor) ? (uint32_t)kOvrRange << (3 * k) : 0u) | (lanes(pb) ? (uint32_t)kOvrBeam << (3 * k) : 0u);
+        ovr[k / 10] |= (lanes(oor) ? (uint32_t)kOvrRange << (3 * (k % 10)) : 0u) | (lanes(pb) ? (uint32_t)kOvrBeam << (3 * (k % 10)) : 0u);
       }
     }
     if (bad != 0ull) {
@@ -1545,7 +1552,7 @@ __device__ __forceinline__ uint32_t unit_core(
       const uint32_t left = ((1u << (Lr + 1)) - 1u) << (15 - Lr);      // jumps at q-1 .. q-1-Lr reach q
       const uint32_t right = ((1u << (Rr + 1)) - 1u) << 16;            // jumps at q+1 .. q+1+Rr reach q
       if (LFX_STAGE_ON(256u)) {
-        ovr |= ((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u ? kOvrOccluded << (3 * k) : 0u;
+        ovr[k / 10] |= ((get_win(U, kBitJL, k, W0) & left) | (get_win(U, kBitJR, k, W1) & right)) != 0u ? kOvrOccluded << (3 * (k % 10)) : 0u;
       }
       // inside the block the links are cut at its ends (label.hpp:157-159): clamp the runs
       const int Lb = Lr < q - qb0 ? Lr : q - qb0;
@@ -1819,7 +1826,7 @@ __device__ __forceinline__ uint32_t unit_core(
     // occluded, then out of range, then parallel beam: the last one set wins -- a table of eight nibbles by the three bits
     constexpr uint32_t kOverride = (uint32_t)kOccluded << 4 | (uint32_t)kOutOfRange << 8 | (uint32_t)kOutOfRange << 12 |
       (uint32_t)kParallelBeam << 16 | (uint32_t)kParallelBeam << 20 | (uint32_t)kParallelBeam << 24 | (uint32_t)kParallelBeam << 28;
-    const uint32_t t = (ovr >> (3 * k)) & 7u;
+    const uint32_t t = (ovr[k / 10] >> (3 * (k % 10))) & 7u;
     l = t != 0u ? (kOverride >> (4u * t)) & 15u : l;
     return lanes(in_span(q, qo0, qo1)) ? l : (uint32_t)kDefault;
   };
@@ -1929,9 +1936,11 @@ __device__ __forceinline__ void unit_body(
   // ---- A. load; x, y also to the wave's LDS slab (neighbours are read by position)
   {
     uint32_t * z = &U.bits[0][0];
-    z[lane] = 0u;
-    if (lane + 64 < kUnitBitArrays * UnitLds<CH>::kBitWords) {z[lane + 64] = 0u;}
-    static_assert(kUnitBitArrays * UnitLds<CH>::kBitWords <= 128, "two stores per lane zero the bit arrays");
+    constexpr int kBitDwords = kUnitBitArrays * UnitLds<CH>::kBitWords;
+#pragma unroll
+    for (int w0 = 0; w0 < kBitDwords; w0 += 64) {
+      if (w0 + 64 <= kBitDwords || lane + w0 < kBitDwords) {z[lane + w0] = 0u;}
+    }
   }
   // z and the original index are only needed for the feature records at the very end; loaded here,
   // with x and y, their latency hides behind the whole computation instead of ending it (registers

@@ -512,7 +512,31 @@ def test_long_blocks_take_the_lds_labelling_path(fx):
     f.close()
 
 
-@pytest.mark.parametrize("chunks", [3, 4, 5, 6])
+@pytest.mark.parametrize("organised", [True, False])
+def test_long_rings_take_the_long_form_of_the_unit_kernel(organised):
+    """Rings of more than ~2 230 points (6 blocks) have units of more than 384 positions: the 12-chunk form of the unit
+    kernels takes them (blocks of up to 768 positions, rings of up to ~4 500 points) -- a 0.1-degree sensor's 3 600 columns
+    -- on the organised route and on the bucketing route (records shuffled, some dropped), with the reference's default
+    thresholds and with others, rings turned; a 7-block setting and a ring capacity of the maximum.  Rings too long even
+    for that (4 096 points in 4 blocks) are still the workgroup-per-ring kernel's."""
+    rng = np.random.default_rng(5)
+    for rings, cols, hp, kw in [(8, 3600, HyperParameters(), {}), (4, 4090, HyperParameters(), {}),
+                                (8, 3000, HyperParameters(edge_threshold=0.1, surface_threshold=0.02), {}),
+                                (4, 3600, HyperParameters(n_blocks=7), {}), (4, 3600, HyperParameters(), {"start_col": 700}),
+                                (4, 4096, HyperParameters(n_blocks=4), {})]:
+        clouds = [make_scan(rings, cols, seed=int(rng.integers(1 << 30)), drop_fraction=0.0 if organised else 0.03,
+                            shuffle=not organised, **kw) for _ in range(3)]
+        f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=3, max_points_per_ring=cols, max_rings=rings)
+        for _ in range(2 if kw else 1):                      # (turned rings: the ring transforms come with the second batch)
+            got = f.extract_batch(clouds)
+        for i, c in enumerate(clouds):
+            assert_scan_equal(got[i], OB.extract(c, oracle_params(hp), canonical_ties=False), "%dx%d/%d" % (rings, cols, i))
+        if organised and hp.n_blocks >= 6:
+            assert list(f.scan_routes(3)) == [2 if kw else 1] * 3, "read in place by the organised-scan kernel"
+        f.close()
+
+
+@pytest.mark.parametrize("chunks", [3, 4, 5, 6, 12])
 def test_every_unit_kernel_variant(chunks):
     """The wave-per-unit kernel is instantiated for spans of 3..6 chunks of 64 positions and the host picks
     one from max_points_per_ring; here each variant is forced in turn.  900-column rings fit all of them;
