@@ -1053,7 +1053,7 @@ static_assert(sizeof(UnitLds<5>) % 128 == 32 && sizeof(UnitLds<3>) % 128 == 32 &
 #define LFX_LIBRARY_SQRT 0
 #endif
 #ifndef LFX_COS_BAND
-#define LFX_COS_BAND 0x1p-19f
+#define LFX_COS_BAND 0x1p-20f
 #endif
 constexpr int kUnitMaxChunks = 12;        // the long form: blocks of up to 768 positions (rings of up to ~4 500 points in 6 blocks)
 constexpr int unit_waves_per_simd(int ch) {return ch > 6 ? 3 : (ch == 6 ? 6 : (ch == 5 ? LFX_UNIT_WAVES_CH5 : 8));}
@@ -1435,8 +1435,8 @@ __device__ __forceinline__ uint32_t unit_core(
     // 64-bit one never, so every use of a literal was one or two scalar moves -- sixteen per chunk; the scalar unit is as
     // busy as the vector unit here and its registers are all taken, the vector file has a few to spare in this stage.
     double c_dd = dist_diff, c_min = min_range, c_max = max_range;
-    float c_one_lo = 1.0f - LFX_COS_BAND, c_one_hi = 1.0f + LFX_COS_BAND, c_tiny = 1e-18f, c_big = 1e30f, c_zero = 0.f;
-    asm volatile ("" : "+v"(c_dd), "+v"(c_min), "+v"(c_max), "+v"(c_one_lo), "+v"(c_one_hi), "+v"(c_tiny), "+v"(c_big), "+v"(c_zero));
+    float c_one_lo = 1.0f - LFX_COS_BAND, c_one_hi = 1.0f + LFX_COS_BAND, c_tiny = 1e-18f, c_big = 1e30f, c_zero = 0.f, c_small = 1e-30f;
+    asm volatile ("" : "+v"(c_dd), "+v"(c_min), "+v"(c_max), "+v"(c_one_lo), "+v"(c_one_hi), "+v"(c_tiny), "+v"(c_big), "+v"(c_zero), "+v"(c_small));
 #pragma unroll
     for (int k = 0; k < CH; k++) {
       if (k < K) {
@@ -1454,10 +1454,14 @@ __device__ __forceinline__ uint32_t unit_core(
           rn = q == 0 ? rw3[1] : rn;
         }
         zero_pair |= pair & in_span(q, qo0, qo1) & bal(rk == 0.) & bal(rn == 0.);       // math.cpp:40-42 throws
-        // cos_bound <= cos <= 1 (neighbor.hpp:44-48 via the cosine bound): classified in f32 first.
-        // |dot| <= r0*r1, so the f32 cosine is within ~4 ulp(1) = 5e-7 of the exact one; a value more
-        // than 2^-19 (1.9e-6) away from both ends decides the test, anything closer (or not finite)
-        // takes the exact f64 division.
+        // cos_bound <= cos <= 1 (neighbor.hpp:44-48 via the cosine bound): classified in f32 first.  With r0 r1 in
+        // [1e-30, 1e30] (no product below the normal range matters, nothing overflows) the f32 cosine is within
+        // 9 x 2^-24 = 5.4e-7 of the exact one: |x0 x1|, |y0 y1| <= r0 r1, so two products and their sum err by 3 x 2^-24
+        // of r0 r1; the two converted ranges and their product by 3 x 2^-24 of it, the reciprocal by one ulp, the last
+        // product by half of one; the bound itself was rounded to f32 (6e-8).  A value more than 2^-20 (9.5e-7) away from
+        // both ends decides the test, anything closer -- or outside that range, or not a number -- takes the exact f64
+        // division.  (2^-19 until round 4: at 3 600 columns neighbours are 1.5e-6 below cos = 1 and every pair took the
+        // division.)
         {
           uint64_t spec;
           const uint64_t less = polar_less_masks(x[k], y[k], nb.x, nb.y, spec, c_tiny);
@@ -1468,7 +1472,7 @@ __device__ __forceinline__ uint32_t unit_core(
         const float cosf = dotf * __builtin_amdgcn_rcpf(denf);
         const uint64_t yes = bal(cosf > cbf + LFX_COS_BAND) & bal(cosf < c_one_lo);
         const uint64_t no = bal(cosf < cbf - LFX_COS_BAND) | bal(cosf > c_one_hi);
-        const uint64_t fin = bal(fabsf(cosf) < 4.0f);
+        const uint64_t fin = bal(denf > c_small) & bal(denf < c_big);
         uint64_t lk = yes & ~no & fin & pair;
         const uint64_t undecided = (~(yes | no) | ~fin) & pair;
         if (undecided != 0ull) {

@@ -16,6 +16,9 @@ def draw(rng):
     """One case: (rings, cols, HyperParameters, order, make_scan kwargs, seed, sigma, exact_cap)."""
     rings = int(rng.choice([4, 8, 16, 32, 64]))
     cols = int(rng.integers(150, 2600))
+    if rng.integers(0, 6) == 0:                # long rings: the 12-chunk form of the unit kernels, or (few blocks) the workgroup-per-ring kernel
+        cols = int(rng.integers(2600, 4097))
+        rings = min(rings, 16)
     P = int(rng.choice([1, 2, 3, 5, 5, 5, 8, 15]))
     B = int(rng.choice([1, 2, 3, 6, 6, 6, 9, 17, 40]))
     hp = HyperParameters(padding=P, n_blocks=B,
