@@ -239,6 +239,22 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     // pageable source: the runtime stages it before returning, so the vector may change afterwards
     LFX_HIP(c, hipMemcpyAsync(c->scan_begin.p, c->h_scan_begin.data(), (batch + 1) * 4, hipMemcpyHostToDevice, st));
     c->uploaded_begin = c->h_scan_begin;
+    if (c->fused_possible) {
+      // what every unit of the organised-scan kernel would otherwise work out for itself, the same for all 1 536 units of
+      // a scan: the columns per ring (an integer division) and its block's two boundaries (two f64 divisions each:
+      // index_range.cpp:60-66) -- 6 % of a wave's life.  Same arithmetic here (IEEE double, no contraction).
+      c->h_scan_geom.assign((size_t)batch * lfx::kGeomStride, 0u);
+      const uint32_t R = c->max_rings;
+      const int P = c->dev.P, B = c->dev.B;
+      for (uint32_t s = 0; s < batch; s++) {
+        const uint32_t n = n_points[s], C = n / R;
+        if (C * R != n || C == 0u || C > c->cap) {continue;}               // not R rings x C columns: entry 0 stays 0
+        uint32_t * g = c->h_scan_geom.data() + (size_t)s * lfx::kGeomStride;
+        g[0] = C;
+        for (int j = 0; j <= B && j <= lfx::kUnitMaxBlocks; j++) {g[1 + j] = (uint32_t)lfx::block_boundary((int)C, P, B, j);}
+      }
+      LFX_HIP(c, hipMemcpyAsync(c->scan_geom.p, c->h_scan_geom.data(), c->h_scan_geom.size() * 4, hipMemcpyHostToDevice, st));
+    }
   }
   c->last_batch = batch;
   c->last_points = d_points;
@@ -278,7 +294,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     }
     const uint32_t groups = (c->max_rings + 3u) / 4u;
     void (*kern)(lfx::Params, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t *,
-      const lfx::UnitTables *, const uint32_t *) = nullptr;
+      const lfx::UnitTables *, const uint32_t *, const uint32_t *) = nullptr;
 #define LFX_PICK_ORG(DEFV, XFV) \
     (c->unit_chunks == 5 ? &lfx::ring_unit_org_kernel<5, DEFV, XFV> : c->unit_chunks == 4 ? &lfx::ring_unit_org_kernel<4, DEFV, XFV> : \
      c->unit_chunks == 3 ? &lfx::ring_unit_org_kernel<3, DEFV, XFV> : c->unit_chunks == 6 ? &lfx::ring_unit_org_kernel<6, DEFV, XFV> : \
@@ -291,8 +307,9 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
 #undef LFX_PICK_ORG
     {
       Timed t(c, 7, st);
-      hipLaunchKernelGGL(kern, dim3(groups * (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-        c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p);
+      hipLaunchKernelGGL(kern, dim3(groups, (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
+        c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p,
+        c->scan_geom.p);
     }
   }
   // ---- the bucketing route, over the scans on the fall-back list
@@ -807,7 +824,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   hipError_t e = hipSetDevice(device_id);
   const size_t nb = c->max_batch, tc = c->total_cap, tables = nb * lfx::kRings, chunk_tab = nb * c->max_chunks * lfx::kRings;
   auto ok = [&](hipError_t r) {if (e == hipSuccess) {e = r;}};
-  ok(c->scan_begin.alloc(nb + 1)); ok(c->scan_info.alloc(nb * 4));
+  ok(c->scan_begin.alloc(nb + 1)); ok(c->scan_info.alloc(nb * 4)); ok(c->scan_geom.alloc(nb * (size_t)lfx::kGeomStride));
   ok(c->chunk_base.alloc(chunk_tab));
   ok(c->ring_count.alloc(tables)); ok(c->chunk_flags.alloc(nb * c->max_chunks));
   ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
@@ -865,7 +882,7 @@ void lfx_destroy(lfx_ctx * c)
   if (c->stream) {(void)hipStreamSynchronize(c->stream);}
   for (auto & sp : c->spans) {(void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);}
   for (auto & ev : c->free_events) {(void)hipEventDestroy(ev);}
-  c->scan_begin.release(); c->scan_info.release(); c->chunk_base.release();
+  c->scan_begin.release(); c->scan_info.release(); c->scan_geom.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
   c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();

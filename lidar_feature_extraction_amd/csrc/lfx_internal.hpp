@@ -131,7 +131,7 @@ struct lfx_ctx
   void * log_user = nullptr;
 
   // device scratch
-  lfx_host::DevBuf<uint32_t> scan_begin, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
+  lfx_host::DevBuf<uint32_t> scan_begin, scan_geom, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
     ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list, xform,
     sidx, rec_idx, edge_idx,
     surf_idx, d_sidx;
@@ -153,6 +153,7 @@ struct lfx_ctx
 
   hipStream_t stream = nullptr;          // used by the synchronous host entry points
   std::vector<uint32_t> h_scan_begin;    // of the last batch
+  std::vector<uint32_t> h_scan_geom;     // [batch][kGeomStride]: columns per ring and block boundaries of every scan (organised-scan kernel)
   std::vector<uint32_t> uploaded_begin;  // what scan_begin on the device currently holds
   uint32_t last_batch = 0;
   const void * last_points = nullptr;

@@ -424,7 +424,7 @@ __device__ inline bool sort_less(float ax, float ay, uint32_t ai, float bx, floa
 }
 
 // Boundary j of the padded block range: index_range.cpp:60-66 with start=P, end=N-P.
-__device__ inline int block_boundary(int N, int P, int B, int j)
+__host__ __device__ inline int block_boundary(int N, int P, int B, int j)
 {
   const double s = (double)P, e = (double)(N - P), n = (double)B;
   return (int)(s * (1. - j / n) + e * j / n);
@@ -1016,6 +1016,9 @@ __device__ inline uint8_t process_ring(
 constexpr int kUnitWaves = 4;
 constexpr int kUnitSpan = 64 * kWaveChunks;
 constexpr int kUnitMaxBlocks = 64;        // per-unit count tables are sized for n_blocks <= 64
+// Per scan, from the host with the scan's first index (the organised-scan kernel): [0] columns per ring, 0 if the scan is
+// not max_rings x columns with the columns within the ring capacity; [1 + j] boundary j of its rings' blocks, j = 0 .. B
+constexpr int kGeomStride = kUnitMaxBlocks + 2;
 enum { kDeferOrder = 1u, kDeferOther = 2u, kDeferMask = 3u, kRingSorted = 4u /* put in order by ring_order_kernel */ };
 
 // Wave-uniform bit arrays in LDS.  A 64-bit ballot word per chunk, stored by the whole wave (every lane
@@ -1332,6 +1335,7 @@ struct OrgScan
   uint32_t * __restrict__ ring_count_out;
   uint32_t R, r0, wave, drop_zero;
   const uint32_t * __restrict__ xform;    // [batch][256] ring transforms (XF instantiations only)
+  const uint32_t * __restrict__ geom;     // [batch][kGeomStride]
 };
 
 #ifndef LFX_ORG_FULL
@@ -1893,14 +1897,21 @@ __device__ __forceinline__ void unit_body(
   UnitLds<CH> & U = slabs[ORG ? og.wave : 0u];
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
   int N;
+  int org_b0 = 0, org_b1 = 0;
   uint32_t scan_first = 0;                 // ORG: index of the scan's first point
   if (ORG) {
-    // the scan must be R rings x C columns, C within the ring capacity (every unit of the scan sees the same)
+    // the scan must be R rings x C columns, C within the ring capacity (every unit of the scan sees the same: the host
+    // has looked, and left the columns per ring and the block boundaries in the scan's row of `geom`)
+    // (all four words are asked for before the first of them is tested: one round trip, not three)
     scan_first = og.scan_begin[s];
-    const uint32_t n = og.scan_begin[s + 1] - scan_first;
-    const uint32_t C = n / og.R;
+    const uint32_t C = og.geom[s * kGeomStride];
+    org_b0 = (int)og.geom[s * kGeomStride + 1 + j];
+    org_b1 = (int)og.geom[s * kGeomStride + 2 + j];
+    // (the empty statement needs the values: left alone the compiler moves each load down to its first use, behind the
+    // tests before it -- a memory round trip per test at the head of every wave)
+    asm volatile ("" :: "s"(scan_first), "s"(C), "s"(org_b0), "s"(org_b1), "s"(ring_cap), "s"(B));
     N = (int)C;
-    if (C * og.R != n || C == 0u || C > ring_cap) {
+    if (C == 0u) {
       if (og.r0 == 0u && j == 0 && og.wave == 0 && lane == 0) {scan_falls_back(tab, s);}
       return;
     }
@@ -1929,9 +1940,16 @@ __device__ __forceinline__ void unit_body(
     if (j == 0) {LFX_DEFER(kDeferOther);}
     return;
   }
-  // both boundaries from one evaluation of the f64 formula: even lanes take j, odd lanes j + 1
-  const int bj = block_boundary(N, P, B, j + (lane & 1));
-  const int b0 = __builtin_amdgcn_readlane(bj, 0), b1 = __builtin_amdgcn_readlane(bj, 1);
+  int b0, b1;
+  if (ORG) {
+    b0 = org_b0;
+    b1 = org_b1;
+  } else {
+    // both boundaries from one evaluation of the f64 formula: even lanes take j, odd lanes j + 1
+    const int bj = block_boundary(N, P, B, j + (lane & 1));
+    b0 = __builtin_amdgcn_readlane(bj, 0);
+    b1 = __builtin_amdgcn_readlane(bj, 1);
+  }
   const UnitGeom G = unit_geometry(N, P, B, j, b0, b1, FULL ? CH : 0);
   if (b1 - b0 < 2 || G.span > (64 * CH)) {LFX_DEFER(kDeferOther);}
   const int o0 = G.o0, o1 = G.o1, g0 = G.g0, qlo = G.qlo, qhi = G.qhi;
@@ -2078,7 +2096,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   UnitLds<CH> * U = &lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
-  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr};
+  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr};
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
@@ -2137,15 +2155,15 @@ template<int CH, bool DEF, bool XF>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) LFX_ORG_ATTR void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform)
+  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform, const uint32_t * __restrict__ geom)
 {
   __shared__ UnitLds<CH> lds[kUnitWaves];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t groups = (max_rings + 3u) >> 2;
-  const uint32_t g = blockIdx.x % groups;
-  const int j = (int)(blockIdx.x / groups);
-  const uint32_t s = blockIdx.y;
-  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform};
+  // grid = (groups of four rings, blocks, scans): dispatched in the order group, block, scan, no division to find them
+  const uint32_t g = blockIdx.x;
+  const int j = (int)blockIdx.y;
+  const uint32_t s = blockIdx.z;
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, geom};
   const uint32_t slot = 4u * g + wave;
   if (DEF || prm.P == 5) {
     unit_body<5, CH, DEF, true, LFX_ORG_FULL, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
