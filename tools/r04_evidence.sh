@@ -17,5 +17,6 @@ run bench_shuffled $B --shuffle --batch 256 --steps 5 --warmup 2
 run bench_streams2 $B --streams 2
 run bench_force_gather $B --force-gather
 run bench_force_gather_rotate $B --force-gather --gather-dst rotate
+run bench_64x3600_long_form $B --cols 3600 --batch 512
 run bench_cfg3_128x2048x32_long $B --rings 128 --cols 2048 --batch 32 --steps 200 --warmup 20
 timeout -k 10 600 python tools/stress.py 12000 404 > $OUT/stress_12000_cases.txt 2>&1; tail -1 $OUT/stress_12000_cases.txt
