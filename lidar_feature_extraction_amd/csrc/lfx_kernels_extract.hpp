@@ -423,6 +423,20 @@ __device__ inline bool sort_less(float ax, float ay, uint32_t ai, float bx, floa
   return ai < bi;
 }
 
+// A 32-bit key that grows with the polar angle as polar_less orders it (y < 0 first, the positive x axis and points of
+// zero length at 0, the negative x axis last): the pseudo-angle y / (|x| + |y|) unfolded over the four quadrants, in
+// (-2, 2], as an unsigned integer of the same order.  Rounded f32 arithmetic: two points whose angles differ by less than a
+// few ulp may come out equal or swapped -- whoever sorts by it verifies the result with the predicate.
+__device__ inline uint32_t polar_key(float x, float y)
+{
+  const float len = x * x + y * y;                       // (what the predicate calls a zero point: its squared length rounds to 0)
+  const float p = y * __builtin_amdgcn_rcpf(fabsf(x) + fabsf(y));
+  float t = x < 0.f ? (y < 0.f ? -2.f - p : 2.f - p) : p;
+  t = len == 0.f ? 0.f : t + 0.f;                        // (-0 -> +0)
+  const uint32_t u = __float_as_uint(t);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 // Boundary j of the padded block range: index_range.cpp:60-66 with start=P, end=N-P.
 __host__ __device__ inline int block_boundary(int N, int P, int B, int j)
 {
@@ -2326,9 +2340,9 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
   uint32_t * ls = reinterpret_cast<uint32_t *>(lz + M);   // sidx as bucketed
   int * cnt = reinterpret_cast<int *>(ls + M);            // [8] counters
   // Two uses.  After the first unit pass (all_rings = 0): the rings on the defer list.  Before it (all_rings = 1,
-  // switched on by the host while a stream keeps arriving rotated or reversed): every ring of the listed scans;
-  // a rotation / reversal is undone here, so that the first pass takes the ring and no second pass is needed;
-  // rings in order are only read, rings that need a real sort are left to the normal route.
+  // switched on by the host while a stream keeps arriving out of order): every ring of the listed scans is put in order
+  // here -- a rotation / reversal undone, anything else sorted -- so that the first pass takes the ring and no second
+  // pass is needed; rings in order are only read.
   const uint32_t n_items = all_rings ? *fb_count * max_rings : *defer_count;
   for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
     const uint32_t e = all_rings ? fb_list[item / max_rings] * kRings + item % max_rings : defer_list[item];
@@ -2393,11 +2407,45 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
         mode = 3; cut = down_at + 1;                    // two decreasing runs: sorted = reverse([0..cut-1]) then reverse([cut..N-1])
       }
       if (tid == 0) {cnt[4] = mode;}
-      if (all_rings && (up_breaks == 0 || mode == 0)) {
-        // in order already, or in need of a real sort: not this pass's business
+      if (all_rings && up_breaks == 0) {
+        // in order already
       } else if (mode == 0) {
         uint32_t Ms = 1;
         while (Ms < (uint32_t)N) {Ms <<= 1;}
+        // First by KEY: (polar_key, position as bucketed = order of arrival) as one 64-bit integer per point, sorted by
+        // the same bitonic network -- two 8-byte LDS reads and an integer compare per exchange instead of six reads and
+        // the predicate twice -- then every adjacent pair of the result is put to the exact predicate (with the arrival
+        // index as tie-break: a strict total order, so a sequence whose adjacent pairs all pass IS the sorted one).  Only
+        // a ring that fails (points a few ulp apart in angle) is sorted again by the predicate itself, below.
+        uint64_t * k64 = reinterpret_cast<uint64_t *>(li);          // over li and lp
+        for (uint32_t i = tid; i < Ms; i += T) {
+          k64[i] = ((uint64_t)(i < (uint32_t)N ? polar_key(lx[i], ly[i]) : 0xFFFFFFFFu) << 32) | i;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= Ms; k <<= 1) {
+          for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < Ms / 2; t += T) {
+              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const uint32_t p = i | j;
+              const uint64_t a = k64[i], b = k64[p];
+              if (((i & k) == 0) == (b < a)) {k64[i] = b; k64[p] = a;}
+            }
+            __syncthreads();
+          }
+        }
+        bool out_of_order = false;
+        for (int i = tid; i + 1 < N; i += T) {
+          const uint32_t a = (uint32_t)k64[i], b = (uint32_t)k64[i + 1];
+          if (!sort_less(lx[a], ly[a], ls[a], lx[b], ly[b], ls[b])) {out_of_order = true;}
+        }
+        if (!__syncthreads_or(out_of_order)) {
+          for (int i = tid; i < N; i += T) {
+            const uint32_t src = (uint32_t)k64[i];
+            sxy[off + i] = make_float2(lx[src], ly[src]);
+            sz[off + i] = lz[src];
+            sidx[off + i] = ls[src];
+          }
+        } else {
         for (uint32_t i = tid; i < Ms; i += T) {
           const bool in = i < (uint32_t)N;
           li[i] = in ? ls[i] : kSentinel;
@@ -2429,6 +2477,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
           sz[off + i] = lz[src];
           sidx[off + i] = li[i];
         }
+        }
       } else {
         for (int i = tid; i < N; i += T) {
           int src;
@@ -2446,7 +2495,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
       }
     }
     if (all_rings) {
-      if (tid == 0 && fixable && cnt[0] != 0 && cnt[4] != 0) {
+      if (tid == 0 && fixable && cnt[0] != 0) {
         ring_flags[e] = kRingSorted;
         atomicAdd(pre_fixed, 1u);
       }
