@@ -427,14 +427,24 @@ __device__ inline bool sort_less(float ax, float ay, uint32_t ai, float bx, floa
 // zero length at 0, the negative x axis last): the pseudo-angle y / (|x| + |y|) unfolded over the four quadrants, in
 // (-2, 2], as an unsigned integer of the same order.  Rounded f32 arithmetic: two points whose angles differ by less than a
 // few ulp may come out equal or swapped -- whoever sorts by it verifies the result with the predicate.
-__device__ inline uint32_t polar_key(float x, float y)
+__device__ inline float polar_pseudo_angle(float x, float y)
 {
   const float len = x * x + y * y;                       // (what the predicate calls a zero point: its squared length rounds to 0)
   const float p = y * __builtin_amdgcn_rcpf(fabsf(x) + fabsf(y));
-  float t = x < 0.f ? (y < 0.f ? -2.f - p : 2.f - p) : p;
-  t = len == 0.f ? 0.f : t + 0.f;                        // (-0 -> +0)
+  const float t = x < 0.f ? (y < 0.f ? -2.f - p : 2.f - p) : p;
+  return len == 0.f ? 0.f : t + 0.f;                     // (-0 -> +0)
+}
+__device__ inline uint32_t polar_key(float t /* polar_pseudo_angle */)
+{
   const uint32_t u = __float_as_uint(t);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// ... and one of kOrderBuckets equal slices of (-2, 2] (a non-decreasing function of the same number: buckets and keys agree)
+constexpr int kOrderBuckets = 1024;
+__device__ inline uint32_t polar_bucket(float t)
+{
+  const float b = (t + 2.f) * (0.25f * kOrderBuckets);
+  return b >= (float)(kOrderBuckets - 1) ? (uint32_t)(kOrderBuckets - 1) : (b > 0.f ? (uint32_t)b : 0u);     // (a NaN lands in bucket 0)
 }
 
 // Boundary j of the padded block range: index_range.cpp:60-66 with start=P, end=N-P.
@@ -2339,6 +2349,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
   float * lz = reinterpret_cast<float *>(lp + M);
   uint32_t * ls = reinterpret_cast<uint32_t *>(lz + M);   // sidx as bucketed
   int * cnt = reinterpret_cast<int *>(ls + M);            // [8] counters
+  uint32_t * hist = reinterpret_cast<uint32_t *>(cnt + 8);  // [kOrderBuckets + 8]: bucket counts, then their prefix; the waves' totals
   // Two uses.  After the first unit pass (all_rings = 0): the rings on the defer list.  Before it (all_rings = 1,
   // switched on by the host while a stream keeps arriving out of order): every ring of the listed scans is put in order
   // here -- a rotation / reversal undone, anything else sorted -- so that the first pass takes the ring and no second
@@ -2418,8 +2429,73 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
         // index as tie-break: a strict total order, so a sequence whose adjacent pairs all pass IS the sorted one).  Only
         // a ring that fails (points a few ulp apart in angle) is sorted again by the predicate itself, below.
         uint64_t * k64 = reinterpret_cast<uint64_t *>(li);          // over li and lp
+        // The keys are placed by COUNTING first: a histogram over kOrderBuckets slices of the angle, its prefix, every
+        // key to its bucket's range -- the points of a ring are spread over the angle, a bucket holds one or two of them --
+        // and what is left inside and between neighbouring buckets by odd-even exchanges of adjacent keys until a round
+        // of both parities moves nothing: a dozen barriers where the bitonic network has sixty-six, each over the whole
+        // ring.  A ring that is not done after kOrderRounds rounds (its points crowd into few buckets) takes the network.
+        bool placed = false;
+        if ((uint32_t)N <= 8u * (uint32_t)T) {
+          constexpr int kOrderRounds = 8;
+          uint32_t key[8], old[8], bkt[8];
+          for (int b = tid; b < kOrderBuckets; b += T) {hist[b] = 0u;}
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int i = tid + u * T;
+            key[u] = 0u; old[u] = 0u; bkt[u] = 0u;
+            if (i < N) {
+              const float t = polar_pseudo_angle(lx[i], ly[i]);
+              key[u] = polar_key(t);
+              bkt[u] = polar_bucket(t);
+              old[u] = atomicAdd(&hist[bkt[u]], 1u);
+            }
+          }
+          __syncthreads();
+          {
+            // exclusive prefix of the bucket counts: kOrderBuckets / T per thread, along the lanes, across the waves
+            constexpr int kPer = kOrderBuckets / 512;
+            static_assert(kOrderBuckets % 512 == 0, "buckets per thread");
+            uint32_t c[kPer], sum = 0;
+            if (tid < 512) {
+#pragma unroll
+              for (int q = 0; q < kPer; q++) {c[q] = hist[tid * kPer + q]; sum += c[q];}
+            }
+            const uint32_t incl = wave_inclusive_sum(sum);
+            if ((tid & 63) == 63) {hist[kOrderBuckets + (tid >> 6)] = incl;}
+            __syncthreads();
+            uint32_t base = 0;
+            for (int w2 = 0; w2 < (tid >> 6); w2++) {base += hist[kOrderBuckets + w2];}
+            if (tid < 512) {
+              uint32_t run = base + incl - sum;
+#pragma unroll
+              for (int q = 0; q < kPer; q++) {hist[tid * kPer + q] = run; run += c[q];}
+            }
+            __syncthreads();
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int i = tid + u * T;
+            if (i < N) {k64[hist[bkt[u]] + old[u]] = ((uint64_t)key[u] << 32) | (uint32_t)i;}
+          }
+          __syncthreads();
+          for (int round = 0; round < kOrderRounds && !placed; round++) {
+            bool moved = false;
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+              for (int i = 2 * tid + par; i + 1 < N; i += 2 * T) {
+                const uint64_t a = k64[i], b = k64[i + 1];
+                if (b < a) {k64[i] = b; k64[i + 1] = a; moved = true;}
+              }
+              __syncthreads();
+            }
+            placed = !__syncthreads_or(moved);
+          }
+        }
+        if (!placed) {
         for (uint32_t i = tid; i < Ms; i += T) {
-          k64[i] = ((uint64_t)(i < (uint32_t)N ? polar_key(lx[i], ly[i]) : 0xFFFFFFFFu) << 32) | i;
+          const float t = i < (uint32_t)N ? polar_pseudo_angle(lx[i], ly[i]) : 0.f;
+          k64[i] = ((uint64_t)(i < (uint32_t)N ? polar_key(t) : 0xFFFFFFFFu) << 32) | i;
         }
         __syncthreads();
         for (uint32_t k = 2; k <= Ms; k <<= 1) {
@@ -2432,6 +2508,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
             }
             __syncthreads();
           }
+        }
         }
         bool out_of_order = false;
         for (int i = tid; i + 1 < N; i += T) {
@@ -2526,7 +2603,7 @@ __host__ __device__ inline size_t order_lds_bytes(uint32_t cap)
 {
   uint32_t M = 1;
   while (M < cap) {M <<= 1;}
-  return (size_t)M * 24 + 64;
+  return (size_t)M * 24 + 64 + (kOrderBuckets + 8) * 4;
 }
 
 // ------------------------------------------------------------------------------------------
