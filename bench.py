@@ -206,10 +206,19 @@ def main():
     # kernel of the previous one (+8 % scans/s at 3 streams); the default is 1 so that the per-kernel
     # durations in "roofline" are those of undisturbed kernels
     n_streams = max(1, a.streams)
+    # (with the gather: two contexts taking turns on ONE stream, so that the packing of step k's clouds -- on a stream of
+    # its own, behind step k's last kernel -- runs under the kernels of step k + 1, which write another context's clouds)
+    will_gather = (world > 1 and not a.no_gather) or a.force_gather
+    if will_gather:
+        n_streams = 2
     fxs = [FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
                              max_points_per_ring=cap, max_rings=a.rings, drop_zero_points=a.drop_zero) for _ in range(n_streams)]
     fx = fxs[0]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
+    if will_gather:
+        streams = [torch.cuda.current_stream()] * n_streams
+    pack_stream = torch.cuda.Stream(device=dev) if will_gather else None
+    pack_done = [None] * n_streams
     stream = streams[0].cuda_stream
     step_no = [0]
 
@@ -272,14 +281,22 @@ def main():
     def step():
         k = step_no[0] % n_streams
         step_no[0] += 1
-        if use_gather:
-            k = 0                      # the gather runs on torch's current stream
+        if will_gather and not use_gather:
+            k = 0                      # (the gather was given up: one context, as without it)
+        if use_gather and pack_done[k] is not None:
+            streams[k].wait_event(pack_done[k])        # this context's clouds of two steps ago have been packed
         fxs[k].extract_batch_device(d_points.data_ptr(), n_list, streams[k].cuda_stream)
         if use_gather:
+            extracted = torch.cuda.Event()
+            extracted.record(streams[k])
             edge_buf, surf_buf, offs = bufs[step_no[0] % len(bufs)]
-            gather.wait_buffer(edge_buf)       # the gather that last read this set must be done
-            fxs[k].pack_xyz12(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, stream)
-            gather.submit(edge_buf, surf_buf, offs, a.batch)
+            with torch.cuda.stream(pack_stream):
+                pack_stream.wait_event(extracted)
+                gather.wait_buffer(edge_buf)       # the gather that last read this set must be done
+                fxs[k].pack_xyz12(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, pack_stream.cuda_stream)
+                pack_done[k] = torch.cuda.Event()
+                pack_done[k].record(pack_stream)
+                gather.submit(edge_buf, surf_buf, offs, a.batch)
 
     def fence():
         if use_gather:
