@@ -1,4 +1,7 @@
 #!/bin/bash
+# tools/ldsgran.sh -- on the GPU box: what a few hundred bytes of LDS more per workgroup cost the 5-chunk organised-scan kernel
+# (LFX_DEBUG_UNIT_LDS_PAD 0 / 1024 / 1200 / 1300 / 1700 on the headline configuration).  Round 4: +1.2 % for every non-zero pad --
+# the seventh workgroup per CU is lost with the first kilobyte (allocation granularity) and is worth that much to this variant.
 mkdir -p gpurun_out
 : > gpurun_out/ldsgran.txt
 for round in 1 2; do
