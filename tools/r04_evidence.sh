@@ -15,7 +15,7 @@ run bench_reversed $B --reverse
 run bench_ragged_5pct $B --drop-fraction 0.05
 run bench_shuffled $B --shuffle --batch 256 --steps 5 --warmup 2
 run bench_streams2 $B --streams 2
-run bench_force_gather $B --force-gather
+run bench_force_gather $B --force-gather --gather-dst 0
 run bench_force_gather_rotate $B --force-gather --gather-dst rotate
 run bench_64x3600_long_form $B --cols 3600 --batch 512
 run bench_cfg3_128x2048x32_long $B --rings 128 --cols 2048 --batch 32 --steps 200 --warmup 20
