@@ -94,7 +94,7 @@ WORKLOADS = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800):
              (64, 3600): "64x3600 (a 0.1-degree sensor: units of 612 positions, the 12-chunk form of the unit kernels; not a BASELINE.json configuration)"}
 
 
-def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, repeats=3):
+def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, repeats=3, curvature=True):
     """One of BASELINE.json's other configurations, measured inside the same run as the headline (a few steps, the same
     fences, HIP-event kernel durations, one scan checked against the oracle): so that every number DESIGN.md quotes for them
     has a driver-observed line behind it.  Single GPU, one stream, inputs resident in HBM."""
@@ -111,8 +111,12 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
     tiled = [clouds[j % n_unique] for j in range(batch)]
     d_points = torch.from_numpy(concat(tiled).view(np.uint8)).to(dev)
     n_list = np.array([len(c) for c in tiled], np.uint32)
+    # curvature = False: a context created without LFX_OUT_CURVATURE (the per-point curvature array is not produced; the
+    # clouds, the labels and the index sets are): 17 instead of 25 algorithmic bytes per point
+    from lidar_feature_extraction_amd import binding as LB
     fx = FeatureExtraction(HyperParameters(), device=dev.index, max_points_per_scan=max(len(c) for c in clouds), max_batch=batch,
-                           max_points_per_ring=max(cols, 64), max_rings=rings, drop_zero_points=drop_zero_fraction > 0.0)
+                           max_points_per_ring=max(cols, 64), max_rings=rings, drop_zero_points=drop_zero_fraction > 0.0,
+                           outputs=0 if curvature else (LB.OUT_FEATURES | LB.OUT_LABELS | LB.OUT_SORTED_INDEX))
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(warmup):
         fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
@@ -140,16 +144,19 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
         if j == 0:
             keep = np.nonzero(valid[0])[0]
             w = oracle.extract(np.ascontiguousarray(clouds[0][keep]), canonical_ties=False)
-            parity = bool(np.array_equal(g.labels[keep], w["labels"]) and g.curvature[keep].tobytes() == w["curvature"].tobytes()
+            parity = bool(np.array_equal(g.labels[keep], w["labels"]) and (not curvature or g.curvature[keep].tobytes() == w["curvature"].tobytes())
                           and np.array_equal(g.edge_index, keep[w["edge_index"]].astype(np.uint32))
-                          and np.array_equal(g.surface_index, keep[w["surface_index"]].astype(np.uint32)))
-    algo = 25 * sum(int(valid[j % n_unique].sum()) for j in range(batch)) + 16 * sum(feats[j % n_unique] for j in range(batch))
+                          and np.array_equal(g.surface_index, keep[w["surface_index"]].astype(np.uint32))
+                          and g.edge_points.tobytes() == w["edge_points"].tobytes() and g.surface_points.tobytes() == w["surface_points"].tobytes())
+    algo = (25 if curvature else 17) * sum(int(valid[j % n_unique].sum()) for j in range(batch)) + 16 * sum(feats[j % n_unique] for j in range(batch))
     fx.close()
     del d_points
     torch.cuda.empty_cache()
     name = WORKLOADS.get((rings, cols), "%dx%d" % (rings, cols))
     if drop_zero_fraction > 0.0:
         name += ", %.0f %% of the returns written as (0, 0, 0) and filtered (convert.py:162-163)" % (100 * drop_zero_fraction)
+    if not curvature:
+        name += ", a context without LFX_OUT_CURVATURE (clouds, labels and index sets only: what the node publishes; 17 algorithmic bytes per point)"
     return {"workload": name, "scans_per_step": batch, "steps": steps, "value": round(batch * steps / dt, 2), "unit": "scans/s",
             "ms_per_step": round(1e3 * dt / steps, 4), "dominant_kernel": dominant,
             "frac": round(algo / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
@@ -527,7 +534,7 @@ def main():
         torch.cuda.empty_cache()
         configs = []
         for args in ((16, 900, 1024, 20, 3), (16, 1800, 1024, 20, 3), (128, 2048, 32, 40, 5), (64, 1800, 1024, 8, 2, 0.05),
-                     (64, 3600, 256, 8, 2)):
+                     (64, 3600, 256, 8, 2), (64, 1800, 1024, 8, 2, 0.0, 3, False)):
             try:
                 configs.append(side_config(dev, *args))
             except Exception as e:         # noqa: BLE001  (a side measurement must not cost the line its headline)

@@ -89,7 +89,10 @@ typedef struct lfx_config {
                                    * table always come back; labels, curvature and sorted_index are per-point arrays
                                    * (13 bytes per point over PCIe) that the node itself does not consume
                                    * (feature_extraction.cpp:161-170 publishes the two clouds; labels only feed the
-                                   * colored_scan debug cloud): a caller that does not need them leaves them out     */
+                                   * colored_scan debug cloud): a caller that does not need them leaves them out.
+                                   * Without LFX_OUT_CURVATURE the per-point curvature is not PRODUCED either (the
+                                   * device view's curvature_sorted is NULL; the feature points still carry theirs as
+                                   * intensity): 8 of the 9 bytes the kernels write per point, +5 % scans/s          */
   uint32_t stream_hint;           /* LFX_STREAM_*: what the caller knows about the order its driver publishes in.  The
                                    * library finds the route for a stream from what the first batches report (nothing to
                                    * configure); a hint only spares the FIRST batch of a stream the slower route         */
@@ -178,7 +181,7 @@ typedef struct lfx_device_view {
   uint32_t ring_capacity;         /* positions per ring (max_points_per_ring rounded up to 64)   */
   const uint32_t *scan_begin;     /* device [batch+1] (in points)                                */
   const uint8_t *labels_sorted;   /* device: label of ring position k                            */
-  const double *curvature_sorted; /* device                                                      */
+  const double *curvature_sorted; /* device; NULL in a context created without LFX_OUT_CURVATURE */
   const uint32_t *sorted_index;   /* device: original index (within its scan) of ring position k */
   const uint32_t *scan_info;      /* device [batch][4]: occupied rings, error bits, n_edge, n_surface */
   const uint32_t *ring_count;     /* device [batch][256] by ring id                              */

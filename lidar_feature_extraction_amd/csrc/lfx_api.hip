@@ -379,7 +379,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     const dim3 grid = c->fast_path ? dim3(list_grid) : dim3(c->max_rings, batch);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
       c->dev, c->cap, c->stage_flags, short_tail ? 2u : (c->fast_path ? 1u : 0u), pts, c->layout, c->scan_begin.p,
-      c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, c->curv_s.p, c->rec_pts.p,
+      c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p,
       c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p, c->ring_flags.p,
       short_tail ? fb_count : slow_count, short_tail ? c->fb_list.p : c->slow_list.p, c->max_rings);
   }
@@ -435,6 +435,7 @@ int fetch_queue(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uin
   if (count == 0 || first + count > c->last_batch) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "scan index outside the last batch");}
   const uint32_t p0 = c->h_scan_begin[first];
   const size_t P = c->h_scan_begin[first + count] - p0;
+  mask &= c->outputs | ~(uint32_t)LFX_OUT_CURVATURE;        // (a context created without the per-point curvature has none to fetch)
   const bool want_lab = mask & LFX_OUT_LABELS, want_curv = mask & LFX_OUT_CURVATURE, want_sidx = mask & LFX_OUT_SORTED_INDEX;
   // pinned block: headers | edge_pts | surf_pts | curvature | edge_idx | surf_idx | sorted_index | labels
   const size_t o_hdr = 0, o_ep = align16((size_t)count * lfx::kResultHeaderBytes), o_sp = o_ep + P * 16, o_cv = o_sp + P * 16,
@@ -465,7 +466,7 @@ int fetch_queue(lfx_ctx * c, uint32_t first, uint32_t count, hipStream_t st, uin
     LFX_HIP(c, hipMemsetAsync(c->d_label.p, 0, P, st));
     LFX_HIP(c, hipMemsetAsync(c->d_curv.p, 0, P * 8, st));
     hipLaunchKernelGGL(lfx::densify_kernel, dim3(c->max_rings, count), dim3(256), 0, st,
-      first, p0, c->scan_begin.p, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, c->curv_s.p, c->sidx.p, c->d_label.p,
+      first, p0, c->scan_begin.p, c->max_rings, c->cap, c->ring_count.p, c->label_s.p, want_curv ? c->curv_s.p : nullptr, c->sidx.p, c->d_label.p,
       c->d_curv.p, c->d_sidx.p, c->scan_info.p, c->xform.p);
     LFX_HIP(c, hipGetLastError());
     if (want_lab) {LFX_HIP(c, hipMemcpyAsync(H + o_lb, c->d_label.p, P, hipMemcpyDeviceToHost, st));}
@@ -846,7 +847,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   }
   if (e == hipSuccess) {e = hipEventCreateWithFlags(&c->report_landed, hipEventDisableTiming);}
   if (e == hipSuccess) {
-    const lfx::UnitTables t{c->label_s.p, c->curv_s.p, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
+    // (no per-point curvature asked for: the kernels find no array to write it to -- a fifth of the unit kernel's HBM traffic)
+    const lfx::UnitTables t{c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
       c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p, c->ring_nedge.p, c->ring_nsurf.p};
     e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
@@ -921,7 +923,7 @@ int lfx_device_results(const lfx_ctx * c, lfx_device_view * v)
   v->ring_capacity = c->cap;
   v->scan_begin = c->scan_begin.p;
   v->labels_sorted = c->label_s.p;
-  v->curvature_sorted = c->curv_s.p;
+  v->curvature_sorted = (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr;
   v->sorted_index = c->sidx.p;
   v->scan_info = c->scan_info.p;
   v->ring_count = c->ring_count.p;

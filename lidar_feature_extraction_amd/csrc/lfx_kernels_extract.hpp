@@ -1886,7 +1886,7 @@ __device__ __forceinline__ uint32_t unit_core(
       const double cv = U.c[q];
       if (own) {
         label_u[(uint32_t)q] = (uint8_t)l;
-        curv_u[(uint32_t)q] = cv;
+        if (curv_s != nullptr) {curv_u[(uint32_t)q] = cv;}       // (wave-uniform: a context created without LFX_OUT_CURVATURE has no such array)
       }
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
       if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
@@ -2673,7 +2673,7 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
       const int stored = (uint32_t)N < cap ? N : (int)cap;
       for (int i = tid; i < stored; i += T) {
         label_s[off + i] = kDefault;
-        curv_s[off + i] = 0.;
+        if (curv_s != nullptr) {curv_s[off + i] = 0.;}
       }
       if (tid == 0) {ring_status[s * kRings + slot] = status;}
       __syncthreads();
@@ -2711,7 +2711,7 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
       const uint8_t lab = w.lab[i];
       const double c = w.c[i];
       label_s[off + i] = lab;
-      curv_s[off + i] = c;
+      if (curv_s != nullptr) {curv_s[off + i] = c;}
       if (lab == kEdge || lab == kSurface) {
         const uint64_t below = (1ull << (i & 63)) - 1ull;
         const uint32_t orig = sidx[off + i];
@@ -2938,7 +2938,7 @@ __global__ __launch_bounds__(256) void densify_kernel(
     d_sidx[dense + i] = orig;
     if (orig < n_points) {
       d_label[orig] = label_s[off + i];
-      d_curv[orig] = curv_s[off + i];
+      if (curv_s != nullptr) {d_curv[orig] = curv_s[off + i];}
     }
   }
 }

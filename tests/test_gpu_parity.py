@@ -294,6 +294,36 @@ def test_organised_scan_kernel_zero_point_filter_and_colored_scan():
     f.close()
 
 
+def test_context_without_the_per_point_curvature():
+    """lfx_config.outputs without LFX_OUT_CURVATURE: the kernels do not write the per-point curvature at all (8 of the 9
+    bytes they store per point); everything else -- labels, index sets, the two clouds with the curvature of their points
+    as intensity, the ring projection -- is what a full context gives, on the organised route, the bucketing route (a
+    shuffled and a ragged scan in the batch) and the workgroup-per-ring kernel (a ring of 3 000 points in 2 blocks)."""
+    from lidar_feature_extraction_amd import binding as LB
+    clouds = [make_scan(16, 900, seed=7300), make_scan(16, 900, seed=7301, shuffle=True), make_scan(16, 900, seed=7302, drop_fraction=0.05)]
+    f = FeatureExtraction(device=0, max_points_per_scan=16 * 900, max_batch=3, max_points_per_ring=900, max_rings=16,
+                          outputs=LB.OUT_FEATURES | LB.OUT_LABELS | LB.OUT_SORTED_INDEX)
+    for rep in range(2):
+        got = f.extract_batch(clouds)
+        for i, c in enumerate(clouds):
+            w = OB.extract(c, canonical_ties=False)
+            assert len(got[i].curvature) == 0
+            assert np.array_equal(got[i].labels, w["labels"]), "scan %d labels" % i
+            assert np.array_equal(got[i].sorted_index, w["sorted_index"].astype(np.uint32))
+            assert np.array_equal(got[i].edge_index, w["edge_index"].astype(np.uint32))
+            assert np.array_equal(got[i].surface_index, w["surface_index"].astype(np.uint32))
+            assert got[i].edge_points.tobytes() == w["edge_points"].tobytes() and got[i].surface_points.tobytes() == w["surface_points"].tobytes()
+    assert not f.device_view().curvature_sorted
+    f.close()
+    hp = HyperParameters(n_blocks=2)
+    c = make_scan(2, 3000, seed=7303)
+    f = FeatureExtraction(hp, device=0, max_points_per_scan=len(c), max_batch=1, outputs=LB.OUT_FEATURES | LB.OUT_LABELS)
+    g, w = f.ExtractFeatures(c), OB.extract(c, oracle_params(hp), canonical_ties=False)
+    assert np.array_equal(g.labels, w["labels"]) and g.edge_points.tobytes() == w["edge_points"].tobytes()
+    assert g.surface_points.tobytes() == w["surface_points"].tobytes() and len(g.curvature) == 0
+    f.close()
+
+
 def test_contexts_of_different_ring_capacity_side_by_side():
     """Two lidars of different width in one process: the dynamic-LDS limits of the workgroup-per-ring kernels are per
     function, not per context, so a later, smaller context must not lower them for an earlier, larger one."""
