@@ -1243,6 +1243,64 @@ __device__ inline uint32_t get_win(const UnitLds<CH> & U, int arr, int k, const 
 #endif
 }
 
+// 32 positions of array `arr` starting at position `first` (bit i of the result <-> position first + i), first >= -64
+template<int CH>
+__device__ inline uint32_t get_win_at(const UnitLds<CH> & U, int arr, int first)
+{
+#ifdef LFX_WHATIF_NOLDS
+  return __builtin_amdgcn_alignbit((uint32_t)arr * 0x9E3779B9u + threadIdx.x, (uint32_t)first * 0x85EBCA6Bu ^ threadIdx.x, (uint32_t)first & 31u);
+#else
+  const uint32_t bit = (uint32_t)(first + 64);
+  const u32_alias_t * b = reinterpret_cast<const u32_alias_t *>(&U.bits[arr][bit >> 5]);
+  return __builtin_amdgcn_alignbit(b[1], b[0], bit & 31u);
+#endif
+}
+
+// The ROWS form of the block labelling (unit_core, stages D and F).  A lane holds CH CONSECUTIVE positions, CH * lane + d,
+// and every point set of the pick rounds is CH bits of one vector register per lane (bit d <-> position CH * lane + d).
+// What a position needs to see -- PT positions either side -- lies in its own lane and the two lanes next to it (PT <= CH):
+// the FRAME of a set is [the top PT bits of the lane below | the lane's own CH bits | the low PT bits of the lane above],
+// bit i <-> position CH * lane - PT + i, put together from two wave-wide DPP shifts (wave_shr:1 / wave_shl:1 cross the
+// rows of 16 lanes on gfx9; the wave's two ends read 0).  A round of the priority fix-point is then AND / MIN / shift-OR on
+// registers: no ballot, no scalar mask, no LDS bit array -- the chunk form paid, per chunk and per round, a ballot, scalar
+// logic, two v_writelane, an LDS store and an LDS read back (round 4's per-wave counters: 1 086 scalar and 179 LDS
+// instructions, the scalar file at 94 registers).
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v) {return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);}   // wave_shr:1
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);}   // wave_shl:1
+
+template<int CH, int PT>
+__device__ __forceinline__ uint32_t row_frame(uint32_t own)
+{
+  static_assert(PT >= 1 && PT <= CH && CH + 2 * PT <= 32, "the halo of a lane's positions must lie in the two lanes next to it");
+  const uint32_t below = from_lane_below(own), above = from_lane_above(own);
+  uint32_t f = (own << PT) | (below >> (CH - PT));
+  if constexpr (CH == PT) {f |= above << (PT + CH);} else {f |= (above & ((1u << PT) - 1u)) << (PT + CH);}
+  return f;
+}
+
+// bit d of the result <-> the frame meets mask[d]
+template<int CH>
+__device__ __forceinline__ uint32_t row_hits(uint32_t frame, const uint32_t (&mask)[CH])
+{
+  uint32_t h = 0;
+#pragma unroll
+  for (int d = 0; d < CH; d++) {
+    const uint32_t t = frame & mask[d];
+    h |= (t < 1u ? t : 1u) << d;
+  }
+  return h;
+}
+
+// which lane holds position q of the rows form, q < 64 * CH: q / CH by one 24-bit multiply (checked for every q below)
+template<int CH> struct RowDiv { static constexpr uint32_t kShift = 18, kMul = ((1u << 18) + CH - 1) / CH; };
+template<int CH> constexpr bool row_div_exact()
+{
+  for (uint32_t q = 0; q < 64u * CH; q++) {
+    if (((q * RowDiv<CH>::kMul) >> RowDiv<CH>::kShift) != q / CH) {return false;}
+  }
+  return true;
+}
+
 // sqrt of a sum of two squares of floats, in f64, correctly rounded (math.hpp:36-39: std::sqrt of the double sum).  The
 // library's sqrt scales its argument first, for values below 2^-767 -- which x * x + y * y of two floats never is (zero, or
 // at least 2^-298: the square of the smallest subnormal float) -- so its own iteration is used without the scaling: the
@@ -1569,10 +1627,24 @@ __device__ __forceinline__ uint32_t unit_core(
     }
   }
   LFX_STAMP(4);
+  // ROWS: for the two window stages (E and the order masks of F) a lane takes CH CONSECUTIVE positions, CH * lane + d,
+  // instead of one position per chunk: the windows of its positions overlap, so it reads 2 PT + CH values where the chunk
+  // form reads CH x (2 PT + 1) -- 15 against 55 LDS reads per stage.  (Lane stride CH doubles: conflict-free for odd CH.)
+  // Only the first and the last lane would read outside the slab; their window is moved inside, and what they then compute
+  // is thrown away: with PT <= CH <= PT + 1 all their positions lie outside any block (a block keeps PT + 1 positions away
+  // from either end of the span).  Round 5: the occlusion fills, the reach and the pick rounds are in the rows form too
+  // (kRowPick; see row_frame above) and the labels come back to the chunk form as ONE word per lane.
+  constexpr bool kRows = PT > 0 && (CH == PT || CH == PT + 1);
+  constexpr bool kRowPick = kRows && !FULL;
+  constexpr int kRowWin = kRows ? 2 * PT + CH : 1;
+  constexpr int kSetStride = CH < 4 ? 4 : CH;          // rows -> chunk form: the sets of a lane's word lie this far apart (final_label)
+  const int p0 = CH * lane;
   // ---- D. occlusion fills (occlusion.hpp:37-91) and the reach of a pick inside the block (fill.hpp:101-117)
   uint32_t reach[CH];
+  uint32_t rch[CH];                   // rows: reach of position p0 + d in the pick frame (bit PT + d = itself), 0 outside the block
+  uint32_t occ_rows = 0, own_rows = 0;        // rows: bit d <-> position p0 + d is occluded / lies in the block
 #pragma unroll
-  for (int k = 0; k < CH; k++) {
+  for (int k = 0; k < (kRowPick ? 0 : CH); k++) {
     reach[k] = 0;
     if (k < K) {
       const int q = 64 * k + lane;
@@ -1594,16 +1666,7 @@ __device__ __forceinline__ uint32_t unit_core(
   }
   LFX_WAVE_SYNC();        // the x / y slab is dead from here on: the curvature slab takes its place
   LFX_STAMP(5);
-  // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0
-  // ROWS: for the two window stages (E and the order masks of F) a lane takes CH CONSECUTIVE positions, CH * lane + d,
-  // instead of one position per chunk: the windows of its positions overlap, so it reads 2 PT + CH values where the chunk
-  // form reads CH x (2 PT + 1) -- 15 against 55 LDS reads per stage, and the LDS pipe is the kernel's busiest resource.
-  // (Lane stride CH doubles: conflict-free for odd CH.)  Only the first and the last lane would read outside the slab;
-  // their window is moved inside, and what they then compute is thrown away: with PT <= CH <= PT + 1 all their positions
-  // lie outside any block (a block keeps PT + 1 positions away from either end of the span).
-  constexpr bool kRows = PT > 0 && (CH == PT || CH == PT + 1);
-  constexpr int kRowWin = kRows ? 2 * PT + CH : 1;
-  const int p0 = CH * lane;
+  // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0 (by rows where kRows, see above)
   int row_base = p0 - PT;
   row_base = row_base < 0 ? 0 : row_base;
   row_base = row_base > 64 * CH - kRowWin ? 64 * CH - kRowWin : row_base;
@@ -1655,7 +1718,96 @@ __device__ __forceinline__ uint32_t unit_core(
   uint32_t lt[CH];
   uint64_t ecand[CH], scand[CH];
   constexpr uint32_t kEdgeCand = 1u << ((PT > 0 ? PT : 1) + 18), kSurfCand = 1u << ((PT > 0 ? PT : 1) + 17);     // (just above the order bits)
-  if constexpr (kRows) {
+  if constexpr (kRowPick) {
+    // rows all the way: lt[d] = the order mask of position p0 + d in the pick frame (bit PT + d + t <-> its neighbour at
+    // offset t; the position's own bit 0), the candidates as bits of two words
+    // (lanes 0 and 63, whose window was moved: every position of theirs lies outside the block, so their reach is 0 and
+    // with it everything these masks are met with)
+    constexpr int PR = PT > 0 ? PT : 1;
+    double w[kRowWin];
+    lds_window_f64(&U.c[row_base], w);
+    uint32_t ec = 0, sc = 0;
+#pragma unroll
+    for (int d = 0; d < CH; d++) {
+      const double ci = w[d + PR];
+      uint32_t m = 0;
+#pragma unroll
+      for (int t = PR; t >= 1; t--) {m = m + m + (uint32_t)(w[d + PR + t] < ci);}
+      m = m + m;
+#pragma unroll
+      for (int t = 1; t <= PR; t++) {m = m + m + (uint32_t)(w[d + PR - t] <= ci);}
+      lt[d] = m << d;
+      ec |= (ci >= edge_thr ? 1u : 0u) << d;                   // label.hpp:80-82
+      sc |= (ci <= surf_thr ? 1u : 0u) << d;                   // label.hpp:119-121
+    }
+    // ---- D by rows (here rather than ahead of stage E: the reach masks are not live while the two windows are)
+    {
+      constexpr int kFrame = CH + 2 * PR;
+      // link and jump windows: bit i <-> position p0 - PT - 1 + i (position p0 + d at PT + 1 + d)
+      const uint32_t LW = get_win_at(U, kBitLK, p0 - PR - 1);
+      uint32_t JLW = 0, JRW = 0;
+      if (LFX_STAGE_ON(256u)) {
+        JLW = get_win_at(U, kBitJL, p0 - PR - 1);
+        JRW = get_win_at(U, kBitJR, p0 - PR - 1);
+      }
+      const uint32_t NL = ~LW, RNL = __builtin_bitreverse32(NL);
+      // the block in the pick frame (bit i <-> position p0 - PT + i); the links are cut at its ends (label.hpp:157-159), which
+      // for runs that start at a position of the block is the same as meeting them with the block
+      int lo = qb0 - p0 + PR, hi = qb1 - p0 + PR;
+      lo = lo < 0 ? 0 : (lo > kFrame ? kFrame : lo);
+      hi = hi < 0 ? 0 : (hi > kFrame ? kFrame : hi);
+      const uint32_t IB = hi > lo ? (((1u << (hi - lo)) - 1u) << lo) : 0u;
+      own_rows = (IB >> PR) & ((1u << CH) - 1u);
+#pragma unroll
+      for (int d = 0; d < CH; d++) {
+        const int fj = PR + 1 + d, fp = PR + d;
+        // links at p - 1, p - 2, ... and at p, p + 1, ...: runs of at most PT (the stop bit), counted from the top
+        const uint32_t Lr = (uint32_t)__builtin_clz((NL << (32 - fj)) | (1u << (31 - PR)));
+        const uint32_t Rr = (uint32_t)__builtin_clz((RNL << fj) | (1u << (31 - PR)));
+        // jumps at p - 1 .. p - 1 - Lr (far side to the right) and at p + 1 .. p + 1 + Rr (far side to the left) reach p
+        const uint32_t o = ((JLW << (32 - fj)) >> (31u - Lr)) | ((JRW >> (fj + 1)) << (31u - Rr));
+        occ_rows |= (o < 1u ? o : 1u) << d;
+        const uint32_t run = (((1u << (Lr + Rr + 1u)) - 1u) << ((uint32_t)fp - Lr)) & IB;
+        rch[d] = ((IB >> fp) & 1u) != 0u ? run : 0u;
+      }
+    }
+    LFX_STAMP(7);
+    // The pick rounds (label.hpp:72-95,113-134 / fill.hpp:101-117 as a priority fix-point): a live candidate with no live
+    // candidate of higher priority in reach is picked; everything a pick reaches (the pick included) leaves the live set.
+    uint32_t hp[CH];
+    auto pick_pass = [&](uint32_t live) -> uint32_t {
+      uint32_t sel = 0;
+      for (;; ) {
+        const uint32_t pk = live & ~row_hits<CH>(row_frame<CH, PR>(live), hp);
+        // With a total order the live candidate of highest priority is always picked.  No pick at all means there is no
+        // candidate left -- or the order is inconsistent (NaN curvature from non-finite input): stop instead of spinning.
+        if (__builtin_amdgcn_ballot_w64(pk != 0u) == 0ull) {break;}
+        sel |= pk;
+        live &= ~row_hits<CH>(row_frame<CH, PR>(pk), rch);
+        if (__builtin_amdgcn_ballot_w64(live != 0u) == 0ull) {break;}
+      }
+      return sel;
+    };
+    uint32_t sel_e = 0, sel_s = 0, by_e = 0, by_s = 0;         // picks; positions an edge / a surface pick reaches
+    if (LFX_STAGE_KEPT(1u)) {
+#pragma unroll
+      for (int d = 0; d < CH; d++) {hp[d] = ~lt[d] & rch[d] & ~(1u << (PR + d));}      // edges: the higher curvature first
+      sel_e = pick_pass(ec & own_rows);
+      by_e = row_hits<CH>(row_frame<CH, PR>(sel_e), rch);
+    }
+    LFX_STAMP(8);
+    if (LFX_STAGE_KEPT(64u)) {
+#pragma unroll
+      for (int d = 0; d < CH; d++) {hp[d] = lt[d] & rch[d];}                           // surfaces: the lower curvature first
+      sel_s = pick_pass(sc & own_rows & ~by_e);                // in the block and still Default (label.hpp:119-121)
+      by_s = row_hits<CH>(row_frame<CH, PR>(sel_s), rch);
+    }
+    // back to the chunk form: one word per lane through the range slab (dead since stage E), five sets of CH bits
+    static_assert(5 * kSetStride <= 32, "the five sets of a lane share a word");
+    reinterpret_cast<u32_alias_t *>(U.r)[lane] =
+      by_e | by_s << kSetStride | sel_s << (2 * kSetStride) | sel_e << (3 * kSetStride) | occ_rows << (4 * kSetStride);
+    LFX_WAVE_SYNC();
+  } else if constexpr (kRows) {
     // (the range slab is dead since stage E: its first half passes the masks from the lanes that made them to the lanes
     // of the chunk form, which everything after this works in)
     u32_alias_t * const pass_on = reinterpret_cast<u32_alias_t *>(U.r);
@@ -1723,9 +1875,9 @@ __device__ __forceinline__ uint32_t unit_core(
       }
     }
   }
-  LFX_STAMP(7);
+  if constexpr (!kRowPick) {LFX_STAMP(7);}
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass < (kRowPick ? 0 : 2); pass++) {
     const bool edge = pass == 0;
     if (!edge) {LFX_STAMP(8);}
     if (!LFX_STAGE_KEPT(edge ? 1u : 64u)) {continue;}
@@ -1849,16 +2001,42 @@ __device__ __forceinline__ uint32_t unit_core(
   double * __restrict__ curv_s = tab->curv_s;
   // final label of position q = 64 k + lane (feature_extraction.cpp:133-138: the masks override the block labelling)
   auto final_label = [&](int k, int q) -> uint32_t {
-    const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
     uint32_t l = kDefault;
-    l = (wE & reach[k]) != 0u ? (uint32_t)kEdgeNeighbor : l;
-    l = (wS & reach[k]) != 0u ? (uint32_t)kSurfaceNeighbor : l;
-    l = (wS & (1u << 16)) != 0u ? (uint32_t)kSurface : l;
-    l = (wE & (1u << 16)) != 0u ? (uint32_t)kEdge : l;
+    uint32_t t = (ovr[k / 10] >> (3 * (k % 10))) & 7u;
+    if constexpr (kRowPick) {
+      // position q is bit q mod CH of the five sets in the word of lane q / CH
+      static_assert(row_div_exact<CH>(), "q / CH by multiplication");
+      const uint32_t row = __umul24((uint32_t)q, RowDiv<CH>::kMul) >> RowDiv<CH>::kShift, d = (uint32_t)q - (uint32_t)CH * row;
+      const uint32_t sets = reinterpret_cast<const u32_alias_t *>(U.r)[row] >> d;
+      // the four labelling bits side by side: reached by an edge pick | by a surface pick << 1 | surface pick << 2 | edge
+      // pick << 3.  One multiplication moves bit i * S to bit 3 * (S - 1) + i (S = kSetStride): the partial product of bit
+      // i * S with term 2^((3 - j)(S - 1)) lies at 3 (S - 1) + j + (i - j) S, which for i != j is outside the four bits
+      // wanted when S >= 4, and the sixteen products are sixteen different powers of two (S and S - 1 are coprime, |j - j'|
+      // < S), so nothing carries
+      constexpr int S = kSetStride;
+      constexpr uint32_t kFour = 1u | 1u << S | 1u << (2 * S) | 1u << (3 * S);
+      constexpr uint32_t kGather = 1u | 1u << (S - 1) | 1u << (2 * (S - 1)) | 1u << (3 * (S - 1));
+      const uint32_t idx = (__umul24(sets & kFour, kGather) >> (3 * (S - 1))) & 15u;
+      // EdgeNeighbor, then SurfaceNeighbor, then Surface, then Edge: the last one set wins (as the chunk form below)
+      constexpr auto block_label = [](uint32_t i) -> uint64_t {
+        return (i & 8u) ? kEdge : ((i & 4u) ? kSurface : ((i & 2u) ? kSurfaceNeighbor : ((i & 1u) ? kEdgeNeighbor : kDefault)));
+      };
+      constexpr uint64_t kBlockLabel =
+        block_label(0) | block_label(1) << 4 | block_label(2) << 8 | block_label(3) << 12 | block_label(4) << 16 | block_label(5) << 20 |
+        block_label(6) << 24 | block_label(7) << 28 | block_label(8) << 32 | block_label(9) << 36 | block_label(10) << 40 |
+        block_label(11) << 44 | block_label(12) << 48 | block_label(13) << 52 | block_label(14) << 56 | block_label(15) << 60;
+      l = (uint32_t)(kBlockLabel >> (4u * idx)) & 7u;
+      t |= (sets >> (4 * S)) & 1u;                              // occluded (kOvrOccluded)
+    } else {
+      const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
+      l = (wE & reach[k]) != 0u ? (uint32_t)kEdgeNeighbor : l;
+      l = (wS & reach[k]) != 0u ? (uint32_t)kSurfaceNeighbor : l;
+      l = (wS & (1u << 16)) != 0u ? (uint32_t)kSurface : l;
+      l = (wE & (1u << 16)) != 0u ? (uint32_t)kEdge : l;
+    }
     // occluded, then out of range, then parallel beam: the last one set wins -- a table of eight nibbles by the three bits
     constexpr uint32_t kOverride = (uint32_t)kOccluded << 4 | (uint32_t)kOutOfRange << 8 | (uint32_t)kOutOfRange << 12 |
       (uint32_t)kParallelBeam << 16 | (uint32_t)kParallelBeam << 20 | (uint32_t)kParallelBeam << 24 | (uint32_t)kParallelBeam << 28;
-    const uint32_t t = (ovr[k / 10] >> (3 * (k % 10))) & 7u;
     l = t != 0u ? (kOverride >> (4u * t)) & 15u : l;
     return lanes(in_span(q, qo0, qo1)) ? l : (uint32_t)kDefault;
   };
@@ -2183,10 +2361,24 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) LFX_ORG_A
 {
   __shared__ UnitLds<CH> lds[kUnitWaves];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // grid = (groups of four rings, blocks, scans): dispatched in the order group, block, scan, no division to find them
-  const uint32_t g = blockIdx.x;
+  // grid = (groups of four rings, blocks, scans): dispatched in the order group, block, scan, no division to find them.
+  // Workgroups go to the eight XCDs round-robin by their linear index, i.e. by blockIdx.x mod 8 when the sensor has a
+  // multiple of 32 rings -- and the records of ring group g are the 128-byte lines whose address bits 7-10 are g: taken
+  // as they come, an XCD would only ever ask for ONE eighth of the address patterns (memory channels), and whatever makes
+  // one of those slower holds up that XCD's whole share of the launch (round 5: stamps showed the waves of one XCD
+  // waiting twice as long for their records as the others', its shader engines of the others idle for 17 % of the kernel).
+  // So the ring group is turned by the scan index: every XCD sees every group.
   const int j = (int)blockIdx.y;
   const uint32_t s = blockIdx.z;
+  uint32_t g = blockIdx.x;
+#ifndef LFX_NO_GROUP_TURN
+  {
+    const uint32_t groups = gridDim.x;
+    const uint32_t turn = s & ((1u << (31 - __builtin_clz(groups))) - 1u);       // < groups
+    g += turn;
+    g = g >= groups ? g - groups : g;
+  }
+#endif
   const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, geom};
   const uint32_t slot = 4u * g + wave;
   if (DEF || prm.P == 5) {
@@ -2849,7 +3041,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     for (uint32_t t0 = 0; t0 < total; t0 += 256) {
       size_t src[4], dst[4];
       bool edge[4], valid[4];
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < 4; i++) {
         valid[i] = t0 + 64 * i + lane < total;
         edge[i] = false;
@@ -2861,7 +3053,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         const uint32_t ne = __builtin_amdgcn_readlane(ne_k, u), ns = __builtin_amdgcn_readlane(ns_k, u);
         const uint32_t span = __builtin_amdgcn_readlane(span_k, u);
         const size_t first = off + (span & 0xFFFFu), last = off + (span >> 16);
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < 4; i++) {
           const uint32_t q = t0 + 64 * i + lane - cum;       // index inside unit u (wraps when the record lies before it)
           if (q < ne + ns) {
@@ -2876,7 +3068,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       }
       float4 rp[4];
       uint32_t ri[4];
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < 4; i++) {
         rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         ri[i] = 0;
@@ -2885,7 +3077,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
           ri[i] = rec_idx[src[i]];
         }
       }
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < 4; i++) {
         if (valid[i]) {
           if (edge[i]) {

@@ -18,7 +18,7 @@ for line in text:
         if re.match(r"^_ZN3lfx\w*%s\w*:" % re.escape(want), line):
             inside = True
         continue
-    if "s_endpgm" in line:
+    if line.startswith(".Lfunc_end"):           # (not the first s_endpgm: an early exit may sit anywhere in the listing)
         break
     m = re.search(r"; LFX_MARK (\d+)", line)
     if m:

@@ -38,3 +38,23 @@ print("lifetime (stamp 0 -> 10): median %d  p10 %d  p90 %d shader cycles" % (np.
 for k in range(10):
     dt = t[:, k + 1] - t[:, k]
     print("%-22s median %6d  (%4.1f %%)" % (NAMES[k + 1], np.median(dt), 100.0 * np.median(dt) / np.median(life)))
+if "--by-ring" in sys.argv:
+    # a unit's stamps sit at index ring * B + j (B = 6 blocks): life and the two pick passes per group of four rings, and per
+    # XCD as the grid's x index lands on them (ring group mod 8)
+    B_ = 6
+    full = np.frombuffer(buf, dtype=np.uint64).reshape(384, 16).astype(np.int64)
+    ring = np.arange(384) // B_
+    lifef = full[:, 10] - full[:, 0]
+    picks = full[:, 9] - full[:, 7]
+    print("group  life(mean)  picks(mean)  picks(max)")
+    for g in range(16):
+        m = (ring // 4 == g) & (full[:, 10] > full[:, 0])
+        print("%5d  %10.0f  %11.0f  %10d" % (g, lifef[m].mean(), picks[m].mean(), picks[m].max()))
+    for x in range(8):
+        m = ((ring // 4) % 8 == x) & (full[:, 10] > full[:, 0])
+        print("xcd %d: life sum %d" % (x, lifef[m].sum()))
+    print("stage means per group (columns: stages 0->1 ... 9->10), then start time of the group's first unit relative to the scan's first")
+    t0 = full[full[:, 0] > 0, 0].min()
+    for g in range(16):
+        m = (ring // 4 == g) & (full[:, 10] > full[:, 0])
+        print("%2d " % g + " ".join("%6.0f" % (full[m, k + 1] - full[m, k]).mean() for k in range(10)) + "   start %d" % (full[m, 0].min() - t0))
