@@ -2191,7 +2191,9 @@ __device__ __forceinline__ void unit_body(
     for (int m = 0; m < CH; m++) {
       const int q = 64 * m + 16 * (int)og.wave + (int)cq;
       int i = g0 + q;
-      i = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+      // (positions outside the span ask for the span's first / last record again: the same line as a neighbouring lane's,
+      // where a ring point beyond the span would be a line nobody needs -- 3 % of the kernel's reads at 1800 columns)
+      i = i < g0 + qlo ? g0 + qlo : (i > g0 + qhi - 1 ? g0 + qhi - 1 : i);
       const uint32_t col = XF ? ring_column(xf, (uint32_t)i, (uint32_t)N) : (uint32_t)i;
       const uint8_t * p = base + (col * og.R + rload) * 32u;                // a scan is < 2^27 points (host check)
       rec[m] = *reinterpret_cast<const float4 *>(p);
@@ -2369,12 +2371,23 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) LFX_ORG_A
   // waiting twice as long for their records as the others', its shader engines of the others idle for 17 % of the kernel).
   // So the ring group is turned by the scan index: every XCD sees every group.
   const int j = (int)blockIdx.y;
-  const uint32_t s = blockIdx.z;
+  uint32_t s = blockIdx.z;
   uint32_t g = blockIdx.x;
+#ifdef LFX_GROUP_QUADS      // (experiment: an XCD takes FOUR adjacent groups of one scan, two scans sharing 32 workgroups)
+  if (gridDim.x == 16u && (s | 1u) < gridDim.z) {
+    const uint32_t k = g & 7u, h = g >> 3, zb = s & 1u;
+    s = (s & ~1u) + (k >> 2);
+    g = 4u * (k & 3u) + h + 2u * zb;
+    g = (g + 4u * (s >> 1)) & 15u;
+  } else
+#endif
 #ifndef LFX_NO_GROUP_TURN
   {
+    // (and with sixteen groups or a multiple an XCD takes two ADJACENT groups, 256 contiguous bytes of every column, at a
+    // time: -2 % on the kernel, same box)
     const uint32_t groups = gridDim.x;
-    const uint32_t turn = s & ((1u << (31 - __builtin_clz(groups))) - 1u);       // < groups
+    if ((groups & 15u) == 0u) {g = (g & ~15u) | ((g & 7u) << 1) | ((g >> 3) & 1u);}
+    const uint32_t turn = (2u * s) & ((1u << (31 - __builtin_clz(groups))) - 1u);       // < groups
     g += turn;
     g = g >= groups ? g - groups : g;
   }

@@ -83,12 +83,117 @@ __global__ __launch_bounds__(256) void write_outputs(uint8_t * __restrict__ lab,
   }
 }
 
+// The unit kernel's memory operations with nothing between them but a wait: workgroup = block j of G adjacent rings (grid
+// = groups x blocks x scans as ring_unit_org_kernel's), one ring per wave (64 G threads), every lane asks for 5 x (16 + 4)
+// bytes, the workgroup meets at a barrier, each wave then "computes" for `work` rounds of dependent vector instructions and
+// stores its ring's 300 labels and curvatures and ~12 % of them as 20-byte feature records.  MAP: 0 = ring group =
+// blockIdx.x; 1 = turned by the scan index; 2 = two adjacent groups per XCD, turned.  Dynamic LDS sets the workgroups per CU.
+// OUT: bit 0 labels, bit 1 curvature, bit 2 records.
+template<int MAP, int G = 4, int OUT = 7>
+__global__ __launch_bounds__(64 * G) void unit_memory(const uint8_t * __restrict__ pts, uint8_t * __restrict__ lab, double * __restrict__ cur,
+  float4 * __restrict__ rec, uint32_t * __restrict__ idx, float * __restrict__ out, int work)
+{
+  extern __shared__ uint8_t dyn[];
+  constexpr uint32_t groups = R / G;
+  const uint32_t s = blockIdx.z, j = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t g = blockIdx.x;
+  if (MAP == 1) {g = (g + s) % groups;}
+  if (MAP == 2) {g = (groups >= 16 ? ((((g & 7u) << 1) | (g >> 3)) + 2u * s) : (g + s)) % groups;}
+  const uint32_t sub = lane % G, cq = lane / G;
+  constexpr uint32_t per_wave = 64 / G;              // columns one instruction of a wave covers
+  const uint8_t * base = pts + (size_t)s * R * C * 32;
+  float4 v[5]; uint32_t w[5];
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    uint32_t c = j * 298 + 64 * m + per_wave * wave + cq;
+    c = c < (uint32_t)C ? c : C - 1;
+    const uint8_t * p = base + ((size_t)c * R + G * g + sub) * 32;
+    v[m] = *reinterpret_cast<const float4 *>(p);
+    w[m] = *reinterpret_cast<const uint32_t *>(p + 20);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int m = 0; m < 5; m++) {consume(v[m], w[m], acc);}
+  reinterpret_cast<float *>(dyn)[threadIdx.x] = acc;
+  __syncthreads();
+  acc += reinterpret_cast<float *>(dyn)[threadIdx.x ^ 64];
+  for (int i = 0; i < work; i++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {asm volatile ("v_fma_f32 %0, %0, %0, %0" : "+v"(acc));}
+  }
+  const uint32_t ring = G * g + wave;
+  const size_t off = ((size_t)s * R + ring) * 1856 + j * 300;
+  const bool feat = (lane & 7u) == 3u;             // one position in eight: ~12 % feature points
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t q = 64 * k + lane;
+    if (q < 300) {
+      if (OUT & 1) {lab[off + q] = (uint8_t)(q & 7);}
+      if (OUT & 2) {cur[off + q] = (double)acc;}
+      if ((OUT & 4) && feat) {
+        rec[off + 8 * k + (lane >> 3)] = make_float4(acc, acc, acc, acc);
+        idx[off + 8 * k + (lane >> 3)] = q;
+      }
+      if ((OUT & 2048) && feat) {       // 32-byte records chunk by chunk into the unit's slot of 64
+        float4 * r32 = rec + 2 * ((((size_t)s * R + ring) * 6 + j) * 64 + 8 * k + (lane >> 3));
+        r32[0] = make_float4(acc, acc, acc, acc);
+        r32[1] = make_float4(__uint_as_float(q), 0.f, 0.f, 0.f);
+      }
+      if ((OUT & 8) && feat) {          // one 32-byte record per feature (two float4 halves of one sector, one instruction pair)
+        float4 * r32 = rec + 2 * (off + 8 * k + (lane >> 3));
+        r32[0] = make_float4(acc, acc, acc, acc);
+        r32[1] = make_float4(__uint_as_float(q), 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  if (OUT & 16) {                       // all of the unit's ~38 records by ONE instruction per array at the end
+    if (lane < 38) {
+      rec[off + lane] = make_float4(acc, acc, acc, acc);
+      idx[off + lane] = lane;
+    }
+  }
+  if (OUT & (64 | 128)) {               // records where a bump allocator puts them (64: one counter per scan, 128: one in all): dense in time
+    uint32_t * counter = reinterpret_cast<uint32_t *>(out) + 16 + ((OUT & 64) ? s : 0u);
+    uint32_t at = 0;
+    if (lane == 0) {at = atomicAdd(counter, 38u);}
+    at = __builtin_amdgcn_readfirstlane(at) % (R * 1856u - 64u);      // (38 records from `at` stay inside the scan's part of the arrays)
+    const size_t o2 = (size_t)s * R * 1856 + at;
+    if (lane < 38) {
+      rec[o2 + lane] = make_float4(acc, acc, acc, acc);
+      idx[o2 + lane] = lane;
+    }
+  }
+  if (OUT & 256) {                      // 32-byte records by one store, in a slot of 64 per unit (2 KB apart instead of 4.8)
+    const size_t u2 = ((((size_t)s * R + ring) * 6 + j) * 64) * 2;
+    if (lane < 76) {rec[u2 + lane] = make_float4(acc, acc, acc, acc);}
+  }
+  if (OUT & 512) {                      // 20-byte records (five dwords) packed, 38 of them = 190 dwords by three dword stores
+    float * r20 = reinterpret_cast<float *>(rec) + (off * 5);
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      if (64 * t + lane < 190) {r20[64 * t + lane] = acc;}
+    }
+  }
+  if (OUT & 1024) {                     // 32-byte records by one non-temporal store
+    if (lane < 76) {__builtin_nontemporal_store(acc, reinterpret_cast<float *>(rec + 2 * off + lane)); 
+      __builtin_nontemporal_store(acc, reinterpret_cast<float *>(rec + 2 * off + lane) + 1);
+      __builtin_nontemporal_store(acc, reinterpret_cast<float *>(rec + 2 * off + lane) + 2);
+      __builtin_nontemporal_store(acc, reinterpret_cast<float *>(rec + 2 * off + lane) + 3);}
+  }
+  if (OUT & 32) {                       // ... as 32-byte records: lanes 2 i and 2 i + 1 write the two halves of record i
+    if (lane < 76) {
+      rec[2 * off + lane] = make_float4(acc, acc, acc, acc);
+    }
+  }
+  if (acc == 1.2345e30f) {out[0] = acc;}
+}
+
 int main(int argc, char ** argv)
 {
   const int scans = argc > 1 ? atoi(argv[1]) : 1024;
   const size_t n = (size_t)scans * R * C, bytes = n * 32;
   uint8_t * pts; float * out; uint8_t * lab; double * cur;
-  hipMalloc(&pts, bytes); hipMalloc(&out, 64);
+  hipMalloc(&pts, bytes); hipMalloc(&out, 64 + 4 * 4096); hipMemset(out, 0, 64 + 4 * 4096);
   hipMalloc(&lab, (size_t)scans * R * 1856); hipMalloc(&cur, (size_t)scans * R * 1856 * 8);
   hipMemset(pts, 1, bytes);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -110,5 +215,44 @@ int main(int argc, char ** argv)
   time("64 rings per workgroup", [&] {hipLaunchKernelGGL(read_groups<64>, dim3(1 * 90, scans), dim3(256), 0, 0, pts, out);}, gb * 20 * 90 / 1800);
   const double wgb = (double)scans * R * 1800 * 9 / 1e9;
   time("outputs: 1 B + 8 B per point", [&] {hipLaunchKernelGGL(write_outputs, dim3(16 * 6, scans), dim3(256), 0, 0, lab, cur, 0, pts);}, wgb);
+  // the unit kernel's memory side alone: what is left when the computation between loads and stores shrinks
+  {
+    float4 * rec; uint32_t * idx;
+    hipMalloc(&rec, (size_t)scans * R * 1856 * 32); hipMalloc(&idx, (size_t)scans * R * 1856 * 4);
+    const double rgb = gb * 320 * 6 / 1800, lgb = (double)scans * R * 1800 / 1e9, cgb = 8 * lgb, fgb = (double)scans * R * 6 * 38 * 20 / 1e9;
+    const double ugb = rgb + lgb + cgb + fgb;
+    const int works[] = {0, 64, 96, 128};
+    const int ldss[] = {18000, 22144, 26000};       // 8 / 7 / 6 workgroups per CU
+    for (int lds : ldss) {
+      for (int work : works) {
+        char name[96];
+        snprintf(name, sizeof name, "unit memory, lds %d, work %d x16 fma", lds, work);
+        time(name, [&] {hipLaunchKernelGGL(unit_memory<2>, dim3(16, 6, scans), dim3(256), lds, 0, pts, lab, cur, rec, idx, out, work);}, ugb);
+      }
+    }
+#define UM(NAME, MAPV, GV, OUTV, LDS, GBV) \
+    time(NAME, [&] {hipLaunchKernelGGL((unit_memory<MAPV, GV, OUTV>), dim3(R / GV, 6, scans), dim3(64 * GV), LDS, 0, pts, lab, cur, rec, idx, out, 64);}, GBV)
+    UM("plain map, work 64", 0, 4, 7, 22144, ugb);
+    UM("turned, work 64", 1, 4, 7, 22144, ugb);
+    UM("pairs: no outputs at all", 2, 4, 0, 22144, rgb);
+    UM("pairs: labels only", 2, 4, 1, 22144, rgb + lgb);
+    UM("pairs: curvature only", 2, 4, 2, 22144, rgb + cgb);
+    UM("pairs: records only", 2, 4, 4, 22144, rgb + fgb);
+    UM("pairs: labels + curvature", 2, 4, 3, 22144, rgb + lgb + cgb);
+    UM("pairs: labels + records (no curvature)", 2, 4, 5, 22144, rgb + lgb + fgb);
+    UM("pairs: l + c + records as 32 B per feature", 2, 4, 11, 22144, ugb);
+    UM("pairs: l + c + records by one store per array", 2, 4, 19, 22144, ugb);
+    UM("pairs: l + c + 32 B records by one store", 2, 4, 35, 22144, ugb);
+    UM("pairs: l + c + 32 B records by one store, slots of 64", 2, 4, 259, 22144, ugb);
+    UM("pairs: l + c + 20 B records packed, three dword stores", 2, 4, 515, 22144, ugb);
+    UM("pairs: l + c + 32 B records, non-temporal dwords", 2, 4, 1027, 22144, ugb);
+    UM("pairs: l + c + 32 B records chunk by chunk, slots of 64", 2, 4, 2051, 22144, ugb);
+    UM("pairs: l + c + records (again)", 2, 4, 7, 22144, ugb);
+    UM("pairs: l + c + 32 B records by one store (again)", 2, 4, 35, 22144, ugb);
+    UM("8 rings per workgroup, turned, all outputs", 2, 8, 7, 44288, ugb);
+    UM("16 rings per workgroup, turned, all outputs", 2, 16, 7, 88576, ugb);
+    UM("8 rings per workgroup, no outputs", 2, 8, 0, 44288, rgb);
+    UM("16 rings per workgroup, no outputs", 2, 16, 0, 88576, rgb);
+  }
   return 0;
 }
