@@ -1059,20 +1059,26 @@ struct UnitLds
 {
   static constexpr int kSpan = 64 * CH;
   static constexpr int kBitWords = 2 * (CH + 2);      // dwords per array; position p is bit p + 64
+  // (the bit arrays come first and a pad last: the rows form of the window stages reads up to 2 CH values before r[0] and
+  // behind the last c[] -- positions outside every block, whose results are thrown away -- and those reads stay inside the
+  // wave's own slab)
+  uint32_t bits[kUnitBitArrays][kBitWords];
   double r[kSpan];                                            // (organised-scan kernel: z of the hand-over until stage B)
   union {
     double c[kSpan + 2];                                      // from stage E on
     float2 pxy[kSpan + 2];                                    // stages A-C: x, y by position
   };
-  uint32_t bits[kUnitBitArrays][kBitWords];
   // slab stride = 8 dwords mod 32: the four slabs of a workgroup start 8 LDS banks apart, so the hand-over stores of the
   // organised-scan kernel (16 lanes = 4 columns x 4 slabs, 8 bytes each) fall on 16 different bank pairs
   static constexpr int kBaseDwords = (kSpan * 8 + (kSpan + 2) * 8 + kUnitBitArrays * kBitWords * 4) / 4;
-  static constexpr int kPadDwords = ((8 - kBaseDwords % 32) + 32) % 32;
-  uint32_t pad_[kPadDwords ? kPadDwords : 32];
+  static constexpr int kMinPadDwords = 2 * (2 * CH - 2);      // 2 CH - 2 doubles behind c[kSpan + 2]
+  static constexpr int kPadDwords = ((8 - kBaseDwords % 32) + 32) % 32 + (((8 - kBaseDwords % 32) + 32) % 32 < kMinPadDwords ? 32 : 0);
+  uint32_t pad_[kPadDwords];
 };
 static_assert(sizeof(UnitLds<5>) % 128 == 32 && sizeof(UnitLds<3>) % 128 == 32 && sizeof(UnitLds<4>) % 128 == 32 &&
   sizeof(UnitLds<6>) % 128 == 32 && sizeof(UnitLds<12>) % 128 == 32, "slab stride");
+static_assert(7 * 4 * sizeof(UnitLds<5>) <= 160 * 1024 && 6 * 4 * sizeof(UnitLds<6>) <= 160 * 1024 && 8 * 4 * sizeof(UnitLds<4>) <= 160 * 1024,
+  "workgroups per CU the launch bounds count on");
 #ifndef LFX_UNIT_WAVES_CH5
 #define LFX_UNIT_WAVES_CH5 7
 #endif
@@ -1136,7 +1142,24 @@ __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)
       : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
         "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
   } else {
-    static_assert(NW == 1 || NW == 3 || NW == 7 || NW == 9, "add the wait for this window width");
+    static_assert(NW == 1 || NW == 3 || NW == 7 || NW == 8 || NW == 9 || NW == 10 || NW == 13 || NW == 14, "add the wait for this window width");
+    if constexpr (NW == 8) {
+      asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+    }
+    if constexpr (NW == 10) {
+      asm volatile ("s_waitcnt lgkmcnt(0)"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]));
+    }
+    if constexpr (NW == 13) {
+      asm volatile ("s_waitcnt lgkmcnt(0)"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
+          "+v"(w[11]), "+v"(w[12]));
+    }
+    if constexpr (NW == 14) {
+      asm volatile ("s_waitcnt lgkmcnt(0)"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
+          "+v"(w[11]), "+v"(w[12]), "+v"(w[13]));
+    }
     if constexpr (NW == 1) {asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]));}
     if constexpr (NW == 3) {asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));}
     if constexpr (NW == 7) {
@@ -1271,10 +1294,14 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {return (uint32_
 template<int CH, int PT>
 __device__ __forceinline__ uint32_t row_frame(uint32_t own)
 {
-  static_assert(PT >= 1 && PT <= CH && CH + 2 * PT <= 32, "the halo of a lane's positions must lie in the two lanes next to it");
+  static_assert(PT >= 1 && PT <= 2 * CH && 3 * CH + PT <= 32, "the halo of a lane's positions must lie in the two lanes either side of it");
   const uint32_t below = from_lane_below(own), above = from_lane_above(own);
-  uint32_t f = (own << PT) | (below >> (CH - PT));
-  if constexpr (CH == PT) {f |= above << (PT + CH);} else {f |= (above & ((1u << PT) - 1u)) << (PT + CH);}
+  uint32_t f = (own << PT) | (above << (PT + CH));                   // (bits beyond the frame's CH + 2 PT meet no mask)
+  if constexpr (PT >= CH) {f |= below << (PT - CH);} else {f |= below >> (CH - PT);}
+  if constexpr (PT > CH) {
+    f |= from_lane_below(below) >> (2 * CH - PT);
+    f |= from_lane_above(above) << (PT + 2 * CH);
+  }
   return f;
 }
 
@@ -1630,11 +1657,13 @@ __device__ __forceinline__ uint32_t unit_core(
   // ROWS: for the two window stages (E and the order masks of F) a lane takes CH CONSECUTIVE positions, CH * lane + d,
   // instead of one position per chunk: the windows of its positions overlap, so it reads 2 PT + CH values where the chunk
   // form reads CH x (2 PT + 1) -- 15 against 55 LDS reads per stage.  (Lane stride CH doubles: conflict-free for odd CH.)
-  // Only the first and the last lane would read outside the slab; their window is moved inside, and what they then compute
-  // is thrown away: with PT <= CH <= PT + 1 all their positions lie outside any block (a block keeps PT + 1 positions away
-  // from either end of the span).  Round 5: the occlusion fills, the reach and the pick rounds are in the rows form too
-  // (kRowPick; see row_frame above) and the labels come back to the chunk form as ONE word per lane.
-  constexpr bool kRows = PT > 0 && (CH == PT || CH == PT + 1);
+  // The first and the last lanes' windows reach outside the two slabs: into the bit arrays before r[], the pad behind c[]
+  // (UnitLds) -- finite or not, what is computed from such a value belongs to a position within PT of either end of the
+  // slab, outside every block (a block keeps PT + 1 positions away from both ends of the span), and is thrown away: the
+  // curvature is written as 0 there and the order mask of such a position meets an empty reach.  Round 5: the occlusion
+  // fills, the reach and the pick rounds are in the rows form too (kRowPick; see row_frame above) and the labels come back
+  // to the chunk form as ONE word per lane.  For every compile-time PT a span of 3 .. 6 chunks can hold.
+  constexpr bool kRows = PT > 0 && PT <= 2 * CH && CH <= 6;
   constexpr bool kRowPick = kRows && !FULL;
   constexpr int kRowWin = kRows ? 2 * PT + CH : 1;
   constexpr int kSetStride = CH < 4 ? 4 : CH;          // rows -> chunk form: the sets of a lane's word lie this far apart (final_label)
@@ -1667,9 +1696,7 @@ __device__ __forceinline__ uint32_t unit_core(
   LFX_WAVE_SYNC();        // the x / y slab is dead from here on: the curvature slab takes its place
   LFX_STAMP(5);
   // ---- E. curvature of the block's points (curvature.cpp:44-50); borders and halo stay 0 (by rows where kRows, see above)
-  int row_base = p0 - PT;
-  row_base = row_base < 0 ? 0 : row_base;
-  row_base = row_base > 64 * CH - kRowWin ? 64 * CH - kRowWin : row_base;
+  const int row_base = p0 - PT;
   if constexpr (kRows) {
     double w[kRowWin];
     lds_window_f64(&U.r[row_base], w);
@@ -1807,32 +1834,6 @@ __device__ __forceinline__ uint32_t unit_core(
     reinterpret_cast<u32_alias_t *>(U.r)[lane] =
       by_e | by_s << kSetStride | sel_s << (2 * kSetStride) | sel_e << (3 * kSetStride) | occ_rows << (4 * kSetStride);
     LFX_WAVE_SYNC();
-  } else if constexpr (kRows) {
-    // (the range slab is dead since stage E: its first half passes the masks from the lanes that made them to the lanes
-    // of the chunk form, which everything after this works in)
-    u32_alias_t * const pass_on = reinterpret_cast<u32_alias_t *>(U.r);
-    const uint32_t keep = row_base == p0 - PT ? ~0u : 0u;       // (a moved window: positions outside any block, no candidates)
-    double w[kRowWin];
-    lds_window_f64(&U.c[row_base], w);
-    // (forcing the bits in as the carry of an add, one vector instruction per compare and fewer instructions by a third,
-    // ran 8 % SLOWER in the whole kernel than the selects the compiler builds the word from: measured, round 4)
-#pragma unroll
-    for (int d = 0; d < CH; d++) {
-      const double ci = w[d + PT];
-      uint32_t m = 0;
-#pragma unroll
-      for (int t = PT; t >= 1; t--) {m = m + m + (uint32_t)(w[d + PT + t] < ci);}
-      m = m + m;
-#pragma unroll
-      for (int t = 1; t <= PT; t++) {m = m + m + (uint32_t)(w[d + PT - t] <= ci);}
-      m <<= 16 - PT;
-      m |= ci >= edge_thr ? kEdgeCand : 0u;
-      m |= ci <= surf_thr ? kSurfCand : 0u;
-      pass_on[p0 + d] = m & keep;
-    }
-    LFX_WAVE_SYNC();
-#pragma unroll
-    for (int k = 0; k < CH; k++) {lt[k] = k < K ? pass_on[64 * k + lane] : 0u;}
   } else {
     // order masks, see order_masks(); the slab has no pad here: neighbours are read at clamped
     // positions, and what a clamped read yields is masked by `reach` (zero outside the block)
