@@ -83,7 +83,7 @@ def parse():
 def kernels_sha256():
     """Hash of the extraction kernels' sources: ties profiles/pmc_traffic.json to the code it was measured on."""
     h = hashlib.sha256()
-    for name in ("lfx_kernels_common.hpp", "lfx_kernels_extract.hpp"):
+    for name in ("lfx_kernels_common.hpp", "lfx_kernels_unit.hpp", "lfx_kernels_extract.hpp"):
         with open(os.path.join(ROOT, "lidar_feature_extraction_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -94,7 +94,7 @@ WORKLOADS = {(64, 1800): "hdl64-64x1800 (BASELINE.json configs[2])", (16, 1800):
              (64, 3600): "64x3600 (a 0.1-degree sensor: units of 612 positions, the 12-chunk form of the unit kernels; not a BASELINE.json configuration)"}
 
 
-def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, repeats=3, curvature=True):
+def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, repeats=3, curvature=True, params="code defaults"):
     """One of BASELINE.json's other configurations, measured inside the same run as the headline (a few steps, the same
     fences, HIP-event kernel durations, one scan checked against the oracle): so that every number DESIGN.md quotes for them
     has a driver-observed line behind it.  Single GPU, one stream, inputs resident in HBM."""
@@ -114,7 +114,12 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
     # curvature = False: a context created without LFX_OUT_CURVATURE (the per-point curvature array is not produced; the
     # clouds, the labels and the index sets are): 17 instead of 25 algorithmic bytes per point
     from lidar_feature_extraction_amd import binding as LB
-    fx = FeatureExtraction(HyperParameters(), device=dev.index, max_points_per_scan=max(len(c) for c in clouds), max_batch=batch,
+    # params: "code defaults" (hyper_parameter.hpp:35-43) or "launch_yaml" (lidar_feature_extraction.param.yaml:3-10, what the
+    # reference's launch file starts the node with: padding 2, 3 degrees, edge threshold 50, max_range 1000)
+    hp = HyperParameters.launch_yaml() if params == "launch_yaml" else HyperParameters()
+    op = oracle.Params(hp.padding, hp.neighbor_degree_threshold, hp.distance_diff_threshold, hp.parallel_beam_min_range_ratio,
+                       hp.edge_threshold, hp.surface_threshold, hp.min_range, hp.max_range, hp.n_blocks)
+    fx = FeatureExtraction(hp, device=dev.index, max_points_per_scan=max(len(c) for c in clouds), max_batch=batch,
                            max_points_per_ring=max(cols, 64), max_rings=rings, drop_zero_points=drop_zero_fraction > 0.0,
                            outputs=0 if curvature else (LB.OUT_FEATURES | LB.OUT_LABELS | LB.OUT_SORTED_INDEX))
     stream = torch.cuda.current_stream().cuda_stream
@@ -143,7 +148,7 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
         feats.append(len(g.edge_index) + len(g.surface_index))
         if j == 0:
             keep = np.nonzero(valid[0])[0]
-            w = oracle.extract(np.ascontiguousarray(clouds[0][keep]), canonical_ties=False)
+            w = oracle.extract(np.ascontiguousarray(clouds[0][keep]), op, canonical_ties=False)
             parity = bool(np.array_equal(g.labels[keep], w["labels"]) and (not curvature or g.curvature[keep].tobytes() == w["curvature"].tobytes())
                           and np.array_equal(g.edge_index, keep[w["edge_index"]].astype(np.uint32))
                           and np.array_equal(g.surface_index, keep[w["surface_index"]].astype(np.uint32))
@@ -155,9 +160,11 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
     name = WORKLOADS.get((rings, cols), "%dx%d" % (rings, cols))
     if drop_zero_fraction > 0.0:
         name += ", %.0f %% of the returns written as (0, 0, 0) and filtered (convert.py:162-163)" % (100 * drop_zero_fraction)
+    if params != "code defaults":
+        name += ", parameters of the reference's launch file (lidar_feature_extraction.param.yaml:3-10)"
     if not curvature:
         name += ", a context without LFX_OUT_CURVATURE (clouds, labels and index sets only: what the node publishes; 17 algorithmic bytes per point)"
-    return {"workload": name, "scans_per_step": batch, "steps": steps, "value": round(batch * steps / dt, 2), "unit": "scans/s",
+    return {"workload": name, "params": params, "scans_per_step": batch, "steps": steps, "value": round(batch * steps / dt, 2), "unit": "scans/s",
             "ms_per_step": round(1e3 * dt / steps, 4), "dominant_kernel": dominant,
             "frac": round(algo / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
             "whole_path_frac": round(algo / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
@@ -352,6 +359,17 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gather_ms_per_step = float(t.item())
 
+    # what THIS box gives right now (outside the timed region, ~50 ms): a plain float4 copy of 1 GiB and the shader clock
+    # with every SIMD busy -- so that a slower box and a slower kernel can be told apart in one line of the driver's record
+    box = None
+    try:
+        copy_gbs, clock_mhz = fx.box_calibration(0, stream)
+        box = {"copy_gbs": round(copy_gbs, 1), "clock_mhz": round(clock_mhz, 1),
+               "note": "lfx_box_calibration right after the timed region: read + written bytes per second of a float4 copy of 1 GiB (best of 3); "
+                       "shader clock from a chain of dependent 32-bit adds, four waves per SIMD on every CU"}
+    except Exception as e:                 # noqa: BLE001
+        box = {"error": "%s: %s" % (type(e).__name__, e)}
+
     kt = {}
     for f in fxs:
         for k, (ms, cnt) in f.kernel_times().items():
@@ -401,7 +419,23 @@ def main():
                                    if traffic else ("stale: profiles/pmc_traffic.json was measured on other kernel sources" if traffic_stale else None)),
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items()},
-                "whole_path_frac": round(algo_bytes / (max(sum_us, 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+                # the whole path by the wall clock of the timed region (as the side configs; N > 1: this rank's share of it) and
+                # by the sum of the kernels' own HIP-event spans
+                "whole_path_frac": round(algo_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                "whole_path_frac_kernel_sum": round(algo_bytes / (max(sum_us, 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+    if box and box.get("copy_gbs"):
+        # against what a copy reaches on this box at this moment: the dominant kernel's REAL traffic where the committed PMC
+        # profile is of these sources (else its algorithmic bytes), and the same for the whole path
+        roofline["frac_of_box_copy"] = round((traffic if traffic else algo_bytes) / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9 / box["copy_gbs"], 5)
+        roofline["frac_of_box_copy_bytes"] = "hbm traffic (PMC)" if traffic else "algorithmic"
+        roofline["algorithmic_frac_of_box_copy"] = round(achieved / box["copy_gbs"], 5)
+    # the ceiling of this path with 32-byte records: the bytes that have to cross HBM (PMC: 32 B per point read, 9 B written,
+    # the feature records written, read and written again) at the rate a copy reaches, as a fraction of the spec peak in
+    # ALGORITHMIC bytes -- what `frac` could be at best
+    if traffic and box and box.get("copy_gbs"):
+        tj_all = sum(v for v in tj.get("hbm_bytes_per_launch", {}).values() if isinstance(v, (int, float)))
+        roofline["ceiling"] = {"whole_path_frac_at_box_copy_rate": round(algo_bytes / (tj_all / (box["copy_gbs"] * 1e9)) / 1e9 / HBM_PEAK_GBS, 5),
+                               "hbm_bytes_per_step": int(tj_all)}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, bounded sample
     cpu = None
@@ -534,7 +568,7 @@ def main():
         torch.cuda.empty_cache()
         configs = []
         for args in ((16, 900, 1024, 20, 3), (16, 1800, 1024, 20, 3), (128, 2048, 32, 40, 5), (64, 1800, 1024, 8, 2, 0.05),
-                     (64, 3600, 256, 8, 2), (64, 1800, 1024, 8, 2, 0.0, 3, False)):
+                     (64, 3600, 256, 8, 2), (64, 1800, 1024, 8, 2, 0.0, 3, False), (64, 1800, 1024, 8, 2, 0.0, 3, True, "launch_yaml")):
             try:
                 configs.append(side_config(dev, *args))
             except Exception as e:         # noqa: BLE001  (a side measurement must not cost the line its headline)
@@ -557,7 +591,7 @@ def main():
                        "streams": 1 if use_gather else n_streams,
                        "sharding": "scan i -> gpu i mod N" + ((", RCCL gather of clouds to rank %s per step, %d in flight" % ("k mod N of step k" if a.gather_dst == "rotate" else a.gather_dst, n_lanes)) if use_gather else "") +
                                    (" (gather unavailable: %s)" % gather_error if gather_error else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
+            "roofline": roofline, "box": box, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
             "configs": configs,
         }
         if world > 1:

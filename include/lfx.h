@@ -511,6 +511,11 @@ int lfx_set_profiling_interval(lfx_ctx *ctx, uint32_t every_n_batches);
 /* Sum of HIP-event durations per kernel since profiling was enabled, and launches counted. */
 int lfx_kernel_times(lfx_ctx *ctx, double ms[LFX_N_KERNELS], uint64_t launches[LFX_N_KERNELS]);
 const char *lfx_kernel_name(int k);
+/* What THIS device gives at this moment, so that a rate measured on it can be told from a rate measured on another box of the
+ * same model: copy_gbs = bytes read + bytes written per second by a plain float4 copy of `bytes` bytes (0: 1 GiB), the best
+ * of three; clock_mhz = the shader clock a wave sees while every SIMD of the device runs a chain of dependent 32-bit adds
+ * (a SIMD-32 takes a wave in two cycles, four waves share it).  Allocates and frees 2 x bytes of device memory; about 10 ms; on `stream` (a hipStream_t, or NULL). */
+int lfx_box_calibration(lfx_ctx *ctx, size_t bytes, void *stream, double *copy_gbs, double *clock_mhz);
 
 #ifdef __cplusplus
 }

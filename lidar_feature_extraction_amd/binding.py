@@ -88,20 +88,25 @@ EXPORTS = [
     "lfx_localize_batch", "lfx_localize_host",
     "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
-    "lfx_route_choice", "lfx_set_log_callback",
+    "lfx_route_choice", "lfx_set_log_callback", "lfx_box_calibration",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
 
-_lib = None
+HOOKS_LIB_PATH = os.path.join(_HERE, "_lib", "liblfx_testhooks.so")
+"""Test infrastructure: the same library built -DLFX_TEST_HOOKS -- the only build whose lfx_create reads the LFX_DEBUG_*
+switches (route pins, span variants, ablation flags) and whose gather takes another RCCL (LFX_RCCL_LIB)."""
+
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(test_hooks=False):
+    """The library (test_hooks: its test-hooks build; with LFX_LIB_PATH set, that file either way)."""
+    path = LIB_PATH if (not test_hooks or os.environ.get("LFX_LIB_PATH")) else HOOKS_LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError(
-            "liblfx.so is not built (%s): run `python __graft_entry__.py` -- there is no CPU fallback" % LIB_PATH)
+            "liblfx.so is not built (%s): run `python __graft_entry__.py` -- there is no CPU fallback" % path)
     # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (SONAME libamdhip64.so.7,
     # the name liblfx.so needs).  Loading torch first makes liblfx.so bind to that copy; the other
     # order would put a second runtime into the process, and the later one sees no GPU.
@@ -109,7 +114,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     L.lfx_default_params.argtypes = [C.POINTER(Params)]
     L.lfx_default_params.restype = None
@@ -177,10 +182,11 @@ def load():
     L.lfx_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.lfx_kernel_name.argtypes = [i32]
     L.lfx_kernel_name.restype = C.c_char_p
-    _lib = L
+    L.lfx_box_calibration.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _libs[path] = L
     return L
 
 
-def check(ctx, rc):
+def check(ctx, rc, lib=None):
     if rc != 0:
-        raise LfxError(rc, (load().lfx_last_error(ctx) or b"").decode())
+        raise LfxError(rc, ((lib or load()).lfx_last_error(ctx) or b"").decode())

@@ -7,6 +7,14 @@
 #include <cstddef>
 #include "lfx_kernels_extract.hpp"
 
+// The switches tests and experiments pin routes and variants with exist in the test-hooks build of the library
+// only (liblfx_testhooks.so, -DLFX_TEST_HOOKS): the shipped library reads no environment variable in lfx_create.
+#ifdef LFX_TEST_HOOKS
+#define LFX_DEBUG_ENV(name) std::getenv("LFX_DEBUG_" name)
+#else
+#define LFX_DEBUG_ENV(name) static_cast<const char *>(nullptr)
+#endif
+
 using namespace lfx_host;
 
 namespace
@@ -293,23 +301,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
         pts, c->scan_begin.p, c->max_rings, c->cap, c->xform.p, counters);
     }
     const uint32_t groups = (c->max_rings + 3u) / 4u;
-    void (*kern)(lfx::Params, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t *,
-      const lfx::UnitTables *, const uint32_t *, const uint32_t *) = nullptr;
-#define LFX_PICK_ORG(DEFV, XFV) \
-    (c->unit_chunks == 5 ? &lfx::ring_unit_org_kernel<5, DEFV, XFV> : c->unit_chunks == 4 ? &lfx::ring_unit_org_kernel<4, DEFV, XFV> : \
-     c->unit_chunks == 3 ? &lfx::ring_unit_org_kernel<3, DEFV, XFV> : c->unit_chunks == 6 ? &lfx::ring_unit_org_kernel<6, DEFV, XFV> : \
-     &lfx::ring_unit_org_kernel<lfx::kUnitMaxChunks, DEFV, XFV>)
-    if (c->default_thresholds) {
-      kern = xf ? LFX_PICK_ORG(true, true) : LFX_PICK_ORG(true, false);
-    } else {
-      kern = xf ? LFX_PICK_ORG(false, true) : LFX_PICK_ORG(false, false);
-    }
-#undef LFX_PICK_ORG
     {
       Timed t(c, 7, st);
-      hipLaunchKernelGGL(kern, dim3(groups, (uint32_t)c->dev.B, batch), dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-        c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p, c->xform.p,
-        c->scan_geom.p);
+      const UnitOrgArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p,
+        c->xform.p, c->scan_geom.p};
+      launch_unit_org(c->unit_variant, (int)c->unit_chunks, xf, dim3(groups, (uint32_t)c->dev.B, batch), c->unit_lds_pad, st, a);
     }
   }
   // ---- the bucketing route, over the scans on the fall-back list
@@ -339,17 +335,10 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       Timed t(c, 1, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
       // the looping form only where the list's length is a guess (behind the organised-scan kernel)
-#define LFX_PICK_UNIT(DEFV, LOOPV) \
-      (c->unit_chunks == 5 ? &lfx::ring_unit_kernel<false, 5, DEFV, LOOPV> : c->unit_chunks == 4 ? &lfx::ring_unit_kernel<false, 4, DEFV, LOOPV> : \
-       c->unit_chunks == 3 ? &lfx::ring_unit_kernel<false, 3, DEFV, LOOPV> : c->unit_chunks == 6 ? &lfx::ring_unit_kernel<false, 6, DEFV, LOOPV> : \
-       &lfx::ring_unit_kernel<false, lfx::kUnitMaxChunks, DEFV, LOOPV>)
-      auto kern = c->default_thresholds ? (fused ? LFX_PICK_UNIT(true, true) : LFX_PICK_UNIT(true, false)) :
-        (fused ? LFX_PICK_UNIT(false, true) : LFX_PICK_UNIT(false, false));
-#undef LFX_PICK_UNIT
-      hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, fb_grid),
-        dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
-        defer_count, c->defer_list.p, fb_count, c->fb_list.p, 0u);
+      const UnitArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
+        defer_count, c->defer_list.p, fb_count, c->fb_list.p, 0u};
+      launch_unit(c->unit_variant, false, (int)c->unit_chunks, fused, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, fb_grid),
+        c->unit_lds_pad, st, a);
     }
     const uint32_t redo_cap = choice.redo_cap;
     {
@@ -363,15 +352,9 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 3, st);
       const uint32_t units = redo_cap * (uint32_t)c->dev.B;
-      auto kern = &lfx::ring_unit_kernel<true, lfx::kUnitMaxChunks, false>;
-      if (c->unit_chunks == 6) {kern = &lfx::ring_unit_kernel<true, 6, false>;}
-      if (c->unit_chunks == 5) {kern = &lfx::ring_unit_kernel<true, 5, false>;}
-      if (c->unit_chunks == 4) {kern = &lfx::ring_unit_kernel<true, 4, false>;}
-      if (c->unit_chunks == 3) {kern = &lfx::ring_unit_kernel<true, 3, false>;}
-      hipLaunchKernelGGL(kern, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves),
-        dim3(64 * lfx::kUnitWaves), c->unit_lds_pad, st,
-        c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
-        slow_count, c->slow_list.p, redo_count, c->redo_list.p, redo_cap);
+      const UnitArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
+        slow_count, c->slow_list.p, redo_count, c->redo_list.p, redo_cap};
+      launch_unit(c->unit_variant, true, (int)c->unit_chunks, false, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves), c->unit_lds_pad, st, a);
     }
   }
   {
@@ -742,10 +725,11 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   {
     lfx_params d;
     lfx_default_params(&d);
-    c->default_thresholds = params->padding == 5 && params->distance_diff_threshold == d.distance_diff_threshold &&
+    const bool defaults = params->padding == 5 && params->distance_diff_threshold == d.distance_diff_threshold &&
       params->parallel_beam_min_range_ratio == d.parallel_beam_min_range_ratio && params->edge_threshold == d.edge_threshold &&
       params->surface_threshold == d.surface_threshold && params->min_range == d.min_range && params->max_range == d.max_range &&
-      std::getenv("LFX_DEBUG_GENERIC_THRESHOLDS") == nullptr;
+      LFX_DEBUG_ENV("GENERIC_THRESHOLDS") == nullptr;
+    c->unit_variant = defaults ? 0 : (params->padding == 5 ? 1 : (params->padding == 2 ? 2 : 3));
   }
   const lfx_layout & L = config->layout;
   if (L.point_step == 0) {
@@ -794,24 +778,24 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     // (3 .. 6 chunks, or the long form for anything above -- blocks of up to 768 positions; longer ones are the
     // workgroup-per-ring kernel's)
     c->unit_chunks = (uint32_t)(ch < 3 ? 3 : (ch > 6 ? lfx::kUnitMaxChunks : ch));
-    if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_CHUNKS")) {c->unit_chunks = (uint32_t)std::atoi(dbg);}
+    if (const char * dbg = LFX_DEBUG_ENV("UNIT_CHUNKS")) {c->unit_chunks = (uint32_t)std::atoi(dbg);}
     if (c->unit_chunks < 3 || c->unit_chunks > 6) {c->unit_chunks = (uint32_t)lfx::kUnitMaxChunks;}
   }
-  if (const char * dbg = std::getenv("LFX_DEBUG_RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
-  c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && std::getenv("LFX_DEBUG_NO_FAST_PATH") == nullptr;
+  if (const char * dbg = LFX_DEBUG_ENV("RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
+  c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && LFX_DEBUG_ENV("NO_FAST_PATH") == nullptr;
   // the organised-scan kernel needs to know the sensor's ring count (max_rings given) and reads PointXYZIR records
   c->fused_possible = c->fast_path && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
-  if (const char * dbg = std::getenv("LFX_DEBUG_FUSED")) {c->route_pins.fused = std::atoi(dbg) != 0 ? 1 : 0;}
-  if (const char * dbg = std::getenv("LFX_DEBUG_TOTALS_KERNEL")) {c->totals_env = std::atoi(dbg) != 0 ? 1 : 0;}
-  if (const char * dbg = std::getenv("LFX_DEBUG_SHORT_TAIL")) {c->route_pins.short_tail = std::atoi(dbg) != 0 ? 1 : 0;}
-  if (const char * dbg = std::getenv("LFX_DEBUG_XFORM")) {c->route_pins.xform = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = LFX_DEBUG_ENV("FUSED")) {c->route_pins.fused = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = LFX_DEBUG_ENV("TOTALS_KERNEL")) {c->totals_env = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = LFX_DEBUG_ENV("SHORT_TAIL")) {c->route_pins.short_tail = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = LFX_DEBUG_ENV("XFORM")) {c->route_pins.xform = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
-  if (const char * dbg = std::getenv("LFX_DEBUG_REDO_CAP")) {c->route_pins.redo_cap = (uint32_t)std::atoi(dbg);}
-  if (const char * dbg = std::getenv("LFX_DEBUG_PRE_ORDER")) {c->route_pins.pre_order = std::atoi(dbg) != 0 ? 1 : 0;}
-  if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_FLAGS")) {c->unit_flags = (uint32_t)std::atoi(dbg);}
-  if (const char * dbg = std::getenv("LFX_DEBUG_UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}
-  if (const char * dbg = std::getenv("LFX_DEBUG_RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = LFX_DEBUG_ENV("REDO_CAP")) {c->route_pins.redo_cap = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = LFX_DEBUG_ENV("PRE_ORDER")) {c->route_pins.pre_order = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = LFX_DEBUG_ENV("UNIT_FLAGS")) {c->unit_flags = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = LFX_DEBUG_ENV("UNIT_LDS_PAD")) {c->unit_lds_pad = (uint32_t)std::atoi(dbg);}
+  if (const char * dbg = LFX_DEBUG_ENV("RING_THREADS")) {c->ring_threads = (uint32_t)std::atoi(dbg);}
   c->ring_lds = lfx::ring_lds_bytes(c->cap);
   c->order_lds = lfx::order_lds_bytes(c->cap);
   c->max_chunks = (c->max_points + lfx::kChunkPoints - 1) / lfx::kChunkPoints;
@@ -1253,15 +1237,4 @@ int lfx_kernel_times(lfx_ctx * c, double ms[LFX_N_KERNELS], uint64_t launches[LF
 
 }  // extern "C"
 
-#ifdef LFX_STAMPS
-// Diagnostic build only: copy the unit kernel's stage stamps (see LFX_STAMP) to the host.
-extern "C" int lfx_debug_read_stamps(unsigned long long * out, int n)
-{
-  const int total = lfx::kStampUnits * lfx::kStampSlots;
-  if (!out || n < total) {return -total;}
-  if (hipDeviceSynchronize() != hipSuccess) {return LFX_ERR_HIP;}
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lfx::g_unit_stamps), sizeof(unsigned long long) * total) != hipSuccess) {return LFX_ERR_HIP;}
-  return total;
-}
-#endif
 

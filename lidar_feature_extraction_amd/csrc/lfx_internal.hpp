@@ -16,13 +16,57 @@
 
 #include "lfx_kernels_common.hpp"
 
-namespace lfx
-{
-struct UnitTables;      // lfx_kernels_extract.hpp
-}
-
 namespace lfx_host
 {
+
+// The unit kernels live in four translation units of their own, one per variant of the parameters (lfx_unit_v0.hip ...
+// lfx_unit_v3.hip over lfx_unit_variant.inl; UnitVariant in lfx_kernels_unit.hpp); run_batch launches them through these.
+struct UnitOrgArgs
+{
+  lfx::Params prm;
+  uint32_t cap, flags, max_rings, drop_zero;
+  const uint8_t * pts;
+  const uint32_t * scan_begin;
+  uint32_t * ring_count;
+  const lfx::UnitTables * tab;
+  const uint32_t * xform, * geom;
+};
+struct UnitArgs
+{
+  lfx::Params prm;
+  uint32_t cap, flags, max_rings;
+  const uint32_t * ring_count;
+  const float2 * sxy;
+  const float * sz;
+  const uint32_t * sidx;
+  const lfx::UnitTables * tab;
+  uint32_t * defer_count, * defer_list;
+  const uint32_t * list_count, * list;
+  uint32_t redo_cap;
+};
+#define LFX_DECLARE_UNIT_LAUNCHERS(V) \
+  void launch_unit_org_v##V(int chunks, bool xf, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a); \
+  void launch_unit_v##V(bool second, int chunks, bool loop, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitArgs & a);
+LFX_DECLARE_UNIT_LAUNCHERS(0) LFX_DECLARE_UNIT_LAUNCHERS(1) LFX_DECLARE_UNIT_LAUNCHERS(2) LFX_DECLARE_UNIT_LAUNCHERS(3)
+#undef LFX_DECLARE_UNIT_LAUNCHERS
+inline void launch_unit_org(int variant, int chunks, bool xf, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a)
+{
+  switch (variant) {
+    case 0: launch_unit_org_v0(chunks, xf, grid, lds_pad, st, a); break;
+    case 1: launch_unit_org_v1(chunks, xf, grid, lds_pad, st, a); break;
+    case 2: launch_unit_org_v2(chunks, xf, grid, lds_pad, st, a); break;
+    default: launch_unit_org_v3(chunks, xf, grid, lds_pad, st, a); break;
+  }
+}
+inline void launch_unit(int variant, bool second, int chunks, bool loop, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitArgs & a)
+{
+  switch (variant) {
+    case 0: launch_unit_v0(second, chunks, loop, grid, lds_pad, st, a); break;
+    case 1: launch_unit_v1(second, chunks, loop, grid, lds_pad, st, a); break;
+    case 2: launch_unit_v2(second, chunks, loop, grid, lds_pad, st, a); break;
+    default: launch_unit_v3(second, chunks, loop, grid, lds_pad, st, a); break;
+  }
+}
 
 template<typename T>
 struct DevBuf
@@ -107,7 +151,7 @@ struct lfx_ctx
   size_t total_cap = 0, ring_lds = 0, order_lds = 0;
   uint32_t stage_flags = LFX_STAGE_ALL;  // LFX_DEBUG_RING_FLAGS overrides it for slow-kernel ablations (wrong results)
   uint32_t unit_lds_pad = 0;             // LFX_DEBUG_UNIT_LDS_PAD: extra LDS per workgroup (occupancy experiments)
-  bool default_thresholds = false;       // padding 5 and the seven thresholds of hyper_parameter.hpp:35-43: literal-threshold unit kernel
+  int unit_variant = 3;                  // which compilation of the unit kernels serves the parameters (UnitVariant, lfx_kernels_unit.hpp)
   uint32_t unit_chunks = 6;              // chunks of 64 positions per unit wave (3..6), from the configured ring length
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   uint32_t drop_zero = 0;                // lfx_config::drop_zero_points

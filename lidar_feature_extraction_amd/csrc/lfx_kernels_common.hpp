@@ -152,4 +152,61 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
   return t;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Shared by the unit kernels (lfx_kernels_unit.hpp) and the kernels around them (lfx_kernels_extract.hpp)
+constexpr int kUnitWaves = 4;
+constexpr int kUnitMaxBlocks = 64;        // per-unit count tables are sized for n_blocks <= 64
+// Per scan, from the host with the scan's first index (the organised-scan kernel): [0] columns per ring, 0 if the scan is
+// not max_rings x columns with the columns within the ring capacity; [1 + j] boundary j of its rings' blocks, j = 0 .. B
+constexpr int kGeomStride = kUnitMaxBlocks + 2;
+enum { kDeferOrder = 1u, kDeferOther = 2u, kDeferMask = 3u, kRingSorted = 4u /* put in order by ring_order_kernel */ };
+
+constexpr int kUnitMaxChunks = 12;        // the long form: blocks of up to 768 positions (rings of up to ~4 500 points in 6 blocks)
+
+// AHasSmallerPolarAngleThanB for float fields (ring.hpp:54-99): the squares, the product of the
+// y's and the determinant are evaluated in float, each operation rounded on its own.
+__device__ inline bool polar_less(float ax, float ay, float bx, float by)
+{
+  if (ax == bx && ay == by) {return false;}
+  const float lena = ax * ax + ay * ay;
+  const float lenb = bx * bx + by * by;
+  if (lena == 0.f) {
+    if (by == 0.f) {return bx < 0.f;}
+    return by > 0.f;
+  }
+  if (lenb == 0.f) {return ay < 0.f;}
+  if (ay == 0.f) {return (ax >= 0.f) && (by >= 0.f);}
+  if (by == 0.f) {return !((bx >= 0.f) && (ay >= 0.f));}
+  if (ay * by > 0.f) {
+    const float det = ax * by - ay * bx;
+    return det > 0.f;
+  }
+  return ay < 0.f;
+}
+
+
+// Boundary j of the padded block range: index_range.cpp:60-66 with start=P, end=N-P.
+__host__ __device__ inline int block_boundary(int N, int P, int B, int j)
+{
+  const double s = (double)P, e = (double)(N - P), n = (double)B;
+  return (int)(s * (1. - j / n) + e * j / n);
+}
+
+// Output tables of the unit kernel, read through one pointer: sixteen kernel-argument pointers held in
+// scalar registers from the first instruction on crowd out the wave-uniform masks the kernel works
+// with (the scalar file is the scarce one here).  The entries are fetched where they are first needed.
+struct UnitTables
+{
+  uint8_t * label_s;
+  double * curv_s;
+  float4 * rec_pts;
+  uint32_t * rec_idx;
+  uint8_t * ring_status;
+  uint32_t * unit_ne, * unit_ns, * unit_span;
+  uint32_t * ring_flags;
+  uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
+  uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
+};
+
 }  // namespace lfx

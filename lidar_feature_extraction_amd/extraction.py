@@ -7,6 +7,7 @@ construct with HyperParameters, call ExtractFeatures(cloud) per scan.  Everythin
 HIP library through the C ABI (binding.py); nothing is computed in Python.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -92,8 +93,13 @@ class FeatureExtraction:
     """One context = one GPU = one calling thread (feature_extraction.cpp:65-87,185)."""
 
     def __init__(self, params=None, device=0, max_points_per_scan=262144, max_batch=1,
-                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None, outputs=0, stream_hint=0):
-        self._L = B.load()
+                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None, outputs=0, stream_hint=0, test_hooks=None):
+        # test_hooks: the context comes from the test-hooks build of the library (B.HOOKS_LIB_PATH), the only one whose
+        # lfx_create reads the LFX_DEBUG_* switches (tests and tools/ only).  None: that build exactly when such a switch is
+        # set in the environment -- the shipped library would not see it
+        if test_hooks is None:
+            test_hooks = any(k.startswith("LFX_DEBUG_") for k in os.environ)
+        self._L = B.load(bool(test_hooks))
         self.params = params or HyperParameters()
         self._ctx = C.c_void_p()
         # layout: (point_step, off_x, off_y, off_z, off_ring[, ring_datatype, big_endian]) of the records or a
@@ -145,7 +151,7 @@ class FeatureExtraction:
         ptrs = (C.c_void_p * nb)(*[c.ctypes.data for c in clouds])
         ns = (C.c_size_t * nb)(*[len(c) for c in clouds])
         res = (B.ScanResult * nb)()
-        B.check(self._ctx, self._L.lfx_extract_batch(self._ctx, ptrs, ns, nb, res))
+        B.check(self._ctx, self._L.lfx_extract_batch(self._ctx, ptrs, ns, nb, res), self._L)
         return [_result(res[i]) for i in range(nb)]
 
     def submit(self, cloud):
@@ -155,13 +161,13 @@ class FeatureExtraction:
         if cloud.dtype.itemsize != self._step:
             raise TypeError("clouds must be arrays of %d-byte records (POINT_DTYPE for PointXYZIR)" % self._step)
         t = C.c_uint64(0)
-        B.check(self._ctx, self._L.lfx_extract_submit(self._ctx, C.c_void_p(cloud.ctypes.data), len(cloud), C.byref(t)))
+        B.check(self._ctx, self._L.lfx_extract_submit(self._ctx, C.c_void_p(cloud.ctypes.data), len(cloud), C.byref(t)), self._L)
         return int(t.value)
 
     def wait(self, ticket, raw=False):
         """lfx_extract_wait: the ScanFeatures of that ticket (raw=True: the ctypes result, nothing copied)."""
         res = B.ScanResult()
-        B.check(self._ctx, self._L.lfx_extract_wait(self._ctx, C.c_uint64(int(ticket)), C.byref(res)))
+        B.check(self._ctx, self._L.lfx_extract_wait(self._ctx, C.c_uint64(int(ticket)), C.byref(res)), self._L)
         return res if raw else _result(res)
 
     def pinned_like(self, cloud):
@@ -169,7 +175,7 @@ class FeatureExtraction:
         staging it.  Owned by this object (freed by close())."""
         cloud = np.ascontiguousarray(cloud)
         ptr = C.c_void_p()
-        B.check(self._ctx, self._L.lfx_host_alloc(self._ctx, max(cloud.nbytes, 1), C.byref(ptr)))
+        B.check(self._ctx, self._L.lfx_host_alloc(self._ctx, max(cloud.nbytes, 1), C.byref(ptr)), self._L)
         self._pinned.append(ptr)
         buf = (C.c_uint8 * cloud.nbytes).from_address(ptr.value)
         out = np.frombuffer(buf, dtype=cloud.dtype, count=len(cloud))
@@ -273,13 +279,13 @@ class FeatureExtraction:
     def scan_routes(self, n_scans, stream=0):
         """lfx_scan_routes: per scan of the last batch 1 = read in place, 2 = in place through ring transforms, 0 = bucketed."""
         out = np.zeros(n_scans, np.uint8)
-        B.check(self._ctx, self._L.lfx_scan_routes(self._ctx, C.c_void_p(int(stream)), C.c_void_p(out.ctypes.data)))
+        B.check(self._ctx, self._L.lfx_scan_routes(self._ctx, C.c_void_p(int(stream)), C.c_void_p(out.ctypes.data)), self._L)
         return out
 
     def batch_status(self, stream=0):
         """lfx_batch_status: raises LfxError if a scan of the last device batch carries an error bit."""
         bad = C.c_uint32(0)
-        B.check(self._ctx, self._L.lfx_batch_status(self._ctx, C.c_void_p(int(stream)), C.byref(bad)))
+        B.check(self._ctx, self._L.lfx_batch_status(self._ctx, C.c_void_p(int(stream)), C.byref(bad)), self._L)
 
     def extract_batch_device(self, d_points, n_points, stream=0):
         """d_points: device address of the scans' records back to back; asynchronous on `stream`."""
@@ -290,7 +296,7 @@ class FeatureExtraction:
 
     def device_view(self):
         v = B.DeviceView()
-        B.check(self._ctx, self._L.lfx_device_results(self._ctx, C.byref(v)))
+        B.check(self._ctx, self._L.lfx_device_results(self._ctx, C.byref(v)), self._L)
         return v
 
     def pack_features(self, d_edge_out, d_surface_out, d_offsets_out, capacity_points, stream=0):
@@ -319,7 +325,7 @@ class FeatureExtraction:
 
     def download(self, scan, stream=0):
         r = B.ScanResult()
-        B.check(self._ctx, self._L.lfx_download_scan(self._ctx, scan, C.c_void_p(int(stream)), C.byref(r)))
+        B.check(self._ctx, self._L.lfx_download_scan(self._ctx, scan, C.c_void_p(int(stream)), C.byref(r)), self._L)
         return _result(r)
 
     # --- per-stage entry points ------------------------------------------------------------
@@ -386,13 +392,19 @@ class FeatureExtraction:
     # --- measurement ---------------------------------------------------------------------
     def set_profiling(self, on, every=1):
         """HIP events around the kernels of every `every`-th batch (lfx_set_profiling_interval)."""
-        B.check(self._ctx, self._L.lfx_set_profiling_interval(self._ctx, int(every)))
-        B.check(self._ctx, self._L.lfx_set_profiling(self._ctx, int(bool(on))))
+        B.check(self._ctx, self._L.lfx_set_profiling_interval(self._ctx, int(every)), self._L)
+        B.check(self._ctx, self._L.lfx_set_profiling(self._ctx, int(bool(on))), self._L)
+
+    def box_calibration(self, nbytes=0, stream=0):
+        """(copy GB/s, shader clock MHz) of this device now: lfx_box_calibration."""
+        gbs, mhz = C.c_double(0), C.c_double(0)
+        B.check(self._ctx, self._L.lfx_box_calibration(self._ctx, int(nbytes), C.c_void_p(int(stream)), C.byref(gbs), C.byref(mhz)), self._L)
+        return gbs.value, mhz.value
 
     def kernel_times(self):
         ms = (C.c_double * B.LFX_N_KERNELS)()
         cnt = (C.c_uint64 * B.LFX_N_KERNELS)()
-        B.check(self._ctx, self._L.lfx_kernel_times(self._ctx, ms, cnt))
+        B.check(self._ctx, self._L.lfx_kernel_times(self._ctx, ms, cnt), self._L)
         return {self._L.lfx_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(B.LFX_N_KERNELS)}
 
 

@@ -202,3 +202,12 @@ def test_alignment_texts_and_null_arguments(lib):
     assert lib.lfx_localize_batch(null, null, null, 15, 20, C.c_float(1.0), 1, None, None, null) == -1
     assert lib.lfx_localize_host(null, null, null, 15, 20, C.c_float(1.0), null, 0, null, 0, None, None, null) == -1
     lib.lfx_map_destroy(null)                 # a no-op
+
+
+def test_the_shipped_library_reads_no_debug_switch(lib):
+    """The LFX_DEBUG_* switches (route pins, span variants, ablation flags) and the RCCL override exist in the test-hooks
+    build only (liblfx_testhooks.so, -DLFX_TEST_HOOKS): the shipped library does not even hold their names."""
+    data = open(LB.LIB_PATH, "rb").read()
+    assert b"LFX_DEBUG_" not in data and b"LFX_RCCL_LIB" not in data
+    hooks = open(LB.HOOKS_LIB_PATH, "rb").read()
+    assert b"LFX_DEBUG_FUSED" in hooks and b"LFX_RCCL_LIB" in hooks

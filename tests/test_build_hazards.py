@@ -9,7 +9,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lidar_feature_extraction_amd", "csrc")
 BUILD = os.path.join(ROOT, "lidar_feature_extraction_amd", "_build")
-UNITS = ["lfx_api", "lfx_wire", "lfx_downsample", "lfx_localize"]          # (lfx_gather.hip holds no device code)
+UNITS = ["lfx_api", "lfx_unit_v0", "lfx_unit_v1", "lfx_unit_v2", "lfx_unit_v3", "lfx_wire", "lfx_downsample", "lfx_localize"]          # (lfx_gather.hip holds no device code)
 
 
 def test_no_scalar_move_with_a_64_bit_literal():

@@ -9,8 +9,8 @@ import re
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-want = sys.argv[1] if len(sys.argv) > 1 else "ring_unit_org_kernelILi5ELb1"
-text = open(os.path.join(root, "lidar_feature_extraction_amd", "_build", "lfx_api_gfx950_marks.s")).read().splitlines()
+want = sys.argv[1] if len(sys.argv) > 1 else "ring_unit_org_kernelILi0ELi5ELb0"
+text = open(os.path.join(root, "lidar_feature_extraction_amd", "_build", "lfx_unit_v0_gfx950_marks.s")).read().splitlines()
 inside, stage = False, "pre"
 cnt = collections.defaultdict(collections.Counter)
 for line in text:

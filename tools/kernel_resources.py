@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""tools/kernel_resources.py [ASM] [substring] -- registers, spills, LDS and occupancy of every kernel in the device
-assembly (lidar_feature_extraction_amd/_build/lfx_api_gfx950.s, `make -C lidar_feature_extraction_amd/csrc asmfile`)."""
+"""tools/kernel_resources.py [ASM|all] [substring] -- registers, spills, LDS and occupancy of every kernel in the device
+assembly (lidar_feature_extraction_amd/_build/lfx_api_gfx950.s and the four lfx_unit_v*_gfx950.s; `make -C
+lidar_feature_extraction_amd/csrc asmfile`)."""
 import re
 import subprocess
 import sys
 
-path = sys.argv[1] if len(sys.argv) > 1 else "lidar_feature_extraction_amd/_build/lfx_api_gfx950.s"
+import glob
+path = sys.argv[1] if len(sys.argv) > 1 else "all"
 want = sys.argv[2] if len(sys.argv) > 2 else ""
-text = open(path).read()
+paths = [path] if path != "all" else ["lidar_feature_extraction_amd/_build/lfx_api_gfx950.s"] + sorted(glob.glob("lidar_feature_extraction_amd/_build/lfx_unit_v?_gfx950.s"))
+text = "\n".join(open(p).read() for p in paths)
 rows = []
 for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size: +\d+", text, re.S):
     blk = m.group(0)

@@ -188,6 +188,20 @@ __global__ __launch_bounds__(64 * G) void unit_memory(const uint8_t * __restrict
   if (acc == 1.2345e30f) {out[0] = acc;}
 }
 
+// plain copies: U float4 in flight per thread, grid-stride
+template<int U>
+__global__ __launch_bounds__(256) void copy_f4(const float4 * __restrict__ src, float4 * __restrict__ dst, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += U * stride) {
+    float4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {const size_t j = i + k * stride; v[k] = src[j < n ? j : n - 1];}
+#pragma unroll
+    for (int k = 0; k < U; k++) {const size_t j = i + k * stride; if (j < n) {dst[j] = v[k];}}
+  }
+}
+
 int main(int argc, char ** argv)
 {
   const int scans = argc > 1 ? atoi(argv[1]) : 1024;
@@ -207,6 +221,22 @@ int main(int argc, char ** argv)
     printf("%-34s %8.1f us  %7.1f GB/s\n", name, best * 1e3, gb / (best * 1e-3));
   };
   const double gb = bytes / 1e9;
+  {
+    // a copy of 1 GiB inside the input buffer (read + written bytes counted)
+    const size_t cb = (size_t)1 << 30, cn = cb / 16;
+    const float4 * s4 = reinterpret_cast<const float4 *>(pts); float4 * d4 = reinterpret_cast<float4 *>(pts + cb);
+    const int grids[] = {1024, 2048, 4096, 8192, 16384};
+    for (int g : grids) {
+      char name[64];
+      snprintf(name, sizeof name, "copy 1 GiB, 4 in flight, grid %d", g);
+      time(name, [&] {hipLaunchKernelGGL(copy_f4<4>, dim3(g), dim3(256), 0, 0, s4, d4, cn);}, 2.0 * cb / 1e9);
+      snprintf(name, sizeof name, "copy 1 GiB, 8 in flight, grid %d", g);
+      time(name, [&] {hipLaunchKernelGGL(copy_f4<8>, dim3(g), dim3(256), 0, 0, s4, d4, cn);}, 2.0 * cb / 1e9);
+      snprintf(name, sizeof name, "copy 1 GiB, 1 in flight, grid %d", 16 * g);
+      time(name, [&] {hipLaunchKernelGGL(copy_f4<1>, dim3(16 * g), dim3(256), 0, 0, s4, d4, cn);}, 2.0 * cb / 1e9);
+    }
+    hipMemset(pts, 1, bytes);
+  }
   time("linear (grid 8192)", [&] {hipLaunchKernelGGL(read_linear, dim3(8192), dim3(256), 0, 0, pts, out, n);}, gb);
   time("4 rings per workgroup", [&] {hipLaunchKernelGGL(read_groups<4>, dim3(16 * 6, scans), dim3(256), 0, 0, pts, out);}, gb * 320 * 6 / 1800);
   time("4 rings per workgroup, XCD-local", [&] {hipLaunchKernelGGL((read_groups<4, 1>), dim3(16 * 6, scans), dim3(256), 0, 0, pts, out);}, gb * 320 * 6 / 1800);

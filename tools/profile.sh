@@ -42,7 +42,7 @@ write = {k: v["WRITE_SIZE"] for k, v in mean_per_kernel(out + "/pmc_write", "WRI
 hbm = {k: int(2 * fetch.get(k, 0) * 1024 + write.get(k, 0) * 1024) for k in set(fetch) | set(write)}
 import hashlib, os
 h = hashlib.sha256()
-for name in ("lfx_kernels_common.hpp", "lfx_kernels_extract.hpp"):
+for name in ("lfx_kernels_common.hpp", "lfx_kernels_unit.hpp", "lfx_kernels_extract.hpp"):
     h.update(open(os.path.join("lidar_feature_extraction_amd", "csrc", name), "rb").read())
 json.dump({"batch": opt("--batch", 1024), "rings": opt("--rings", 64), "cols": opt("--cols", 1800),
            "kernels_sha256": h.hexdigest(),      # bench.py quotes these bytes only for the sources they were measured on
