@@ -29,7 +29,7 @@ extern "C" {
 #define LFX_VERSION 1
 #define LFX_MAX_PADDING 15          /* convolution_padding supported by the window kernels        */
 #define LFX_MAX_RING_ID 255         /* ring ids must be < 256 (every spinning lidar fielded today) */
-#define LFX_MAX_RING_POINTS 4096    /* points of one ring must fit one workgroup's LDS             */
+#define LFX_MAX_RING_POINTS 4608    /* points of one ring must fit one workgroup's LDS (25 B each); 6 blocks of the unit kernels' long form */
 
 /* The nine node parameters: extraction/include/lidar_feature_extraction/hyper_parameter.hpp:32-65
  * (same names, same units; the neighbour threshold is in DEGREES, converted as

@@ -427,6 +427,16 @@ __device__ inline uint32_t polar_bucket(float t)
 }
 
 
+// Pair t of step (k, j) of a bitonic sorting network over M = 2^m places in its ALL-ASCENDING form: the first step of
+// every merge (j = k / 2) pairs place i with its mirror image inside the block of k places, i ^ (k - 1), the later ones
+// with i | j; every exchange puts the smaller element at i < p.  Places beyond the N elements there are stand for +infinity
+// and are never moved, so a caller skips the pairs with p >= N and stores N elements only.
+__device__ inline void bitonic_partner(uint32_t t, uint32_t k, uint32_t j, uint32_t & i, uint32_t & p)
+{
+  i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));                        // bit j clear
+  p = j == (k >> 1) ? (i ^ (k - 1u)) : (i | j);
+}
+
 // ------------------------------------------------------------------------------------------
 // Angle order.  w.x / w.y hold the ring as bucketed.  If it is strictly increasing under the
 // predicate it IS the sorted order (whatever sort the reference runs) and nothing is done.
@@ -444,30 +454,32 @@ __device__ inline bool angle_sort(
   if (!__syncthreads_or(bad)) {return false;}
   uint32_t M = 1;
   while (M < (uint32_t)N) {M <<= 1;}
-  // 12*M <= 24*N <= 25*cap bytes: the scratch fits the workspace
+  // 12 N <= 25 cap bytes: the scratch fits the workspace
   float * sx = reinterpret_cast<float *>(w.base);
-  float * sy = sx + M;
-  uint32_t * si = reinterpret_cast<uint32_t *>(sy + M);
-  for (uint32_t i = tid; i < M; i += T) {
-    const bool in = i < (uint32_t)N;
-    const float2 v = in ? gxy[i] : make_float2(0.f, 0.f);
+  float * sy = sx + N;
+  uint32_t * si = reinterpret_cast<uint32_t *>(sy + N);
+  for (uint32_t i = tid; i < (uint32_t)N; i += T) {
+    const float2 v = gxy[i];
     sx[i] = v.x;
     sy[i] = v.y;
-    si[i] = in ? gidx[i] : kSentinel;
+    si[i] = gidx[i];
   }
   __syncthreads();
+  // the bitonic network in the form whose every exchange puts the smaller element at the LOWER index (bitonic_partner):
+  // the places N .. M - 1 of the power of two above N then stand for elements larger than any, which no exchange ever
+  // moves -- they need no storage, and a ring's length is not bound to a power of two that fits the LDS
   for (uint32_t k = 2; k <= M; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       for (uint32_t t = tid; t < M / 2; t += T) {
-        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // bit j clear
-        const uint32_t p = i | j;
-        const bool asc = (i & k) == 0;
-        const float ax = sx[i], ay = sy[i], bx = sx[p], by = sy[p];
-        const uint32_t ai = si[i], bi = si[p];
-        const bool swap = asc ? sort_less(bx, by, bi, ax, ay, ai) : sort_less(ax, ay, ai, bx, by, bi);
-        if (swap) {
-          sx[i] = bx; sy[i] = by; si[i] = bi;
-          sx[p] = ax; sy[p] = ay; si[p] = ai;
+        uint32_t i, p;
+        bitonic_partner(t, k, j, i, p);
+        if (p < (uint32_t)N) {
+          const float ax = sx[i], ay = sy[i], bx = sx[p], by = sy[p];
+          const uint32_t ai = si[i], bi = si[p];
+          if (sort_less(bx, by, bi, ax, ay, ai)) {
+            sx[i] = bx; sy[i] = by; si[i] = bi;
+            sx[p] = ax; sy[p] = ay; si[p] = ai;
+          }
         }
       }
       __syncthreads();
@@ -1003,7 +1015,7 @@ __device__ inline uint8_t process_ring(
 // The ring transforms of an organised stream whose rings do not arrive in angle order: a driver that starts its scans
 // at another azimuth delivers every ring as a ROTATION of its sorted order, a clockwise sensor as its REVERSE (or
 // both).  One wave per ring: direction by majority over 64 sampled adjacent pairs, then the column of the ring's
-// smallest angle by a 64-ary search for the wrap (two rounds of loads for rings of up to 4096 points) with the exact
+// smallest angle by a 64-ary search for the wrap (two or three rounds of loads) with the exact
 // predicate (ring.hpp:54-99).  Nothing is moved: ring_unit_org_kernel<XF> applies the transform in its loads and still
 // verifies every adjacent pair, so a ring that is not a rotation / reversal of its sorted order falls back as before.
 constexpr int kCutThreads = 256, kCutWindow = 32;
@@ -1135,8 +1147,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
       }
     }
   }
-  uint32_t M = 1;                                     // power of two >= cap: room for the sort
-  while (M < cap) {M <<= 1;}
+  const uint32_t M = cap;                             // (a multiple of 64; the sorting networks need no power of two: bitonic_partner)
   float * lx = reinterpret_cast<float *>(lds_raw);
   float * ly = lx + M;
   uint32_t * li = reinterpret_cast<uint32_t *>(ly + M);   // arrival index (tie-break)
@@ -1288,18 +1299,19 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
           }
         }
         if (!placed) {
-        for (uint32_t i = tid; i < Ms; i += T) {
-          const float t = i < (uint32_t)N ? polar_pseudo_angle(lx[i], ly[i]) : 0.f;
-          k64[i] = ((uint64_t)(i < (uint32_t)N ? polar_key(t) : 0xFFFFFFFFu) << 32) | i;
+        for (uint32_t i = tid; i < (uint32_t)N; i += T) {
+          k64[i] = ((uint64_t)polar_key(polar_pseudo_angle(lx[i], ly[i])) << 32) | i;
         }
         __syncthreads();
-        for (uint32_t k = 2; k <= Ms; k <<= 1) {
+        for (uint32_t k = 2; k <= Ms; k <<= 1) {                     // (all-ascending form over N elements: bitonic_partner)
           for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < Ms / 2; t += T) {
-              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-              const uint32_t p = i | j;
-              const uint64_t a = k64[i], b = k64[p];
-              if (((i & k) == 0) == (b < a)) {k64[i] = b; k64[p] = a;}
+              uint32_t i, p;
+              bitonic_partner(t, k, j, i, p);
+              if (p < (uint32_t)N) {
+                const uint64_t a = k64[i], b = k64[p];
+                if (b < a) {k64[i] = b; k64[p] = a;}
+              }
             }
             __syncthreads();
           }
@@ -1318,26 +1330,24 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
             sidx[off + i] = ls[src];
           }
         } else {
-        for (uint32_t i = tid; i < Ms; i += T) {
-          const bool in = i < (uint32_t)N;
-          li[i] = in ? ls[i] : kSentinel;
+        for (uint32_t i = tid; i < (uint32_t)N; i += T) {
+          li[i] = ls[i];
           lp[i] = i;
-          if (!in) {lx[i] = 0.f; ly[i] = 0.f;}
         }
         __syncthreads();
         for (uint32_t k = 2; k <= Ms; k <<= 1) {
           for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < Ms / 2; t += T) {
-              const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-              const uint32_t p = i | j;
-              const bool asc = (i & k) == 0;
-              const float ax = lx[i], ay = ly[i], bx = lx[p], by = ly[p];
-              const uint32_t ai = li[i], bi = li[p];
-              const bool swap = asc ? sort_less(bx, by, bi, ax, ay, ai) : sort_less(ax, ay, ai, bx, by, bi);
-              if (swap) {
-                const uint32_t pa = lp[i], pb = lp[p];
-                lx[i] = bx; ly[i] = by; li[i] = bi; lp[i] = pb;
-                lx[p] = ax; ly[p] = ay; li[p] = ai; lp[p] = pa;
+              uint32_t i, p;
+              bitonic_partner(t, k, j, i, p);
+              if (p < (uint32_t)N) {
+                const float ax = lx[i], ay = ly[i], bx = lx[p], by = ly[p];
+                const uint32_t ai = li[i], bi = li[p];
+                if (sort_less(bx, by, bi, ax, ay, ai)) {
+                  const uint32_t pa = lp[i], pb = lp[p];
+                  lx[i] = bx; ly[i] = by; li[i] = bi; lp[i] = pb;
+                  lx[p] = ax; ly[p] = ay; li[p] = ai; lp[p] = pa;
+                }
               }
             }
             __syncthreads();
@@ -1396,9 +1406,7 @@ __global__ __launch_bounds__(512) void ring_order_kernel(
 
 __host__ __device__ inline size_t order_lds_bytes(uint32_t cap)
 {
-  uint32_t M = 1;
-  while (M < cap) {M <<= 1;}
-  return (size_t)M * 24 + 64 + (kOrderBuckets + 8) * 4;
+  return (size_t)cap * 24 + 64 + (kOrderBuckets + 8) * 4;      // (the networks store a ring's N elements, not the power of two above)
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1218,7 +1218,7 @@ __device__ __forceinline__ void unit_body(
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
     tab->unit_ne[ui] = pe;
     tab->unit_ns[ui] = ps;
-    tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= 4096
+    tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= LFX_MAX_RING_POINTS < 65536
     if (ORG) {
       // the ring's totals, for the compaction (no kernel of their own on this route): two adds nobody waits for.  If the
       // scan falls back after all, the compaction takes the bucketing route's unit tables instead (feature_compact_kernel).
