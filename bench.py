@@ -64,6 +64,12 @@ def parse():
                     help="destination rank of the per-step gather: 'rotate' (step k's clouds land whole on rank k mod N: consecutive "
                          "steps use different xGMI links) or a fixed rank (every sender is then bound by its ONE link to that rank: "
                          "~77 GB/s each way = 512 k scans/s per GPU, 66 %% of the kernel rate, whatever N)")
+    ap.add_argument("--gather-pairs", type=int, default=-1,
+                    help="1: two consecutive steps' clouds travel as ONE grouped exchange on ONE communicator (lfx_gather_payload2: two links of "
+                         "every sender busy at once); default: 1 with a rotating destination unless --gather-lanes asks for lanes")
+    ap.add_argument("--watchdog-seconds", type=float, default=120.0,
+                    help="N > 1 (or --force-gather): a step or a fence that makes no progress for this long ends the process with exit code 4 and says where")
+    ap.add_argument("--test-stall-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests only: this rank stops making progress in its third step (the watchdog's test)
     ap.add_argument("--gather-lanes", type=int, default=0,
                     help="gathers in flight (a communicator and a side stream each; step k on lane k mod L): 0 = 2 with a rotating "
                          "destination (the steps' exchanges overlap on their different links), 1 with a fixed one")
@@ -244,11 +250,15 @@ def main():
         feat_cap = int(a.batch * n_pts * 0.35) + 1024
         # x, y, z only (12 bytes per point): what the node publishes (pcl::PointXYZ clouds,
         # feature_extraction.cpp:163-166) and a quarter less to push through rank 0's links
-        n_lanes = a.gather_lanes if a.gather_lanes > 0 else (2 if a.gather_dst == "rotate" else 1)
+        # rotating destination: two steps as one grouped exchange on one communicator (pairs) by default; --gather-lanes 2
+        # is the older form with two communicators on two side streams
+        use_pairs = (a.gather_pairs == 1) or (a.gather_pairs < 0 and a.gather_dst == "rotate" and a.gather_lanes <= 0)
+        n_lanes = 1 if use_pairs else (a.gather_lanes if a.gather_lanes > 0 else 1)
         # one set more than there are gathers in flight: while those read their sets, the next step packs into a free one
+        # (pairs: the pair on its way and the pair being packed)
         bufs = [(torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
                  torch.zeros((feat_cap, 3), dtype=torch.float32, device=dev),
-                 torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(n_lanes + 1)]
+                 torch.zeros(2 * (a.batch + 1), dtype=torch.int32, device=dev)) for _ in range(4 if use_pairs else n_lanes + 1)]
         # RCCL through the library's own entry points (lfx_comm_*, lfx_gather_*); torch.distributed only carries the
         # 128-byte communicator id from rank 0 to the others
         # If the communicator cannot be made on some rank (the RCCL library does not open, the id does not arrive), every
@@ -278,7 +288,7 @@ def main():
                 all_ids = bytes(idt.cpu().numpy().tobytes())
                 gather = CloudGather(fx, rank, world, [all_ids[128 * k:128 * (k + 1)] for k in range(n_lanes)],
                                      dst="rotate" if a.gather_dst == "rotate" else int(a.gather_dst), device=dev,
-                                     capacity_points=feat_cap * world, batch=a.batch)
+                                     capacity_points=feat_cap * world, batch=a.batch, pairs=use_pairs, profile=True)
             except Exception as e:         # noqa: BLE001
                 gather_error = "rank %d: %s" % (rank, e)
         if world > 1:
@@ -292,7 +302,36 @@ def main():
                 gather.close()
             use_gather = False
 
+    # Watchdog (N > 1): the first real multi-rank run of a flow is the one the driver times, and a hang there would cost
+    # the record instead of telling what hung.  A thread looks at where the main thread last reported to be; no progress for
+    # --watchdog-seconds ends the PROCESS with a message and exit code 4 (a plain exit: never a re-exec, never a retry).
+    progress = {"where": "start", "step": 0, "t": time.monotonic()}
+
+    def mark(where):
+        progress["where"], progress["step"], progress["t"] = where, step_no[0], time.monotonic()
+
+    if (world > 1 or a.force_gather) and a.watchdog_seconds > 0:
+        import threading
+
+        def watch():
+            while True:
+                time.sleep(min(5.0, a.watchdog_seconds / 4))
+                idle = time.monotonic() - progress["t"]
+                if progress["where"] == "done":
+                    return
+                if idle > a.watchdog_seconds:
+                    lane = ("pair of steps %d, %d" % ((progress["step"] - 1) & ~1, ((progress["step"] - 1) & ~1) + 1)) if (use_gather and gather is not None and gather.pairs) \
+                        else ("lane %d" % ((progress["step"] - 1) % max(1, len(gather.lanes))) if use_gather and gather is not None else "no gather")
+                    print("bench.py watchdog: rank %d of %d has made no progress for %.0f s in '%s' at step %d (%s, destination %s): giving up"
+                          % (rank, world, idle, progress["where"], progress["step"], lane, a.gather_dst), file=sys.stderr)
+                    sys.stderr.flush()
+                    os._exit(4)
+        threading.Thread(target=watch, daemon=True).start()
+
     def step():
+        mark("step")
+        if a.test_stall_rank == rank and step_no[0] == 2:
+            time.sleep(1e6)
         k = step_no[0] % n_streams
         step_no[0] += 1
         if will_gather and not use_gather:
@@ -313,12 +352,16 @@ def main():
                 gather.submit(edge_buf, surf_buf, offs, a.batch)
 
     def fence():
+        mark("fence: flush of the last gathers")
         if use_gather:
             gather.flush()             # the last step's clouds
+        mark("fence: device synchronise")
         torch.cuda.synchronize()
         if world > 1 or a.force_gather:
+            mark("fence: barrier")
             dist.barrier()
         torch.cuda.synchronize()
+        mark("fence passed")
 
     for _ in range(a.warmup):
         step()
@@ -589,7 +632,9 @@ def main():
                                       ((", %.0f %% of the returns %s" % (100 * a.drop_fraction, "written as (0, 0, 0) and filtered" if a.drop_zero else "missing"))
                                        if a.drop_fraction > 0 else ""),
                        "streams": 1 if use_gather else n_streams,
-                       "sharding": "scan i -> gpu i mod N" + ((", RCCL gather of clouds to rank %s per step, %d in flight" % ("k mod N of step k" if a.gather_dst == "rotate" else a.gather_dst, n_lanes)) if use_gather else "") +
+                       "sharding": "scan i -> gpu i mod N" + ((", RCCL gather of clouds to rank %s per step, %s" % (
+                           "k mod N of step k" if a.gather_dst == "rotate" else a.gather_dst,
+                           "two steps per grouped exchange on one communicator" if use_pairs else "%d in flight" % n_lanes)) if use_gather else "") +
                                    (" (gather unavailable: %s)" % gather_error if gather_error else "")},
             "roofline": roofline, "box": box, "cpu_baseline": cpu, "end_to_end": end_to_end, "consumer": consumer, "parity_spot_check": parity,
             "configs": configs,
@@ -601,6 +646,7 @@ def main():
             out["gather_ms_per_step"] = round(gather_ms_per_step, 4)
         print(json.dumps(out))
         sys.stdout.flush()
+    mark("closing")
     if use_gather:
         gather.close()
     for f in fxs:
@@ -608,6 +654,7 @@ def main():
     if world > 1 or a.force_gather:
         dist.barrier()
         dist.destroy_process_group()
+    mark("done")
 
 
 if __name__ == "__main__":

@@ -323,6 +323,27 @@ int lfx_gather_counts(lfx_ctx *ctx, lfx_comm *comm, const uint32_t *d_offsets, u
  * [4] all-gathers of totals.  `dst` of lfx_gather_payload may change from call to call (every rank gives the same). */
 #define LFX_COMM_STATS 5
 int lfx_comm_stats(const lfx_comm *comm, uint64_t out[LFX_COMM_STATS]);
+/* Two steps' exchanges as ONE group on ONE communicator: step A's clouds travel to steps[0].dst, step B's to steps[1].dst,
+ * every rank posting its sends and receives of both between one ncclGroupStart / ncclGroupEnd -- two of a rank's xGMI links
+ * carry data at once (a sender reaches a destination over one link), with no second communicator whose kernels could
+ * start in another order on another rank.  Each step's totals come from the slot its lfx_gather_counts_slot call named
+ * (LFX_GATHER_SLOTS = 2 may be out at once; lfx_gather_counts = slot 0).  n_steps = 1 or 2; batch, floats_per_point and
+ * capacity_points are common to the steps; if either step's clouds do not fit, every rank returns LFX_ERR_CAPACITY and
+ * nothing of either is sent.  Every rank must make the same sequence of calls with the same dst and slot values. */
+#define LFX_GATHER_SLOTS 2
+typedef struct lfx_gather_step
+{
+  int dst;                          /* destination rank of this step                                              */
+  uint32_t slot;                    /* which lfx_gather_counts_slot call carries its totals                        */
+  const float *d_edge, *d_surface;  /* this rank's packed clouds of the step (lfx_pack_xyz12 / _xyz / _features)   */
+  const uint32_t *d_offsets;
+  float *d_edge_all, *d_surface_all;    /* where this rank is dst: capacity_points records each; else may be NULL  */
+  uint32_t *d_offsets_all;              /* [world][2][batch+1]                                                      */
+  uint64_t *counts_out;                 /* host [world][2] or NULL: every rank's totals of the step                 */
+} lfx_gather_step;
+int lfx_gather_counts_slot(lfx_ctx *ctx, lfx_comm *comm, uint32_t slot, const uint32_t *d_offsets, uint32_t batch, void *stream);
+int lfx_gather_payload2(lfx_ctx *ctx, lfx_comm *comm, const lfx_gather_step *steps, uint32_t n_steps, uint32_t batch,
+                        uint32_t floats_per_point, size_t capacity_points, void *stream);
 int lfx_gather_payload(lfx_ctx *ctx, lfx_comm *comm, int dst, const float *d_edge, const float *d_surface,
                        const uint32_t *d_offsets, uint32_t batch, uint32_t floats_per_point, float *d_edge_all,
                        float *d_surface_all, uint32_t *d_offsets_all, size_t capacity_points, uint64_t *counts_out,

@@ -51,6 +51,12 @@ class Config(C.Structure):
                 ("layout", Layout), ("outputs", C.c_uint32), ("stream_hint", C.c_uint32)]
 
 
+class GatherStep(C.Structure):
+    """lfx_gather_step (include/lfx.h): one step of a grouped exchange, lfx_gather_payload2."""
+    _fields_ = [("dst", C.c_int), ("slot", C.c_uint32), ("d_edge", C.c_void_p), ("d_surface", C.c_void_p), ("d_offsets", C.c_void_p),
+                ("d_edge_all", C.c_void_p), ("d_surface_all", C.c_void_p), ("d_offsets_all", C.c_void_p), ("counts_out", C.c_void_p)]
+
+
 OUT_FEATURES, OUT_LABELS, OUT_CURVATURE, OUT_SORTED_INDEX, OUT_ALL = 1, 2, 4, 8, 15
 STREAM_UNKNOWN, STREAM_TURNED_RINGS, STREAM_NO_GRID = 0, 1, 2
 
@@ -88,7 +94,7 @@ EXPORTS = [
     "lfx_localize_batch", "lfx_localize_host",
     "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
-    "lfx_route_choice", "lfx_set_log_callback", "lfx_box_calibration",
+    "lfx_route_choice", "lfx_set_log_callback", "lfx_box_calibration", "lfx_gather_counts_slot", "lfx_gather_payload2",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
 
@@ -147,6 +153,8 @@ def load(test_hooks=False):
     L.lfx_comm_stats.argtypes = [vp, vp]
     L.lfx_gather_counts.argtypes = [vp, vp, vp, u32, vp]
     L.lfx_gather_payload.argtypes = [vp, vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]
+    L.lfx_gather_counts_slot.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.lfx_gather_payload2.argtypes = [vp, vp, C.POINTER(GatherStep), u32, u32, u32, C.c_size_t, vp]
     L.lfx_voxel_downsample.argtypes = [vp, vp, vp, vp, u32, u32, C.c_size_t, C.c_float, vp, vp, vp, vp]
     L.lfx_map_create.argtypes = [vp, vp, u32, C.c_float, C.POINTER(vp), vp]
     L.lfx_map_create_host.argtypes = [vp, vp, u32, C.c_float, C.POINTER(vp), vp]

@@ -54,9 +54,23 @@ class RcclGather:
         self._L.lfx_comm_stats(self._comm, C.cast(out, C.c_void_p))
         return dict(zip(("sends", "receives", "bytes_sent", "bytes_received", "all_gathers"), [int(v) for v in out]))
 
-    def counts(self, d_offsets, batch, stream=0):
-        B.check(self._fx._ctx, self._L.lfx_gather_counts(self._fx._ctx, self._comm, C.c_void_p(int(d_offsets)), batch,
-                                                         C.c_void_p(int(stream))))
+    def counts(self, d_offsets, batch, stream=0, slot=0):
+        B.check(self._fx._ctx, self._L.lfx_gather_counts_slot(self._fx._ctx, self._comm, int(slot), C.c_void_p(int(d_offsets)), batch,
+                                                              C.c_void_p(int(stream))))
+
+    def payload_group(self, steps, batch, floats_per_point, capacity_points, stream=0):
+        """lfx_gather_payload2: one or two steps as ONE grouped exchange.  steps: dicts with dst, slot, edge, surface, offsets
+        (device pointers of this rank's packed clouds) and, where this rank is the destination, edge_all, surface_all,
+        offsets_all.  Returns every step's totals of every rank, a list of [world, 2] arrays."""
+        arr = (B.GatherStep * len(steps))()
+        counts = [np.zeros((self.world, 2), np.uint64) for _ in steps]
+        for i, st in enumerate(steps):
+            arr[i] = B.GatherStep(int(st["dst"]), int(st["slot"]), int(st["edge"]), int(st["surface"]), int(st["offsets"]),
+                                  int(st.get("edge_all") or 0) or None, int(st.get("surface_all") or 0) or None,
+                                  int(st.get("offsets_all") or 0) or None, counts[i].ctypes.data)
+        B.check(self._fx._ctx, self._L.lfx_gather_payload2(self._fx._ctx, self._comm, arr, len(steps), batch, floats_per_point,
+                                                           int(capacity_points), C.c_void_p(int(stream))))
+        return counts
 
     def payload(self, dst, d_edge, d_surface, d_offsets, batch, floats_per_point, d_edge_all, d_surface_all, d_offsets_all,
                 capacity_points, stream=0):
@@ -95,7 +109,8 @@ class CloudGather:
     `unique_id` may be a list of communicator ids, one lane (communicator + side stream) each; step k's exchange runs on
     lane k mod len(ids), so that step k - 1's payload is still on its way while step k's leaves."""
 
-    def __init__(self, fx, rank, world, unique_id, dst=0, device=None, capacity_points=0, batch=1, floats_per_point=3):
+    def __init__(self, fx, rank, world, unique_id, dst=0, device=None, capacity_points=0, batch=1, floats_per_point=3, pairs=False,
+                 profile=False):
         # dst = "rotate": step k's clouds go to rank k mod world (every rank then needs receive buffers): no single
         # rank's links carry all of the ingest
         self.rotate = dst == "rotate"
@@ -114,9 +129,26 @@ class CloudGather:
                           torch.zeros((world, 2 * (batch + 1)), dtype=torch.int32, device=device)) for _ in range(2)]
         else:
             self.recv = [(None, None, None)] * 2
+        # pairs: steps 2m and 2m + 1 travel as ONE grouped exchange on the one communicator (lfx_gather_payload2): with a
+        # rotating destination their clouds go to two different ranks, i.e. over two of every sender's links at once -- what
+        # two lanes buy, without a second communicator whose kernels could start in another order on another rank.  The pair
+        # is posted one step after its second member was submitted (its totals have landed by then: the host does not wait),
+        # so a caller needs FOUR sets of send buffers.
+        self.pairs = bool(pairs)
+        if self.pairs:
+            assert len(self.lanes) == 1, "pairs: one communicator"
+            # four receive sets: a pair's two destinations may be this rank twice in a row (world = 1 rehearsal), and a consumer
+            # may still read the pair before
+            if self.rotate or rank == self.dst:
+                self.recv = self.recv + [(torch.zeros_like(self.recv[0][0]), torch.zeros_like(self.recv[0][1]), torch.zeros_like(self.recv[0][2]))
+                                         for _ in range(2)]
+        self.queue = []                # pairs: submitted steps whose payload has not been posted yet
+        self.submitted = 0
+        self.phase = 0
         self.step = 0
-        self.received = 0              # gathers this rank has been the destination of: alternates the two receive sets
-        self.spans = []                # (start, end) events on the side streams around every gather (gather_ms)
+        self.received = 0              # gathers this rank has been the destination of: alternates the receive sets
+        self.profile = bool(profile)   # record (start, end) timing events around every gather (gather_ms); off: nothing is kept
+        self.spans = []
 
     def close(self):
         for rccl, _ in self.lanes:
@@ -129,6 +161,8 @@ class CloudGather:
             torch.cuda.current_stream().wait_event(ev)
 
     def submit(self, edge, surface, offsets, batch):
+        if self.pairs:
+            return self._submit_paired(edge, surface, offsets, batch)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         rccl, side = self.lanes[(self.step + (1 if self.pending is not None else 0)) % len(self.lanes)]     # this step's lane
@@ -151,20 +185,74 @@ class CloudGather:
         ea, sa, oa = self.recv[self.received % 2] if self.rank == dst else (None, None, None)
         if self.rank == dst:
             self.received += 1
-        t0 = torch.cuda.Event(enable_timing=True)
-        t0.record(side)
+        t0 = None
+        if self.profile:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(side)
         counts = rccl.payload(dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
                               ea.data_ptr() if ea is not None else 0, sa.data_ptr() if sa is not None else 0,
                               oa.data_ptr() if oa is not None else 0, self.cap, side.cuda_stream)
-        ev = torch.cuda.Event(enable_timing=True)
+        ev = torch.cuda.Event(enable_timing=self.profile)
         ev.record(side)
-        self.spans.append((t0, ev))
+        if self.profile:
+            self.spans.append((t0, ev))
         for t in (edge, surface, offsets):
             self.buffer_free[t.data_ptr()] = ev
         self.done = ev
         if self.rank != dst:
             return None
         return split_gathered(ea, sa, oa, counts, batch)
+
+    # ---- pairs (lfx_gather_payload2)
+    def _submit_paired(self, edge, surface, offsets, batch):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        rccl, side = self.lanes[0]
+        k = self.submitted                 # the step's number in the stream: its destination where that rotates
+        slot = self.phase % 2              # its place in its pair = the slot of its totals (pairs start afresh after a flush)
+        self.submitted += 1
+        self.phase += 1
+        out = None
+        # a complete pair whose second member was submitted a step ago: its totals are on the host by now
+        if len(self.queue) >= 2 and slot == 0:
+            out = self._finish_group(self.queue[:2])
+            self.queue = self.queue[2:]
+        side.wait_event(ready)
+        rccl.counts(offsets.data_ptr(), batch, side.cuda_stream, slot=slot)
+        self.queue.append((edge, surface, offsets, batch, k, slot))
+        return out
+
+    def _finish_group(self, items):
+        rccl, side = self.lanes[0]
+        steps, recv_sets = [], []
+        for edge, surface, offsets, batch, k, slot in items:
+            dst = k % self.world if self.rotate else self.dst
+            self.last_dst = dst
+            st = {"dst": dst, "slot": slot, "edge": edge.data_ptr(), "surface": surface.data_ptr(), "offsets": offsets.data_ptr()}
+            if self.rank == dst:
+                ea, sa, oa = self.recv[self.received % len(self.recv)]
+                self.received += 1
+                st.update(edge_all=ea.data_ptr(), surface_all=sa.data_ptr(), offsets_all=oa.data_ptr())
+                recv_sets.append((ea, sa, oa))
+            else:
+                recv_sets.append(None)
+            steps.append(st)
+        t0 = None
+        if self.profile:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(side)
+        counts = rccl.payload_group(steps, items[0][3], self.fpp, self.cap, side.cuda_stream)
+        ev = torch.cuda.Event(enable_timing=self.profile)
+        ev.record(side)
+        if self.profile:
+            self.spans.append((t0, ev))
+        for edge, surface, offsets, _, _, _ in items:
+            for t in (edge, surface, offsets):
+                self.buffer_free[t.data_ptr()] = ev
+        self.done = ev
+        self.step += len(items)
+        outs = [split_gathered(r[0], r[1], r[2], c, items[0][3]) if r is not None else None for r, c in zip(recv_sets, counts)]
+        return outs
 
     def gather_ms(self, reset=True):
         """(sum, count) of the side streams' time inside the gathers completed so far (payload exchange incl. its waits for
@@ -176,6 +264,16 @@ class CloudGather:
         return total, n
 
     def flush(self):
+        if self.pairs:
+            out = []
+            while self.queue:
+                n = 2 if len(self.queue) >= 2 and self.queue[0][5] == 0 else 1
+                out += self._finish_group(self.queue[:n])
+                self.queue = self.queue[n:]
+            self.phase = 0
+            for _, side in self.lanes:
+                side.synchronize()
+            return out
         prev, self.pending = self.pending, None
         out = self._finish(prev) if prev is not None else None
         for _, side in self.lanes:

@@ -151,10 +151,16 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
   Comm * c = reinterpret_cast<Comm *>(comm);
   if (!c) {return ncclSuccess;}
-  // (the last rank to leave removes what is left; files of a rank that died stay until /dev/shm is cleaned)
-  std::remove((c->dir + "/here_" + std::to_string(c->rank)).c_str());
-  if (c->collectives > 0) {std::remove((c->dir + "/ag_" + std::to_string(c->collectives - 1) + "_" + std::to_string(c->rank)).c_str());}
-  rmdir(c->dir.c_str());        // (succeeds for the last rank to leave)
+  // Nobody removes a file a peer may still be waiting for: a rank says it is leaving and waits (briefly) for the others to
+  // say so too -- a rank that finished its last all-gather may be a whole step ahead of one still polling for that file.
+  // What is left (the leave markers, the directory) is a few empty files; the tests remove /dev/shm/lfxshim_* afterwards.
+  (void)publish(c->dir + "/bye_" + std::to_string(c->rank), "", 0);
+  bool all_left = true;
+  for (int k = 0; k < c->world && all_left; k++) {all_left = take(c->dir + "/bye_" + std::to_string(k), nullptr, 0, false);}
+  if (all_left) {
+    std::remove((c->dir + "/here_" + std::to_string(c->rank)).c_str());
+    if (c->collectives > 0) {std::remove((c->dir + "/ag_" + std::to_string(c->collectives - 1) + "_" + std::to_string(c->rank)).c_str());}
+  }
   delete c;
   return ncclSuccess;
 }

@@ -17,6 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM_DIR = os.path.join(ROOT, "tests", "shim")
 
 
+def _sweep():
+    """What the shim's communicators leave under /dev/shm (leave markers, files of a rank that was ended)."""
+    import glob
+    import shutil
+    for d in glob.glob("/dev/shm/lfxshim_*"):
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def _shim():
     so = os.path.join(SHIM_DIR, "_build", "librccl_shim.so")
     src = os.path.join(SHIM_DIR, "rccl_shim.cpp")
@@ -31,16 +39,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("dst", ["0", "rotate"])
+@pytest.mark.parametrize("dst", ["0", "rotate", "rotate-lanes"])
 def test_bench_runs_with_two_ranks(dst):
+    """dst 0: every step's clouds to rank 0; rotate (the default): step k's to rank k mod N, two steps per grouped exchange
+    on ONE communicator (lfx_gather_payload2); rotate-lanes: the older form, two communicators on two side streams."""
     world = 2
+    lanes = dst == "rotate-lanes"
+    dst = "rotate" if lanes else dst
     base = dict(os.environ, WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                 LFX_RCCL_LIB=_shim(), LFX_LIB_PATH=os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx_testhooks.so"))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--batch", "8", "--steps", "3", "--warmup", "1",
-           "--repeats", "2", "--no-cpu-baseline", "--dist-backend", "gloo", "--gather-dst", dst]
+           "--repeats", "2", "--no-cpu-baseline", "--dist-backend", "gloo", "--gather-dst", dst] + (["--gather-lanes", "2"] if lanes else [])
     procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
              for r in range(world)]
     outs = [p.communicate(timeout=420) for p in procs]
+    _sweep()
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d exit %s:\n%s" % (r, p.returncode, outs[r][1].decode(errors="replace")[-3000:])
     lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
@@ -50,9 +63,28 @@ def test_bench_runs_with_two_ranks(dst):
     assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak"
     assert "RCCL gather of clouds to rank" in d["config"]["sharding"] and "unavailable" not in d["config"]["sharding"], d["config"]["sharding"]
     assert ("k mod N" in d["config"]["sharding"]) == (dst == "rotate")
-    assert ("2 in flight" if dst == "rotate" else "1 in flight") in d["config"]["sharding"]      # the rotating form runs two lanes
+    assert ("2 in flight" if lanes else ("two steps per grouped exchange on one communicator" if dst == "rotate" else "1 in flight")) in d["config"]["sharding"]
     assert d["parity_spot_check"] is True
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["gather_ms_per_step"] > 0
     assert d["cpu_baseline"] is None and "N=1" in d["cpu_baseline_from"]
     # whole-job aggregate: both ranks' scans over the slowest rank's time
     assert abs(d["value"] - world * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+
+
+def test_a_rank_that_stops_is_reported_not_waited_for():
+    """bench.py's watchdog (N > 1): rank 1 stops making progress in its third step; rank 0 then sits in the fence behind it.
+    Both processes end by themselves with exit code 4 and say where they were -- the driver gets a reason, not a hang."""
+    world = 2
+    base = dict(os.environ, WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                LFX_RCCL_LIB=_shim(), LFX_LIB_PATH=os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx_testhooks.so"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--batch", "8", "--steps", "3", "--warmup", "1",
+           "--repeats", "1", "--no-cpu-baseline", "--dist-backend", "gloo", "--watchdog-seconds", "12", "--test-stall-rank", "1"]      # (under the 30 s after which the shim itself gives a transfer up)
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    _sweep()
+    for r, p in enumerate(procs):
+        err = outs[r][1].decode(errors="replace")
+        assert p.returncode == 4, "rank %d exit %s:\n%s" % (r, p.returncode, err[-2000:])
+        assert "bench.py watchdog: rank %d of 2 has made no progress" % r in err, err[-2000:]
+        assert not [l for l in outs[r][0].decode().splitlines() if l.startswith("{")], "no line from a run that hung"

@@ -7,10 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
+@pytest.mark.parametrize("lanes", [1, 2, "pairs"])
 def test_extract_pack_gather_reassemble_one_rank(lanes):
-    """lanes = 2: two communicators, two side streams, step k's exchange on lane k mod 2 (what bench.py runs with a rotating
-    destination), three sets of send buffers: every step's clouds must still arrive whole and in order."""
+    """lanes = 2: two communicators, two side streams, step k's exchange on lane k mod 2, three sets of send buffers.
+    "pairs" (what bench.py runs with a rotating destination): ONE communicator, steps 2m and 2m + 1 as one grouped exchange
+    (lfx_gather_payload2) through a real RCCL, four sets of send buffers, an odd number of steps (the last one travels
+    alone).  Every step's clouds must arrive whole and in order."""
+    pairs = lanes == "pairs"
+    lanes = 1 if pairs else lanes
     import torch
     from lidar_feature_extraction_amd import FeatureExtraction, make_scan, concat
     from lidar_feature_extraction_amd.gather import CloudGather, RcclGather, reassemble
@@ -20,10 +24,11 @@ def test_extract_pack_gather_reassemble_one_rank(lanes):
     fx = FeatureExtraction(device=0, max_points_per_scan=rings * cols, max_batch=batch, max_points_per_ring=cols, max_rings=rings)
     uid = [RcclGather.unique_id() for _ in range(lanes)]
     cap = batch * rings * cols
-    g = CloudGather(fx, 0, 1, uid if lanes > 1 else uid[0], dst="rotate" if lanes > 1 else 0, device=dev, capacity_points=cap, batch=batch)
+    g = CloudGather(fx, 0, 1, uid if lanes > 1 else uid[0], dst="rotate" if (lanes > 1 or pairs) else 0, device=dev, capacity_points=cap, batch=batch,
+                    pairs=pairs)
     stream = torch.cuda.current_stream().cuda_stream
     bufs = [(torch.zeros((cap, 3), dtype=torch.float32, device=dev), torch.zeros((cap, 3), dtype=torch.float32, device=dev),
-             torch.zeros(2 * (batch + 1), dtype=torch.int32, device=dev)) for _ in range(lanes + 1)]
+             torch.zeros(2 * (batch + 1), dtype=torch.int32, device=dev)) for _ in range(4 if pairs else lanes + 1)]
     scans, outs, keep = [], [], []
     for step in range(steps):
         clouds = [make_scan(rings, cols, seed=5000 + step * batch + k, start_col=(17 * k if step == 1 else 0)) for k in range(batch)]
@@ -37,9 +42,11 @@ def test_extract_pack_gather_reassemble_one_rank(lanes):
         out = g.submit(e, s, o, batch)
         if out is not None:
             g.done.synchronize()
-            outs.append([{k: v.cpu().numpy().copy() for k, v in r.items()} for r in out])
+            for o1 in (out if pairs else [out]):             # (pairs: a list of two steps' results)
+                outs.append([{k: v.cpu().numpy().copy() for k, v in r.items()} for r in o1])
     out = g.flush()
-    outs.append([{k: v.cpu().numpy().copy() for k, v in r.items()} for r in out])
+    for o1 in (out if pairs else [out]):
+        outs.append([{k: v.cpu().numpy().copy() for k, v in r.items()} for r in o1])
     fx.batch_status(stream)
     assert len(outs) == steps
     for step in range(steps):
