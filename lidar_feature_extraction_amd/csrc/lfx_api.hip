@@ -279,10 +279,19 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   //      bucketing for every scan: choose_route() over what earlier batches reported.  A batch's last kernel writes its
   //      report into pinned memory unasked; it is read only once the event behind that kernel has passed (with two scans in
   //      flight the previous batch may still be running), otherwise the report before it stands.
-  if (c->report_pending && hipEventQuery(c->report_landed) == hipSuccess) {
-    std::memcpy(c->route.report, c->h_counters, sizeof(c->route.report));
-    c->route.report_rings = c->report_rings_pending;
-    c->report_pending = false;
+  if (c->h_counters) {
+    // (a seqlock read of the pinned block: end serial, the counters, begin serial -- the device writes them the other way round)
+    const uint32_t end = __atomic_load_n(c->h_counters + 1 + lfx::kCounters, __ATOMIC_ACQUIRE);
+    uint32_t got[lfx::kCounters];
+    for (int i = 0; i < lfx::kCounters; i++) {got[i] = __atomic_load_n(c->h_counters + 1 + i, __ATOMIC_RELAXED);}
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const uint32_t begin = __atomic_load_n(c->h_counters, __ATOMIC_RELAXED);
+    if (end != 0u && end == begin && end != c->report_taken) {
+      static_assert(sizeof(c->route.report) == sizeof(got), "the report is the counters block");
+      std::memcpy(c->route.report, got, sizeof(got));
+      c->route.report_rings = got[lfx::kCntBatch] * c->max_rings;
+      c->report_taken = end;
+    }
   }
   const RouteChoice choice = choose_route(c->route, c->route_pins, c->fused_possible && canon && chunks != 0, batch, c->max_rings);
   const bool fused = choice.fused, short_tail = choice.short_tail;
@@ -379,20 +388,14 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
         c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
         c->ring_ebase.p, c->ring_sbase.p, n_units, c->max_rings);
     }
+    c->batch_serial = c->batch_serial + 1u == 0u ? 1u : c->batch_serial + 1u;
     {
       Timed t(c, 6, st);
       hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
         n_units, c->cap, c->scan_begin.p, c->ring_count.p, self_totals ? nullptr : c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
         c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->ring_nedge.p, c->ring_nsurf.p);
+        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->batch_serial, c->ring_nedge.p, c->ring_nsurf.p);
     }
-  }
-  if (c->h_counters) {
-    // what this batch reports, for the next batches' choice of route, has been written to pinned memory by the last kernel;
-    // nobody waits for it
-    LFX_HIP(c, hipEventRecord(c->report_landed, st));
-    c->report_pending = true;
-    c->report_rings_pending = batch * c->max_rings;
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -826,10 +829,9 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
   if (e == hipSuccess) {
-    e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 4 * lfx::kCounters, hipHostMallocDefault);
-    if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * lfx::kCounters);}
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 4 * (lfx::kCounters + 2), hipHostMallocDefault);
+    if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * (lfx::kCounters + 2));}
   }
-  if (e == hipSuccess) {e = hipEventCreateWithFlags(&c->report_landed, hipEventDisableTiming);}
   if (e == hipSuccess) {
     // (no per-point curvature asked for: the kernels find no array to write it to -- a fifth of the unit kernel's HBM traffic)
     const lfx::UnitTables t{c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
@@ -875,7 +877,6 @@ void lfx_destroy(lfx_ctx * c)
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
-  if (c->report_landed) {(void)hipEventDestroy(c->report_landed);}
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
   c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release(); c->h_align.release(); c->h_loc.release();

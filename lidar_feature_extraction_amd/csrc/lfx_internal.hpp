@@ -156,11 +156,15 @@ struct lfx_ctx
   uint32_t unit_flags = 65u;             // LFX_DEBUG_UNIT_FLAGS: 1 edge pass, 64 surface pass (ablations only)
   uint32_t drop_zero = 0;                // lfx_config::drop_zero_points
   // What a batch reports about its stream (the counters block behind ring_flags) is copied to pinned memory at the end of
-  // the batch, nobody waiting; the next batches' route is chosen from the last report that has LANDED (report_landed).
-  uint32_t * h_counters = nullptr;       // pinned [lfx::kCounters]
-  hipEvent_t report_landed = nullptr;
-  bool report_pending = false;
-  uint32_t report_rings_pending = 0;
+  // the batch, nobody waiting; the next batches' route is chosen from the last report that has LANDED.
+  // No event stands behind it: a host that runs ahead of the device (a loop of lfx_extract_batch_device calls, the pipelined
+  // pair) would ask about the batch it has just queued and never find that event passed.  The block carries the batch's
+  // serial number before and after the counters (feature_compact_kernel writes begin, fence, counters, fence, end; the
+  // host reads end, counters, begin): a block whose two serials agree is one batch's report, whichever batch has got that
+  // far -- the route follows the stream a few batches behind instead of not at all.
+  uint32_t * h_counters = nullptr;       // pinned [1 + lfx::kCounters + 1]
+  uint32_t batch_serial = 0;             // serial of the batch queued last (never 0 in the block)
+  uint32_t report_taken = 0;             // serial of the report the route state was last fed with
   RouteState route;
   RoutePins route_pins;
   bool pre_order = false;                // this batch's choice (run_batch)

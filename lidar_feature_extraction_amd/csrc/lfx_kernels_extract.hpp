@@ -1587,14 +1587,28 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
   uint32_t max_rings, uint32_t * __restrict__ scan_info /* read for the scan's route; its totals written here where ring_ebase == nullptr */,
-  const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory, or nullptr */,
-  const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf)
+  const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory [1 + kCounters + 1], or nullptr */,
+  uint32_t serial /* of this batch, never 0 */, const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf)
 {
   const uint32_t lane = threadIdx.x & 63, s = blockIdx.y;
   // the batch's last kernel also hands what the batch reports about its stream to the host (the next batches' route is
   // chosen from it, lfx_api.hip choose_route): a dozen words written straight into pinned memory -- as a copy of its own
   // it would put another engine's work between this batch's kernels and the next one's
-  if (report && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kCounters) {report[threadIdx.x] = counters[threadIdx.x];}
+  // (nobody waits for it and no event says it has arrived: the block carries the batch's serial number before and after
+  // the counters, written in this order with system-scope fences between, and the host reads it the other way round)
+  if (report && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(report, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x < kCounters) {
+      __hip_atomic_store(report + 1 + threadIdx.x, counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {__hip_atomic_store(report + 1 + kCounters, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);}
+  }
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (slot >= max_rings) {return;}
   {

@@ -216,6 +216,38 @@ def test_stream_of_turned_rings_stays_on_the_organised_route(kind):
     f.close()
 
 
+def test_route_follows_the_stream_while_the_host_runs_ahead():
+    """A caller that queues batch after batch without ever waiting (a loop of lfx_extract_batch_device calls: the bench, a
+    pipeline): the report of a batch reaches the host through pinned memory with the batch's serial number before and after
+    it, and the next batch's route is chosen from the newest block that is whole -- not from an event of the batch just
+    queued, which such a caller would never find passed.  A stream of rotated scans (three batches, waited for: the ring
+    transforms are on) turns into one in angle order: forty batches, no synchronise, the host far ahead of the device -- the
+    later ones are read without the transforms (route 1) although the host never waited for any of them."""
+    import torch
+    R, Ccols, nb = 16, 900, 1024
+    st = torch.cuda.current_stream().cuda_stream
+    f = FeatureExtraction(device=0, max_points_per_scan=R * Ccols, max_batch=nb, max_points_per_ring=Ccols, max_rings=R)
+
+    def resident(scans):
+        tiled = [scans[i % len(scans)] for i in range(nb)]
+        return torch.from_numpy(synth.concat(tiled).view(np.uint8).copy()).cuda(), np.array([len(c) for c in tiled], np.uint32)
+
+    turned = [make_scan(R, Ccols, seed=2600 + i, start_col=211) for i in range(8)]
+    plain = [make_scan(R, Ccols, seed=2700 + i) for i in range(8)]
+    d_t, n_t = resident(turned)
+    d_p, n_p = resident(plain)
+    for _ in range(3):
+        f.extract_batch_device(d_t.data_ptr(), n_t, st)
+        routes = f.scan_routes(nb, st).tolist()
+    assert routes == [2] * nb, sorted(set(routes))
+    for _ in range(40):
+        f.extract_batch_device(d_p.data_ptr(), n_p, st)
+    routes = f.scan_routes(nb, st).tolist()
+    assert routes == [1] * nb, "the route did not follow the stream while the host ran ahead: %s" % sorted(set(routes))
+    assert_scan_equal(f.download(3, st), OB.extract(plain[3], canonical_ties=False), "scan 3 of the last batch")
+    f.close()
+
+
 @pytest.mark.parametrize("tail", [None, "short"])
 def test_organised_scan_kernel_more_fall_backs_than_expected(tail):
     """The bucketing route is launched for as many scans as earlier batches sent to it (plus a few); scans beyond
