@@ -434,6 +434,10 @@ int lfx_edge_residuals(lfx_ctx *ctx, const lfx_map *map, const double pose[12], 
 #define LFX_ALIGN_LARGER_SCALE 2   /* "The scale is larger than previous iteration"   success */
 #define LFX_ALIGN_MAX_ITERATION 3  /* "The iteration reached the maximum value"       failure */
 #define LFX_ALIGN_EMPTY_INPUT 4    /* "The input data is empty"                       failure */
+#define LFX_ALIGN_NO_PLANE 5       /* "No surface neighbourhood spans a plane"        failure: not a status of the reference --
+                                    * every surface row of the scan was a zero row (its k nearest map points coincide, lie on
+                                    * one line or on a plane through the origin: surface.hpp:78-83 has a zero pivot there and
+                                    * Eigen's solve() hands back NaN, with which the reference runs to its iteration limit) */
 #define LFX_ALIGN_SUCCESS(code) ((code) <= LFX_ALIGN_LARGER_SCALE)
 typedef struct lfx_align_result {   /* OptimizationResult, optimization_result.hpp:35-43 */
   double pose[12];                  /* [R | t] row-major 3 x 4 */

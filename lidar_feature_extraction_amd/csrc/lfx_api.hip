@@ -824,7 +824,9 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->unit_span.alloc(tables * lfx::kUnitMaxBlocks));
   const size_t rc = nb * c->max_rings * c->cap;      // ring-major arrays: fixed capacity per ring id
   ok(c->sxy.alloc(rc)); ok(c->sz.alloc(rc)); ok(c->sidx.alloc(rc)); ok(c->rec_pts.alloc(rc)); ok(c->rec_idx.alloc(rc));
-  ok(c->label_s.alloc(rc)); ok(c->curv_s.alloc(rc));
+  ok(c->label_s.alloc(rc));
+  // (a context created without LFX_OUT_CURVATURE has no per-point curvature array at all: 8 bytes per ring position)
+  if (c->outputs & LFX_OUT_CURVATURE) {ok(c->curv_s.alloc(rc));}
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));

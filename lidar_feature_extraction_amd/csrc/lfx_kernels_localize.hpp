@@ -35,7 +35,7 @@ struct AlignState
   double prev_error, prev_scale;
   double error, scale;                    // OptimizationResult
   double cur_error, cur_scale;            // this iteration's, from align_scale_kernel to align_update_kernel
-  int32_t iteration, code, done, pad;
+  int32_t iteration, code, done, surface_rows_with_plane;      // (the last one: counted by the row kernels of the iteration, reset by align_scale_kernel)
   double prev_m[12];                      // the pose of the iteration before (the searches bound how far a query has moved)
 };
 
@@ -552,6 +552,14 @@ __device__ __forceinline__ void row_from_neighbours(
 // how a query finds its neighbours
 enum : int {kSearchWholeMap = 0, kSearchGridWave = 2};
 
+// A surface row whose neighbourhood spans a plane (|u| = 1; the others are zero rows, row_from_neighbours) is counted in its
+// scan's state: align_scale_kernel ends a scan that HAS surface points but not one such row with a status of its own instead
+// of letting rows that say nothing read as "converged" (the reference's arithmetic yields NaN there and fails differently).
+__device__ inline void count_surface_row_with_a_plane(const AlignState * __restrict__ align, uint32_t s)
+{
+  (void)__hip_atomic_fetch_add(const_cast<int32_t *>(&align[s].surface_rows_with_plane), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // the rows of one workgroup: `bx` = its index along x among the workgroups of its kind
 template<bool SURFACE, int SEARCH>
 __device__ __forceinline__ void scan_to_map_rows(
@@ -599,7 +607,9 @@ __device__ __forceinline__ void scan_to_map_rows(
   }
   if (!valid) {return;}
   if (SURFACE) {
-    row_from_neighbours<true>(P, p0, q, kk, idx, map, jacobian + 7 * (size_t)(rb + i), residual + (size_t)(rb + i));
+    double * J = jacobian + 7 * (size_t)(rb + i);
+    row_from_neighbours<true>(P, p0, q, kk, idx, map, J, residual + (size_t)(rb + i));
+    if (align && (J[4] != 0. || J[5] != 0. || J[6] != 0.)) {count_surface_row_with_a_plane(align, s);}
   } else {
     row_from_neighbours<false>(P, p0, q, kk, idx, map, jacobian + 21 * (size_t)(rb + i), residual + 3 * (size_t)(rb + i));
   }
@@ -714,7 +724,9 @@ __global__ __launch_bounds__(kRowThreads) void rows_from_neighbours_kernel(
       idx[4 * j] = v.x; idx[4 * j + 1] = v.y; idx[4 * j + 2] = v.z; idx[4 * j + 3] = v.w;
     }
     if (surf) {
-      row_from_neighbours<true>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 7 * (size_t)(rb + i), R.residual + (size_t)(rb + i));
+      double * J = R.jacobian + 7 * (size_t)(rb + i);
+      row_from_neighbours<true>(P, p0, q, kk, idx, R.mi.pts, J, R.residual + (size_t)(rb + i));
+      if (J[4] != 0. || J[5] != 0. || J[6] != 0.) {count_surface_row_with_a_plane(align, s);}
     } else {
       row_from_neighbours<false>(P, p0, q, kk, idx, R.mi.pts, R.jacobian + 21 * (size_t)(rb + i), R.residual + 3 * (size_t)(rb + i));
     }
@@ -919,7 +931,7 @@ __global__ void downsample_passthrough_kernel(
 // sums of WeightedUpdate, the 6 x 6 solve, the pose update and the three stopping tests); a finished scan's kernels return
 // at once.  PARITY UNPINNED (Eigen's arithmetic; sums are taken in a fixed tree order here, not row by row).
 constexpr int kAlignThreads = 256, kAlignKeysLds = 6144;
-enum AlignCode : int32_t {kAlignConverged = 0, kAlignLargerError = 1, kAlignLargerScale = 2, kAlignMaxIteration = 3, kAlignEmpty = 4};
+enum AlignCode : int32_t {kAlignConverged = 0, kAlignLargerError = 1, kAlignLargerScale = 2, kAlignMaxIteration = 3, kAlignEmpty = 4, kAlignNoPlane = 5};
 
 // Eigen::Quaterniond(Matrix3d): the branch on the trace, then on the largest diagonal entry
 __device__ inline void quaternion_of_rotation(const double (&m)[12], double & w, double (&v)[3])
@@ -976,7 +988,7 @@ __global__ void align_begin_kernel(AlignState * __restrict__ states, const doubl
   a.q[0] = w; a.q[1] = v[0]; a.q[2] = v[1]; a.q[3] = v[2];
   a.t[0] = m[3]; a.t[1] = m[7]; a.t[2] = m[11];
   a.prev_error = 1.7976931348623157e308; a.prev_scale = 1.7976931348623157e308;   // std::numeric_limits<double>::max()
-  a.error = 0.; a.scale = 0.; a.cur_error = 0.; a.cur_scale = 0.; a.iteration = 0; a.code = kAlignMaxIteration; a.done = 0; a.pad = 0;
+  a.error = 0.; a.scale = 0.; a.cur_error = 0.; a.cur_scale = 0.; a.iteration = 0; a.code = kAlignMaxIteration; a.done = 0; a.surface_rows_with_plane = 0;
   refresh_pose(a);
   for (int i = 0; i < 12; i++) {a.prev_m[i] = a.pose.m[i];}
   states[s] = a;
@@ -1239,6 +1251,15 @@ __global__ __launch_bounds__(kScaleThreads) void align_scale_kernel(
   const uint32_t n1 = count1 ? n1_ : 0u, b1 = count1 ? b1_ : 0u, n = n3 + n1;
   if (n == 0u) {                                            // EmptyInput (optimization_result.hpp:46-50)
     if (tid == 0) {align_finish(st, out[s], iter, 0., 0., kAlignEmpty, active);}
+    return;
+  }
+  // surface points, and not one of their neighbourhoods spans a plane (a degenerate map: every surface row is the zero row):
+  // no row says anything about the pose along the planes' normals -- a failure of its own kind, not "converged"
+  const int32_t with_plane = st.surface_rows_with_plane;
+  __syncthreads();
+  if (tid == 0) {st.surface_rows_with_plane = 0;}           // (the next iteration's row kernels count afresh)
+  if (n1 != 0u && with_plane == 0) {
+    if (tid == 0) {align_finish(st, out[s], iter, 0., 0., kAlignNoPlane, active);}
     return;
   }
   double * w_out = weights + (size_t)b3 + b1;

@@ -398,6 +398,7 @@ const char * lfx_align_message(int code)
     case LFX_ALIGN_LARGER_SCALE: return "The scale is larger than previous iteration";
     case LFX_ALIGN_MAX_ITERATION: return "The iteration reached the maximum value";
     case LFX_ALIGN_EMPTY_INPUT: return "The input data is empty";
+    case LFX_ALIGN_NO_PLANE: return "No surface neighbourhood spans a plane";
     default: return "unknown";
   }
 }

@@ -382,7 +382,8 @@ bool WeightedUpdateOf(const double M[42], const std::vector<double> & weights, c
 }
 
 // Optimizer::Run (optimizer.hpp:79-123).  make(pose, rows) is ProblemType::Make.  result: pose[12], error, error_scale,
-// iteration, code (0 converged, 1 larger error, 2 larger scale, 3 maximum iteration, 4 empty input); returns success.
+// iteration, code (0 converged, 1 larger error, 2 larger scale, 3 maximum iteration, 4 empty input, 5 no surface row with a
+// plane: not the reference's, see below); returns success.
 int RunOptimizer(const std::function<void(const double *, RowSet &)> & make, const double * initial_pose, int max_iter,
   double * pose_out, double * error_out, double * scale_out, int * iteration_out, int * code_out)
 {
@@ -403,6 +404,19 @@ int RunOptimizer(const std::function<void(const double *, RowSet &)> & make, con
     make(pose, rows);
     if (rows.size() == 0) {return finish(iter, 0., 0., 4);}
     const size_t n3 = rows.r3.size() / 3;
+    {
+      // Not the reference's: where a surface neighbourhood spans no plane, surface.hpp:78-83 solves with a zero pivot and
+      // Eigen hands back NaN (the reference then runs to its iteration limit with a NaN pose); that arithmetic is not
+      // available here, such a row is the zero row (SurfaceRows below), and a scan whose surface rows are ALL zero rows ends
+      // with a failure of its own (code 5) instead of reading rows that say nothing as "converged".
+      const size_t n1 = rows.r1.size();
+      size_t with_plane = 0;
+      for (size_t i = 0; i < n1; i++) {
+        const double * J = &rows.J1[7 * i];
+        if (J[4] != 0. || J[5] != 0. || J[6] != 0.) {with_plane++;}
+      }
+      if (n1 != 0 && with_plane == 0) {return finish(iter, 0., 0., 5);}
+    }
     std::vector<double> errors(rows.size());
     for (size_t i = 0; i < rows.size(); i++) {
       if (i < n3) {

@@ -190,7 +190,7 @@ def test_alignment_texts_and_null_arguments(lib):
     lib.lfx_align_message.restype = C.c_char_p
     texts = {0: "Optimization successfully converged", 1: "The error is larger than previous iteration",
              2: "The scale is larger than previous iteration", 3: "The iteration reached the maximum value",
-             4: "The input data is empty"}
+             4: "The input data is empty", 5: "No surface neighbourhood spans a plane"}
     for code, text in texts.items():
         assert lib.lfx_align_message(code).decode() == text
     assert lib.lfx_align_message(99) == b"unknown"

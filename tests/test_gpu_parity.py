@@ -620,10 +620,11 @@ def test_every_unit_kernel_variant(chunks):
 
 
 def test_organised_kernel_gives_a_scan_up_half_way():
-    """The organised-scan kernel writes its feature points straight into the scan's clouds, every unit behind the counts
-    its predecessors publish (unit_look_back).  A scan that breaks the pattern in a late unit has by then written part of
-    its clouds: the unit that gives up publishes an empty count (nobody may wait for it), the scan is redone whole by the
-    bucketing route, whose compaction overwrites what was there.  Scans in order, one such scan, rotated rings."""
+    """A scan that breaks the organised pattern in a LATE unit: by then the earlier units of the scan have written their
+    labels, curvatures, per-unit feature records and their counts into their rings' totals.  The unit that finds the break
+    puts the scan on the fall-back list (scan_falls_back); the bucketing route redoes it whole in the same call and
+    overwrites all of that -- the unit tables, the ring counts, and the compaction takes the bucketing route's tables for
+    such a scan (feature_compact_kernel, by_ring).  Scans in order, one such scan, rotated rings."""
     f = FeatureExtraction(device=0, max_points_per_scan=64 * 1800, max_batch=4, max_points_per_ring=1800, max_rings=64)
     clouds = [make_scan(64, 1800, seed=880 + i) for i in range(4)]
     clouds[2] = clouds[2].copy()
