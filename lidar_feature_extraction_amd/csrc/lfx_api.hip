@@ -394,7 +394,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
         n_units, c->cap, c->scan_begin.p, c->ring_count.p, self_totals ? nullptr : c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
         c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->batch_serial, c->ring_nedge.p, c->ring_nsurf.p);
+        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->batch_serial, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p);
     }
   }
   LFX_HIP(c, hipGetLastError());
@@ -830,6 +830,15 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
+  if (c->fused_possible) {
+    // the organised-scan kernel's record slots: 2 KB per unit (kRecSlot records of 32 bytes), units back to back
+    const size_t slots = nb * c->max_rings * (size_t)c->dev.B;
+    if (slots * lfx::kRecSlot * 32u <= ((size_t)8 << 30)) {
+      ok(c->rec32.alloc(slots * lfx::kRecSlot * 2u));
+    } else {
+      c->fused_possible = false;           // (hundreds of blocks per ring on a large batch: the bucketing route takes every scan)
+    }
+  }
   if (e == hipSuccess) {
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 4 * (lfx::kCounters + 2), hipHostMallocDefault);
     if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * (lfx::kCounters + 2));}
@@ -838,7 +847,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     // (no per-point curvature asked for: the kernels find no array to write it to -- a fifth of the unit kernel's HBM traffic)
     const lfx::UnitTables t{c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
-      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p, c->ring_nedge.p, c->ring_nsurf.p};
+      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p};
     e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
@@ -879,6 +888,7 @@ void lfx_destroy(lfx_ctx * c)
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
+  c->rec32.release();
   c->curv_s.release(); c->edge_pts.release(); c->surf_pts.release(); c->edge_idx.release(); c->surf_idx.release();
   c->staging.release();
   c->h_in.release(); c->h_out.release(); c->vox_scratch.release(); c->align_scratch.release(); c->align_surface.release(); c->h_align.release(); c->h_loc.release();

@@ -207,6 +207,10 @@ struct UnitTables
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
   uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
+  float4 * rec32;                                   // organised-scan kernel: the units' record slots, [batch][max_rings][n_blocks][kRecSlot] x 32 bytes
 };
+// Records per slot of an organised scan's unit: {x, y, z, (float)c | original index, 12 bytes unused}, edges then surfaces,
+// each in position order; what does not fit lies at its rank in rec_pts / rec_idx from the unit's first owned position.
+constexpr uint32_t kRecSlot = 64;
 
 }  // namespace lfx

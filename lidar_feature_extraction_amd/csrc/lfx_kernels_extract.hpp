@@ -1588,7 +1588,8 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
   uint32_t max_rings, uint32_t * __restrict__ scan_info /* read for the scan's route; its totals written here where ring_ebase == nullptr */,
   const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory [1 + kCounters + 1], or nullptr */,
-  uint32_t serial /* of this batch, never 0 */, const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf)
+  uint32_t serial /* of this batch, never 0 */, const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf,
+  const float4 * __restrict__ rec32 /* the record slots of the organised scans' units (UnitTables), or nullptr */)
 {
   const uint32_t lane = threadIdx.x & 63, s = blockIdx.y;
   // the batch's last kernel also hands what the batch reports about its stream to the host (the next batches' route is
@@ -1614,6 +1615,10 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   {
     const size_t b = scan_begin[s];
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+    // a scan the organised-scan kernel took keeps its units' records in their slots (32-byte records in rank order, edges
+    // then surfaces; beyond kRecSlot at their ranks in the old arrays); any other scan in rec_pts / rec_idx, edges from the
+    // front of the unit's positions and surfaces from their back
+    const bool slots = rec32 != nullptr && scan_is_organised(scan_info[s * 4 + kInfoError]);
     size_t eb, fb;
     if (ring_ebase) {
       eb = b + ring_ebase[s * kRings + slot];
@@ -1665,11 +1670,12 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     for (int o = 32; o > 0; o >>= 1) {total += __shfl_xor(total, o);}
     for (uint32_t t0 = 0; t0 < total; t0 += 256) {
       size_t src[4], dst[4];
-      bool edge[4], valid[4];
+      bool edge[4], valid[4], in_slot[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         valid[i] = t0 + 64 * i + lane < total;
         edge[i] = false;
+        in_slot[i] = false;
         src[i] = off;
         dst[i] = b;
       }
@@ -1683,7 +1689,12 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
           const uint32_t q = t0 + 64 * i + lane - cum;       // index inside unit u (wraps when the record lies before it)
           if (q < ne + ns) {
             edge[i] = q < ne;
-            src[i] = edge[i] ? first + q : last - 1 - (q - ne);
+            if (slots) {
+              in_slot[i] = q < kRecSlot;
+              src[i] = in_slot[i] ? (((size_t)s * max_rings + slot) * n_units + u) * kRecSlot + q : first + q;
+            } else {
+              src[i] = edge[i] ? first + q : last - 1 - (q - ne);
+            }
             dst[i] = edge[i] ? eb + ecum + q : fb + scum + (q - ne);
           }
         }
@@ -1698,8 +1709,13 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         ri[i] = 0;
         if (valid[i]) {
-          rp[i] = rec_pts[src[i]];
-          ri[i] = rec_idx[src[i]];
+          if (in_slot[i]) {
+            rp[i] = rec32[2 * src[i]];
+            ri[i] = __float_as_uint(rec32[2 * src[i] + 1].x);
+          } else {
+            rp[i] = rec_pts[src[i]];
+            ri[i] = rec_idx[src[i]];
+          }
         }
       }
 #pragma unroll

@@ -1014,10 +1014,18 @@ __device__ __forceinline__ uint32_t unit_core(
   g_f32x4_t * const rec_u = (g_f32x4_t *)tab->rec_pts + (off + rec_lo);
   g_u32_t * const idx_u = (g_u32_t *)tab->rec_idx + (off + rec_lo);
   const uint32_t rec_n = rec_hi - rec_lo;          // edges from the front of the unit's positions, surfaces from their back
+  // ORG: the unit's feature records do not go out chunk by chunk as 16 + 4 bytes into two arrays at the unit's place among
+  // the ring's positions -- a handful of partial writes 4.8 KB away from the next unit's, which cost the kernel 150-180 us
+  // of its 1 020 (measured with the records ablated; tools/membench models it) -- but as 32-byte records {x, y, z, c | index}
+  // in rank order (edges, then surfaces) into the unit's SLOT of kRecSlot records (2 KB per unit, units back to back),
+  // staged in the wave's LDS and written by two stores of a kilobyte each.  A unit with more features than the stage holds
+  // puts the rest at their ranks in the old arrays (feature_compact_kernel reads both).
+  uint32_t lab[ORG ? CH : 1];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
+    if (ORG) {lab[k] = kDefault;}
     if (k < K) {
-      const int q = 64 * k + lane, i = g0 + q;
+      const int q = 64 * k + lane;
       const bool own = lanes(in_span(q, qo0, qo1));
       const uint32_t l = final_label(k, q);
       const double cv = U.c[q];
@@ -1026,18 +1034,65 @@ __device__ __forceinline__ uint32_t unit_core(
         if (curv_s != nullptr) {curv_u[(uint32_t)q] = cv;}       // (wave-uniform: a context created without LFX_OUT_CURVATURE has no such array)
       }
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
-      if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
+      if constexpr (ORG) {
+        lab[k] = l;
+      } else if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
         // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
         const f32x4_t rec = {x[k], y[k], z[k], (float)cv};
         const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
         const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
         const uint32_t at = l == kEdge ? pe + be : rec_n - 1u - (ps + bs);
         rec_u[at] = rec;
-        // ORG: position i of ring `slot` is point column * R + slot
-        idx_u[at] = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
+        idx_u[at] = src[k];
       }
       pe += __popcll(fe);
       ps += __popcll(fs);
+    }
+  }
+  if constexpr (ORG) {
+    if ((pe | ps) != 0u && LFX_STAGE_ON(1024u)) {
+      constexpr uint32_t kStage = 16 * CH < kRecSlot ? 16 * CH : kRecSlot;      // records the range slab holds (dead since stage E; its words of the labelling have been read)
+      LFX_WAVE_SYNC();
+      f32x4_t * const stage = reinterpret_cast<f32x4_t *>(U.r);
+      g_f32x4_t * const slot_u = (g_f32x4_t *)tab->rec32 + ((((size_t)s * og.R + slot) * (uint32_t)B + (uint32_t)j) * (2u * kRecSlot));
+      uint32_t re = 0, rs = pe;                      // ranks: the edges first, the surfaces behind them, each in position order
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (k < K) {
+          const uint64_t fe = bal(lab[k] == kEdge), fs = bal(lab[k] == kSurface);
+          if ((fe | fs) != 0ull) {
+            if (lanes(fe | fs)) {
+              const int q = 64 * k + lane, i = g0 + q;
+              const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
+              const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
+              const uint32_t rank = lab[k] == kEdge ? re + be : rs + bs;
+              // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature; position i of ring `slot` is
+              // point column * R + slot
+              const f32x4_t rec = {x[k], y[k], z[k], (float)U.c[q]};
+              const uint32_t idx = (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot;
+              if (rank < kStage) {
+                stage[2u * rank] = rec;
+                reinterpret_cast<u32_alias_t *>(stage + 2u * rank + 1u)[0] = idx;
+              } else if (rank < kRecSlot) {          // (a short slab stages fewer records than the slot holds: straight to the slot)
+                slot_u[2u * rank] = rec;
+                reinterpret_cast<g_u32_t *>(slot_u + 2u * rank + 1u)[0] = idx;
+              } else {
+                rec_u[rank] = rec;                   // (more features than a slot holds: at their ranks among the unit's positions)
+                idx_u[rank] = idx;
+              }
+            }
+            re += (uint32_t)__popcll(fe);
+            rs += (uint32_t)__popcll(fs);
+          }
+        }
+      }
+      LFX_WAVE_SYNC();
+      const uint32_t staged = pe + ps < kStage ? pe + ps : kStage;
+#pragma unroll
+      for (uint32_t t = 0; t < 2u * kStage; t += 64u) {        // half records: a kilobyte per store instruction
+        const uint32_t h = t + (uint32_t)lane;
+        if (h < 2u * staged) {slot_u[h] = stage[h];}
+      }
     }
   }
   LFX_STAMP(10);
