@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="scans per step per GPU (118 M points, ~15 GB of device memory with all scratch)")
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--cols", type=int, default=1800)
+    ap.add_argument("--params", default="code defaults", choices=["code defaults", "launch_yaml"],
+                    help="hyper-parameters: the reference's code defaults (hyper_parameter.hpp:35-43, the headline) or its launch file's set (lidar_feature_extraction.param.yaml:3-10)")
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic scans per GPU (tiled to --batch)")
     ap.add_argument("--start-col", type=int, default=0, help="first column of every scan (a driver that does not cut its scans at -pi: every ring arrives rotated)")
     ap.add_argument("--reverse", action="store_true", help="clockwise sensor: every ring arrives in descending angle order")
@@ -231,7 +233,8 @@ def main():
     will_gather = (world > 1 and not a.no_gather) or a.force_gather
     if will_gather:
         n_streams = 2
-    fxs = [FeatureExtraction(HyperParameters(), device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
+    hp_main = HyperParameters.launch_yaml() if a.params == "launch_yaml" else HyperParameters()
+    fxs = [FeatureExtraction(hp_main, device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
                              max_points_per_ring=cap, max_rings=a.rings, drop_zero_points=a.drop_zero) for _ in range(n_streams)]
     fx = fxs[0]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
@@ -432,7 +435,9 @@ def main():
             from oracle import binding as oracle          # checker only (never timed as the product)
             # (with the zero filter on, the reference sees the cloud without its (0, 0, 0) records: convert.py:162-163)
             keep = np.nonzero(valid[0])[0]
-            w = oracle.extract(np.ascontiguousarray(clouds[0][keep]), canonical_ties=False)
+            op = oracle.Params(hp_main.padding, hp_main.neighbor_degree_threshold, hp_main.distance_diff_threshold, hp_main.parallel_beam_min_range_ratio,
+                               hp_main.edge_threshold, hp_main.surface_threshold, hp_main.min_range, hp_main.max_range, hp_main.n_blocks)
+            w = oracle.extract(np.ascontiguousarray(clouds[0][keep]), op, canonical_ties=False)
             parity = bool(np.array_equal(g.labels[keep], w["labels"]) and g.curvature[keep].tobytes() == w["curvature"].tobytes()
                           and np.array_equal(g.edge_index, keep[w["edge_index"]].astype(np.uint32))
                           and np.array_equal(g.surface_index, keep[w["surface_index"]].astype(np.uint32)))
@@ -626,7 +631,7 @@ def main():
             "ms_per_step": round(1e3 * dt / a.steps, 4), "ms_per_scan": round(1e3 * dt / (a.batch * a.steps), 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "rings": a.rings, "cols": a.cols,
-                       "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": "code defaults",
+                       "points_per_scan": n_pts, "scans_per_step_per_gpu": a.batch, "params": a.params,
                        "input_order": ("shuffled" if a.shuffle else ("rings in angle order" if not (a.start_col or a.reverse) else
                                        "rings %s%s" % ("reversed " if a.reverse else "", "rotated by %d columns" % a.start_col if a.start_col else ""))) +
                                       ((", %.0f %% of the returns %s" % (100 * a.drop_fraction, "written as (0, 0, 0) and filtered" if a.drop_zero else "missing"))

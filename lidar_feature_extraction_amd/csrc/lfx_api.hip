@@ -831,10 +831,10 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
   if (c->fused_possible) {
-    // the organised-scan kernel's record slots: 2 KB per unit (kRecSlot records of 32 bytes), units back to back
+    // the organised-scan kernel's record slots: 1 280 bytes per unit (kRecSlot points and their indices), units back to back
     const size_t slots = nb * c->max_rings * (size_t)c->dev.B;
-    if (slots * lfx::kRecSlot * 32u <= ((size_t)8 << 30)) {
-      ok(c->rec32.alloc(slots * lfx::kRecSlot * 2u));
+    if (slots * lfx::kRecSlotBytes <= ((size_t)8 << 30)) {
+      ok(c->rec32.alloc(slots * (lfx::kRecSlotBytes / 16u)));
     } else {
       c->fused_possible = false;           // (hundreds of blocks per ring on a large batch: the bucketing route takes every scan)
     }
@@ -847,7 +847,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     // (no per-point curvature asked for: the kernels find no array to write it to -- a fifth of the unit kernel's HBM traffic)
     const lfx::UnitTables t{c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
       c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
-      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p};
+      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p, c->dev};
     e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}

@@ -1615,7 +1615,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   {
     const size_t b = scan_begin[s];
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
-    // a scan the organised-scan kernel took keeps its units' records in their slots (32-byte records in rank order, edges
+    // a scan the organised-scan kernel took keeps its units' records in their slots (points, then indices, in rank order: edges
     // then surfaces; beyond kRecSlot at their ranks in the old arrays); any other scan in rec_pts / rec_idx, edges from the
     // front of the unit's positions and surfaces from their back
     const bool slots = rec32 != nullptr && scan_is_organised(scan_info[s * 4 + kInfoError]);
@@ -1691,7 +1691,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
             edge[i] = q < ne;
             if (slots) {
               in_slot[i] = q < kRecSlot;
-              src[i] = in_slot[i] ? (((size_t)s * max_rings + slot) * n_units + u) * kRecSlot + q : first + q;
+              src[i] = in_slot[i] ? (((size_t)s * max_rings + slot) * n_units + u) * (kRecSlotBytes / 4u) + 4u * q : first + q;    // (slot: in dwords)
             } else {
               src[i] = edge[i] ? first + q : last - 1 - (q - ne);
             }
@@ -1710,8 +1710,9 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         ri[i] = 0;
         if (valid[i]) {
           if (in_slot[i]) {
-            rp[i] = rec32[2 * src[i]];
-            ri[i] = __float_as_uint(rec32[2 * src[i] + 1].x);
+            const uint32_t * w = reinterpret_cast<const uint32_t *>(rec32) + src[i];          // the point; its index 4 kRecSlot - 3 q dwords on
+            rp[i] = *reinterpret_cast<const float4 *>(w);
+            ri[i] = w[4u * kRecSlot - 3u * ((src[i] % (kRecSlotBytes / 4u)) / 4u)];
           } else {
             rp[i] = rec_pts[src[i]];
             ri[i] = rec_idx[src[i]];

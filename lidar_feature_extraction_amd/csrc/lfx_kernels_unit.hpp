@@ -63,7 +63,9 @@ static_assert(7 * 4 * sizeof(UnitLds<5>) <= 160 * 1024 && 6 * 4 * sizeof(UnitLds
 #ifndef LFX_COS_BAND
 #define LFX_COS_BAND 0x1p-20f
 #endif
-constexpr int unit_waves_per_simd(int ch) {return ch > 6 ? 3 : (ch == 6 ? 6 : (ch == 5 ? LFX_UNIT_WAVES_CH5 : 8));}
+// (variant 0, the headline's, keeps 7 workgroups per CU at 5 chunks in 72 registers without a spill; the other variants hold
+// their thresholds in registers and get the 80 of 6 workgroups per CU -- 6 against 7 made no measurable difference, round 5)
+constexpr int unit_waves_per_simd(int ch, int variant = 0) {return ch > 6 ? 3 : (ch == 6 ? 6 : (ch == 5 ? (variant == 0 ? LFX_UNIT_WAVES_CH5 : 6) : 8));}
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
 // lane's LDS read above another lane's LDS write of the same wave.
@@ -455,11 +457,8 @@ __device__ __forceinline__ uint32_t unit_core(
   (void)B;
   // DEF: the thresholds are the reference's code defaults (hyper_parameter.hpp:35-43; the host checks) and become
   // literals: seven fewer long-lived scalar values in a kernel that spills scalar registers (-3.4 % time)
-  const double dist_diff = DEF ? 0.3 : prm.dist_diff;
-  const double edge_thr = DEF ? 0.05 : prm.edge_thr, surf_thr = DEF ? 0.05 : prm.surf_thr;
-  const double min_range = DEF ? 0.1 : prm.min_range, max_range = DEF ? 100.0 : prm.max_range;
-  const double pb_ratio = DEF ? 0.02 : prm.pb_ratio;
-  const float pb_ratio_f = DEF ? 0.02f : prm.pb_ratio_f;
+  // (!DEF: the thresholds come from the copy of the parameter block behind `tab`, fetched where a stage first needs them
+  // -- as kernel arguments they sat in nineteen scalar registers from the first instruction to the last)
   const int N = G.N, o0 = G.o0, o1 = G.o1, g0 = G.g0, span = G.span, K = G.K;
   const int qb0 = G.qb0, qb1 = G.qb1, qo0 = G.qo0, qo1 = G.qo1, qlo = G.qlo, qhi = G.qhi;
   (void)o0; (void)o1;
@@ -491,12 +490,18 @@ __device__ __forceinline__ uint32_t unit_core(
     // (one walk over the chunks, one read of the neighbour's x, y for the order test and the link's dot product; a
     // chunk's links are final -- the undecided ones settled by the exact division at once -- before its jumps are taken
     // from the same two ranges)
+    asm volatile ("" ::: "memory");
+    const double dist_diff = DEF ? 0.3 : tab->prm.dist_diff;
+    const double min_range = DEF ? 0.1 : tab->prm.min_range, max_range = DEF ? 100.0 : tab->prm.max_range;
+    const double pb_ratio = DEF ? 0.02 : tab->prm.pb_ratio;
+    const float pb_ratio_f = DEF ? 0.02f : tab->prm.pb_ratio_f;
+    const double cos_bound = tab->prm.cos_bound;
     const int pair_end = qo1 < qhi - 1 ? qo1 : qhi - 1;                // owned pairs (q, q+1): q in [qo0, pair_end)
     uint64_t bad = 0;
     uint64_t zero_pair = 0;
     uint64_t prev_top = 0;                               // link of the pair (64k - 1, 64k)
     WordVec vlk, vjl, vjr;
-    const float cbf = prm.cos_bound_f;
+    const float cbf = tab->prm.cos_bound_f;
     // parallel_beam.hpp:43-49: (float)(|dr| / r) > ratio on both sides.  f32 pre-filter: the
     // differences of the f32 ranges are within 2 ulp(r) of the exact ones, i.e. within
     // 2^-22 * r; against the threshold ratio * r that is a relative error of 2^-22 / ratio, so a
@@ -549,7 +554,7 @@ __device__ __forceinline__ uint32_t unit_core(
         if (undecided != 0ull) {
           const double dot = (double)x[k] * (double)nb.x + (double)y[k] * (double)nb.y;
           const double cosang = dot / (rk * rn);                         // math.cpp:44-45
-          lk |= undecided & bal(cosang >= prm.cos_bound) & bal(cosang <= 1.0);    // acos(cos) < threshold; NaN -> false
+          lk |= undecided & bal(cosang >= cos_bound) & bal(cosang <= 1.0);    // acos(cos) < threshold; NaN -> false
         }
         vlk.set(k, lk);
         const double rq = rk + c_dd;
@@ -700,6 +705,8 @@ __device__ __forceinline__ uint32_t unit_core(
   // lt: the order masks, and on top of them the position's candidacy where the curvature is in a register: bit 31
   // c >= edge threshold (label.hpp:80-82), bit 30 c <= surface threshold (label.hpp:119-121)
   // (a run-time P may need every bit for the order: the candidates then are wave masks of their own)
+  asm volatile ("" ::: "memory");
+  const double edge_thr = DEF ? 0.05 : tab->prm.edge_thr, surf_thr = DEF ? 0.05 : tab->prm.surf_thr;
   uint32_t lt[CH];
   uint64_t ecand[CH], scand[CH];
   constexpr uint32_t kEdgeCand = 1u << ((PT > 0 ? PT : 1) + 18), kSurfCand = 1u << ((PT > 0 ? PT : 1) + 17);     // (just above the order bits)
@@ -1014,12 +1021,12 @@ __device__ __forceinline__ uint32_t unit_core(
   g_f32x4_t * const rec_u = (g_f32x4_t *)tab->rec_pts + (off + rec_lo);
   g_u32_t * const idx_u = (g_u32_t *)tab->rec_idx + (off + rec_lo);
   const uint32_t rec_n = rec_hi - rec_lo;          // edges from the front of the unit's positions, surfaces from their back
-  // ORG: the unit's feature records do not go out chunk by chunk as 16 + 4 bytes into two arrays at the unit's place among
-  // the ring's positions -- a handful of partial writes 4.8 KB away from the next unit's, which cost the kernel 150-180 us
-  // of its 1 020 (measured with the records ablated; tools/membench models it) -- but as 32-byte records {x, y, z, c | index}
-  // in rank order (edges, then surfaces) into the unit's SLOT of kRecSlot records (2 KB per unit, units back to back),
-  // staged in the wave's LDS and written by two stores of a kilobyte each.  A unit with more features than the stage holds
-  // puts the rest at their ranks in the old arrays (feature_compact_kernel reads both).
+  // ORG: the unit's feature records do not go out chunk by chunk into two arrays at the unit's place among the ring's
+  // positions -- a handful of partial writes 4.8 KB away from the next unit's, which cost the kernel 150-180 us of its 1 020
+  // (measured with the records ablated; tools/membench models it) -- but in rank order (edges, then surfaces) into the unit's
+  // SLOT: kRecSlot points {x, y, z, c} and behind them their kRecSlot indices, 1 280 bytes per unit, units back to back;
+  // staged in the wave's LDS and written by one store per part.  A unit with more features than a slot holds puts the rest
+  // at their ranks in the old arrays (feature_compact_kernel reads both).
   uint32_t lab[ORG ? CH : 1];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
@@ -1051,10 +1058,10 @@ __device__ __forceinline__ uint32_t unit_core(
   }
   if constexpr (ORG) {
     if ((pe | ps) != 0u && LFX_STAGE_ON(1024u)) {
-      constexpr uint32_t kStage = 16 * CH < kRecSlot ? 16 * CH : kRecSlot;      // records the range slab holds (dead since stage E; its words of the labelling have been read)
-      LFX_WAVE_SYNC();
-      f32x4_t * const stage = reinterpret_cast<f32x4_t *>(U.r);
-      g_f32x4_t * const slot_u = (g_f32x4_t *)tab->rec32 + ((((size_t)s * og.R + slot) * (uint32_t)B + (uint32_t)j) * (2u * kRecSlot));
+      static_assert(20 * kRecSlot <= 8 * 64 * CH, "the range slab stages a slot's records");
+      LFX_WAVE_SYNC();                               // (the range slab is dead since stage E; its words of the labelling have been read)
+      f32x4_t * const stage_pts = reinterpret_cast<f32x4_t *>(U.r);
+      u32_alias_t * const stage_idx = reinterpret_cast<u32_alias_t *>(stage_pts + kRecSlot);
       uint32_t re = 0, rs = pe;                      // ranks: the edges first, the surfaces behind them, each in position order
 #pragma unroll
       for (int k = 0; k < CH; k++) {
@@ -1070,12 +1077,9 @@ __device__ __forceinline__ uint32_t unit_core(
               // point column * R + slot
               const f32x4_t rec = {x[k], y[k], z[k], (float)U.c[q]};
               const uint32_t idx = (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot;
-              if (rank < kStage) {
-                stage[2u * rank] = rec;
-                reinterpret_cast<u32_alias_t *>(stage + 2u * rank + 1u)[0] = idx;
-              } else if (rank < kRecSlot) {          // (a short slab stages fewer records than the slot holds: straight to the slot)
-                slot_u[2u * rank] = rec;
-                reinterpret_cast<g_u32_t *>(slot_u + 2u * rank + 1u)[0] = idx;
+              if (rank < kRecSlot) {
+                stage_pts[rank] = rec;
+                stage_idx[rank] = idx;
               } else {
                 rec_u[rank] = rec;                   // (more features than a slot holds: at their ranks among the unit's positions)
                 idx_u[rank] = idx;
@@ -1087,11 +1091,12 @@ __device__ __forceinline__ uint32_t unit_core(
         }
       }
       LFX_WAVE_SYNC();
-      const uint32_t staged = pe + ps < kStage ? pe + ps : kStage;
-#pragma unroll
-      for (uint32_t t = 0; t < 2u * kStage; t += 64u) {        // half records: a kilobyte per store instruction
-        const uint32_t h = t + (uint32_t)lane;
-        if (h < 2u * staged) {slot_u[h] = stage[h];}
+      const uint32_t staged = pe + ps < kRecSlot ? pe + ps : kRecSlot;
+      g_f32x4_t * const slot_pts = (g_f32x4_t *)tab->rec32 + ((((size_t)s * og.R + slot) * (uint32_t)B + (uint32_t)j) * (kRecSlotBytes / 16u));
+      g_u32_t * const slot_idx = reinterpret_cast<g_u32_t *>(slot_pts + kRecSlot);
+      if ((uint32_t)lane < staged) {                 // one store of up to a kilobyte, one of up to 256 bytes
+        slot_pts[lane] = stage_pts[lane];
+        slot_idx[lane] = stage_idx[lane];
       }
     }
   }
@@ -1311,7 +1316,7 @@ template<int V> struct UnitVariant
 };
 
 template<int V, bool SECOND, int CH, bool LOOP = false>
-__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring_unit_kernel(
+__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
@@ -1357,17 +1362,17 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) void ring
   }
 }
 
-// The organised-scan kernel (unit_body<ORG>): workgroup = block j of the four adjacent rings 4g .. 4g+3 of scan
-// blockIdx.y, one ring per wave.  blockIdx.x = j * groups + g: workgroups dispatched together take neighbouring ring
-// groups of the same block, i.e. neighbouring 128-byte lines of the same columns -- whole DRAM pages between them.
-// (Every scan on ONE XCD, so that the six units of a ring share an L2: measured, no difference -- profiles/r04_slices.)
+// The organised-scan kernel (unit_body<ORG>): workgroup = block j = blockIdx.y of four adjacent rings 4g .. 4g+3 of scan
+// blockIdx.z, one ring per wave; which group g a workgroup takes follows from blockIdx.x and the scan (below).
+// (Every scan on ONE XCD, so that the six units of a ring share an L2: measured, no difference -- profiles/r04_slices.
+// An XCD taking FOUR adjacent groups of one scan, two scans sharing 32 workgroups: 1 061-1 064 against 1 052-1 054 us, round 5.)
 #ifdef LFX_ORG_SGPRS       // (A/B: what the scalar-register budget of 8 workgroups per CU would cost this kernel)
 #define LFX_ORG_ATTR __attribute__((amdgpu_num_sgpr(LFX_ORG_SGPRS)))
 #else
 #define LFX_ORG_ATTR
 #endif
 template<int V, int CH, bool XF>
-__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) LFX_ORG_ATTR void ring_unit_org_kernel(
+__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) LFX_ORG_ATTR void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
   const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform, const uint32_t * __restrict__ geom)
@@ -1382,16 +1387,8 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH)) LFX_ORG_A
   // waiting twice as long for their records as the others', its shader engines of the others idle for 17 % of the kernel).
   // So the ring group is turned by the scan index: every XCD sees every group.
   const int j = (int)blockIdx.y;
-  uint32_t s = blockIdx.z;
+  const uint32_t s = blockIdx.z;
   uint32_t g = blockIdx.x;
-#ifdef LFX_GROUP_QUADS      // (experiment: an XCD takes FOUR adjacent groups of one scan, two scans sharing 32 workgroups)
-  if (gridDim.x == 16u && (s | 1u) < gridDim.z) {
-    const uint32_t k = g & 7u, h = g >> 3, zb = s & 1u;
-    s = (s & ~1u) + (k >> 2);
-    g = 4u * (k & 3u) + h + 2u * zb;
-    g = (g + 4u * (s >> 1)) & 15u;
-  } else
-#endif
 #ifndef LFX_NO_GROUP_TURN
   {
     // (and with sixteen groups or a multiple an XCD takes two ADJACENT groups, 256 contiguous bytes of every column, at a

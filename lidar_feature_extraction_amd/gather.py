@@ -315,6 +315,44 @@ def gather_clouds(edge, surface, offsets, batch, dst=0, group=None):
             for r in range(world)]
 
 
+def gather_clouds_pair(steps, batch, group=None):
+    """The protocol of lfx_gather_payload2 over torch.distributed (gloo): TWO steps' clouds, each to its own destination, with
+    every send and receive of both steps posted before any is waited for (one group).  steps: [(edge, surface, offsets,
+    dst), (edge, surface, offsets, dst)] with this rank's packed clouds of each step.  Returns a list of two: what
+    gather_clouds returns for the step on its destination rank, None elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    totals = []
+    for edge, surface, offsets, _ in steps:                 # the totals of both steps first (lfx_gather_counts_slot, slots 0 and 1)
+        t = _totals(offsets, batch)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t, group=group)
+        totals.append(torch.stack(every).cpu())
+    ops, recv = [], []
+    for (edge, surface, offsets, dst), tot in zip(steps, totals):
+        ne, ns = int(tot[rank, 0]), int(tot[rank, 1])
+        if rank != dst:
+            for t in (edge[:ne].contiguous(), surface[:ns].contiguous(), offsets.contiguous()):
+                ops.append(dist.P2POp(dist.isend, t, dst, group))
+            recv.append(None)
+            continue
+        parts = []
+        for r in range(world):
+            if r == dst:
+                parts.append({"edge": edge[:ne].clone(), "surface": surface[:ns].clone(), "offsets": offsets.clone()})
+                continue
+            p = {"edge": torch.empty((int(tot[r, 0]),) + tuple(edge.shape[1:]), dtype=edge.dtype),
+                 "surface": torch.empty((int(tot[r, 1]),) + tuple(surface.shape[1:]), dtype=surface.dtype),
+                 "offsets": torch.empty_like(offsets)}
+            for k in ("edge", "surface", "offsets"):
+                ops.append(dist.P2POp(dist.irecv, p[k], r, group))
+            parts.append(p)
+        recv.append(parts)
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return recv
+
+
 def shard_scans(n_scans, rank, world):
     """scan i -> rank i mod world."""
     return list(range(rank, n_scans, world))

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lidar_feature_extraction_amd.gather import gather_clouds, reassemble, shard_scans
+from lidar_feature_extraction_amd.gather import gather_clouds, gather_clouds_pair, reassemble, shard_scans
 
 
 def _free_port():
@@ -114,6 +114,50 @@ def test_stream_sharded_over_two_ranks_reassembles_to_the_oracle_clouds():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_stream_worker, args=(world, _free_port(), n_scans, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def _pair_worker(rank, world, port, batch, ret):
+    """Two steps as ONE exchange (the protocol of lfx_gather_payload2): step A's clouds to rank 0, step B's to rank 1, every
+    send and receive of both posted together; in step B rank 1 has no edge point in its first scan and rank 0 none at all."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def data(step, r):
+        e, s, o, n_e, n_s = _make_rank_data(10 * step + r, batch)
+        if step == 1 and r == 0:                                   # a rank without a single feature in this step
+            o = np.zeros_like(o)
+            n_e = n_s = 0
+        return e, s, o, n_e, n_s
+
+    steps = []
+    for step, dst in ((0, 0), (1, 1)):
+        e, s, o, _, _ = data(step, rank)
+        steps.append((torch.from_numpy(e), torch.from_numpy(s), torch.from_numpy(o), dst))
+    out = gather_clouds_pair(steps, batch)
+    ok = len(out) == 2
+    for step, dst in ((0, 0), (1, 1)):
+        if rank != dst:
+            ok = ok and out[step] is None
+            continue
+        ok = ok and out[step] is not None and len(out[step]) == world
+        for r in range(world):
+            e, s, o, n_e, n_s = data(step, r)
+            got = out[step][r]
+            ok = ok and got["edge"].shape[0] == n_e and got["surface"].shape[0] == n_s
+            ok = ok and np.array_equal(got["edge"].numpy(), e[:n_e]) and np.array_equal(got["surface"].numpy(), s[:n_s])
+            ok = ok and np.array_equal(got["offsets"].numpy(), o)
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_steps_as_one_exchange_two_ranks_gloo():
+    world, batch = 2, 5
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pair_worker, args=(world, _free_port(), batch, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 
