@@ -1613,30 +1613,54 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (slot >= max_rings) {return;}
   {
-    const size_t b = scan_begin[s];
+    // Everything a wave needs before it can ask for its records is asked for at ONCE -- the scan's first point and route, the
+    // ring's length, the totals of the rings before it, its units' counts and spans: a wave's life was five memory round
+    // trips in series (15 us; the kernel ran at 3.7 TB/s of its own bytes, round 5), three of which only decided which of
+    // the others to make.  (The totals of the earlier rings are read from the organised route's table whether or not the
+    // scan took that route: it is a valid address either way, and the other route's sums follow below.)
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+    const size_t b = scan_begin[s];
+    const uint32_t err = scan_info[s * 4 + kInfoError];
+    const uint32_t n_ring = ring_count[s * kRings + slot];
+    uint32_t ne_k = 0, ns_k = 0, span_k = 0;               // lane j holds unit j's entries (n_units <= 64)
+    if (lane < n_units) {
+      ne_k = unit_ne[ui + lane];
+      ns_k = unit_ns[ui + lane];
+      span_k = unit_span[ui + lane];
+    }
+    uint32_t e_before = 0, f_before = 0, e_base = 0, f_base = 0;
+    if (ring_ebase) {
+      e_base = ring_ebase[s * kRings + slot];
+      f_base = ring_sbase[s * kRings + slot];
+    } else {
+      for (uint32_t r = lane; r < slot; r += 64) {
+        e_before += ring_nedge[s * kRings + r];
+        f_before += ring_nsurf[s * kRings + r];
+      }
+    }
+    asm volatile ("" : "+v"(ne_k), "+v"(ns_k), "+v"(span_k), "+v"(e_before), "+v"(f_before), "+v"(e_base), "+v"(f_base));    // (every load out before the first branch on one of them)
     // a scan the organised-scan kernel took keeps its units' records in their slots (points, then indices, in rank order: edges
     // then surfaces; beyond kRecSlot at their ranks in the old arrays); any other scan in rec_pts / rec_idx, edges from the
     // front of the unit's positions and surfaces from their back
-    const bool slots = rec32 != nullptr && scan_is_organised(scan_info[s * 4 + kInfoError]);
+    const bool by_ring = scan_is_organised(err);
+    const bool slots = rec32 != nullptr && by_ring;
     size_t eb, fb;
     if (ring_ebase) {
-      eb = b + ring_ebase[s * kRings + slot];
-      fb = b + ring_sbase[s * kRings + slot];
+      eb = b + e_base;
+      fb = b + f_base;
     } else {
       // No ring_totals_kernel ahead of this one.  A scan the organised-scan kernel took: its units added their counts to
       // their rings' totals (unit_body), lane r, r + 64, ... takes ring r < slot.  Any other scan (a scan that kernel gave up,
       // redone by the bucketing route; a small batch on the bucketing route): the same sums from the unit tables
       // themselves.  The last ring's wave also writes the scan's totals.
-      const bool by_ring = scan_is_organised(scan_info[s * 4 + kInfoError]);
-      uint32_t e = 0, f = 0;
-      for (uint32_t r = lane; r < slot; r += 64) {
-        if (by_ring) {
-          e += ring_nedge[s * kRings + r];
-          f += ring_nsurf[s * kRings + r];
-        } else if (ring_count[s * kRings + r] != 0u) {
-          const size_t ur = ((size_t)s * kRings + r) * kUnitMaxBlocks;
-          for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ur + j]; f += unit_ns[ur + j];}
+      uint32_t e = e_before, f = f_before;
+      if (!by_ring) {
+        e = 0; f = 0;
+        for (uint32_t r = lane; r < slot; r += 64) {
+          if (ring_count[s * kRings + r] != 0u) {
+            const size_t ur = ((size_t)s * kRings + r) * kUnitMaxBlocks;
+            for (uint32_t j = 0; j < n_units; j++) {e += unit_ne[ur + j]; f += unit_ns[ur + j];}
+          }
         }
       }
       e = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(e), 63);
@@ -1644,12 +1668,8 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       eb = b + e;
       fb = b + f;
       if (slot == max_rings - 1u) {
-        uint32_t oe = 0, of = 0;
-        if (by_ring) {
-          if (lane == 0) {oe = ring_nedge[s * kRings + slot]; of = ring_nsurf[s * kRings + slot];}
-        } else if (ring_count[s * kRings + slot] != 0u && lane < n_units) {
-          oe = unit_ne[ui + lane]; of = unit_ns[ui + lane];
-        }
+        // (this ring's own totals: the sum of its units' counts, already here)
+        uint32_t oe = n_ring != 0u || by_ring ? ne_k : 0u, of = n_ring != 0u || by_ring ? ns_k : 0u;
         oe = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(oe), 63);
         of = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(of), 63);
         if (lane == 0) {
@@ -1658,14 +1678,8 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         }
       }
     }
-    if (ring_count[s * kRings + slot] == 0u) {return;}
+    if (n_ring == 0u) {return;}
     const size_t off = ring_base(s, slot, max_rings, cap);
-    uint32_t ne_k = 0, ns_k = 0, span_k = 0;               // lane j holds unit j's entries (n_units <= 64)
-    if (lane < n_units) {
-      ne_k = unit_ne[ui + lane];
-      ns_k = unit_ns[ui + lane];
-      span_k = unit_span[ui + lane];
-    }
     uint32_t total = ne_k + ns_k;
     for (int o = 32; o > 0; o >>= 1) {total += __shfl_xor(total, o);}
     for (uint32_t t0 = 0; t0 < total; t0 += 256) {
