@@ -12,8 +12,10 @@ import torch
 from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan, concat
 from lidar_feature_extraction_amd import binding as B
 
-NAMES = ["entry->checks", "boundaries", "A load", "B range", "C order+links+jumps", "D occlusion+reach",
-         "E curvature", "F order masks", "F edge pass", "F surface pass", "G parallel beam+labels+records"]
+# (round 5, rows path: stage D runs with the order masks, after stage E -- the slot between stamps 4 and 5 holds only a wave
+# sync; the labels' way back to the chunk form belongs to the surface pass's slot)
+NAMES = ["entry->checks", "boundaries", "A load", "B range", "C order+links+jumps+range+beam", "(sync)",
+         "E curvature", "F order masks + D occlusion+reach", "F edge pass", "F surface pass + labels word", "G labels+curvature+records"]
 batch, rings, cols = 256, 64, 1800
 clouds = [make_scan(rings, cols, seed=1234 + i) for i in range(8)]
 tiled = [clouds[i % 8] for i in range(batch)]
@@ -35,9 +37,18 @@ t = t[ok]
 print("units stamped:", len(t))
 life = t[:, 10] - t[:, 0]
 print("lifetime (stamp 0 -> 10): median %d  p10 %d  p90 %d shader cycles" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
+stages = {}
 for k in range(10):
     dt = t[:, k + 1] - t[:, k]
-    print("%-22s median %6d  (%4.1f %%)" % (NAMES[k + 1], np.median(dt), 100.0 * np.median(dt) / np.median(life)))
+    print("%-36s median %6d  p90 %6d  (%4.1f %%)" % (NAMES[k + 1], np.median(dt), np.percentile(dt, 90), 100.0 * np.median(dt) / np.median(life)))
+    stages[NAMES[k + 1]] = {"median": int(np.median(dt)), "p90": int(np.percentile(dt, 90))}
+if "--json" in sys.argv:
+    import json
+    out = sys.argv[sys.argv.index("--json") + 1]
+    json.dump({"note": "shader-clock stamps (s_memtime) at the stage boundaries of ring_unit_org_kernel<0, 5, false>, the %d units of one 64 x 1800 scan in a "
+                       "batch of %d, diagnostic build (make stamps); cycles between consecutive stamps" % (len(t), batch),
+               "units": int(len(t)), "life": {"median": int(np.median(life)), "p10": int(np.percentile(life, 10)), "p90": int(np.percentile(life, 90))},
+               "stages": stages}, open(out, "w"), indent=1)
 if "--by-ring" in sys.argv:
     # a unit's stamps sit at index ring * B + j (B = 6 blocks): life and the two pick passes per group of four rings, and per
     # XCD as the grid's x index lands on them (ring group mod 8)
