@@ -65,7 +65,11 @@ static_assert(7 * 4 * sizeof(UnitLds<5>) <= 160 * 1024 && 6 * 4 * sizeof(UnitLds
 #endif
 // (variant 0, the headline's, keeps 7 workgroups per CU at 5 chunks in 72 registers without a spill; the other variants hold
 // their thresholds in registers and get the 80 of 6 workgroups per CU -- 6 against 7 made no measurable difference, round 5)
-constexpr int unit_waves_per_simd(int ch, int variant = 0) {return ch > 6 ? 3 : (ch == 6 ? 6 : (ch == 5 ? (variant == 0 ? LFX_UNIT_WAVES_CH5 : 6) : 8));}
+// (... and so do the kernels that apply ring transforms in their loads: 8 spilled vector registers at 72)
+constexpr int unit_waves_per_simd(int ch, int variant = 0, bool xf = false)
+{
+  return ch > 6 ? 3 : (ch == 6 ? 6 : (ch == 5 ? (variant == 0 && !xf ? LFX_UNIT_WAVES_CH5 : 6) : (ch == 4 ? 7 : 8)));     // (4 chunks: 72 registers, no spills)
+}
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
 // lane's LDS read above another lane's LDS write of the same wave.
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) void r
 #define LFX_ORG_ATTR
 #endif
 template<int V, int CH, bool XF>
-__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) LFX_ORG_ATTR void ring_unit_org_kernel(
+__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF)) LFX_ORG_ATTR void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
   const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform, const uint32_t * __restrict__ geom)
