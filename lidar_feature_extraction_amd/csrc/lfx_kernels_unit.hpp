@@ -65,10 +65,12 @@ static_assert(7 * 4 * sizeof(UnitLds<5>) <= 160 * 1024 && 6 * 4 * sizeof(UnitLds
 #endif
 // (variant 0, the headline's, keeps 7 workgroups per CU at 5 chunks in 72 registers without a spill; the other variants hold
 // their thresholds in registers and get the 80 of 6 workgroups per CU -- 6 against 7 made no measurable difference, round 5)
-// (... and so do the kernels that apply ring transforms in their loads: 8 spilled vector registers at 72)
+// (... and so do the kernels that apply ring transforms in their loads: 8 spilled vector registers at 72.  6 chunks: 5
+// workgroups per CU and 96 registers -- at 6 the kernel spilled 8 registers to scratch, and scratch traffic costs a kernel
+// that is bound by its memory operations 5 %: 270 -> 284 k scans/s at 128 x 2048 x 32, round 5)
 constexpr int unit_waves_per_simd(int ch, int variant = 0, bool xf = false)
 {
-  return ch > 6 ? 3 : (ch == 6 ? 6 : (ch == 5 ? (variant == 0 && !xf ? LFX_UNIT_WAVES_CH5 : 6) : (ch == 4 ? 7 : 8)));     // (4 chunks: 72 registers, no spills)
+  return ch > 6 ? 3 : (ch == 6 ? 5 : (ch == 5 ? (variant == 0 && !xf ? LFX_UNIT_WAVES_CH5 : 6) : (ch == 4 ? 7 : 8)));     // (4 chunks: 72 registers, no spills)
 }
 
 // LDS traffic of one wave is executed in order; this only stops the compiler from moving a
