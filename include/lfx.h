@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 #define LFX_VERSION 1
-#define LFX_MAX_PADDING 15          /* convolution_padding supported by the window kernels        */
+#define LFX_MAX_PADDING 63          /* convolution_padding: up to 15 the window kernels (the fast routes); 16 .. 63 every ring takes the
+                                    * workgroup-per-ring kernel, whose labelling then walks the positions in reach (slow, same results) */
 #define LFX_MAX_RING_ID 255         /* ring ids must be < 256 (every spinning lidar fielded today) */
 #define LFX_MAX_RING_POINTS 4608    /* points of one ring must fit one workgroup's LDS (25 B each); 6 blocks of the unit kernels' long form */
 

@@ -785,7 +785,8 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     if (c->unit_chunks < 3 || c->unit_chunks > 6) {c->unit_chunks = (uint32_t)lfx::kUnitMaxChunks;}
   }
   if (const char * dbg = LFX_DEBUG_ENV("RING_FLAGS")) {c->stage_flags = (uint32_t)std::atoi(dbg);}
-  c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && LFX_DEBUG_ENV("NO_FAST_PATH") == nullptr;
+  // (a padding beyond the kernels' 32-position windows: the workgroup-per-ring kernel for every ring, lfx_kernels_extract.hpp label_pass_wide)
+  c->fast_path = c->dev.B <= lfx::kUnitMaxBlocks && c->dev.P <= lfx::kWindowPadding && LFX_DEBUG_ENV("NO_FAST_PATH") == nullptr;
   // the organised-scan kernel needs to know the sensor's ring count (max_rings given) and reads PointXYZIR records
   c->fused_possible = c->fast_path && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;

@@ -894,13 +894,91 @@ __device__ inline void label_pass(
   }
 }
 
+// The same pass for a padding the 32-position windows do not span (P > kWindowPadding = 15; the reference accepts any
+// padding > 0, hyper_parameter.hpp:45): the reach of a position is kept as its two run lengths and every test walks the
+// positions in reach.  O(P) per position and round where the window form is O(1): the workgroup-per-ring kernel is the slow
+// path already, and such a padding takes it for every ring.
+template<bool EDGE>
+__device__ inline void label_pass_wide(
+  RingWork & w, const Params & prm, int N, int Npad, bool single_block, uint64_t * selAll, uint64_t * covAll)
+{
+  const int T = blockDim.x, tid = threadIdx.x, P = prm.P;
+  const int first = single_block ? 0 : P, last = single_block ? N : N - P;
+  uint32_t * reach = w.hmask();                                      // run of intact links leftwards | rightwards << 16
+  for (int i0 = 0; i0 < Npad; i0 += T) {
+    const int i = i0 + tid;
+    bool cd = false;
+    if (i >= first && i < last) {
+      const double c = w.c[i];
+      cd = EDGE ? (c >= prm.edge_thr) : (c <= prm.surf_thr && !bit_at(w.covE, i));
+    }
+    const int w0 = i0 + (tid & ~63);
+    store_word(w.cand, w0, Npad, cd);
+    store_word(w.alive, w0, Npad, cd);
+    store_word(selAll, w0, Npad, false);
+    store_word(covAll, w0, Npad, false);
+  }
+  for (int i = tid; i < N; i += T) {
+    int L = 0, R = 0;                                                // fill.hpp:101-117 around i, links cut at the block ends (llink)
+    while (L < P && i - 1 - L >= 0 && bit_at(w.llink, i - 1 - L)) {L++;}
+    while (R < P && i + R < N && bit_at(w.llink, i + R)) {R++;}
+    reach[i] = (uint32_t)L | ((uint32_t)R << 16);
+  }
+  __syncthreads();
+  for (;; ) {
+    int picked = 0;
+    for (int i0 = 0; i0 < Npad; i0 += T) {
+      const int i = i0 + tid;
+      bool s = false;
+      if (i < N && bit_at(w.alive, i)) {
+        const int L = (int)(reach[i] & 0xFFFFu), R = (int)(reach[i] >> 16);
+        const double ci = w.c[i];
+        s = true;
+        for (int j = i - L; j <= i + R && s; j++) {
+          if (j != i && bit_at(w.alive, j)) {
+            const double cj = w.c[j];
+            if (EDGE ? (cj > ci || (cj == ci && j > i)) : (cj < ci || (cj == ci && j < i))) {s = false;}
+          }
+        }
+      }
+      const int w0 = i0 + (tid & ~63);
+      store_word(w.sel, w0, Npad, s);
+      or_word(selAll, w0, Npad, s);
+      picked |= s;
+    }
+    if (!__syncthreads_or(picked)) {break;}
+    int any = 0;
+    for (int i0 = 0; i0 < Npad; i0 += T) {
+      const int i = i0 + tid;
+      bool hit = false, live = false;
+      if (i < N) {
+        const int L = (int)(reach[i] & 0xFFFFu), R = (int)(reach[i] >> 16);    // (j reaches i exactly when i reaches j)
+        for (int j = i - L; j <= i + R && !hit; j++) {hit = bit_at(w.sel, j);}
+        live = bit_at(w.alive, i) && !hit;
+      }
+      const int w0 = i0 + (tid & ~63);
+      or_word(covAll, w0, Npad, hit);
+      store_word(w.alive, w0, Npad, live);
+      any |= live;
+    }
+    if (!__syncthreads_or(any)) {break;}
+  }
+}
+
+constexpr int kWindowPadding = 15;        // the paddings the 32-position windows of the kernels span
+
 __device__ inline void label_blocks_lds(RingWork & w, const Params & prm, int N, int Npad, bool single_block)
 {
   const int T = blockDim.x, tid = threadIdx.x;
   block_phase(w, prm, N, Npad, single_block);
   if (tid == 0) {w.flags[kFlagXYClobbered] = 1;}
-  label_pass<true>(w, prm, N, Npad, single_block, w.selE, w.covE);
-  label_pass<false>(w, prm, N, Npad, single_block, w.selS, w.covS);
+  if (prm.P > kWindowPadding) {
+    label_pass_wide<true>(w, prm, N, Npad, single_block, w.selE, w.covE);
+    label_pass_wide<false>(w, prm, N, Npad, single_block, w.selS, w.covS);
+  } else {
+    label_pass<true>(w, prm, N, Npad, single_block, w.selE, w.covE);
+    label_pass<false>(w, prm, N, Npad, single_block, w.selS, w.covS);
+  }
   for (int i = tid; i < N; i += T) {
     uint8_t lab = kDefault;
     if (bit_at(w.selE, i)) {
@@ -941,7 +1019,16 @@ __device__ inline void mask_phase(RingWork & w, const Params & prm, int N, int N
     uint8_t lab = kDefault;
     if (i < N) {
       lab = w.lab[i];
-      if (do_occ) {
+      if (do_occ && P > kWindowPadding) {
+        // (a padding beyond the windows: the same two fills by walking the positions)
+        int Lr = 0, Rr = 0;
+        while (Lr < P && i - 1 - Lr >= 0 && bit_at(w.link, i - 1 - Lr)) {Lr++;}
+        while (Rr < P && i + Rr < N && bit_at(w.link, i + Rr)) {Rr++;}
+        bool occ = false;
+        for (int j = i - 1 - Lr; j <= i - 1 && !occ; j++) {occ = j >= 0 && bit_at(w.jumpL, j);}
+        for (int j = i + 1; j <= i + 1 + Rr && !occ; j++) {occ = j < N && bit_at(w.jumpR, j);}
+        if (occ) {lab = kOccluded;}
+      } else if (do_occ) {
         const uint32_t lk = window32(w.link, i);
         // FillFromLeft from a jump at i-k (k = 1..P+1) reaches i when links i-k+1 .. i-1 hold
         int Lr = __clz((int)~(lk << 16));
@@ -997,7 +1084,7 @@ __device__ inline uint8_t process_ring(
   if (w.flags[kFlagZeroPair]) {return kZeroNormPair;}
   if (w.flags[kFlagBlockSmall]) {return kBlockTooSmall;}
   if (do_label) {
-    if (w.flags[kFlagBlockBig]) {
+    if (w.flags[kFlagBlockBig] || P > kWindowPadding) {
       label_blocks_lds(w, prm, N, Npad, single_block);
     } else if (P == 5) {
       label_blocks_wave<5>(w, prm, N, single_block);

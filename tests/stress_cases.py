@@ -17,9 +17,9 @@ def draw(rng):
     rings = int(rng.choice([4, 8, 16, 32, 64]))
     cols = int(rng.integers(150, 2600))
     if rng.integers(0, 6) == 0:                # long rings: the 12-chunk form of the unit kernels, or (few blocks) the workgroup-per-ring kernel
-        cols = int(rng.integers(2600, 4097))
+        cols = int(rng.integers(2600, 4609))        # (up to LFX_MAX_RING_POINTS)
         rings = min(rings, 16)
-    P = int(rng.choice([1, 2, 3, 5, 5, 5, 8, 15]))
+    P = int(rng.choice([1, 2, 3, 5, 5, 5, 8, 15, 20, 33]))      # (16 and up: beyond the windows, the workgroup-per-ring kernel for every ring)
     B = int(rng.choice([1, 2, 3, 6, 6, 6, 9, 17, 40]))
     hp = HyperParameters(padding=P, n_blocks=B,
                          neighbor_degree_threshold=float(rng.uniform(0.5, 6.0)),

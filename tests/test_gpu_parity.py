@@ -600,6 +600,24 @@ def test_long_rings_take_the_long_form_of_the_unit_kernel(organised):
         f.close()
 
 
+@pytest.mark.parametrize("padding", [16, 23, 40, 63])
+def test_paddings_beyond_the_windows(padding):
+    """The reference accepts any convolution_padding > 0 (hyper_parameter.hpp:45-53).  Up to 15 the kernels' 32-position windows
+    span a pick's reach; beyond that (16 .. LFX_MAX_PADDING = 63) every ring takes the workgroup-per-ring kernel, whose labelling
+    and occlusion fills then walk the positions in reach.  Same results as the oracle: sorted and shuffled input, a ring too short
+    for the padding (skipped as the reference skips it), the launch file's thresholds."""
+    for hp in (HyperParameters(padding=padding), HyperParameters(padding=padding, neighbor_degree_threshold=3.0, edge_threshold=50.0, max_range=1000.0)):
+        clouds = [make_scan(8, 1200, seed=4100 + padding), make_scan(8, 700, seed=4200 + padding, shuffle=True),
+                  make_scan(4, 2 * padding + 3, seed=4300 + padding, spikes=False)]
+        f = FeatureExtraction(hp, device=0, max_points_per_scan=8 * 1200, max_batch=3, max_points_per_ring=1200, max_rings=8)
+        got = f.extract_batch(clouds)
+        for i, c in enumerate(clouds):
+            want = OB.extract(c, oracle_params(hp), canonical_ties=False)
+            assert_scan_equal(got[i], want, "padding %d, scan %d" % (padding, i))
+        assert any(len(g.edge_index) + len(g.surface_index) > 0 for g in got)
+        f.close()
+
+
 @pytest.mark.parametrize("chunks", [3, 4, 5, 6, 12])
 def test_every_unit_kernel_variant(chunks):
     """The wave-per-unit kernel is instantiated for spans of 3..6 chunks of 64 positions and the host picks
