@@ -202,6 +202,38 @@ __global__ __launch_bounds__(256) void copy_f4(const float4 * __restrict__ src, 
   }
 }
 
+// The bucketing kernel's memory side: a chunk of 2 048 column-major points read once (16 + 4 bytes of each 32-byte record),
+// written ring-major -- per chunk and ring a run of 32 positions.  AOS = 0: three staging arrays (x, y | z | index: runs of
+// 256, 128 and 128 bytes, as ring_scatter_kernel writes them); 1: one array of 16-byte records {x, y, z, index} (runs of 512).
+template<int AOS>
+__global__ __launch_bounds__(256) void scatter_model(const uint8_t * __restrict__ pts, float2 * __restrict__ sxy, float * __restrict__ sz,
+  uint32_t * __restrict__ sidx, float4 * __restrict__ sp)
+{
+  const uint32_t s = blockIdx.y, c = blockIdx.x, t = threadIdx.x;
+  const uint8_t * base = pts + ((size_t)s * R * C + (size_t)c * 2048) * 32;
+  float4 v[8]; uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    // pass k: the chunk's points whose ring is 8 k + t / 32, position t % 32 of the run: record (32 c + t % 32) * 64 + ring
+    const uint32_t ring = 8 * k + (t >> 5), pos = t & 31u;
+    const uint32_t col = 32 * c + pos;
+    const uint8_t * p = base + ((size_t)pos * R + ring) * 32;
+    if (col < (uint32_t)C) {v[k] = *reinterpret_cast<const float4 *>(p); w[k] = *reinterpret_cast<const uint32_t *>(p + 20);} else {v[k] = make_float4(0, 0, 0, 0); w[k] = 0;}
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t ring = 8 * k + (t >> 5), pos = t & 31u, col = 32 * c + pos;
+    if (col < (uint32_t)C) {
+      const size_t at = ((size_t)s * R + ring) * 1856 + col;
+      if (AOS) {
+        sp[at] = make_float4(v[k].x, v[k].y, v[k].z, __uint_as_float(w[k]));
+      } else {
+        sxy[at] = make_float2(v[k].x, v[k].y); sz[at] = v[k].z; sidx[at] = w[k];
+      }
+    }
+  }
+}
+
 int main(int argc, char ** argv)
 {
   const int scans = argc > 1 ? atoi(argv[1]) : 1024;
@@ -245,6 +277,15 @@ int main(int argc, char ** argv)
   time("64 rings per workgroup", [&] {hipLaunchKernelGGL(read_groups<64>, dim3(1 * 90, scans), dim3(256), 0, 0, pts, out);}, gb * 20 * 90 / 1800);
   const double wgb = (double)scans * R * 1800 * 9 / 1e9;
   time("outputs: 1 B + 8 B per point", [&] {hipLaunchKernelGGL(write_outputs, dim3(16 * 6, scans), dim3(256), 0, 0, lab, cur, 0, pts);}, wgb);
+  {
+    float2 * sxy; float * sz; uint32_t * sidx; float4 * sp;
+    const size_t rc = (size_t)scans * R * 1856;
+    hipMalloc(&sxy, rc * 8); hipMalloc(&sz, rc * 4); hipMalloc(&sidx, rc * 4); hipMalloc(&sp, rc * 16);
+    const double sgb = gb + (double)scans * R * C * 16 / 1e9;
+    time("bucketing model: three staging arrays", [&] {hipLaunchKernelGGL(scatter_model<0>, dim3((C + 31) / 32, scans), dim3(256), 0, 0, pts, sxy, sz, sidx, sp);}, sgb);
+    time("bucketing model: one 16-byte record array", [&] {hipLaunchKernelGGL(scatter_model<1>, dim3((C + 31) / 32, scans), dim3(256), 0, 0, pts, sxy, sz, sidx, sp);}, sgb);
+    hipFree(sxy); hipFree(sz); hipFree(sidx); hipFree(sp);
+  }
   // the unit kernel's memory side alone: what is left when the computation between loads and stores shrinks
   {
     float4 * rec; uint32_t * idx;
