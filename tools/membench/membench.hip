@@ -234,6 +234,26 @@ __global__ __launch_bounds__(256) void scatter_model(const uint8_t * __restrict_
   }
 }
 
+// The compaction's memory side: a wave per ring copies the ~33 used records of each of its six units' slots (64 points then
+// 64 indices, 1 280 bytes per slot, slots back to back) into dense arrays (points 16 bytes, indices 4), no table lookups.
+__global__ __launch_bounds__(256) void compact_model(const float4 * __restrict__ slots, float4 * __restrict__ pts_out, uint32_t * __restrict__ idx_out)
+{
+  const uint32_t s = blockIdx.y, ring = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const size_t unit0 = ((size_t)s * R + ring) * 6;
+  const size_t out0 = ((size_t)s * R + ring) * 200;            // 6 x 33 = 198 records per ring, dense
+  float4 v[6]; uint32_t w[6];
+#pragma unroll
+  for (int u = 0; u < 6; u++) {
+    const float4 * slot = slots + (unit0 + u) * 80;           // 1 280 bytes = 80 float4
+    v[u] = slot[lane < 33 ? lane : 0];
+    w[u] = reinterpret_cast<const uint32_t *>(slot + 64)[lane < 33 ? lane : 0];
+  }
+#pragma unroll
+  for (int u = 0; u < 6; u++) {
+    if (lane < 33) {pts_out[out0 + 33 * u + lane] = v[u]; idx_out[out0 + 33 * u + lane] = w[u];}
+  }
+}
+
 int main(int argc, char ** argv)
 {
   const int scans = argc > 1 ? atoi(argv[1]) : 1024;
@@ -285,6 +305,15 @@ int main(int argc, char ** argv)
     time("bucketing model: three staging arrays", [&] {hipLaunchKernelGGL(scatter_model<0>, dim3((C + 31) / 32, scans), dim3(256), 0, 0, pts, sxy, sz, sidx, sp);}, sgb);
     time("bucketing model: one 16-byte record array", [&] {hipLaunchKernelGGL(scatter_model<1>, dim3((C + 31) / 32, scans), dim3(256), 0, 0, pts, sxy, sz, sidx, sp);}, sgb);
     hipFree(sxy); hipFree(sz); hipFree(sidx); hipFree(sp);
+  }
+  {
+    float4 * slots; float4 * po; uint32_t * io;
+    const size_t n_slots = (size_t)scans * R * 6;
+    hipMalloc(&slots, n_slots * 1280); hipMalloc(&po, (size_t)scans * R * 200 * 16); hipMalloc(&io, (size_t)scans * R * 200 * 4);
+    hipMemset(slots, 0, n_slots * 1280);
+    time("compaction model: 33 of 64 records per slot, wave per ring", [&] {hipLaunchKernelGGL(compact_model, dim3(R / 4, scans), dim3(256), 0, 0, slots, po, io);},
+      (double)n_slots * 33 * 40 / 1e9);
+    hipFree(slots); hipFree(po); hipFree(io);
   }
   // the unit kernel's memory side alone: what is left when the computation between loads and stores shrinks
   {
