@@ -91,7 +91,7 @@ constexpr int unit_waves_per_simd(int ch, int variant = 0, bool xf = false)
 template<int NW>
 __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)[NW])
 {
-  static_assert(NW <= 16, "extend the wait's operand list");
+  static_assert(NW <= 22, "extend the wait's operand list");
 #ifdef LFX_WHATIF_NOLDS
   {
     double seed = (double)(int)(threadIdx.x + 1u);
@@ -124,7 +124,7 @@ __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)
       : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
         "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
   } else {
-    static_assert(NW == 1 || NW == 3 || NW == 7 || NW == 8 || NW == 9 || NW == 10 || NW == 13 || NW == 14, "add the wait for this window width");
+    static_assert(NW == 1 || NW == 3 || NW == 7 || NW == 8 || NW == 9 || NW == 10 || NW == 13 || NW == 14 || NW == 22, "add the wait for this window width");
     if constexpr (NW == 8) {
       asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
     }
@@ -136,6 +136,12 @@ __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)
       asm volatile ("s_waitcnt lgkmcnt(0)"
         : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
           "+v"(w[11]), "+v"(w[12]));
+    }
+    if constexpr (NW == 22) {
+      asm volatile ("s_waitcnt lgkmcnt(0)"
+        : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
+          "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]), "+v"(w[16]), "+v"(w[17]), "+v"(w[18]), "+v"(w[19]), "+v"(w[20]),
+          "+v"(w[21]));
     }
     if constexpr (NW == 14) {
       asm volatile ("s_waitcnt lgkmcnt(0)"
@@ -276,7 +282,8 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {return (uint32_
 template<int CH, int PT>
 __device__ __forceinline__ uint32_t row_frame(uint32_t own)
 {
-  static_assert(PT >= 1 && PT <= 2 * CH && 3 * CH + PT <= 32, "the halo of a lane's positions must lie in the two lanes either side of it");
+  static_assert(PT >= 1 && PT <= 2 * CH && (PT > CH ? 3 * CH + PT : 2 * CH + PT) <= 32,
+    "the halo of a lane's positions must lie in the two lanes either side of it, the frame in one register");
   const uint32_t below = from_lane_below(own), above = from_lane_above(own);
   uint32_t f = (own << PT) | (above << (PT + CH));                   // (bits beyond the frame's CH + 2 PT meet no mask)
   if constexpr (PT >= CH) {f |= below << (PT - CH);} else {f |= below >> (CH - PT);}
@@ -631,8 +638,9 @@ __device__ __forceinline__ uint32_t unit_core(
   // slab, outside every block (a block keeps PT + 1 positions away from both ends of the span), and is thrown away: the
   // curvature is written as 0 there and the order mask of such a position meets an empty reach.  Round 5: the occlusion
   // fills, the reach and the pick rounds are in the rows form too (kRowPick; see row_frame above) and the labels come back
-  // to the chunk form as ONE word per lane.  For every compile-time PT a span of 3 .. 6 chunks can hold.
-  constexpr bool kRows = PT > 0 && PT <= 2 * CH && CH <= 6;
+  // to the chunk form as ONE word per lane (two for the 12-chunk form).  For every compile-time PT a span of 3 .. 6 chunks
+  // can hold, and for the long form of 12.
+  constexpr bool kRows = PT > 0 && PT <= 2 * CH && (CH <= 6 || (CH == 12 && PT <= 5));     // (12 chunks: a window of 22 doubles per lane)
   constexpr bool kRowPick = kRows && !FULL;
   constexpr int kRowWin = kRows ? 2 * PT + CH : 1;
   constexpr int kSetStride = CH < 4 ? 4 : CH;          // rows -> chunk form: the sets of a lane's word lie this far apart (final_label)
@@ -801,9 +809,15 @@ __device__ __forceinline__ uint32_t unit_core(
       by_s = row_hits<CH>(row_frame<CH, PR>(sel_s), rch);
     }
     // back to the chunk form: one word per lane through the range slab (dead since stage E), five sets of CH bits
-    static_assert(5 * kSetStride <= 32, "the five sets of a lane share a word");
-    reinterpret_cast<u32_alias_t *>(U.r)[lane] =
-      by_e | by_s << kSetStride | sel_s << (2 * kSetStride) | sel_e << (3 * kSetStride) | occ_rows << (4 * kSetStride);
+    if constexpr (5 * kSetStride <= 32) {
+      reinterpret_cast<u32_alias_t *>(U.r)[lane] =
+        by_e | by_s << kSetStride | sel_s << (2 * kSetStride) | sel_e << (3 * kSetStride) | occ_rows << (4 * kSetStride);
+    } else {
+      // (the long form: five sets of twelve bits are sixty -- a pair of words per lane)
+      static_assert(5 * kSetStride <= 64, "the five sets of a lane share two words");
+      reinterpret_cast<u64_alias_t *>(U.r)[lane] = (uint64_t)by_e | (uint64_t)by_s << kSetStride | (uint64_t)sel_s << (2 * kSetStride) |
+        (uint64_t)sel_e << (3 * kSetStride) | (uint64_t)occ_rows << (4 * kSetStride);
+    }
     LFX_WAVE_SYNC();
   } else {
     // order masks, see order_masks(); the slab has no pad here: neighbours are read at clamped
@@ -979,16 +993,24 @@ __device__ __forceinline__ uint32_t unit_core(
       // position q is bit q mod CH of the five sets in the word of lane q / CH
       static_assert(row_div_exact<CH>(), "q / CH by multiplication");
       const uint32_t row = __umul24((uint32_t)q, RowDiv<CH>::kMul) >> RowDiv<CH>::kShift, d = (uint32_t)q - (uint32_t)CH * row;
+      constexpr int S = kSetStride;
+      uint32_t idx, occ_bit;
+      if constexpr (5 * S > 32) {
+        const uint64_t sets = reinterpret_cast<const u64_alias_t *>(U.r)[row] >> d;
+        idx = ((uint32_t)sets & 1u) | ((uint32_t)(sets >> (S - 1)) & 2u) | ((uint32_t)(sets >> (2 * S - 2)) & 4u) | ((uint32_t)(sets >> (3 * S - 3)) & 8u);
+        occ_bit = (uint32_t)(sets >> (4 * S)) & 1u;
+      } else {
       const uint32_t sets = reinterpret_cast<const u32_alias_t *>(U.r)[row] >> d;
       // the four labelling bits side by side: reached by an edge pick | by a surface pick << 1 | surface pick << 2 | edge
       // pick << 3.  One multiplication moves bit i * S to bit 3 * (S - 1) + i (S = kSetStride): the partial product of bit
       // i * S with term 2^((3 - j)(S - 1)) lies at 3 (S - 1) + j + (i - j) S, which for i != j is outside the four bits
       // wanted when S >= 4, and the sixteen products are sixteen different powers of two (S and S - 1 are coprime, |j - j'|
       // < S), so nothing carries
-      constexpr int S = kSetStride;
       constexpr uint32_t kFour = 1u | 1u << S | 1u << (2 * S) | 1u << (3 * S);
       constexpr uint32_t kGather = 1u | 1u << (S - 1) | 1u << (2 * (S - 1)) | 1u << (3 * (S - 1));
-      const uint32_t idx = (__umul24(sets & kFour, kGather) >> (3 * (S - 1))) & 15u;
+      idx = (__umul24(sets & kFour, kGather) >> (3 * (S - 1))) & 15u;
+      occ_bit = (sets >> (4 * S)) & 1u;
+      }
       // EdgeNeighbor, then SurfaceNeighbor, then Surface, then Edge: the last one set wins (as the chunk form below)
       constexpr auto block_label = [](uint32_t i) -> uint64_t {
         return (i & 8u) ? kEdge : ((i & 4u) ? kSurface : ((i & 2u) ? kSurfaceNeighbor : ((i & 1u) ? kEdgeNeighbor : kDefault)));
@@ -998,7 +1020,7 @@ __device__ __forceinline__ uint32_t unit_core(
         block_label(6) << 24 | block_label(7) << 28 | block_label(8) << 32 | block_label(9) << 36 | block_label(10) << 40 |
         block_label(11) << 44 | block_label(12) << 48 | block_label(13) << 52 | block_label(14) << 56 | block_label(15) << 60;
       l = (uint32_t)(kBlockLabel >> (4u * idx)) & 7u;
-      t |= (sets >> (4 * S)) & 1u;                              // occluded (kOvrOccluded)
+      t |= occ_bit;                                             // occluded (kOvrOccluded)
     } else {
       const uint32_t wE = get_win(U, kBitSelE, k, W0), wS = get_win(U, kBitSelS, k, W0);
       l = (wE & reach[k]) != 0u ? (uint32_t)kEdgeNeighbor : l;
