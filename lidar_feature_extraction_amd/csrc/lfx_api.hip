@@ -831,13 +831,14 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
-  if (c->fused_possible) {
-    // the organised-scan kernel's record slots: 1 280 bytes per unit (kRecSlot points and their indices), units back to back
+  if (c->fast_path) {
+    // the unit kernels' record slots: 1 280 bytes per unit (kRecSlot points and their indices), units back to back
     const size_t slots = nb * c->max_rings * (size_t)c->dev.B;
-    if (slots * lfx::kRecSlotBytes <= ((size_t)8 << 30)) {
+    if (slots * lfx::kRecSlotBytes <= ((size_t)16 << 30)) {
       ok(c->rec32.alloc(slots * (lfx::kRecSlotBytes / 16u)));
     } else {
-      c->fused_possible = false;           // (hundreds of blocks per ring on a large batch: the bucketing route takes every scan)
+      c->fast_path = false;                // (hundreds of blocks per ring on a large batch without the sensor's ring count:
+      c->fused_possible = false;           // the workgroup-per-ring kernel takes every ring)
     }
   }
   if (e == hipSuccess) {

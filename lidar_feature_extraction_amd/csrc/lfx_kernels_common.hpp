@@ -207,12 +207,13 @@ struct UnitTables
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
   uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
-  float4 * rec32;                                   // organised-scan kernel: the units' record slots, [batch][max_rings][n_blocks] x kRecSlotBytes
+  float4 * rec32;                                   // the unit kernels' record slots, [batch][max_rings][n_blocks] x kRecSlotBytes
   Params prm;                                       // the thresholds, for the kernels that do not have them as literals (read where a stage needs them)
 };
-// A slot of an organised scan's unit: kRecSlot records {x, y, z, (float)c} and, behind them, their kRecSlot original indices;
+// A slot of a (ring, block) unit the unit kernels labelled (both routes): kRecSlot records {x, y, z, (float)c} and, behind them, their kRecSlot original indices;
 // edges then surfaces, each in position order.  What does not fit lies at its rank in rec_pts / rec_idx from the unit's
 // first owned position.
 constexpr uint32_t kRecSlot = 64, kRecSlotBytes = kRecSlot * 20u;
+constexpr uint32_t kUnitRecordsInSlot = 0x80000000u;      // in unit_span: written by the unit kernels, not by the workgroup-per-ring kernel
 
 }  // namespace lfx

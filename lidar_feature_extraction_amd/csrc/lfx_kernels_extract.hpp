@@ -1726,11 +1726,10 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       }
     }
     asm volatile ("" : "+v"(ne_k), "+v"(ns_k), "+v"(span_k), "+v"(e_before), "+v"(f_before), "+v"(e_base), "+v"(f_base));    // (every load out before the first branch on one of them)
-    // a scan the organised-scan kernel took keeps its units' records in their slots (points, then indices, in rank order: edges
-    // then surfaces; beyond kRecSlot at their ranks in the old arrays); any other scan in rec_pts / rec_idx, edges from the
-    // front of the unit's positions and surfaces from their back
+    // a unit the unit kernels labelled keeps its records in its slot (points, then indices, in rank order: edges then surfaces;
+    // beyond kRecSlot at their ranks in the old arrays; the top bit of its span says so); a ring the workgroup-per-ring kernel
+    // took in rec_pts / rec_idx, edges from the front of its positions and surfaces from their back
     const bool by_ring = scan_is_organised(err);
-    const bool slots = rec32 != nullptr && by_ring;
     size_t eb, fb;
     if (ring_ebase) {
       eb = b + e_base;
@@ -1784,7 +1783,8 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       for (uint32_t u = 0; u < n_units; u++) {               // the units' counts are wave-uniform
         const uint32_t ne = __builtin_amdgcn_readlane(ne_k, u), ns = __builtin_amdgcn_readlane(ns_k, u);
         const uint32_t span = __builtin_amdgcn_readlane(span_k, u);
-        const size_t first = off + (span & 0xFFFFu), last = off + (span >> 16);
+        const size_t first = off + (span & 0xFFFFu), last = off + ((span >> 16) & 0x7FFFu);
+        const bool slots = (span & kUnitRecordsInSlot) != 0u;        // a unit of the unit kernels: the first kRecSlot records in its slot
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const uint32_t q = t0 + 64 * i + lane - cum;       // index inside unit u (wraps when the record lies before it)

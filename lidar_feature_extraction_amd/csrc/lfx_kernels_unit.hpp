@@ -463,7 +463,7 @@ template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF>
 __device__ __forceinline__ uint32_t unit_core(
   const Params & prm, UnitLds<CH> & U, const UnitGeom & G, uint32_t dbg_flags, uint32_t s, uint32_t slot, int j,
   const float (&x)[CH], const float (&y)[CH], const float (&z)[CH], const uint32_t (&src)[CH],
-  const UnitTables * __restrict__ tab, bool second_pass, const OrgScan & og, size_t off,
+  const UnitTables * __restrict__ tab, bool second_pass, const OrgScan & og, size_t off, uint32_t max_rings,
   uint32_t rec_lo, uint32_t rec_hi, uint32_t & n_edge, uint32_t & n_surface, const int lane)
 {
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
@@ -1048,17 +1048,17 @@ __device__ __forceinline__ uint32_t unit_core(
   g_f64_t * const curv_u = (g_f64_t *)curv_s + ((ptrdiff_t)off + g0);
   g_f32x4_t * const rec_u = (g_f32x4_t *)tab->rec_pts + (off + rec_lo);
   g_u32_t * const idx_u = (g_u32_t *)tab->rec_idx + (off + rec_lo);
-  const uint32_t rec_n = rec_hi - rec_lo;          // edges from the front of the unit's positions, surfaces from their back
-  // ORG: the unit's feature records do not go out chunk by chunk into two arrays at the unit's place among the ring's
+  (void)rec_hi;
+  // The unit's feature records do not go out chunk by chunk into two arrays at the unit's place among the ring's
   // positions -- a handful of partial writes 4.8 KB away from the next unit's, which cost the kernel 150-180 us of its 1 020
   // (measured with the records ablated; tools/membench models it) -- but in rank order (edges, then surfaces) into the unit's
   // SLOT: kRecSlot points {x, y, z, c} and behind them their kRecSlot indices, 1 280 bytes per unit, units back to back;
   // staged in the wave's LDS and written by one store per part.  A unit with more features than a slot holds puts the rest
   // at their ranks in the old arrays (feature_compact_kernel reads both).
-  uint32_t lab[ORG ? CH : 1];
+  uint32_t lab[CH];
 #pragma unroll
   for (int k = 0; k < CH; k++) {
-    if (ORG) {lab[k] = kDefault;}
+    lab[k] = kDefault;
     if (k < K) {
       const int q = 64 * k + lane;
       const bool own = lanes(in_span(q, qo0, qo1));
@@ -1069,22 +1069,12 @@ __device__ __forceinline__ uint32_t unit_core(
         if (curv_s != nullptr) {curv_u[(uint32_t)q] = cv;}       // (wave-uniform: a context created without LFX_OUT_CURVATURE has no such array)
       }
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
-      if constexpr (ORG) {
-        lab[k] = l;
-      } else if (lanes(fe | fs) && LFX_STAGE_ON(1024u)) {
-        // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-        const f32x4_t rec = {x[k], y[k], z[k], (float)cv};
-        const uint32_t be = __builtin_amdgcn_mbcnt_hi((uint32_t)(fe >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fe, 0u));
-        const uint32_t bs = __builtin_amdgcn_mbcnt_hi((uint32_t)(fs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fs, 0u));
-        const uint32_t at = l == kEdge ? pe + be : rec_n - 1u - (ps + bs);
-        rec_u[at] = rec;
-        idx_u[at] = src[k];
-      }
+      lab[k] = l;
       pe += __popcll(fe);
       ps += __popcll(fs);
     }
   }
-  if constexpr (ORG) {
+  {
     if ((pe | ps) != 0u && LFX_STAGE_ON(1024u)) {
       static_assert(20 * kRecSlot <= 8 * 64 * CH, "the range slab stages a slot's records");
       LFX_WAVE_SYNC();                               // (the range slab is dead since stage E; its words of the labelling have been read)
@@ -1104,7 +1094,7 @@ __device__ __forceinline__ uint32_t unit_core(
               // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature; position i of ring `slot` is
               // point column * R + slot
               const f32x4_t rec = {x[k], y[k], z[k], (float)U.c[q]};
-              const uint32_t idx = (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot;
+              const uint32_t idx = ORG ? (XF ? ring_column(og.xform[s * kRings + slot], (uint32_t)i, (uint32_t)N) : (uint32_t)i) * og.R + slot : src[k];
               if (rank < kRecSlot) {
                 stage_pts[rank] = rec;
                 stage_idx[rank] = idx;
@@ -1120,7 +1110,7 @@ __device__ __forceinline__ uint32_t unit_core(
       }
       LFX_WAVE_SYNC();
       const uint32_t staged = pe + ps < kRecSlot ? pe + ps : kRecSlot;
-      g_f32x4_t * const slot_pts = (g_f32x4_t *)tab->rec32 + ((((size_t)s * og.R + slot) * (uint32_t)B + (uint32_t)j) * (kRecSlotBytes / 16u));
+      g_f32x4_t * const slot_pts = (g_f32x4_t *)tab->rec32 + ((((size_t)s * max_rings + slot) * (uint32_t)B + (uint32_t)j) * (kRecSlotBytes / 16u));
       g_u32_t * const slot_idx = reinterpret_cast<g_u32_t *>(slot_pts + kRecSlot);
       if ((uint32_t)lane < staged) {                 // one store of up to a kilobyte, one of up to 256 bytes
         slot_pts[lane] = stage_pts[lane];
@@ -1298,7 +1288,7 @@ __device__ __forceinline__ void unit_body(
   LFX_WAVE_SYNC();
   uint32_t pe = 0, ps = 0;
   {
-    const uint32_t why = unit_core<PT, CH, DEF, ORG, FULL, XF>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, second_pass, og, off,
+    const uint32_t why = unit_core<PT, CH, DEF, ORG, FULL, XF>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, second_pass, og, off, max_rings,
       (uint32_t)o0, (uint32_t)o1, pe, ps, lane);
     if (why != 0u) {LFX_DEFER(why);}
   }
@@ -1306,7 +1296,8 @@ __device__ __forceinline__ void unit_body(
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
     tab->unit_ne[ui] = pe;
     tab->unit_ns[ui] = ps;
-    tab->unit_span[ui] = ((uint32_t)o1 << 16) | (uint32_t)o0;      // owned positions [o0, o1); N <= LFX_MAX_RING_POINTS < 65536
+    // owned positions [o0, o1) (N <= LFX_MAX_RING_POINTS < 32768); the top bit: this unit's records lie in its slot
+    tab->unit_span[ui] = kUnitRecordsInSlot | ((uint32_t)o1 << 16) | (uint32_t)o0;
     if (ORG) {
       // the ring's totals, for the compaction (no kernel of their own on this route): two adds nobody waits for.  If the
       // scan falls back after all, the compaction takes the bucketing route's unit tables instead (feature_compact_kernel).
