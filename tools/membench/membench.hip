@@ -103,6 +103,16 @@ __global__ __launch_bounds__(64 * G) void unit_memory(const uint8_t * __restrict
   constexpr uint32_t per_wave = 64 / G;              // columns one instruction of a wave covers
   const uint8_t * base = pts + (size_t)s * R * C * 32;
   float4 v[5]; uint32_t w[5];
+  // OUT & 8192, the records' second leg inside the kernel: the unit's slot of the scan kDuty scans earlier is read with
+  // the unit's own records (its latency under the same wait) and written to the dense clouds at the end
+  constexpr uint32_t kDuty = 32, kDenseAt = 64u << 20;
+  float4 duty_p = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t duty_i = 0;
+  const bool duty = (OUT & 8192) && s >= kDuty && lane < 38;
+  if (duty) {
+    const float4 * sl = rec + ((((size_t)(s - kDuty) * R + G * g + wave) * 6 + j) * 80);
+    duty_p = sl[lane];
+    duty_i = reinterpret_cast<const uint32_t *>(sl + 64)[lane];
+  }
 #pragma unroll
   for (int m = 0; m < 5; m++) {
     uint32_t c = j * 298 + 64 * m + per_wave * wave + cq;
@@ -150,6 +160,25 @@ __global__ __launch_bounds__(64 * G) void unit_memory(const uint8_t * __restrict
     if (lane < 38) {
       rec[off + lane] = make_float4(acc, acc, acc, acc);
       idx[off + lane] = lane;
+    }
+  }
+  if (OUT & 4096) {                     // as built: a plane of 16-byte points and a plane of indices in the unit's slot of 1 280 bytes
+    float4 * sl = rec + ((((size_t)s * R + ring) * 6 + j) * 80);
+    if (lane < 38) {
+      sl[lane] = make_float4(acc, acc, acc, acc);
+      reinterpret_cast<uint32_t *>(sl + 64)[lane] = lane;
+    }
+  }
+  if (duty) {
+    const size_t at = (((size_t)(s - kDuty) * R + ring) * 6 + j) * 38 + lane;
+    rec[kDenseAt + at] = duty_p;
+    idx[at] = duty_i;
+  }
+  if (OUT & 16384) {                    // the records straight into dense clouds (what a unit that knew its place would write)
+    const size_t at = (((size_t)s * R + ring) * 6 + j) * 38 + lane;
+    if (lane < 38) {
+      rec[kDenseAt + at] = make_float4(acc, acc, acc, acc);
+      idx[at] = lane;
     }
   }
   if (OUT & (64 | 128)) {               // records where a bump allocator puts them (64: one counter per scan, 128: one in all): dense in time
@@ -349,6 +378,11 @@ int main(int argc, char ** argv)
     UM("pairs: l + c + 32 B records chunk by chunk, slots of 64", 2, 4, 2051, 22144, ugb);
     UM("pairs: l + c + records (again)", 2, 4, 7, 22144, ugb);
     UM("pairs: l + c + 32 B records by one store (again)", 2, 4, 35, 22144, ugb);
+    UM("pairs: l + c + slots as built (20-byte planes)", 2, 4, 4099, 22144, ugb);
+    UM("pairs: l + c + slots + the second leg inside (slot of 32 scans ago -> dense)", 2, 4, 12291, 22144, ugb + 2 * fgb);
+    UM("pairs: l + c + records straight into dense clouds", 2, 4, 16387, 22144, ugb);
+    UM("pairs: l + c + slots as built (again)", 2, 4, 4099, 22144, ugb);
+    UM("pairs: l + c + slots + the second leg inside (again)", 2, 4, 12291, 22144, ugb + 2 * fgb);
     UM("8 rings per workgroup, turned, all outputs", 2, 8, 7, 44288, ugb);
     UM("16 rings per workgroup, turned, all outputs", 2, 16, 7, 88576, ugb);
     UM("8 rings per workgroup, no outputs", 2, 8, 0, 44288, rgb);
