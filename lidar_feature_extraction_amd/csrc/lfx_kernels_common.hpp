@@ -210,7 +210,7 @@ struct UnitTables
   float4 * rec32;                                   // the unit kernels' record slots, [batch][max_rings][n_blocks] x kRecSlotBytes
   Params prm;                                       // the thresholds, for the kernels that do not have them as literals (read where a stage needs them)
 };
-// A slot of a (ring, block) unit the unit kernels labelled (both routes): kRecSlot records {x, y, z, (float)c} and, behind them, their kRecSlot original indices;
+// A slot of a (ring, block) unit the unit kernels labelled (both routes): up to kRecSlot records {x, y, z, (float)c} and, right behind the n that are there, their n original indices (one run of 20 n bytes);
 // edges then surfaces, each in position order.  What does not fit lies at its rank in rec_pts / rec_idx from the unit's
 // first owned position.
 constexpr uint32_t kRecSlot = 64, kRecSlotBytes = kRecSlot * 20u;

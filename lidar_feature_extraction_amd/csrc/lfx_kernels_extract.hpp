@@ -1770,6 +1770,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     for (int o = 32; o > 0; o >>= 1) {total += __shfl_xor(total, o);}
     for (uint32_t t0 = 0; t0 < total; t0 += 256) {
       size_t src[4], dst[4];
+      uint32_t idx_at[4];                                    // a slot's index plane lies behind its points: dwords from the record's point to its index
       bool edge[4], valid[4], in_slot[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -1778,6 +1779,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         in_slot[i] = false;
         src[i] = off;
         dst[i] = b;
+        idx_at[i] = 0;
       }
       uint32_t cum = 0, ecum = 0, scum = 0;
       for (uint32_t u = 0; u < n_units; u++) {               // the units' counts are wave-uniform
@@ -1792,6 +1794,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
             edge[i] = q < ne;
             if (slots) {
               in_slot[i] = q < kRecSlot;
+              idx_at[i] = 4u * (ne + ns < kRecSlot ? ne + ns : kRecSlot) - 3u * q;
               src[i] = in_slot[i] ? (((size_t)s * max_rings + slot) * n_units + u) * (kRecSlotBytes / 4u) + 4u * q : first + q;    // (slot: in dwords)
             } else {
               src[i] = edge[i] ? first + q : last - 1 - (q - ne);
@@ -1811,9 +1814,9 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         ri[i] = 0;
         if (valid[i]) {
           if (in_slot[i]) {
-            const uint32_t * w = reinterpret_cast<const uint32_t *>(rec32) + src[i];          // the point; its index 4 kRecSlot - 3 q dwords on
+            const uint32_t * w = reinterpret_cast<const uint32_t *>(rec32) + src[i];          // the point; its index 4 n - 3 q dwords on (n records in the slot)
             rp[i] = *reinterpret_cast<const float4 *>(w);
-            ri[i] = w[4u * kRecSlot - 3u * ((src[i] % (kRecSlotBytes / 4u)) / 4u)];
+            ri[i] = w[idx_at[i]];
           } else {
             rp[i] = rec_pts[src[i]];
             ri[i] = rec_idx[src[i]];

@@ -1111,7 +1111,7 @@ __device__ __forceinline__ uint32_t unit_core(
       LFX_WAVE_SYNC();
       const uint32_t staged = pe + ps < kRecSlot ? pe + ps : kRecSlot;
       g_f32x4_t * const slot_pts = (g_f32x4_t *)tab->rec32 + ((((size_t)s * max_rings + slot) * (uint32_t)B + (uint32_t)j) * (kRecSlotBytes / 16u));
-      g_u32_t * const slot_idx = reinterpret_cast<g_u32_t *>(slot_pts + kRecSlot);
+      g_u32_t * const slot_idx = reinterpret_cast<g_u32_t *>(slot_pts + staged);      // (right behind the points that are there: one run of 20 bytes per record)
       if ((uint32_t)lane < staged) {                 // one store of up to a kilobyte, one of up to 256 bytes
         slot_pts[lane] = stage_pts[lane];
         slot_idx[lane] = stage_idx[lane];

@@ -169,6 +169,20 @@ __global__ __launch_bounds__(64 * G) void unit_memory(const uint8_t * __restrict
       reinterpret_cast<uint32_t *>(sl + 64)[lane] = lane;
     }
   }
+  if (OUT & 32768) {                    // ... the plane of indices right behind the points that are there (one run of 20 n bytes)
+    float4 * sl = rec + ((((size_t)s * R + ring) * 6 + j) * 80);
+    if (lane < 38) {
+      sl[lane] = make_float4(acc, acc, acc, acc);
+      reinterpret_cast<uint32_t *>(sl + 38)[lane] = lane;
+    }
+  }
+  if (OUT & 65536) {                    // ... slots of 48 records (960 bytes), indices right behind the points
+    float4 * sl = rec + ((((size_t)s * R + ring) * 6 + j) * 60);
+    if (lane < 38) {
+      sl[lane] = make_float4(acc, acc, acc, acc);
+      reinterpret_cast<uint32_t *>(sl + 38)[lane] = lane;
+    }
+  }
   if (duty) {
     const size_t at = (((size_t)(s - kDuty) * R + ring) * 6 + j) * 38 + lane;
     rec[kDenseAt + at] = duty_p;
@@ -381,7 +395,10 @@ int main(int argc, char ** argv)
     UM("pairs: l + c + slots as built (20-byte planes)", 2, 4, 4099, 22144, ugb);
     UM("pairs: l + c + slots + the second leg inside (slot of 32 scans ago -> dense)", 2, 4, 12291, 22144, ugb + 2 * fgb);
     UM("pairs: l + c + records straight into dense clouds", 2, 4, 16387, 22144, ugb);
+    UM("pairs: l + c + slots, indices right behind the points", 2, 4, 32771, 22144, ugb);
+    UM("pairs: l + c + slots of 48, indices right behind the points", 2, 4, 65539, 22144, ugb);
     UM("pairs: l + c + slots as built (again)", 2, 4, 4099, 22144, ugb);
+    UM("pairs: l + c + slots, indices right behind the points (again)", 2, 4, 32771, 22144, ugb);
     UM("pairs: l + c + slots + the second leg inside (again)", 2, 4, 12291, 22144, ugb + 2 * fgb);
     UM("8 rings per workgroup, turned, all outputs", 2, 8, 7, 44288, ugb);
     UM("16 rings per workgroup, turned, all outputs", 2, 16, 7, 88576, ugb);
