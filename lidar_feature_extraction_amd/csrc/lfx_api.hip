@@ -394,7 +394,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
         n_units, c->cap, c->scan_begin.p, c->ring_count.p, self_totals ? nullptr : c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
         c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->batch_serial, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p);
+        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->batch_serial, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p, c->slot_places);
     }
   }
   LFX_HIP(c, hipGetLastError());
@@ -832,10 +832,13 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(1));
   if (c->fast_path) {
-    // the unit kernels' record slots: 1 280 bytes per unit (kRecSlot points and their indices), units back to back
+    // the unit kernels' record slots: 20 bytes per place (a point and its index), 64 or 128 places per unit, units back to back
     const size_t slots = nb * c->max_rings * (size_t)c->dev.B;
-    if (slots * lfx::kRecSlotBytes <= ((size_t)16 << 30)) {
-      ok(c->rec32.alloc(slots * (lfx::kRecSlotBytes / 16u)));
+    const int compiled_for[4] = {5, 5, 2, 0};          // UnitVariant<V>::kPT (lfx_kernels_unit.hpp)
+    c->slot_places = lfx::rec_slot_places(compiled_for[c->unit_variant & 3], (int)c->unit_chunks);
+    const size_t slot_bytes = (size_t)c->slot_places * lfx::kRecBytes;
+    if (slots * slot_bytes <= ((size_t)16 << 30)) {
+      ok(c->rec32.alloc(slots * (slot_bytes / 16u)));
     } else {
       c->fast_path = false;                // (hundreds of blocks per ring on a large batch without the sensor's ring count:
       c->fused_possible = false;           // the workgroup-per-ring kernel takes every ring)

@@ -189,7 +189,8 @@ struct lfx_ctx
   lfx_host::DevBuf<float> sz;
   lfx_host::DevBuf<double> curv_s;
   lfx_host::DevBuf<float4> edge_pts, surf_pts, rec_pts;
-  lfx_host::DevBuf<float4> rec32;         // the record slots of the organised route (lfx_kernels_common.hpp kRecSlot), two float4 per record
+  lfx_host::DevBuf<float4> rec32;         // the record slots of the unit kernels (lfx_kernels_common.hpp rec_slot_places)
+  uint32_t slot_places = 64;              // places per slot: what the context's unit kernels are compiled for
   lfx_host::DevBuf<lfx::UnitTables> unit_tab;      // the unit kernel's output pointers (one element)
   lfx_host::DevBuf<uint32_t> vox_scratch;          // lfx_voxel_downsample: sort keys / values, allocated on first use
   lfx_host::DevBuf<double> align_scratch;          // lfx_scan_to_map_align: states, rows, errors; allocated on first use

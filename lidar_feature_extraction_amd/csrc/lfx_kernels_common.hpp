@@ -207,13 +207,20 @@ struct UnitTables
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
   uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
-  float4 * rec32;                                   // the unit kernels' record slots, [batch][max_rings][n_blocks] x kRecSlotBytes
+  float4 * rec32;                                   // the unit kernels' record slots, [batch][max_rings][n_blocks] x rec_slot_places() x kRecBytes
   Params prm;                                       // the thresholds, for the kernels that do not have them as literals (read where a stage needs them)
 };
-// A slot of a (ring, block) unit the unit kernels labelled (both routes): up to kRecSlot records {x, y, z, (float)c} and, right behind the n that are there, their n original indices (one run of 20 n bytes);
+// A slot of a (ring, block) unit the unit kernels labelled (both routes): up to rec_slot_places() records {x, y, z, (float)c} and, right behind the n that are there, their n original indices (one run of 20 n bytes);
 // edges then surfaces, each in position order.  What does not fit lies at its rank in rec_pts / rec_idx from the unit's
 // first owned position.
-constexpr uint32_t kRecSlot = 64, kRecSlotBytes = kRecSlot * 20u;
+// Places per slot: 64 (the default parameters leave ~33 features in a unit of ~300 positions), 128 where the padding is
+// 1 or 2 -- a pick silences P positions either side, so the launch file's P = 2 leaves ~85 -- and the unit's LDS can stage them
+// (5 chunks or more); one number for the unit kernels of a context and its compaction (lfx_api.hip).
+__host__ __device__ constexpr uint32_t rec_slot_places(int padding_compiled_for, int chunks)
+{
+  return padding_compiled_for > 0 && padding_compiled_for <= 2 && chunks >= 5 ? 128u : 64u;
+}
+constexpr uint32_t kRecBytes = 20u;                       // per place: a 16-byte point and a 4-byte index
 constexpr uint32_t kUnitRecordsInSlot = 0x80000000u;      // in unit_span: written by the unit kernels, not by the workgroup-per-ring kernel
 
 }  // namespace lfx

@@ -1676,7 +1676,8 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   uint32_t max_rings, uint32_t * __restrict__ scan_info /* read for the scan's route; its totals written here where ring_ebase == nullptr */,
   const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory [1 + kCounters + 1], or nullptr */,
   uint32_t serial /* of this batch, never 0 */, const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf,
-  const float4 * __restrict__ rec32 /* the record slots of the organised scans' units (UnitTables), or nullptr */)
+  const float4 * __restrict__ rec32 /* the record slots of the unit kernels' units (UnitTables), or nullptr */,
+  uint32_t slot_places /* per slot: rec_slot_places() of the context's unit kernels */)
 {
   const uint32_t lane = threadIdx.x & 63, s = blockIdx.y;
   // the batch's last kernel also hands what the batch reports about its stream to the host (the next batches' route is
@@ -1727,7 +1728,7 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     }
     asm volatile ("" : "+v"(ne_k), "+v"(ns_k), "+v"(span_k), "+v"(e_before), "+v"(f_before), "+v"(e_base), "+v"(f_base));    // (every load out before the first branch on one of them)
     // a unit the unit kernels labelled keeps its records in its slot (points, then indices, in rank order: edges then surfaces;
-    // beyond kRecSlot at their ranks in the old arrays; the top bit of its span says so); a ring the workgroup-per-ring kernel
+    // beyond the slot's places at their ranks in the old arrays; the top bit of its span says so); a ring the workgroup-per-ring kernel
     // took in rec_pts / rec_idx, edges from the front of its positions and surfaces from their back
     const bool by_ring = scan_is_organised(err);
     size_t eb, fb;
@@ -1786,16 +1787,16 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
         const uint32_t ne = __builtin_amdgcn_readlane(ne_k, u), ns = __builtin_amdgcn_readlane(ns_k, u);
         const uint32_t span = __builtin_amdgcn_readlane(span_k, u);
         const size_t first = off + (span & 0xFFFFu), last = off + ((span >> 16) & 0x7FFFu);
-        const bool slots = (span & kUnitRecordsInSlot) != 0u;        // a unit of the unit kernels: the first kRecSlot records in its slot
+        const bool slots = (span & kUnitRecordsInSlot) != 0u;        // a unit of the unit kernels: the first slot_places records in its slot
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const uint32_t q = t0 + 64 * i + lane - cum;       // index inside unit u (wraps when the record lies before it)
           if (q < ne + ns) {
             edge[i] = q < ne;
             if (slots) {
-              in_slot[i] = q < kRecSlot;
-              idx_at[i] = 4u * (ne + ns < kRecSlot ? ne + ns : kRecSlot) - 3u * q;
-              src[i] = in_slot[i] ? (((size_t)s * max_rings + slot) * n_units + u) * (kRecSlotBytes / 4u) + 4u * q : first + q;    // (slot: in dwords)
+              in_slot[i] = q < slot_places;
+              idx_at[i] = 4u * (ne + ns < slot_places ? ne + ns : slot_places) - 3u * q;
+              src[i] = in_slot[i] ? (((size_t)s * max_rings + slot) * n_units + u) * (slot_places * (kRecBytes / 4u)) + 4u * q : first + q;    // (slot: in dwords)
             } else {
               src[i] = edge[i] ? first + q : last - 1 - (q - ne);
             }

@@ -1052,7 +1052,7 @@ __device__ __forceinline__ uint32_t unit_core(
   // The unit's feature records do not go out chunk by chunk into two arrays at the unit's place among the ring's
   // positions -- a handful of partial writes 4.8 KB away from the next unit's, which cost the kernel 150-180 us of its 1 020
   // (measured with the records ablated; tools/membench models it) -- but in rank order (edges, then surfaces) into the unit's
-  // SLOT: kRecSlot points {x, y, z, c} and behind them their kRecSlot indices, 1 280 bytes per unit, units back to back;
+  // SLOT: up to kRecSlot points {x, y, z, c} and right behind them their indices, 20 kRecSlot bytes per unit, units back to back;
   // staged in the wave's LDS and written by one store per part.  A unit with more features than a slot holds puts the rest
   // at their ranks in the old arrays (feature_compact_kernel reads both).
   uint32_t lab[CH];
@@ -1076,7 +1076,8 @@ __device__ __forceinline__ uint32_t unit_core(
   }
   {
     if ((pe | ps) != 0u && LFX_STAGE_ON(1024u)) {
-      static_assert(20 * kRecSlot <= 8 * 64 * CH, "the range slab stages a slot's records");
+      constexpr uint32_t kRecSlot = rec_slot_places(PT, CH);
+      static_assert(kRecBytes * kRecSlot <= 8 * 64 * CH, "the range slab stages a slot's records");
       LFX_WAVE_SYNC();                               // (the range slab is dead since stage E; its words of the labelling have been read)
       f32x4_t * const stage_pts = reinterpret_cast<f32x4_t *>(U.r);
       u32_alias_t * const stage_idx = reinterpret_cast<u32_alias_t *>(stage_pts + kRecSlot);
@@ -1110,11 +1111,15 @@ __device__ __forceinline__ uint32_t unit_core(
       }
       LFX_WAVE_SYNC();
       const uint32_t staged = pe + ps < kRecSlot ? pe + ps : kRecSlot;
-      g_f32x4_t * const slot_pts = (g_f32x4_t *)tab->rec32 + ((((size_t)s * max_rings + slot) * (uint32_t)B + (uint32_t)j) * (kRecSlotBytes / 16u));
+      g_f32x4_t * const slot_pts = (g_f32x4_t *)tab->rec32 + ((((size_t)s * max_rings + slot) * (uint32_t)B + (uint32_t)j) * (kRecSlot * kRecBytes / 16u));
       g_u32_t * const slot_idx = reinterpret_cast<g_u32_t *>(slot_pts + staged);      // (right behind the points that are there: one run of 20 bytes per record)
-      if ((uint32_t)lane < staged) {                 // one store of up to a kilobyte, one of up to 256 bytes
-        slot_pts[lane] = stage_pts[lane];
-        slot_idx[lane] = stage_idx[lane];
+#pragma unroll
+      for (uint32_t r0 = 0; r0 < kRecSlot; r0 += 64) {
+        const uint32_t r = r0 + (uint32_t)lane;
+        if (r < staged) {                            // one store of up to a kilobyte, one of up to 256 bytes
+          slot_pts[r] = stage_pts[r];
+          slot_idx[r] = stage_idx[r];
+        }
       }
     }
   }

@@ -277,8 +277,10 @@ __global__ __launch_bounds__(256) void scatter_model(const uint8_t * __restrict_
   }
 }
 
-// The compaction's memory side: a wave per ring copies the ~33 used records of each of its six units' slots (64 points then
-// 64 indices, 1 280 bytes per slot, slots back to back) into dense arrays (points 16 bytes, indices 4), no table lookups.
+// The compaction's memory side: a wave per ring copies the ~33 used records of each of its six units' slots (1 280 bytes per
+// slot, slots back to back; the points, then the indices -- BEHIND = 64: behind all 64 places of the points, as first built;
+// 33: right behind the points that are there) into dense arrays (points 16 bytes, indices 4), no table lookups.
+template<int BEHIND>
 __global__ __launch_bounds__(256) void compact_model(const float4 * __restrict__ slots, float4 * __restrict__ pts_out, uint32_t * __restrict__ idx_out)
 {
   const uint32_t s = blockIdx.y, ring = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) void compact_model(const float4 * __restrict__
   for (int u = 0; u < 6; u++) {
     const float4 * slot = slots + (unit0 + u) * 80;           // 1 280 bytes = 80 float4
     v[u] = slot[lane < 33 ? lane : 0];
-    w[u] = reinterpret_cast<const uint32_t *>(slot + 64)[lane < 33 ? lane : 0];
+    w[u] = reinterpret_cast<const uint32_t *>(slot + BEHIND)[lane < 33 ? lane : 0];
   }
 #pragma unroll
   for (int u = 0; u < 6; u++) {
@@ -354,7 +356,9 @@ int main(int argc, char ** argv)
     const size_t n_slots = (size_t)scans * R * 6;
     hipMalloc(&slots, n_slots * 1280); hipMalloc(&po, (size_t)scans * R * 200 * 16); hipMalloc(&io, (size_t)scans * R * 200 * 4);
     hipMemset(slots, 0, n_slots * 1280);
-    time("compaction model: 33 of 64 records per slot, wave per ring", [&] {hipLaunchKernelGGL(compact_model, dim3(R / 4, scans), dim3(256), 0, 0, slots, po, io);},
+    time("compaction model: 33 of 64 records per slot, wave per ring", [&] {hipLaunchKernelGGL(compact_model<64>, dim3(R / 4, scans), dim3(256), 0, 0, slots, po, io);},
+      (double)n_slots * 33 * 40 / 1e9);
+    time("compaction model: ... indices right behind the points", [&] {hipLaunchKernelGGL(compact_model<33>, dim3(R / 4, scans), dim3(256), 0, 0, slots, po, io);},
       (double)n_slots * 33 * 40 / 1e9);
     hipFree(slots); hipFree(po); hipFree(io);
   }
