@@ -1418,8 +1418,11 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF)) LF
     // (and with sixteen groups or a multiple an XCD takes two ADJACENT groups, 256 contiguous bytes of every column, at a
     // time: -2 % on the kernel, same box)
     const uint32_t groups = gridDim.x;
-    if ((groups & 15u) == 0u) {g = (g & ~15u) | ((g & 7u) << 1) | ((g >> 3) & 1u);}
-    const uint32_t turn = (2u * s) & ((1u << (31 - __builtin_clz(groups))) - 1u);       // < groups
+    const bool pairs = (groups & 15u) == 0u;
+    if (pairs) {g = (g & ~15u) | ((g & 7u) << 1) | ((g >> 3) & 1u);}
+    // (by two where the XCDs take pairs, so that a pair stays a pair; by one for the sensors of fewer rings, whose XCDs would
+    // otherwise see every other group only)
+    const uint32_t turn = (pairs ? 2u * s : s) & ((1u << (31 - __builtin_clz(groups))) - 1u);       // < groups
     g += turn;
     g = g >= groups ? g - groups : g;
   }
