@@ -375,11 +375,17 @@ __device__ inline uint64_t polar_less_masks(float ax, float ay, float bx, float 
 #endif
 constexpr int kStampSlots = 16, kStampUnits = 384;
 static __device__ unsigned long long g_unit_stamps[kStampUnits * kStampSlots];     // (one per translation unit: the reader sits with variant 0's kernels)
+// (stamps 0 and 10 also leave the constant-rate REFCLK counter, which all CUs share, in slots 11 and 12: when the units of a
+// scan start and end against one another, tools/stamps.py --skew)
 #define LFX_STAMP(n) \
   do { \
     if (s == (uint32_t)LFX_STAMP_SCAN && (uint32_t)(slot * B + j) < (uint32_t)kStampUnits) { \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
       if (lane == 0) {g_unit_stamps[(slot * B + j) * kStampSlots + (n)] = t_;} \
+      if ((n) == 0 || (n) == 10) { \
+        const unsigned long long r_ = __builtin_amdgcn_s_memrealtime(); \
+        if (lane == 0) {g_unit_stamps[(slot * B + j) * kStampSlots + ((n) == 0 ? 11 : 12)] = r_;} \
+      } \
     } \
   } while (0)
 #elif defined(LFX_MARKS)

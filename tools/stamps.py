@@ -35,6 +35,23 @@ t = np.frombuffer(buf, dtype=np.uint64).reshape(384, 16).astype(np.int64)
 ok = t[:, 10] > t[:, 0]
 t = t[ok]
 print("units stamped:", len(t))
+if "--skew" in sys.argv:
+    # REFCLK (100 MHz, one counter for the chip: slots 11 and 12) at the start and the end of every unit of the scan
+    t0, t1 = t[:, 11], t[:, 12]
+    first = t0.min()
+    print("REFCLK ticks of 10 ns; the scan's units: first start 0, last start %d, first end %d, last end %d" % (t0.max() - first, t1.min() - first, t1.max() - first))
+    wait_all = t1.max() - t1
+    print("an end that waited for the scan's LAST unit would wait: median %.2f us, p90 %.2f us, max %.2f us" % (np.median(wait_all) / 100.0, np.percentile(wait_all, 90) / 100.0, wait_all.max() / 100.0))
+    # ... for every unit before it in the order rings ascending, blocks ascending (the units stamped are in that order)
+    run = np.maximum.accumulate(t1)
+    before = np.concatenate([[t1[0]], run[:-1]])
+    wait_pre = np.maximum(before - t1, 0)
+    print("... for the units BEFORE it (rings ascending, blocks ascending): median %.2f us, p90 %.2f us, max %.2f us" % (np.median(wait_pre) / 100.0, np.percentile(wait_pre, 90) / 100.0, wait_pre.max() / 100.0))
+    print("unit lifetime by the same clock: median %.2f us" % (np.median(t1 - t0) / 100.0))
+    byx = {}
+    for u in range(len(t)):
+        byx.setdefault((u // 6 // 4) % 8, []).append(t1[u] - first)
+    print("mean end per ring group mod 8 (the XCDs, before the groups are turned): " + " ".join("%d:%.1f" % (k, np.mean(v) / 100.0) for k, v in sorted(byx.items())))
 life = t[:, 10] - t[:, 0]
 print("lifetime (stamp 0 -> 10): median %d  p10 %d  p90 %d shader cycles" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
 stages = {}
