@@ -95,10 +95,19 @@ __global__ __launch_bounds__(64 * G) void unit_memory(const uint8_t * __restrict
 {
   extern __shared__ uint8_t dyn[];
   constexpr uint32_t groups = R / G;
-  const uint32_t s = blockIdx.z, j = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t s = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t j = blockIdx.y;
   uint32_t g = blockIdx.x;
   if (MAP == 1) {g = (g + s) % groups;}
   if (MAP == 2) {g = (groups >= 16 ? ((((g & 7u) << 1) | (g >> 3)) + 2u * s) : (g + s)) % groups;}
+  if (MAP == 3 || MAP == 4) {
+    // an XCD (x mod 8) takes TWELVE consecutive (group, block) pairs of the scan, group fastest -- up to 1.5 KB of every
+    // column -- and which twelve turns with the scan (3), or stays (4)
+    const uint32_t r = blockIdx.x % 8u, q = blockIdx.x / 8u + (gridDim.x / 8u) * blockIdx.y, per = gridDim.x * gridDim.y / 8u;
+    const uint32_t b = ((MAP == 3 ? r + s : r) % 8u) * per + q;
+    g = b % groups;
+    j = b / groups;
+  }
   const uint32_t sub = lane % G, cq = lane / G;
   constexpr uint32_t per_wave = 64 / G;              // columns one instruction of a wave covers
   const uint8_t * base = pts + (size_t)s * R * C * 32;
@@ -396,6 +405,11 @@ int main(int argc, char ** argv)
     UM("pairs: l + c + 32 B records chunk by chunk, slots of 64", 2, 4, 2051, 22144, ugb);
     UM("pairs: l + c + records (again)", 2, 4, 7, 22144, ugb);
     UM("pairs: l + c + 32 B records by one store (again)", 2, 4, 35, 22144, ugb);
+    UM("pairs: l + c + slots, indices right behind the points (as built)", 2, 4, 32771, 22144, ugb);
+    UM("an XCD takes 12 consecutive (group, block) pairs, turned by the scan: same outputs", 3, 4, 32771, 22144, ugb);
+    UM("an XCD takes 12 consecutive (group, block) pairs, not turned: same outputs", 4, 4, 32771, 22144, ugb);
+    UM("pairs: no outputs (again)", 2, 4, 0, 22144, rgb);
+    UM("12 consecutive, turned: no outputs", 3, 4, 0, 22144, rgb);
     UM("pairs: l + c + slots as built (20-byte planes)", 2, 4, 4099, 22144, ugb);
     UM("pairs: l + c + slots + the second leg inside (slot of 32 scans ago -> dense)", 2, 4, 12291, 22144, ugb + 2 * fgb);
     UM("pairs: l + c + records straight into dense clouds", 2, 4, 16387, 22144, ugb);
