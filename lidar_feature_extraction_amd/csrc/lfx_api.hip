@@ -834,8 +834,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (c->fast_path) {
     // the unit kernels' record slots: 20 bytes per place (a point and its index), 64 or 128 places per unit, units back to back
     const size_t slots = nb * c->max_rings * (size_t)c->dev.B;
-    const int compiled_for[4] = {5, 5, 2, 0};          // UnitVariant<V>::kPT (lfx_kernels_unit.hpp)
-    c->slot_places = lfx::rec_slot_places(compiled_for[c->unit_variant & 3], (int)c->unit_chunks);
+    c->slot_places = lfx::rec_slot_places(kUnitVariantPadding[c->unit_variant & 3], (int)c->unit_chunks);
     const size_t slot_bytes = (size_t)c->slot_places * lfx::kRecBytes;
     if (slots * slot_bytes <= ((size_t)16 << 30)) {
       ok(c->rec32.alloc(slots * (slot_bytes / 16u)));

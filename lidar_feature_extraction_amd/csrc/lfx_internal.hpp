@@ -21,6 +21,9 @@ namespace lfx_host
 
 // The unit kernels live in four translation units of their own, one per variant of the parameters (lfx_unit_v0.hip ...
 // lfx_unit_v3.hip over lfx_unit_variant.inl; UnitVariant in lfx_kernels_unit.hpp); run_batch launches them through these.
+// the padding the unit kernels of variant V are compiled for (lfx::UnitVariant<V>::kPT: lfx_unit_variant.inl checks; 0 = at run time)
+constexpr int kUnitVariantPadding[4] = {5, 5, 2, 0};
+
 struct UnitOrgArgs
 {
   lfx::Params prm;

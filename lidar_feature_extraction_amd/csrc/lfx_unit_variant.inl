@@ -11,6 +11,8 @@
 namespace lfx_host
 {
 
+static_assert(lfx::UnitVariant<LFX_VARIANT>::kPT == kUnitVariantPadding[LFX_VARIANT], "the host sizes the record slots from this table (lfx_create)");
+
 #define LFX_CAT2(a, b) a##b
 #define LFX_CAT(a, b) LFX_CAT2(a, b)
 
