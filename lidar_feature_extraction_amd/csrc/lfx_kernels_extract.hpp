@@ -1,5 +1,6 @@
-// lfx_kernels_extract.hpp -- the extraction path: ring bucketing, the unit kernels (one wave per (ring, block)), order
-// repair, the workgroup-per-ring slow path, compaction, download.  Overview: lfx_kernels_common.hpp.
+// lfx_kernels_extract.hpp -- the extraction path around the unit kernels (lfx_kernels_unit.hpp): ring bucketing, order
+// repair, the ring transforms of turned streams, the workgroup-per-ring slow path, compaction, download.  Overview:
+// lfx_kernels_common.hpp.
 #pragma once
 
 #include "lfx_kernels_common.hpp"

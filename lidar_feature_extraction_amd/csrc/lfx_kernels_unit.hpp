@@ -426,34 +426,23 @@ struct OrgScan
   const uint32_t * __restrict__ geom;     // [batch][kGeomStride]
 };
 
-#ifndef LFX_ORG_FULL
-#define LFX_ORG_FULL false
-#endif
-#ifdef LFX_FULL_NOSKIP
-#define LFX_NOSKIP(full) (full)
-#else
-#define LFX_NOSKIP(full) false
-#endif
-// FULL (an experiment, off in every instantiation): all CH chunks are processed whatever the span (positions beyond it
-// are no ring points and are masked out everywhere) and no work is skipped for chunks without candidates, so that the
-// body is straight-line code per stage whose LDS reads the compiler can issue together -- a wave is parked in s_waitcnt
-// 43 % of its life (profiles/r02_org1/sq_counters.json).  Measured: the interleaved chunks need 42 more scalar and 24
-// more vector registers than the wave has (spilled), 1700 vs 1440 us per 1024 scans.  Kept because it is what exposed
-// the aliasing hazard described at put_word().
+// (The FULL form of the body -- every chunk processed whatever the span, no chunk skipped, so that a stage is straight-line code --
+// was an experiment of round 2: 1 700 against 1 440 us, 42 scalar and 24 vector registers spilled.  It exposed the aliasing hazard
+// described at put_word() and was taken out in round 5: git show 238d4cf:lidar_feature_extraction_amd/csrc/lfx_kernels_unit.hpp.)
 // What a unit is, in ring positions i and in span coordinates q = i - g0 (wave-uniform, scalar registers).
 struct UnitGeom
 {
   int N, b0, b1, o0, o1, g0, span, K, qb0, qb1, qo0, qo1, qlo, qhi;
 };
 
-__device__ inline UnitGeom unit_geometry(int N, int P, int B, int j, int b0, int b1, int chunks_all /* > 0: FULL */)
+__device__ inline UnitGeom unit_geometry(int N, int P, int B, int j, int b0, int b1)
 {
   UnitGeom G;
   G.N = N; G.b0 = b0; G.b1 = b1;
   G.o0 = j == 0 ? 0 : b0; G.o1 = j == B - 1 ? N : b1;
   const int H = P + 1;
   G.g0 = G.o0 - H; G.span = G.o1 + H - G.g0;
-  G.K = chunks_all > 0 ? chunks_all : (G.span + 63) >> 6;
+  G.K = (G.span + 63) >> 6;
   G.qb0 = b0 - G.g0; G.qb1 = b1 - G.g0;          // the block in span coordinates
   G.qo0 = G.o0 - G.g0; G.qo1 = G.o1 - G.g0;      // the owned positions
   G.qlo = G.g0 < 0 ? -G.g0 : 0;                  // first / one-past-last position that is a ring point
@@ -465,7 +454,7 @@ __device__ inline UnitGeom unit_geometry(int N, int P, int B, int j, int b0, int
 // in registers.  Returns 0, or the reason the unit cannot be taken here (kDeferOrder / kDeferOther); feature records go
 // to positions [rec_lo, ...) (edges, ascending) and (..., rec_hi) (surfaces, descending) of the ring's record arrays,
 // their numbers to n_edge / n_surface.
-template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF>
+template<int PT, int CH, bool DEF, bool ORG, bool XF>
 __device__ __forceinline__ uint32_t unit_core(
   const Params & prm, UnitLds<CH> & U, const UnitGeom & G, uint32_t dbg_flags, uint32_t s, uint32_t slot, int j,
   const float (&x)[CH], const float (&y)[CH], const float (&z)[CH], const uint32_t (&src)[CH],
@@ -647,7 +636,7 @@ __device__ __forceinline__ uint32_t unit_core(
   // to the chunk form as ONE word per lane (two for the 12-chunk form).  For every compile-time PT a span of 3 .. 6 chunks
   // can hold, and for the long form of 12.
   constexpr bool kRows = PT > 0 && PT <= 2 * CH && (CH <= 6 || (CH == 12 && PT <= 5));     // (12 chunks: a window of 22 doubles per lane)
-  constexpr bool kRowPick = kRows && !FULL;
+  constexpr bool kRowPick = kRows;
   constexpr int kRowWin = kRows ? 2 * PT + CH : 1;
   constexpr int kSetStride = CH < 4 ? 4 : CH;          // rows -> chunk form: the sets of a lane's word lie this far apart (final_label)
   const int p0 = CH * lane;
@@ -903,7 +892,7 @@ __device__ __forceinline__ uint32_t unit_core(
     // round rather than once per chunk, was measured and is slower: 1305 vs 1272 us, ten more registers live)
 #pragma unroll
     for (int k = 0; k < CH; k++) {
-      if (k < K && (LFX_NOSKIP(FULL) || A[k] != 0ull)) {
+      if (k < K && A[k] != 0ull) {
         const uint32_t m = get_win(U, kBitA, k, W0) & reach[k] & ~(1u << 16);
         Hp[k] = ((edge ? ~lt[k] : lt[k]) & m) | (1u << 16);
       }
@@ -922,7 +911,7 @@ __device__ __forceinline__ uint32_t unit_core(
       for (int k = 0; k < CH; k++) {
         S[k + 1] = 0;
         if (k < K) {
-          if (LFX_NOSKIP(FULL) || A[k] != 0ull) {
+          if (A[k] != 0ull) {
             S[k + 1] = bal((get_win(U, kBitA, k, W0) & Hp[k]) == (1u << 16));
             vs.set(k, S[k + 1]);
           }
@@ -937,7 +926,7 @@ __device__ __forceinline__ uint32_t unit_core(
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         if (k < K) {
-          if (LFX_NOSKIP(FULL) || (S[k] | S[k + 1] | S[k + 2]) != 0ull) {
+          if ((S[k] | S[k + 1] | S[k + 2]) != 0ull) {
             A[k] &= ~bal((get_win(U, kBitS, k, W0) & reach[k]) != 0u);
             va.set(k, A[k]);
           }
@@ -1135,7 +1124,7 @@ __device__ __forceinline__ uint32_t unit_core(
   return 0u;
 }
 
-template<int PT, int CH, bool DEF, bool ORG, bool FULL, bool XF = false>
+template<int PT, int CH, bool DEF, bool ORG, bool XF = false>
 __device__ __forceinline__ void unit_body(
   const Params & prm, UnitLds<CH> * __restrict__ slabs, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
   uint32_t slot, int j, const uint32_t * __restrict__ ring_count,
@@ -1200,7 +1189,7 @@ __device__ __forceinline__ void unit_body(
     b0 = __builtin_amdgcn_readlane(bj, 0);
     b1 = __builtin_amdgcn_readlane(bj, 1);
   }
-  const UnitGeom G = unit_geometry(N, P, B, j, b0, b1, FULL ? CH : 0);
+  const UnitGeom G = unit_geometry(N, P, B, j, b0, b1);
   if (b1 - b0 < 2 || G.span > (64 * CH)) {LFX_DEFER(kDeferOther);}
   const int o0 = G.o0, o1 = G.o1, g0 = G.g0, qlo = G.qlo, qhi = G.qhi;
 
@@ -1299,7 +1288,7 @@ __device__ __forceinline__ void unit_body(
   LFX_WAVE_SYNC();
   uint32_t pe = 0, ps = 0;
   {
-    const uint32_t why = unit_core<PT, CH, DEF, ORG, FULL, XF>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, second_pass, og, off, max_rings,
+    const uint32_t why = unit_core<PT, CH, DEF, ORG, XF>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, second_pass, og, off, max_rings,
       (uint32_t)o0, (uint32_t)o1, pe, ps, lane);
     if (why != 0u) {LFX_DEFER(why);}
   }
@@ -1435,7 +1424,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF)) LF
 #endif
   const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, geom};
   const uint32_t slot = 4u * g + wave;
-  unit_body<UnitVariant<V>::kPT, CH, UnitVariant<V>::kDEF, true, LFX_ORG_FULL, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
+  unit_body<UnitVariant<V>::kPT, CH, UnitVariant<V>::kDEF, true, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
     nullptr, false, og);
 }
 
