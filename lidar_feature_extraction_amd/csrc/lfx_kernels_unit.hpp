@@ -92,15 +92,6 @@ template<int NW>
 __device__ __forceinline__ void lds_window_f64(const double * first, double (&w)[NW])
 {
   static_assert(NW <= 22, "extend the wait's operand list");
-#ifdef LFX_WHATIF_NOLDS
-  {
-    double seed = (double)(int)(threadIdx.x + 1u);
-    asm volatile ("" : "+v"(seed));
-#pragma unroll
-    for (int i = 0; i < NW; i++) {w[i] = seed;}
-    return;
-  }
-#endif
   const uint32_t addr = (uint32_t)reinterpret_cast<uintptr_t>(first);      // LDS byte address = low half of the generic one
 #pragma unroll
   for (int i = 0; i < NW; i++) {
@@ -187,11 +178,7 @@ typedef float __attribute__((may_alias)) f32_alias_t;
 template<int CH>
 __device__ inline void put_word(UnitLds<CH> & U, int arr, int k, uint64_t w)
 {
-#ifdef LFX_WHATIF_NOLDS
-  asm volatile ("" :: "s"(w));        // what-if build (wrong results): no LDS traffic for the bit arrays
-#else
   *reinterpret_cast<u64_alias_t *>(&U.bits[arr][2 * (k + 1)]) = w;
-#endif
 }
 
 // The words of one bit array, gathered in a register pair before they go to LDS: lane k + 1 holds the word of chunk k
@@ -227,9 +214,6 @@ struct WordVec
 template<int CH>
 __device__ __forceinline__ void put_words(UnitLds<CH> & U, int arr, const WordVec & v, int lane)
 {
-#ifdef LFX_WHATIF_NOLDS
-  asm volatile ("" :: "v"(v.lo), "v"(v.hi));
-#else
   // Lanes 0 .. CH + 1 store.  The execution mask is set inside the statement: written as `if (lane < CH + 2)` the
   // compiler (ROCm 7.2) placed window reads that FOLLOW the store inside the masked region, so that only those seven
   // lanes read their windows (seen in the listing; the pick rounds then never ended).  An LDS write the compiler does
@@ -239,32 +223,23 @@ __device__ __forceinline__ void put_words(UnitLds<CH> & U, int arr, const WordVe
   uint64_t saved;
   asm volatile ("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0"
     : "=&s"(saved) : "v"(addr), "v"(data), "n"((1u << (CH + 2)) - 1u) : "memory");
-#endif
 }
 
 // bit 16 + d of the result <-> position q + d of array `arr`, q = 64k + lane (+1 for the shifted constants)
 template<int CH>
 __device__ inline uint32_t get_win(const UnitLds<CH> & U, int arr, int k, const UnitWin & w)
 {
-#ifdef LFX_WHATIF_NOLDS
-  return __builtin_amdgcn_alignbit((uint32_t)arr * 0x9E3779B9u + threadIdx.x, (uint32_t)k * 0x85EBCA6Bu ^ threadIdx.x, w.sh);
-#else
   const u32_alias_t * b = reinterpret_cast<const u32_alias_t *>(&U.bits[arr][2 * k + w.ofs]);
   return __builtin_amdgcn_alignbit(b[1], b[0], w.sh);
-#endif
 }
 
 // 32 positions of array `arr` starting at position `first` (bit i of the result <-> position first + i), first >= -64
 template<int CH>
 __device__ inline uint32_t get_win_at(const UnitLds<CH> & U, int arr, int first)
 {
-#ifdef LFX_WHATIF_NOLDS
-  return __builtin_amdgcn_alignbit((uint32_t)arr * 0x9E3779B9u + threadIdx.x, (uint32_t)first * 0x85EBCA6Bu ^ threadIdx.x, (uint32_t)first & 31u);
-#else
   const uint32_t bit = (uint32_t)(first + 64);
   const u32_alias_t * b = reinterpret_cast<const u32_alias_t *>(&U.bits[arr][bit >> 5]);
   return __builtin_amdgcn_alignbit(b[1], b[0], bit & 31u);
-#endif
 }
 
 // The ROWS form of the block labelling (unit_core, stages D and F).  A lane holds CH CONSECUTIVE positions, CH * lane + d,
@@ -899,9 +874,6 @@ __device__ __forceinline__ uint32_t unit_core(
     }
     // rounds: a live candidate with no live candidate of higher priority in reach is picked;
     // everything a pick reaches (the pick included) leaves the live set
-#ifdef LFX_WHATIF_NOLDS
-    int whatif_rounds = 0;
-#endif
     for (;; ) {
       uint64_t S[CH + 2];
       uint64_t picked = 0, left = 0;
@@ -935,9 +907,6 @@ __device__ __forceinline__ uint32_t unit_core(
       }
       if (left == 0ull) {break;}
       put_words(U, kBitA, va, lane);
-#ifdef LFX_WHATIF_NOLDS
-      if (++whatif_rounds >= 2) {break;}
-#endif
     }
     {
       WordVec vsel;
@@ -948,32 +917,6 @@ __device__ __forceinline__ uint32_t unit_core(
       put_words(U, sel_arr, vsel, lane);
     }
   }
-#if defined(LFX_PROBE_VALU) || defined(LFX_PROBE_LDS) || defined(LFX_PROBE_SALU)
-  {
-    // resource probes (diagnostic builds only): extra independent work of one kind; the results reach a store that never happens
-    uint32_t acc = (uint32_t)lane;
-    uint32_t sacc = (uint32_t)j;
-#ifdef LFX_PROBE_VALU
-#pragma unroll
-    for (int t = 0; t < LFX_PROBE_VALU; t++) {asm volatile ("v_add_u32 %0, %0, %1" : "+v"(acc) : "v"(lane));}
-#endif
-#ifdef LFX_PROBE_SALU
-#pragma unroll
-    for (int t = 0; t < LFX_PROBE_SALU; t++) {asm volatile ("s_add_u32 %0, %0, 7" : "+s"(sacc));}
-#endif
-#ifdef LFX_PROBE_LDS
-    {
-      const uint32_t addr = (uint32_t)reinterpret_cast<uintptr_t>(&U.r[lane]);
-      double t0;
-#pragma unroll
-      for (int t = 0; t < LFX_PROBE_LDS; t++) {asm volatile ("ds_read_b64 %0, %1 offset:%2" : "=v"(t0) : "v"(addr), "n"(8 * (t % 64)));}
-      asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(t0));
-      acc += (uint32_t)__double_as_longlong(t0);
-    }
-#endif
-    if (acc + sacc == 0x7FFFFFF1u && N == 3) {tab->unit_ne[0] = acc;}
-  }
-#endif
   LFX_STAMP(9);
   // ---- G. final labels of the owned points (feature_extraction.cpp:133-138 order), outputs
   uint32_t pe = 0, ps = 0;
