@@ -8,7 +8,7 @@ mkdir -p $OUT
 bash tools/profile.sh $OUT > $OUT/profile_log.txt 2>&1 || { echo "profile.sh failed"; tail -5 $OUT/profile_log.txt; }
 L=$PWD/lidar_feature_extraction_amd/_lib
 if [ -f $L/liblfx_stamps.so ]; then
-  LFX_LIB_PATH=$L/liblfx_stamps.so timeout -k 10 200 python tools/stamps.py --by-ring --json $OUT/stage_cycles.json > $OUT/stage_cycles.txt 2>&1 || echo "stamps failed"
+  LFX_LIB_PATH=$L/liblfx_stamps.so timeout -k 10 200 python tools/stamps.py --skew --by-ring --json $OUT/stage_cycles.json > $OUT/stage_cycles.txt 2>&1 || echo "stamps failed"
 fi
 [ -x tools/membench/membench ] && timeout -k 10 300 tools/membench/membench > $OUT/membench.txt 2>&1
 run() { name=$1; shift; timeout -k 10 400 "$@" > $OUT/$name.json 2> $OUT/$name.err || { echo "$name failed"; tail -3 $OUT/$name.err; }; echo "$name: $(python3 -c "
