@@ -529,7 +529,7 @@ int lfx_route_choice(const uint32_t report[LFX_ROUTE_REPORT_WORDS], uint32_t rep
                      int organised_possible, uint32_t batch, uint32_t max_rings, uint32_t choice[LFX_ROUTE_CHOICE_WORDS]);
 
 /* --- measurement ------------------------------------------------------------------------- */
-#define LFX_N_KERNELS 9  /* ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract (the bucketing route), ring_totals, feature_compact (compaction), ring_unit_org (organised scans), ring_cut (transforms of rotated / reversed rings) */
+#define LFX_N_KERNELS 12  /* ring_scatter, ring_unit, ring_order, ring_unit (second pass), ring_extract (the bucketing route), ring_totals, feature_compact (compaction), ring_unit_org (organised scans), ring_cut (transforms of rotated / reversed rings), fallback_tail (the organised route's tail), grid_count (valid returns per ring and column piece of a grid with holes), batch_reset */
 int lfx_set_profiling(lfx_ctx *ctx, int enabled);
 /* Record the events around every n-th batch only (default 1).  The event pairs between the kernels of a batch
  * cost ~7 % of the device-resident throughput at 64x1800x256; sampled, the durations stay live and the cost goes. */

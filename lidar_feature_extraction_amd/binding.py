@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LFX_LIB_PATH") or os.path.join(_HERE, "_lib", "liblfx.so")   # override: A/B builds only
 
-LFX_N_KERNELS = 9
+LFX_N_KERNELS = 12
 MAX_RINGS = 256
 
 STAGE_LABEL, STAGE_OCCLUSION, STAGE_OUT_OF_RANGE, STAGE_PARALLEL_BEAM = 1, 2, 4, 8

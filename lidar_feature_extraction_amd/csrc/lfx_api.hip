@@ -24,7 +24,8 @@ std::string g_create_error;
 
 const char * kKernelNames[LFX_N_KERNELS] = {
   "ring_scatter_kernel", "ring_unit_kernel", "ring_order_kernel", "ring_unit_kernel(second pass)", "ring_extract_kernel",
-  "ring_totals_kernel", "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel"};
+  "ring_totals_kernel", "feature_compact_kernel", "ring_unit_org_kernel", "ring_cut_kernel", "fallback_tail_kernel", "grid_count_kernel",
+  "batch_reset_kernel"};
 
 // IsNeighborXY compares acos(cos_angle) with the threshold (neighbor.hpp:44-48, math.cpp:45).
 // acos is monotone, so that test is a bound on cos_angle itself: the smallest double c with
@@ -267,7 +268,14 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   c->last_batch = batch;
   c->last_points = d_points;
   c->profile_now = c->profiling && (c->batch_no++ % c->profile_every) == 0u;
-  uint32_t * counters = c->ring_flags.p + (size_t)c->max_batch * lfx::kRings;     // behind ring_flags[max_batch][256]
+  // this batch's set of accumulators (lfx_kernels_common.hpp kParityCounters); the other one is zeroed by this batch's
+  // compaction for the batch after it
+  const uint32_t par = c->parity;
+  const size_t tables = (size_t)c->max_batch * lfx::kRings;
+  uint32_t * counters = c->counters.p + par * lfx::kParityCounters;
+  uint32_t * scan_flags = c->scan_flags.p + (size_t)par * c->max_batch;
+  uint32_t * ring_nedge = c->ring_nedge.p + par * tables, * ring_nsurf = c->ring_nsurf.p + par * tables;
+  const lfx::UnitTables * unit_tab = c->unit_tab.p + par;
   uint32_t * defer_count = counters + lfx::kCntDefer, * redo_count = counters + lfx::kCntRedo,
     * slow_count = counters + lfx::kCntSlow, * fb_count = counters + lfx::kCntFallback;
   const uint8_t * pts = static_cast<const uint8_t *>(d_points);
@@ -296,11 +304,24 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   const RouteChoice choice = choose_route(c->route, c->route_pins, c->fused_possible && canon && chunks != 0, batch, c->max_rings);
   const bool fused = choice.fused, short_tail = choice.short_tail;
   const uint32_t fb_grid = choice.fb_grid;             // list entries the bucketing kernels are launched for
-  hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
-    c->scan_info.p, batch * 4u, c->ring_count.p, batch * (uint32_t)lfx::kRings, c->chunk_flags.p,
-    batch * c->max_chunks, c->ring_flags.p, batch * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
-    fused ? 0u : 1u, c->xform.p, c->ring_nedge.p, c->ring_nsurf.p);
-  if (chunks == 0) {return LFX_OK;}
+  if (chunks == 0) {
+    // every scan of the batch is empty: no kernel runs; the result tables say so
+    LFX_HIP(c, hipMemsetAsync(c->scan_info.p, 0, (size_t)batch * 16, st));
+    LFX_HIP(c, hipMemsetAsync(c->ring_count.p, 0, (size_t)batch * lfx::kRings * 4, st));
+    return LFX_OK;
+  }
+  // The tail of the organised route is ONE launch that leaves the bucketing route's tables as it found them
+  // (fallback_tail_kernel): a stream that stays on it needs no reset launch.  Any other route dirties them over its scans;
+  // the reset kernel then runs ahead of the next batch, over everything a batch since the last reset may have touched.
+  const bool lazy = fused && short_tail && !choice.xform;
+  if (!lazy || c->aux_dirty != 0u) {
+    const uint32_t n_aux = c->aux_dirty > batch ? c->aux_dirty : batch;
+    Timed t(c, 11, st);
+    hipLaunchKernelGGL(lfx::batch_reset_kernel, dim3(64), dim3(256), 0, st,
+      c->chunk_flags.p, n_aux * c->max_chunks, c->ring_flags.p, n_aux * (uint32_t)lfx::kRings, counters, c->fb_list.p, batch,
+      fused ? 0u : 1u, c->xform.p);
+    c->aux_dirty = lazy ? 0u : batch;
+  }
   c->last_used_xform = fused && choice.xform;
   if (fused) {
     const bool xf = choice.xform;
@@ -312,11 +333,27 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     const uint32_t groups = (c->max_rings + 3u) / 4u;
     {
       Timed t(c, 7, st);
-      const UnitOrgArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, c->unit_tab.p,
+      const UnitOrgArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, unit_tab,
         c->xform.p, c->scan_geom.p};
       launch_unit_org(c->unit_variant, (int)c->unit_chunks, xf, dim3(groups, (uint32_t)c->dev.B, batch), c->unit_lds_pad, st, a);
     }
   }
+  const lfx::RingExtractArgs ex{c->dev, c->cap, c->stage_flags, c->max_rings, pts, c->layout, c->scan_begin.p, c->ring_count.p, c->sxy.p, c->sz.p,
+    c->sidx.p, c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p, c->rec_idx.p, c->ring_status.p,
+    c->unit_ne.p, c->unit_ns.p, c->unit_span.p, c->ring_flags.p};
+  if (lazy) {
+    // ---- the organised route's tail in one launch: the fall-back list is empty as a rule
+    Timed t(c, 9, st);
+    const lfx::ScatterArgs sc{pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p, scan_flags,
+      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero};
+    const uint32_t turns = (batch + lfx::kTailMaxTurns - 1u) / lfx::kTailMaxTurns;
+    const dim3 grid(chunks, fb_grid > turns ? fb_grid : turns);
+    if (canon) {
+      hipLaunchKernelGGL(lfx::fallback_tail_kernel<true>, grid, dim3(lfx::kChunkThreads), c->ring_lds, st, sc, ex, fb_count, c->fb_list.p, c->tail_ticket.p);
+    } else {
+      hipLaunchKernelGGL(lfx::fallback_tail_kernel<false>, grid, dim3(lfx::kChunkThreads), c->ring_lds, st, sc, ex, fb_count, c->fb_list.p, c->tail_ticket.p);
+    }
+  } else {
   // ---- the bucketing route, over the scans on the fall-back list
   {
     Timed t(c, 0, st);
@@ -326,7 +363,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       kern = canon ? &lfx::ring_scatter_kernel<true, true> : &lfx::ring_scatter_kernel<false, true>;
     }
     hipLaunchKernelGGL(kern, dim3(chunks, fb_grid), dim3(lfx::kChunkThreads), 0, st,
-      pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p,
+      pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p, scan_flags,
       c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p);
   }
   // the near-empty launches of the bucketing route are kept small while the organised-scan kernel takes the stream
@@ -344,7 +381,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       Timed t(c, 1, st);
       const uint32_t units = c->max_rings * (uint32_t)c->dev.B;
       // the looping form only where the list's length is a guess (behind the organised-scan kernel)
-      const UnitArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
+      const UnitArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, unit_tab,
         defer_count, c->defer_list.p, fb_count, c->fb_list.p, 0u};
       launch_unit(c->unit_variant, false, (int)c->unit_chunks, fused, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves, fb_grid),
         c->unit_lds_pad, st, a);
@@ -361,7 +398,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     {
       Timed t(c, 3, st);
       const uint32_t units = redo_cap * (uint32_t)c->dev.B;
-      const UnitArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->unit_tab.p,
+      const UnitArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, unit_tab,
         slow_count, c->slow_list.p, redo_count, c->redo_list.p, redo_cap};
       launch_unit(c->unit_variant, true, (int)c->unit_chunks, false, dim3((units + lfx::kUnitWaves - 1) / lfx::kUnitWaves), c->unit_lds_pad, st, a);
     }
@@ -370,10 +407,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     Timed t(c, 4, st);
     const dim3 grid = c->fast_path ? dim3(list_grid) : dim3(c->max_rings, batch);
     hipLaunchKernelGGL(lfx::ring_extract_kernel, grid, dim3(c->ring_threads), c->ring_lds, st,
-      c->dev, c->cap, c->stage_flags, short_tail ? 2u : (c->fast_path ? 1u : 0u), pts, c->layout, c->scan_begin.p,
-      c->ring_count.p, c->sxy.p, c->sz.p, c->sidx.p, c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p,
-      c->rec_idx.p, c->ring_status.p, c->unit_ne.p, c->unit_ns.p, c->unit_span.p, c->ring_flags.p,
-      short_tail ? fb_count : slow_count, short_tail ? c->fb_list.p : c->slow_list.p, c->max_rings);
+      ex, short_tail ? 2u : (c->fast_path ? 1u : 0u), short_tail ? fb_count : slow_count, short_tail ? c->fb_list.p : c->slow_list.p);
+  }
   }
   {
     // compaction: every scan of the batch, whoever labelled it.  Small batches: the compaction kernel finds every ring's
@@ -385,7 +420,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     if (!self_totals) {
       Timed t(c, 5, st);
       hipLaunchKernelGGL(lfx::ring_totals_kernel, dim3(batch), dim3(lfx::kRings), 0, st,
-        c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, c->ring_nedge.p, c->ring_nsurf.p,
+        c->scan_info.p, c->ring_count.p, c->unit_ne.p, c->unit_ns.p, ring_nedge, ring_nsurf,
         c->ring_ebase.p, c->ring_sbase.p, n_units, c->max_rings);
     }
     c->batch_serial = c->batch_serial + 1u == 0u ? 1u : c->batch_serial + 1u;
@@ -394,8 +429,15 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       hipLaunchKernelGGL(lfx::feature_compact_kernel, dim3((c->max_rings + 3) / 4, batch), dim3(256), 0, st,
         n_units, c->cap, c->scan_begin.p, c->ring_count.p, self_totals ? nullptr : c->ring_ebase.p, c->ring_sbase.p, c->unit_ne.p,
         c->unit_ns.p, c->unit_span.p, c->rec_pts.p, c->rec_idx.p, c->edge_pts.p, c->edge_idx.p, c->surf_pts.p,
-        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->batch_serial, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p, c->slot_places);
+        c->surf_idx.p, c->max_rings, c->scan_info.p, counters, c->h_counters, c->batch_serial, ring_nedge, ring_nsurf, c->rec32.p, c->slot_places,
+        scan_flags, c->ring_count.p, batch, fused ? 1u : 0u,
+        c->counters.p + (par ^ 1u) * lfx::kParityCounters, c->scan_flags.p + (size_t)(par ^ 1u) * c->max_batch,
+        c->ring_nedge.p + (par ^ 1u) * tables, c->ring_nsurf.p + (par ^ 1u) * tables, c->par_dirty[par ^ 1u]);
     }
+    // (this batch's set is dirty over its scans from here on; the other one is clean once the compaction has run)
+    c->par_dirty[par ^ 1u] = 0u;
+    c->par_dirty[par] = batch;
+    c->parity = par ^ 1u;
   }
   LFX_HIP(c, hipGetLastError());
   return LFX_OK;
@@ -816,9 +858,11 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->scan_begin.alloc(nb + 1)); ok(c->scan_info.alloc(nb * 4)); ok(c->scan_geom.alloc(nb * (size_t)lfx::kGeomStride));
   ok(c->chunk_base.alloc(chunk_tab));
   ok(c->ring_count.alloc(tables)); ok(c->chunk_flags.alloc(nb * c->max_chunks));
-  ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(tables));
-  ok(c->ring_nsurf.alloc(tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
-  ok(c->ring_flags.alloc(tables + lfx::kCounters)); ok(c->slow_list.alloc(tables)); ok(c->defer_list.alloc(tables));
+  // (the batch's accumulators exist twice, lfx_kernels_common.hpp kParityCounters)
+  ok(c->ring_status.alloc(tables)); ok(c->ring_nedge.alloc(2 * tables));
+  ok(c->ring_nsurf.alloc(2 * tables)); ok(c->ring_ebase.alloc(tables)); ok(c->ring_sbase.alloc(tables));
+  ok(c->counters.alloc(2 * lfx::kParityCounters)); ok(c->scan_flags.alloc(2 * nb)); ok(c->tail_ticket.alloc(nb));
+  ok(c->ring_flags.alloc(tables)); ok(c->slow_list.alloc(tables)); ok(c->defer_list.alloc(tables));
   ok(c->fb_list.alloc(nb)); ok(c->xform.alloc(tables));
   ok(c->redo_list.alloc(tables));
   ok(c->unit_ne.alloc(tables * lfx::kUnitMaxBlocks)); ok(c->unit_ns.alloc(tables * lfx::kUnitMaxBlocks));
@@ -830,7 +874,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (c->outputs & LFX_OUT_CURVATURE) {ok(c->curv_s.alloc(rc));}
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
-  ok(c->unit_tab.alloc(1));
+  ok(c->unit_tab.alloc(2));
   if (c->fast_path) {
     // the unit kernels' record slots: 20 bytes per place (a point and its index), 64 or 128 places per unit, units back to back
     const size_t slots = nb * c->max_rings * (size_t)c->dev.B;
@@ -848,17 +892,43 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     if (e == hipSuccess) {std::memset(c->h_counters, 0, 4 * (lfx::kCounters + 2));}
   }
   if (e == hipSuccess) {
+    // everything a batch's kernels add to or OR into starts clean (and is left clean by the batch before, run_batch); the
+    // tables every route writes before anyone reads them start at zero for the readers of a context that has run nothing
+    ok(hipMemset(c->counters.p, 0, 2 * lfx::kParityCounters * 4)); ok(hipMemset(c->scan_flags.p, 0, 2 * nb * 4));
+    ok(hipMemset(c->ring_nedge.p, 0, 2 * tables * 4)); ok(hipMemset(c->ring_nsurf.p, 0, 2 * tables * 4));
+    ok(hipMemset(c->tail_ticket.p, 0, nb * 4)); ok(hipMemset(c->chunk_flags.p, 0, nb * c->max_chunks * 4));
+    ok(hipMemset(c->ring_flags.p, 0, tables * 4)); ok(hipMemset(c->xform.p, 0, tables * 4));
+    ok(hipMemset(c->scan_info.p, 0, nb * 16)); ok(hipMemset(c->ring_count.p, 0, tables * 4));
+  }
+  if (e == hipSuccess) {
     // (no per-point curvature asked for: the kernels find no array to write it to -- a fifth of the unit kernel's HBM traffic)
-    const lfx::UnitTables t{c->label_s.p, (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr, c->rec_pts.p, c->rec_idx.p, c->ring_status.p, c->unit_ne.p,
-      c->unit_ns.p, c->unit_span.p, c->ring_flags.p, c->scan_info.p,
-      c->ring_flags.p + (size_t)c->max_batch * lfx::kRings + lfx::kCntFallback, c->fb_list.p, c->ring_nedge.p, c->ring_nsurf.p, c->rec32.p, c->dev};
-    e = hipMemcpy(c->unit_tab.p, &t, sizeof(t), hipMemcpyHostToDevice);
+    for (uint32_t par = 0; par < 2u && e == hipSuccess; par++) {
+      lfx::UnitTables t{};
+      t.label_s = c->label_s.p; t.curv_s = (c->outputs & LFX_OUT_CURVATURE) ? c->curv_s.p : nullptr;
+      t.rec_pts = c->rec_pts.p; t.rec_idx = c->rec_idx.p; t.ring_status = c->ring_status.p;
+      t.unit_ne = c->unit_ne.p; t.unit_ns = c->unit_ns.p; t.unit_span = c->unit_span.p; t.ring_flags = c->ring_flags.p;
+      t.scan_info = c->scan_info.p;
+      t.fb_count = c->counters.p + par * lfx::kParityCounters + lfx::kCntFallback;
+      t.fb_list = c->fb_list.p;
+      t.scan_flags = c->scan_flags.p + (size_t)par * nb;
+      t.ring_nedge = c->ring_nedge.p + par * tables; t.ring_nsurf = c->ring_nsurf.p + par * tables;
+      t.rec32 = c->rec32.p; t.prm = c->dev;
+      e = hipMemcpy(c->unit_tab.p + par, &t, sizeof(t), hipMemcpyHostToDevice);
+    }
   }
   if (e == hipSuccess) {e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);}
   // (the attribute is per function, not per context: always the worst case, so that contexts of different ring
   // capacities can live side by side)
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_extract_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx::ring_lds_bytes(LFX_MAX_RING_POINTS));
+  }
+  if (e == hipSuccess) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::fallback_tail_kernel<true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx::ring_lds_bytes(LFX_MAX_RING_POINTS));
+  }
+  if (e == hipSuccess) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::fallback_tail_kernel<false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx::ring_lds_bytes(LFX_MAX_RING_POINTS));
   }
   if (e == hipSuccess) {
@@ -888,7 +958,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->scan_geom.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
-  c->ring_sbase.release(); c->ring_flags.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->counters.release(); c->scan_flags.release(); c->tail_ticket.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}

@@ -185,7 +185,11 @@ struct lfx_ctx
   lfx_host::DevBuf<uint32_t> scan_begin, scan_geom, scan_info, chunk_base, chunk_flags, ring_count, ring_nedge,
     ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list, xform,
     sidx, rec_idx, edge_idx,
-    surf_idx, d_sidx;
+    surf_idx, d_sidx, counters, scan_flags, tail_ticket;
+  // The batch's accumulators (counters, scan_flags, ring_nedge / ring_nsurf) exist twice: batch k uses set `parity`, its
+  // compaction zeroes the other one over the scans the batch before last left dirty there (par_dirty).  aux_dirty: scans whose
+  // bucketing-route tables (look-back flags, ring flags, ring transforms) a batch since the last reset may have touched.
+  uint32_t parity = 0, par_dirty[2] = {0u, 0u}, aux_dirty = 0;
   lfx_host::DevBuf<uint8_t> ring_status, label_s, staging, d_label;
   lfx_host::DevBuf<double> d_curv;
   lfx_host::DevBuf<float2> sxy;

@@ -101,12 +101,17 @@ enum { kInfoRings = 0, kInfoError = 1, kInfoEdge = 2, kInfoSurface = 3 };
 // it); kScanFellBack: that kernel (or the host) handed the scan to the bucketing route, whose staged arrays are valid.
 enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u, kScanOrderFell = 0x400u };
 __host__ __device__ inline bool scan_is_organised(uint32_t err) {return (err & (kScanFused | kScanFellBack)) == kScanFused;}
-// counters[8] behind ring_flags: rings deferred by the first unit pass, repaired after it, sent to the workgroup-per-ring
+// counters[kCounters] (one block per batch parity, see kParityCounters): rings deferred by the first unit pass, repaired after it, sent to the workgroup-per-ring
 // kernel, repaired before it; scans on the fall-back list; whether the organised-scan kernel ran; scans in the batch
 // ... scans the organised-scan kernel gave up on because a ring was not in angle order (the rest of the pattern held);
 // rings ring_cut_kernel found rotated / reversed; whether it ran
 enum { kCntDefer = 0, kCntRedo = 1, kCntSlow = 2, kCntPreFixed = 3, kCntFallback = 4, kCntFusedRan = 5, kCntBatch = 6,
        kCntOrderFell = 7, kCntTurned = 8, kCntCutRan = 9, kCounters = 12 };
+// What a batch accumulates into with atomics -- the counters, the per-scan flag words, the organised route's ring totals --
+// exists TWICE: batch k uses set k mod 2, and its last kernel (feature_compact_kernel) leaves the other set zeroed for batch
+// k + 1.  No reset launch stands in front of a batch then: on the organised route a step is the unit kernel, the fall-back
+// tail and the compaction (round 6; the reset kernel was 5 us of every step, 5 % of a 128 x 2048 x 32 one).
+constexpr uint32_t kParityCounters = 16;                  // words per set of counters
 // Ring transform of an organised scan (ring_cut_kernel): position k of the ring is column (start + k) mod C, or
 // (start - k) mod C for a clockwise sensor; 0 = the ring arrives in angle order.
 constexpr uint32_t kXformReversed = 0x80000000u;
@@ -206,6 +211,7 @@ struct UnitTables
   uint32_t * unit_ne, * unit_ns, * unit_span;
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
+  uint32_t * scan_flags;                            // [batch]: the batch's error / route bits while it runs (feature_compact_kernel moves them into scan_info)
   uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
   float4 * rec32;                                   // the unit kernels' record slots, [batch][max_rings][n_blocks] x rec_slot_places() x kRecBytes
   Params prm;                                       // the thresholds, for the kernels that do not have them as literals (read where a stage needs them)

@@ -11,25 +11,23 @@ namespace lfx
 {
 
 // ------------------------------------------------------------------------------------------
-// Per-batch reset of the small tables in ONE launch (instead of five memset nodes).
+// What the batch's accumulators need before a batch (lfx_kernels_common.hpp: the counters, the per-scan flag words and the
+// organised route's ring totals are kept clean by the batch before; scan_info and ring_count are WRITTEN by every route, never
+// added to).  This kernel is what remains: the tables only the bucketing route dirties -- the look-back flags, the ring flags,
+// the ring transforms -- over the scans a batch since the last reset may have touched, and the fall-back list of a batch
+// that takes the bucketing route whole.  A stream the organised-scan kernel keeps taking never launches it.
 __global__ __launch_bounds__(256) void batch_reset_kernel(
-  uint32_t * __restrict__ scan_info, uint32_t n_info, uint32_t * __restrict__ ring_count, uint32_t n_count,
   uint32_t * __restrict__ chunk_flags, uint32_t n_flags, uint32_t * __restrict__ ring_flags, uint32_t n_rflags,
-  uint32_t * __restrict__ counters /* [kCounters] */, uint32_t * __restrict__ fb_list, uint32_t batch,
+  uint32_t * __restrict__ counters /* this batch's set */, uint32_t * __restrict__ fb_list, uint32_t batch,
   uint32_t all_fall_back /* 1: every scan takes the bucketing route (the organised-scan kernel is not launched) */,
-  uint32_t * __restrict__ xform /* [batch][256] ring transforms: identity unless ring_cut_kernel runs */,
-  uint32_t * __restrict__ ring_nedge, uint32_t * __restrict__ ring_nsurf /* [batch][256]: the organised-scan kernel adds to them */)
+  uint32_t * __restrict__ xform /* [batch][256] ring transforms: identity unless ring_cut_kernel runs */)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  for (uint32_t k = i; k < n_info; k += stride) {scan_info[k] = 0;}
-  for (uint32_t k = i; k < n_count; k += stride) {ring_count[k] = 0; ring_nedge[k] = 0; ring_nsurf[k] = 0;}
   for (uint32_t k = i; k < n_flags; k += stride) {chunk_flags[k] = 0;}
   for (uint32_t k = i; k < n_rflags; k += stride) {ring_flags[k] = 0; xform[k] = 0;}
   if (all_fall_back) {
     for (uint32_t k = i; k < batch; k += stride) {fb_list[k] = k;}
-  }
-  if (i < kCounters) {
-    counters[i] = i == kCntFallback ? (all_fall_back ? batch : 0u) : (i == kCntFusedRan ? (all_fall_back ? 0u : 1u) : (i == kCntBatch ? batch : 0u));
+    if (i == 0) {counters[kCntFallback] = batch;}
   }
 }
 
@@ -49,7 +47,7 @@ template<bool CANON>
 __device__ __forceinline__ void scatter_chunk(
   uint32_t s, const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
-  uint32_t * __restrict__ scan_info, float2 * __restrict__ sxy, float * __restrict__ sz,
+  uint32_t * __restrict__ scan_info, uint32_t * __restrict__ scan_flags, float2 * __restrict__ sxy, float * __restrict__ sz,
   uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero)
 {
   const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
@@ -122,7 +120,7 @@ __device__ __forceinline__ void scatter_chunk(
       if (key[i] < kRings) {atomicAdd(&cstart[key[i]], 1u);}
     }
     __syncthreads();
-    if (bad_ring) {atomicOr(&scan_info[s * 4 + kInfoError], 1u);}
+    if (bad_ring) {atomicOr(&scan_flags[s], 1u);}
     if (tid < kRings) {
       __hip_atomic_store(&chunk_base[(row + chunk) * kRings + tid], cstart[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -166,7 +164,7 @@ __device__ __forceinline__ void scatter_chunk(
         if (++spins > kSpinLimit) {timeout = true; break;}
       }
     }
-    if (timeout) {atomicOr(&scan_info[s * 4 + kInfoError], 4u);}
+    if (timeout) {atomicOr(&scan_flags[s], 4u);}
     __syncthreads();
     // every load of the published counts is an sc1 (L1-bypassing, agent-scope) load; four 16-byte
     // loads are kept in flight per thread (thread = 4 consecutive rings x one quarter of the chunks)
@@ -280,20 +278,20 @@ template<bool CANON, bool ONE = false>
 __global__ __launch_bounds__(kChunkThreads, ONE ? 1 : 4) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
-  uint32_t * __restrict__ scan_info, float2 * __restrict__ sxy, float * __restrict__ sz,
+  uint32_t * __restrict__ scan_info, uint32_t * __restrict__ scan_flags, float2 * __restrict__ sxy, float * __restrict__ sz,
   uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero,
   const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
 {
   const uint32_t n_list = *fb_count;
   if (ONE) {
     if (blockIdx.y < n_list) {
-      scatter_chunk<CANON>(fb_list[blockIdx.y], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
+      scatter_chunk<CANON>(fb_list[blockIdx.y], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, scan_flags, sxy, sz,
         sidx, max_chunks, max_rings, cap, drop_zero);
     }
     return;
   }
   for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
-    scatter_chunk<CANON>(fb_list[it], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, sxy, sz,
+    scatter_chunk<CANON>(fb_list[it], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, scan_flags, sxy, sz,
       sidx, max_chunks, max_rings, cap, drop_zero);
     __syncthreads();                        // the LDS blocks are reused by the next entry
   }
@@ -1502,27 +1500,137 @@ __host__ __device__ inline size_t order_lds_bytes(uint32_t cap)
 // deferred (use_list) or every ring of the batch (n_blocks > 64, debugging).  Writes the ring's
 // feature records as ONE segment (edge from the front of the ring, surface from its back) and
 // marks the ring so that feature_compact_kernel reads it that way.
+struct RingExtractArgs
+{
+  Params prm;
+  uint32_t cap, stage_flags, max_rings;
+  const uint8_t * __restrict__ pts;
+  Layout L;
+  const uint32_t * __restrict__ scan_begin;
+  const uint32_t * __restrict__ ring_count;
+  float2 * __restrict__ sxy;
+  const float * __restrict__ sz;
+  uint32_t * __restrict__ sidx;
+  uint8_t * __restrict__ label_s;
+  double * __restrict__ curv_s;
+  float4 * __restrict__ rec_pts;
+  uint32_t * __restrict__ rec_idx;
+  uint8_t * __restrict__ ring_status;
+  uint32_t * __restrict__ unit_ne, * __restrict__ unit_ns, * __restrict__ unit_span, * __restrict__ ring_flags;
+};
+
+// One ring (scan s, ring id slot) by the whole workgroup.  sorted_already: ring_order_kernel has put the ring in angle
+// order; mark: leave the ring's flag word saying the ring was taken here (the list routes; the fall-back tail leaves the
+// flags as it found them, so that no reset has to follow it).
+__device__ inline void extract_ring(const RingExtractArgs & a, uint8_t * lds_raw, uint32_t s, uint32_t slot, bool sorted_already, bool mark)
+{
+  const int T = blockDim.x, tid = threadIdx.x;
+  const uint32_t cap = a.cap, max_rings = a.max_rings;
+  const int N = (int)a.ring_count[s * kRings + slot];
+  const size_t sb = a.scan_begin[s];
+  const size_t off = ring_base(s, slot, max_rings, cap);
+  const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
+  uint8_t status = kOk;
+  bool resorted = false;
+  RingWork w = carve(lds_raw, cap);
+  if ((uint32_t)N > cap) {
+    status = kTooLarge;
+  } else {
+    for (int i = tid; i < N; i += T) {
+      const float2 v = a.sxy[off + i];
+      w.x[i] = v.x;
+      w.y[i] = v.y;
+    }
+    __syncthreads();
+    if (!sorted_already) {
+      resorted = angle_sort(w, N, a.sxy + off, a.sidx + off);
+    }
+    status = process_ring(w, a.prm, N, a.stage_flags, nullptr, nullptr, nullptr);
+  }
+  // the whole ring is ONE unit with one segment of records: [0, N)
+  if (tid < kUnitMaxBlocks) {a.unit_ne[ui + tid] = 0; a.unit_ns[ui + tid] = 0; a.unit_span[ui + tid] = 0;}
+  if (tid == 0) {
+    if (mark) {a.ring_flags[s * kRings + slot] = 1u;}
+    a.unit_span[ui] = ((uint32_t)((uint32_t)N < cap ? N : (int)cap) << 16);
+  }
+  if (status != kOk) {
+    // the ring contributes nothing (feature_extraction.cpp:116,154-156)
+    const int stored = (uint32_t)N < cap ? N : (int)cap;
+    for (int i = tid; i < stored; i += T) {
+      a.label_s[off + i] = kDefault;
+      if (a.curv_s != nullptr) {a.curv_s[off + i] = 0.;}
+    }
+    if (tid == 0) {a.ring_status[s * kRings + slot] = status;}
+    __syncthreads();
+    return;
+  }
+  __syncthreads();
+  const int nwords = (N + 63) >> 6;
+  if (tid < 64) {
+    uint32_t ce = 0, cs = 0;
+    for (int base = 0; base < nwords; base += 64) {
+      const int k = base + tid;
+      const uint32_t ne = k < nwords ? __popcll(w.featE[k + 1]) : 0u;
+      const uint32_t ns = k < nwords ? __popcll(w.featS[k + 1]) : 0u;
+      uint32_t ie = ne, is = ns;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t te = __shfl_up(ie, d), ts = __shfl_up(is, d);
+        if (tid >= d) {ie += te; is += ts;}
+      }
+      if (k < nwords) {
+        w.wbase[k] = ce + ie - ne;
+        w.wbase[cap / 64 + k] = cs + is - ns;
+      }
+      ce += __shfl(ie, 63);
+      cs += __shfl(is, 63);
+    }
+    if (tid == 0) {
+      a.ring_status[s * kRings + slot] = kOk;
+      a.unit_ne[ui] = ce;
+      a.unit_ns[ui] = cs;
+    }
+  }
+  __syncthreads();
+  const bool reload_xy = w.flags[kFlagXYClobbered] != 0;
+  for (int i = tid; i < N; i += T) {
+    const uint8_t lab = w.lab[i];
+    const double c = w.c[i];
+    a.label_s[off + i] = lab;
+    if (a.curv_s != nullptr) {a.curv_s[off + i] = c;}
+    if (lab == kEdge || lab == kSurface) {
+      const uint64_t below = (1ull << (i & 63)) - 1ull;
+      const uint32_t orig = a.sidx[off + i];
+      // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
+      const float z = resorted ? load_f32(a.pts + (sb + orig) * a.L.step + a.L.oz, a.L.be) : a.sz[off + i];
+      float x = w.x[i], y = w.y[i];
+      if (reload_xy) {const float2 v = a.sxy[off + i]; x = v.x; y = v.y;}
+      size_t at;
+      if (lab == kEdge) {
+        at = off + w.wbase[i >> 6] + __popcll(w.featE[(i >> 6) + 1] & below);
+      } else {
+        at = off + N - 1 - (w.wbase[cap / 64 + (i >> 6)] + __popcll(w.featS[(i >> 6) + 1] & below));
+      }
+      a.rec_pts[at] = make_float4(x, y, z, (float)c);
+      a.rec_idx[at] = orig;
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(512) void ring_extract_kernel(
-  Params prm, uint32_t cap, uint32_t stage_flags, uint32_t use_list, const uint8_t * __restrict__ pts, Layout L,
-  const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ ring_count,
-  float2 * __restrict__ sxy, const float * __restrict__ sz, uint32_t * __restrict__ sidx,
-  uint8_t * __restrict__ label_s, double * __restrict__ curv_s, float4 * __restrict__ rec_pts,
-  uint32_t * __restrict__ rec_idx, uint8_t * __restrict__ ring_status, uint32_t * __restrict__ unit_ne,
-  uint32_t * __restrict__ unit_ns, uint32_t * __restrict__ unit_span, uint32_t * __restrict__ ring_flags,
-  const uint32_t * __restrict__ slow_count, const uint32_t * __restrict__ slow_list, uint32_t max_rings)
+  RingExtractArgs a, uint32_t use_list, const uint32_t * __restrict__ slow_count, const uint32_t * __restrict__ slow_list)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  const int T = blockDim.x, tid = threadIdx.x;
+  const uint32_t max_rings = a.max_rings;
   // use_list: 0 = every ring of the batch, grid (max_rings, batch); 1 = the rings on the slow list; 2 = every ring of
-  // the SCANS listed (slow_count / slow_list are the fall-back list then): the whole bucketing route's tail in one
-  // launch, used while the organised-scan kernel takes the stream and no scan has been falling back
+  // the SCANS listed (slow_count / slow_list are the fall-back list then)
   const uint32_t n_items = use_list == 2u ? *slow_count * max_rings : (use_list ? *slow_count : 1u);
   for (uint32_t item = use_list ? blockIdx.x : 0u; item < n_items; item += use_list ? gridDim.x : 1u) {
     uint32_t slot, s;
     if (use_list == 2u) {
       s = slow_list[item / max_rings];
       slot = item % max_rings;
-      if (ring_count[s * kRings + slot] == 0u) {continue;}
+      if (a.ring_count[s * kRings + slot] == 0u) {continue;}
     } else if (use_list) {
       const uint32_t e = slow_list[item];
       s = e / kRings;
@@ -1530,97 +1638,76 @@ __global__ __launch_bounds__(512) void ring_extract_kernel(
     } else {
       slot = blockIdx.x;
       s = blockIdx.y;
-      if (slot >= max_rings || ring_count[s * kRings + slot] == 0u) {return;}
+      if (slot >= max_rings || a.ring_count[s * kRings + slot] == 0u) {return;}
     }
-    const int N = (int)ring_count[s * kRings + slot];
-    const size_t sb = scan_begin[s];
-    const size_t off = ring_base(s, slot, max_rings, cap);
-    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
-    uint8_t status = kOk;
-    bool resorted = false;
-    RingWork w = carve(lds_raw, cap);
-    if ((uint32_t)N > cap) {
-      status = kTooLarge;
-    } else {
-      for (int i = tid; i < N; i += T) {
-        const float2 v = sxy[off + i];
-        w.x[i] = v.x;
-        w.y[i] = v.y;
-      }
+    extract_ring(a, lds_raw, s, slot, use_list && (a.ring_flags[s * kRings + slot] & kRingSorted), true);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The fall-back tail of the organised route: ONE launch behind ring_unit_org_kernel that does nothing -- its first
+// instruction reads the length of the fall-back list -- on the batches of a stream that kernel keeps taking, and redoes the
+// odd scan out whole otherwise: workgroup (x, y) buckets chunk x of list entries y, y + gridDim.y, ... exactly as
+// ring_scatter_kernel does; the workgroup that finishes a scan's LAST chunk (a ticket per scan) then takes the scan's rings
+// one after the other as ring_extract_kernel would, and leaves the look-back flags and the ticket as it found them: zero.
+// Nobody waits for anybody beyond the look-back of the bucketing itself, whatever the grid.  (Until round 6 this was
+// ring_scatter_kernel + ring_extract_kernel, two launches of ~6 us that found an empty list; a stream that does fall back
+// is moved to the five-launch route by choose_route after its first report.)
+struct ScatterArgs
+{
+  const uint8_t * __restrict__ pts;
+  Layout L;
+  const uint32_t * __restrict__ scan_begin;
+  uint32_t * __restrict__ chunk_base, * __restrict__ chunk_flags, * __restrict__ ring_count, * __restrict__ scan_info, * __restrict__ scan_flags;
+  float2 * __restrict__ sxy;
+  float * __restrict__ sz;
+  uint32_t * __restrict__ sidx;
+  uint32_t max_chunks, max_rings, cap, drop_zero;
+};
+constexpr uint32_t kTailMaxTurns = 128;       // list entries a workgroup may have to take (the host sizes the grid for it)
+
+template<bool CANON>
+__global__ __launch_bounds__(kChunkThreads, 1) void fallback_tail_kernel(
+  ScatterArgs sc, RingExtractArgs ex, const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list,
+  uint32_t * __restrict__ tail_ticket /* [max_batch], zero between batches */)
+{
+  const uint32_t n_list = *fb_count;
+  if (n_list == 0u) {return;}
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  __shared__ uint32_t mine[kTailMaxTurns / 32];
+  const uint32_t tid = threadIdx.x;
+  if (tid < kTailMaxTurns / 32) {mine[tid] = 0u;}
+  __syncthreads();
+  uint32_t turn = 0;
+  for (uint32_t it = blockIdx.y; it < n_list && turn < kTailMaxTurns; it += gridDim.y, turn++) {
+    const uint32_t s = fb_list[it];
+    const uint32_t n = sc.scan_begin[s + 1] - sc.scan_begin[s];
+    const uint32_t n_chunks = (n + kChunkPoints - 1) / kChunkPoints;
+    if (blockIdx.x < n_chunks) {
+      scatter_chunk<CANON>(s, sc.pts, sc.L, sc.scan_begin, sc.chunk_base, sc.chunk_flags, sc.ring_count, sc.scan_info, sc.scan_flags,
+        sc.sxy, sc.sz, sc.sidx, sc.max_chunks, sc.max_rings, sc.cap, sc.drop_zero);
+      // everything this chunk staged is out before its ticket is drawn; the last to draw sees every chunk's
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
-      if (!(use_list && (ring_flags[s * kRings + slot] & kRingSorted))) {
-        resorted = angle_sort(w, N, sxy + off, sidx + off);
-      }
-      status = process_ring(w, prm, N, stage_flags, nullptr, nullptr, nullptr);
-    }
-    // the whole ring is ONE unit with one segment of records: [0, N)
-    if (tid < kUnitMaxBlocks) {unit_ne[ui + tid] = 0; unit_ns[ui + tid] = 0; unit_span[ui + tid] = 0;}
-    if (tid == 0) {
-      ring_flags[s * kRings + slot] = 1u;
-      unit_span[ui] = ((uint32_t)((uint32_t)N < cap ? N : (int)cap) << 16);
-    }
-    if (status != kOk) {
-      // the ring contributes nothing (feature_extraction.cpp:116,154-156)
-      const int stored = (uint32_t)N < cap ? N : (int)cap;
-      for (int i = tid; i < stored; i += T) {
-        label_s[off + i] = kDefault;
-        if (curv_s != nullptr) {curv_s[off + i] = 0.;}
-      }
-      if (tid == 0) {ring_status[s * kRings + slot] = status;}
-      __syncthreads();
-      continue;
-    }
-    __syncthreads();
-    const int nwords = (N + 63) >> 6;
-    if (tid < 64) {
-      uint32_t ce = 0, cs = 0;
-      for (int base = 0; base < nwords; base += 64) {
-        const int k = base + tid;
-        const uint32_t ne = k < nwords ? __popcll(w.featE[k + 1]) : 0u;
-        const uint32_t ns = k < nwords ? __popcll(w.featS[k + 1]) : 0u;
-        uint32_t ie = ne, is = ns;
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t te = __shfl_up(ie, d), ts = __shfl_up(is, d);
-          if (tid >= d) {ie += te; is += ts;}
-        }
-        if (k < nwords) {
-          w.wbase[k] = ce + ie - ne;
-          w.wbase[cap / 64 + k] = cs + is - ns;
-        }
-        ce += __shfl(ie, 63);
-        cs += __shfl(is, 63);
-      }
-      if (tid == 0) {
-        ring_status[s * kRings + slot] = kOk;
-        unit_ne[ui] = ce;
-        unit_ns[ui] = cs;
+      if (tid == 0u) {
+        const uint32_t t = __hip_atomic_fetch_add(&tail_ticket[s], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == n_chunks - 1u) {mine[turn >> 5] |= 1u << (turn & 31u);}
       }
     }
-    __syncthreads();
-    const bool reload_xy = w.flags[kFlagXYClobbered] != 0;
-    for (int i = tid; i < N; i += T) {
-      const uint8_t lab = w.lab[i];
-      const double c = w.c[i];
-      label_s[off + i] = lab;
-      if (curv_s != nullptr) {curv_s[off + i] = c;}
-      if (lab == kEdge || lab == kSurface) {
-        const uint64_t below = (1ull << (i & 63)) - 1ull;
-        const uint32_t orig = sidx[off + i];
-        // AppendXYZIR (label.hpp:166-179): x, y, z and intensity <- (float)curvature
-        const float z = resorted ? load_f32(pts + (sb + orig) * L.step + L.oz, L.be) : sz[off + i];
-        float x = w.x[i], y = w.y[i];
-        if (reload_xy) {const float2 v = sxy[off + i]; x = v.x; y = v.y;}
-        size_t at;
-        if (lab == kEdge) {
-          at = off + w.wbase[i >> 6] + __popcll(w.featE[(i >> 6) + 1] & below);
-        } else {
-          at = off + N - 1 - (w.wbase[cap / 64 + (i >> 6)] + __popcll(w.featS[(i >> 6) + 1] & below));
-        }
-        rec_pts[at] = make_float4(x, y, z, (float)c);
-        rec_idx[at] = orig;
-      }
+    __syncthreads();                        // the LDS blocks are reused by the next entry
+  }
+  turn = 0;
+  for (uint32_t it = blockIdx.y; it < n_list && turn < kTailMaxTurns; it += gridDim.y, turn++) {
+    if (((mine[turn >> 5] >> (turn & 31u)) & 1u) == 0u) {continue;}
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t s = fb_list[it];
+    for (uint32_t slot = 0; slot < sc.max_rings; slot++) {
+      if (ex.ring_count[s * kRings + slot] != 0u) {extract_ring(ex, lds_raw, s, slot, false, false);}
     }
-    __syncthreads();
+    const uint32_t n = sc.scan_begin[s + 1] - sc.scan_begin[s];
+    const uint32_t n_chunks = (n + kChunkPoints - 1) / kChunkPoints;
+    for (uint32_t k = tid; k < n_chunks; k += blockDim.x) {sc.chunk_flags[(size_t)s * sc.max_chunks + k] = 0u;}
+    if (tid == 0u) {tail_ticket[s] = 0u;}
   }
 }
 
@@ -1674,11 +1761,16 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
   const uint32_t * __restrict__ unit_ns, const uint32_t * __restrict__ unit_span,
   const float4 * __restrict__ rec_pts, const uint32_t * __restrict__ rec_idx, float4 * __restrict__ edge_pts,
   uint32_t * __restrict__ edge_idx, float4 * __restrict__ surf_pts, uint32_t * __restrict__ surf_idx,
-  uint32_t max_rings, uint32_t * __restrict__ scan_info /* read for the scan's route; its totals written here where ring_ebase == nullptr */,
+  uint32_t max_rings, uint32_t * __restrict__ scan_info /* the scan's flags and (where ring_ebase == nullptr) totals are written here */,
   const uint32_t * __restrict__ counters, uint32_t * __restrict__ report /* pinned host memory [1 + kCounters + 1], or nullptr */,
   uint32_t serial /* of this batch, never 0 */, const uint32_t * __restrict__ ring_nedge, const uint32_t * __restrict__ ring_nsurf,
   const float4 * __restrict__ rec32 /* the record slots of the unit kernels' units (UnitTables), or nullptr */,
-  uint32_t slot_places /* per slot: rec_slot_places() of the context's unit kernels */)
+  uint32_t slot_places /* per slot: rec_slot_places() of the context's unit kernels */,
+  const uint32_t * __restrict__ scan_flags /* [batch]: what the batch's kernels said about each scan (errors, route) */,
+  uint32_t * __restrict__ ring_count_w /* rows of empty scans are zeroed here (no route writes them) */,
+  uint32_t batch, uint32_t fused_ran /* the report's kCntBatch and kCntFusedRan: the host's own */,
+  uint32_t * __restrict__ next_counters, uint32_t * __restrict__ next_flags, uint32_t * __restrict__ next_nedge,
+  uint32_t * __restrict__ next_nsurf, uint32_t next_scans /* the OTHER set of accumulators (lfx_kernels_common.hpp kParityCounters): zeroed for the next batch */)
 {
   const uint32_t lane = threadIdx.x & 63, s = blockIdx.y;
   // the batch's last kernel also hands what the batch reports about its stream to the host (the next batches' route is
@@ -1693,13 +1785,27 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     }
     __syncthreads();
     if (threadIdx.x < kCounters) {
-      __hip_atomic_store(report + 1 + threadIdx.x, counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint32_t v = threadIdx.x == kCntBatch ? batch : (threadIdx.x == kCntFusedRan ? fused_ran : counters[threadIdx.x]);
+      __hip_atomic_store(report + 1 + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __threadfence_system();
     }
     __syncthreads();
-    if (threadIdx.x == 0) {__hip_atomic_store(report + 1 + kCounters, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);}
+    // (a release at system scope: the closing serial must not be seen before the counters, whoever stored them)
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      __hip_atomic_store(report + 1 + kCounters, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the next batch's accumulators (nobody is using that set now): every wave its ring's totals of the scans s, s + gridDim.y, ...
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kParityCounters) {next_counters[threadIdx.x] = 0u;}
+  if (lane == 0 && slot < (uint32_t)kRings) {
+    for (uint32_t s2 = s; s2 < next_scans; s2 += gridDim.y) {
+      next_nedge[s2 * kRings + slot] = 0u;
+      next_nsurf[s2 * kRings + slot] = 0u;
+      if (slot == 0u) {next_flags[s2] = 0u;}
+    }
+  }
   if (slot >= max_rings) {return;}
   {
     // Everything a wave needs before it can ask for its records is asked for at ONCE -- the scan's first point and route, the
@@ -1709,8 +1815,9 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     // scan took that route: it is a valid address either way, and the other route's sums follow below.)
     const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks;
     const size_t b = scan_begin[s];
-    const uint32_t err = scan_info[s * 4 + kInfoError];
-    const uint32_t n_ring = ring_count[s * kRings + slot];
+    const uint32_t n_scan = scan_begin[s + 1] - (uint32_t)b;
+    const uint32_t err = scan_flags[s];
+    uint32_t n_ring = ring_count[s * kRings + slot];
     uint32_t ne_k = 0, ns_k = 0, span_k = 0;               // lane j holds unit j's entries (n_units <= 64)
     if (lane < n_units) {
       ne_k = unit_ne[ui + lane];
@@ -1728,6 +1835,20 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       }
     }
     asm volatile ("" : "+v"(ne_k), "+v"(ns_k), "+v"(span_k), "+v"(e_before), "+v"(f_before), "+v"(e_base), "+v"(f_base));    // (every load out before the first branch on one of them)
+    // The scan's flag word becomes part of its results here (the batch's kernels OR into a word of their own set, which the
+    // NEXT batch's compaction zeroes again; scan_info itself is only ever written).  An empty scan has been through no kernel
+    // that writes its rows: no rings, no features -- and what the tables still hold of an earlier batch is not its.
+    if (n_scan == 0u) {
+      if (lane == 0) {
+        ring_count_w[s * kRings + slot] = 0u;
+        if (slot == 0u) {
+          scan_info[s * 4 + kInfoRings] = 0u; scan_info[s * 4 + kInfoError] = err;
+          scan_info[s * 4 + kInfoEdge] = 0u; scan_info[s * 4 + kInfoSurface] = 0u;
+        }
+      }
+      return;
+    }
+    if (slot == 0u && lane == 0) {scan_info[s * 4 + kInfoError] = err;}
     // a unit the unit kernels labelled keeps its records in its slot (points, then indices, in rank order: edges then surfaces;
     // beyond the slot's places at their ranks in the old arrays; the top bit of its span says so); a ring the workgroup-per-ring kernel
     // took in rec_pts / rec_idx, edges from the front of its positions and surfaces from their back

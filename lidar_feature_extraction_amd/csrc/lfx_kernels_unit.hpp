@@ -376,7 +376,7 @@ static __device__ unsigned long long g_unit_stamps[kStampUnits * kStampSlots];  
 __device__ inline void scan_falls_back(const UnitTables * __restrict__ tab, uint32_t s, bool order_only = false)
 {
   const uint32_t bits = kScanFellBack | (order_only ? (uint32_t)kScanOrderFell : 0u);
-  const uint32_t old = atomicOr(tab->scan_info + s * 4 + kInfoError, bits);
+  const uint32_t old = atomicOr(tab->scan_flags + s, bits);
   if ((old & kScanFellBack) == 0u) {tab->fb_list[atomicAdd(tab->fb_count, 1u)] = s;}
   // (counted for the host's choice of route: a stream whose rings are rotated / reversed gets ring_cut_kernel)
   if (order_only && (old & kScanOrderFell) == 0u) {atomicAdd(tab->fb_count + (kCntOrderFell - kCntFallback), 1u);}
@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void unit_body(
         og.ring_count_out[s * kRings + slot] = (uint32_t)N;
         if (slot == 0) {
           tab->scan_info[s * 4 + kInfoRings] = og.R;
-          atomicOr(tab->scan_info + s * 4 + kInfoError, (uint32_t)kScanFused);
+          atomicOr(tab->scan_flags + s, (uint32_t)kScanFused);
         }
       }
     }
