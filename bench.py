@@ -83,6 +83,8 @@ def parse():
     ap.add_argument("--no-side-configs", action="store_true", help="skip BASELINE.json's other configurations (the \"configs\" list of the line)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step RCCL gather")
     ap.add_argument("--force-gather", action="store_true", help="run the pack + gather step even with one rank (rehearsal)")
+    ap.add_argument("--warm-seconds", type=float, default=0.25, help="warm-up by the clock after the --warmup steps (0: steps only)")
+    ap.add_argument("--no-second-region", action="store_true", help="N>1 with a rotating destination: skip the short second region that gathers to rank 0")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (each with its own context and scratch) the steps alternate over")
     return ap.parse_args()
@@ -273,13 +275,16 @@ def main():
         # If the communicator cannot be made on some rank (the RCCL library does not open, the id does not arrive), every
         # rank drops the gather together and the line says so ("sharding"): a measurement of the sharded extraction without
         # its exchange is worth more than none.
-        gather, gather_error = None, None
-        idt = torch.zeros(128 * n_lanes, dtype=torch.uint8, device=ddev)
+        gather, gather0, gather_error = None, None, None
+        # (one id more than the lanes: the communicator of the second, fixed-destination region -- see "gather_dst0" below)
+        second_region = a.gather_dst == "rotate" and not a.no_second_region
+        n_ids = n_lanes + (1 if second_region else 0)
+        idt = torch.zeros(128 * n_ids, dtype=torch.uint8, device=ddev)
         # every rank first checks that it CAN enter the collective initialisation (the RCCL library opens and has the
         # entry points: making an id proves both) and the ranks agree on that before anyone calls ncclCommInitRank --
         # a rank that failed earlier would otherwise leave the others waiting inside it
         try:
-            my_ids = b"".join(RcclGather.unique_id() for _ in range(n_lanes))
+            my_ids = b"".join(RcclGather.unique_id(fx) for _ in range(n_ids))
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(my_ids), dtype=torch.uint8))
         except Exception as e:             # noqa: BLE001
@@ -298,6 +303,9 @@ def main():
                 gather = CloudGather(fx, rank, world, [all_ids[128 * k:128 * (k + 1)] for k in range(n_lanes)],
                                      dst="rotate" if a.gather_dst == "rotate" else int(a.gather_dst), device=dev,
                                      capacity_points=feat_cap * world, batch=a.batch, pairs=use_pairs, profile=True)
+                if second_region:
+                    gather0 = CloudGather(fx, rank, world, [all_ids[128 * n_lanes:128 * (n_lanes + 1)]], dst=0, device=dev,
+                                          capacity_points=feat_cap * world, batch=a.batch, pairs=False, profile=True)
             except Exception as e:         # noqa: BLE001
                 gather_error = "rank %d: %s" % (rank, e)
         if world > 1:
@@ -307,14 +315,17 @@ def main():
                 gather_error = "another rank could not create its communicator"
         if gather_error is not None:
             print("bench.py: gather disabled: %s" % gather_error, file=sys.stderr)
-            if gather is not None:
-                gather.close()
+            for g in (gather, gather0):
+                if g is not None:
+                    g.close()
+            gather = gather0 = None
             use_gather = False
 
     # Watchdog (N > 1): the first real multi-rank run of a flow is the one the driver times, and a hang there would cost
     # the record instead of telling what hung.  A thread looks at where the main thread last reported to be; no progress for
     # --watchdog-seconds ends the PROCESS with a message and exit code 4 (a plain exit: never a re-exec, never a retry).
     progress = {"where": "start", "step": 0, "t": time.monotonic()}
+    cur = {"gather": gather if use_gather else None}       # the CloudGather the steps submit to (the second region swaps it)
 
     def mark(where):
         progress["where"], progress["step"], progress["t"] = where, step_no[0], time.monotonic()
@@ -328,9 +339,12 @@ def main():
                 idle = time.monotonic() - progress["t"]
                 if progress["where"] == "done":
                     return
+                if progress["where"] == "host-side measurements":        # (no rank waits for another there: nothing to watch)
+                    continue
                 if idle > a.watchdog_seconds:
-                    lane = ("pair of steps %d, %d" % ((progress["step"] - 1) & ~1, ((progress["step"] - 1) & ~1) + 1)) if (use_gather and gather is not None and gather.pairs) \
-                        else ("lane %d" % ((progress["step"] - 1) % max(1, len(gather.lanes))) if use_gather and gather is not None else "no gather")
+                    g = cur["gather"]
+                    lane = ("pair of steps %d, %d" % ((progress["step"] - 1) & ~1, ((progress["step"] - 1) & ~1) + 1)) if (use_gather and g is not None and g.pairs) \
+                        else ("lane %d" % ((progress["step"] - 1) % max(1, len(g.lanes))) if use_gather and g is not None else "no gather")
                     print("bench.py watchdog: rank %d of %d has made no progress for %.0f s in '%s' at step %d (%s, destination %s): giving up"
                           % (rank, world, idle, progress["where"], progress["step"], lane, a.gather_dst), file=sys.stderr)
                     sys.stderr.flush()
@@ -354,16 +368,16 @@ def main():
             edge_buf, surf_buf, offs = bufs[step_no[0] % len(bufs)]
             with torch.cuda.stream(pack_stream):
                 pack_stream.wait_event(extracted)
-                gather.wait_buffer(edge_buf)       # the gather that last read this set must be done
+                cur["gather"].wait_buffer(edge_buf)       # the gather that last read this set must be done
                 fxs[k].pack_xyz12(edge_buf.data_ptr(), surf_buf.data_ptr(), offs.data_ptr(), feat_cap, pack_stream.cuda_stream)
                 pack_done[k] = torch.cuda.Event()
                 pack_done[k].record(pack_stream)
-                gather.submit(edge_buf, surf_buf, offs, a.batch)
+                cur["gather"].submit(edge_buf, surf_buf, offs, a.batch)
 
     def fence():
         mark("fence: flush of the last gathers")
         if use_gather:
-            gather.flush()             # the last step's clouds
+            cur["gather"].flush()      # the last step's clouds
         mark("fence: device synchronise")
         torch.cuda.synchronize()
         if world > 1 or a.force_gather:
@@ -375,6 +389,22 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    # (the clocks of a device that has just been handed over are still rising after a handful of steps: warm up by the
+    # clock too, as the side configurations are -- every rank the same number of steps, the gathers need that)
+    warm_extra = 0
+    if a.warm_seconds > 0:
+        t_w = time.perf_counter()
+        step()
+        fence()
+        per = max(time.perf_counter() - t_w, 1e-5)
+        warm_extra = int(min(4000, a.warm_seconds / per))
+        if world > 1:
+            t = torch.tensor([warm_extra], dtype=torch.int64, device=ddev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            warm_extra = int(t.item())
+        for _ in range(warm_extra):
+            step()
+        fence()
     # per-kernel durations: HIP events recorded around the launches inside the timed region, on the
     # stream the kernel is launched on (lfx_set_profiling); with one stream they are what
     # rocprofv3 --kernel-trace --stats reports for the same command
@@ -410,6 +440,54 @@ def main():
             t = torch.tensor([gather_ms_per_step], dtype=torch.float64, device=ddev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gather_ms_per_step = float(t.item())
+
+    # ---- N > 1: what RCCL was asked to move, rank by rank, beside what the exchanges' own totals say it should have been
+    #      (proof in the line itself that N ranks took part and the clouds travelled); then a SECOND, short timed region with
+    #      the destination the metric names -- every step's clouds to rank 0 -- on a communicator of its own, so that one
+    #      run of the driver's command holds both numbers
+    def all_ranks(report):
+        keys = ("rank", "sends", "receives", "bytes_sent", "bytes_received", "all_gathers", "points_sent", "points_received",
+                "exchanges", "expected_bytes_sent", "expected_bytes_received", "bytes_match")
+        mine = torch.tensor([int(report[k]) for k in keys], dtype=torch.int64, device=ddev)
+        if world > 1:
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+        else:
+            every = [mine]
+        return [dict(zip(keys, [int(v) for v in t.cpu().tolist()])) for t in every]
+
+    comm_stats, dst0 = None, None
+    if use_gather:
+        mark("comm stats")
+        comm_stats = all_ranks(gather.comm_report())
+        if gather0 is not None:
+            cur["gather"] = gather0
+            steps2 = max(4, a.steps // 2)
+            for _ in range(2):
+                step()
+            fence()
+            gather0.gather_ms()                  # (drop the warm-up's spans)
+            t0 = time.perf_counter()
+            for _ in range(steps2):
+                step()
+            fence()
+            dt2 = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt2], dtype=torch.float64, device=ddev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            g_ms, g_n = gather0.gather_ms()
+            g2 = g_ms / max(g_n, 1)
+            if world > 1:
+                t = torch.tensor([g2], dtype=torch.float64, device=ddev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                g2 = float(t.item())
+            dst0 = {"value": round(a.batch * steps2 * world / dt2, 2), "unit": "scans/s", "steps": steps2, "ms_per_step": round(1e3 * dt2 / steps2, 4),
+                    "gather_ms_per_step": round(g2, 4), "comm_stats": all_ranks(gather0.comm_report()),
+                    "note": "the same steps with every step's clouds gathered to rank 0 (the destination BASELINE.json's metric names), one "
+                            "exchange in flight on a communicator of its own, timed between the same fences right after the headline's region"}
+            cur["gather"] = gather
+    mark("host-side measurements")
 
     # what THIS box gives right now (outside the timed region, ~50 ms): a plain float4 copy of 1 GiB and the shader clock
     # with every SIMD busy -- so that a slower box and a slower kernel can be told apart in one line of the driver's record
@@ -487,7 +565,10 @@ def main():
     # the feature records written, read and written again) at the rate a copy reaches, as a fraction of the spec peak in
     # ALGORITHMIC bytes -- what `frac` could be at best
     if traffic and box and box.get("copy_gbs"):
-        tj_all = sum(v for v in tj.get("hbm_bytes_per_launch", {}).values() if isinstance(v, (int, float)))
+        # (the path's own kernels only: the file also holds the calibration copy, the runtime's fills and the download kernels
+        # of the parity check, none of which is part of a step)
+        tj_all = sum(v for k, v in tj.get("hbm_bytes_per_launch", {}).items()
+                     if isinstance(v, (int, float)) and k.startswith(("ring_", "feature_", "batch_", "fallback_", "grid_")))
         roofline["ceiling"] = {"whole_path_frac_at_box_copy_rate": round(algo_bytes / (tj_all / (box["copy_gbs"] * 1e9)) / 1e9 / HBM_PEAK_GBS, 5),
                                "hbm_bytes_per_step": int(tj_all)}
 
@@ -636,6 +717,7 @@ def main():
             "metric": "scans/sec (%d-ring x %d synthetic scans, extraction hot path, inputs resident in HBM)" % (a.rings, a.cols),
             "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "repeats": len(dts), "value_min": round(scans_total / max(dts), 2), "value_max": round(scans_total / min(dts), 2),
+            "repeat_values": [round(scans_total / d, 1) for d in dts], "warm_steps_by_clock": warm_extra,
             "ms_per_step": round(1e3 * dt / a.steps, 4), "ms_per_scan": round(1e3 * dt / (a.batch * a.steps), 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "rings": a.rings, "cols": a.cols,
@@ -657,11 +739,20 @@ def main():
             out["roofline"]["note"] = "rank 0's kernels (every rank runs the same launches on its own scans)"
         if gather_ms_per_step is not None:
             out["gather_ms_per_step"] = round(gather_ms_per_step, 4)
+        if comm_stats is not None:
+            out["comm_stats"] = comm_stats
+            out["comm_stats_note"] = ("lfx_comm_stats of every rank after the headline's region (warm-up included): ncclSend / ncclRecv calls, the bytes "
+                                      "they carried, counts all-gathers; expected_* = 12 B x the feature points + one offsets table per cloud pair, from "
+                                      "the totals the exchanges themselves returned")
+        if dst0 is not None:
+            out["gather_dst0"] = dst0
         print(json.dumps(out))
         sys.stdout.flush()
     mark("closing")
     if use_gather:
         gather.close()
+        if gather0 is not None:
+            gather0.close()
     for f in fxs:
         f.close()
     if world > 1 or a.force_gather:

@@ -27,20 +27,23 @@ class RcclGather:
     """One RCCL communicator (lfx_comm) tied to a FeatureExtraction context."""
 
     def __init__(self, fx, rank, world, unique_id):
-        self._L = B.load()
+        # the library the context was made by (the test-hooks build where an LFX_DEBUG_* switch asked for it): one copy of
+        # the library, and with it one RCCL handle, per context
+        self._L = fx._L
         self._fx = fx
         self.rank, self.world = rank, world
         self._comm = C.c_void_p()
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
-        B.check(fx._ctx, self._L.lfx_comm_create(fx._ctx, C.cast(buf, C.c_void_p), rank, world, C.byref(self._comm)))
+        B.check(fx._ctx, self._L.lfx_comm_create(fx._ctx, C.cast(buf, C.c_void_p), rank, world, C.byref(self._comm)), self._L)
 
     @staticmethod
-    def unique_id():
-        """Rank 0 makes it; hand the 128 bytes to every rank."""
+    def unique_id(fx=None):
+        """Rank 0 makes it; hand the 128 bytes to every rank.  (fx: through the library of that context.)"""
         buf = (C.c_uint8 * 128)()
-        rc = B.load().lfx_comm_unique_id(C.cast(buf, C.c_void_p))
+        L = fx._L if fx is not None else B.load()
+        rc = L.lfx_comm_unique_id(C.cast(buf, C.c_void_p))
         if rc != 0:
-            raise B.LfxError(rc, (B.load().lfx_last_error(None) or b"").decode())
+            raise B.LfxError(rc, (L.lfx_last_error(None) or b"").decode())
         return bytes(buf)
 
     def close(self):
@@ -56,7 +59,7 @@ class RcclGather:
 
     def counts(self, d_offsets, batch, stream=0, slot=0):
         B.check(self._fx._ctx, self._L.lfx_gather_counts_slot(self._fx._ctx, self._comm, int(slot), C.c_void_p(int(d_offsets)), batch,
-                                                              C.c_void_p(int(stream))))
+                                                              C.c_void_p(int(stream))), self._L)
 
     def payload_group(self, steps, batch, floats_per_point, capacity_points, stream=0):
         """lfx_gather_payload2: one or two steps as ONE grouped exchange.  steps: dicts with dst, slot, edge, surface, offsets
@@ -69,7 +72,7 @@ class RcclGather:
                                   int(st.get("edge_all") or 0) or None, int(st.get("surface_all") or 0) or None,
                                   int(st.get("offsets_all") or 0) or None, counts[i].ctypes.data)
         B.check(self._fx._ctx, self._L.lfx_gather_payload2(self._fx._ctx, self._comm, arr, len(steps), batch, floats_per_point,
-                                                           int(capacity_points), C.c_void_p(int(stream))))
+                                                           int(capacity_points), C.c_void_p(int(stream))), self._L)
         return counts
 
     def payload(self, dst, d_edge, d_surface, d_offsets, batch, floats_per_point, d_edge_all, d_surface_all, d_offsets_all,
@@ -79,7 +82,7 @@ class RcclGather:
         B.check(self._fx._ctx, self._L.lfx_gather_payload(
             self._fx._ctx, self._comm, dst, C.c_void_p(int(d_edge)), C.c_void_p(int(d_surface)), C.c_void_p(int(d_offsets)),
             batch, floats_per_point, C.c_void_p(int(d_edge_all or 0)), C.c_void_p(int(d_surface_all or 0)),
-            C.c_void_p(int(d_offsets_all or 0)), int(capacity_points), C.c_void_p(counts.ctypes.data), C.c_void_p(int(stream))))
+            C.c_void_p(int(d_offsets_all or 0)), int(capacity_points), C.c_void_p(counts.ctypes.data), C.c_void_p(int(stream))), self._L)
         return counts
 
 
@@ -107,7 +110,12 @@ class CloudGather:
     rate, whatever the number of GPUs), and the destination's seven links together take in 0.54 TB/s.  With a rotating
     destination (step k -> rank k mod N) consecutive steps travel over DIFFERENT links -- if they are allowed to overlap:
     `unique_id` may be a list of communicator ids, one lane (communicator + side stream) each; step k's exchange runs on
-    lane k mod len(ids), so that step k - 1's payload is still on its way while step k's leaves."""
+    lane k mod len(ids), so that step k - 1's payload is still on its way while step k's leaves.
+
+    Return shapes.  Without `pairs`, submit() and flush() return ONE step's result: on its destination rank the list
+    split_gathered builds, None elsewhere (and None while nothing has completed).  With `pairs=True` steps complete two at a
+    time: submit() returns None, or a LIST with one such result per step of the pair just completed (None at the places whose
+    destination is another rank); flush() returns the list over every step it completed (possibly empty)."""
 
     def __init__(self, fx, rank, world, unique_id, dst=0, device=None, capacity_points=0, batch=1, floats_per_point=3, pairs=False,
                  profile=False):
@@ -149,6 +157,33 @@ class CloudGather:
         self.received = 0              # gathers this rank has been the destination of: alternates the receive sets
         self.profile = bool(profile)   # record (start, end) timing events around every gather (gather_ms); off: nothing is kept
         self.spans = []
+        # what this rank should have moved, from the totals every exchange returns: the other side of lfx_comm_stats
+        self.acct = {"points_sent": 0, "tables_sent": 0, "points_received": 0, "tables_received": 0, "exchanges": 0}
+
+    def _account(self, dst, counts, batch):
+        self.acct["exchanges"] += 1
+        if self.rank != dst:
+            self.acct["points_sent"] += int(counts[self.rank][0]) + int(counts[self.rank][1])
+            self.acct["tables_sent"] += 1
+        else:
+            for r in range(self.world):
+                if r != dst:
+                    self.acct["points_received"] += int(counts[r][0]) + int(counts[r][1])
+                    self.acct["tables_received"] += 1
+
+    def comm_report(self):
+        """lfx_comm_stats of this rank's communicator(s) beside what the exchanges' own totals say it should have moved:
+        bytes = 4 * floats_per_point per feature point + one offsets table (8 * (batch + 1) bytes) per cloud pair."""
+        st = {"sends": 0, "receives": 0, "bytes_sent": 0, "bytes_received": 0, "all_gathers": 0}
+        for rccl, _ in self.lanes:
+            for k, v in rccl.stats().items():
+                st[k] += v
+        tab = 8 * (self.batch + 1)
+        exp_s = self.acct["points_sent"] * 4 * self.fpp + self.acct["tables_sent"] * tab
+        exp_r = self.acct["points_received"] * 4 * self.fpp + self.acct["tables_received"] * tab
+        return dict(st, rank=self.rank, points_sent=self.acct["points_sent"], points_received=self.acct["points_received"],
+                    exchanges=self.acct["exchanges"], expected_bytes_sent=exp_s, expected_bytes_received=exp_r,
+                    bytes_match=bool(st["bytes_sent"] == exp_s and st["bytes_received"] == exp_r))
 
     def close(self):
         for rccl, _ in self.lanes:
@@ -192,6 +227,7 @@ class CloudGather:
         counts = rccl.payload(dst, edge.data_ptr(), surface.data_ptr(), offsets.data_ptr(), batch, self.fpp,
                               ea.data_ptr() if ea is not None else 0, sa.data_ptr() if sa is not None else 0,
                               oa.data_ptr() if oa is not None else 0, self.cap, side.cuda_stream)
+        self._account(dst, counts, batch)
         ev = torch.cuda.Event(enable_timing=self.profile)
         ev.record(side)
         if self.profile:
@@ -242,6 +278,8 @@ class CloudGather:
             t0 = torch.cuda.Event(enable_timing=True)
             t0.record(side)
         counts = rccl.payload_group(steps, items[0][3], self.fpp, self.cap, side.cuda_stream)
+        for st, cn in zip(steps, counts):
+            self._account(st["dst"], cn, items[0][3])
         ev = torch.cuda.Event(enable_timing=self.profile)
         ev.record(side)
         if self.profile:

@@ -69,6 +69,28 @@ def test_bench_runs_with_two_ranks(dst):
     assert d["cpu_baseline"] is None and "N=1" in d["cpu_baseline_from"]
     # whole-job aggregate: both ranks' scans over the slowest rank's time
     assert abs(d["value"] - world * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+    # the line says what RCCL was asked to move, rank by rank: both ranks took part, and the bytes of their sends and
+    # receives are those of the gathered clouds (12 B per feature point + the offsets tables)
+    def check_stats(stats, fixed_dst):
+        assert [st["rank"] for st in stats] == list(range(world))
+        for st in stats:
+            assert st["all_gathers"] > 0 and st["exchanges"] > 0 and st["bytes_match"], st
+            assert st["bytes_sent"] == 12 * st["points_sent"] + 8 * (8 + 1) * (st["sends"] // 3), st
+            assert st["bytes_received"] == 12 * st["points_received"] + 8 * (8 + 1) * (st["receives"] // 3), st
+        assert sum(st["bytes_sent"] for st in stats) == sum(st["bytes_received"] for st in stats) > 0
+        if fixed_dst:
+            assert stats[0]["sends"] == 0 and stats[0]["points_received"] > 0 and stats[1]["receives"] == 0 and stats[1]["points_sent"] > 0, stats
+        else:
+            assert all(st["points_sent"] > 0 and st["points_received"] > 0 for st in stats), stats
+    check_stats(d["comm_stats"], dst == "0")
+    assert len(d["repeat_values"]) == 2
+    if dst == "rotate":
+        # ... and the same run also holds the destination the metric names: a second timed region, every step to rank 0
+        g0 = d["gather_dst0"]
+        assert g0["value"] > 0 and g0["gather_ms_per_step"] > 0 and g0["steps"] >= 4
+        check_stats(g0["comm_stats"], True)
+    else:
+        assert "gather_dst0" not in d
 
 
 def test_a_rank_that_stops_is_reported_not_waited_for():
