@@ -103,6 +103,9 @@ typedef struct lfx_config {
 #define LFX_STREAM_TURNED_RINGS 1u /* a grid whose rings arrive rotated / reversed (scans not cut at -pi, a clockwise
                                     * sensor): find the rings' transforms from the first batch on                        */
 #define LFX_STREAM_NO_GRID 2u      /* records missing or in arbitrary order: the bucketing route from the first batch on */
+#define LFX_STREAM_GRID_WITH_HOLES 3u /* a grid whose invalid returns are (0, 0, 0) records, with drop_zero_points set (what the
+                                    * reference's converter filters, convert.py:162-163,192): count the valid returns per ring
+                                    * first and read the grid in place, from the first batch on                          */
 
 #define LFX_OUT_FEATURES 1u        /* always on */
 #define LFX_OUT_LABELS 2u
@@ -252,7 +255,8 @@ int lfx_device_results(const lfx_ctx *ctx, lfx_device_view *view);
  * (the clouds of such a scan are not to be used), else LFX_OK.  first_bad (may be NULL): index of the first such scan. */
 int lfx_batch_status(lfx_ctx *ctx, void *stream, uint32_t *first_bad);
 /* Which route each scan of the last batch took (diagnostics; waits for `stream`): routes[s] = 1 read in place by the
- * organised-scan kernel, 2 the same through per-ring transforms (rings rotated / reversed in the stream), 0 bucketed. */
+ * organised-scan kernel, 2 the same through per-ring transforms (rings rotated / reversed in the stream), 3 read in place
+ * as a grid with (0, 0, 0) records that the zero filter dropped (sorted_index holds its points' indices), 0 bucketed. */
 int lfx_scan_routes(lfx_ctx *ctx, void *stream, uint8_t *routes /* [batch] */);
 
 /* Pinned host memory for the caller's point buffers: lfx_extract reads a buffer allocated here by DMA (3.7 MB in
@@ -518,13 +522,15 @@ int lfx_color_points_by_label(const lfx_ctx *ctx, const void *points, size_t n_p
  * batch leaves behind ([0] rings deferred by the first unit pass, [1] repaired after it, [2] sent to the workgroup-per-ring
  * kernel, [3] repaired before it, [4] scans on the fall-back list, [5] whether the organised-scan kernel ran, [6] scans in
  * the batch, [7] scans given up for the angle order of their rings alone, [8] rings found rotated / reversed, [9] whether
- * the transforms were looked for), `report_rings` = rings of that batch (0 = no report yet), `state` in and out = {rings
- * transformed, every scan bucketed, batches until the organised route is tried again, order repair first}, `choice` out =
- * {organised-scan kernel first, with ring transforms, fall-back list entries launched for, two-launch tail, order repair
- * before the first unit pass, rings the second unit pass is launched for}.  tests/test_route_choice.py drives it. */
-#define LFX_ROUTE_REPORT_WORDS 12
-#define LFX_ROUTE_STATE_WORDS 4
-#define LFX_ROUTE_CHOICE_WORDS 6
+ * the transforms were looked for, [10] scans given up for a (0, 0, 0) record alone (zero filter on), [11] whether the holes
+ * form ran, [12] ring groups that held such a record then), `report_rings` = rings of that batch (0 = no report yet),
+ * `state` in and out = {rings transformed, every scan bucketed, batches until the organised route is tried again, order
+ * repair first, grid with holes}, `choice` out = {organised-scan kernel first, with ring transforms, fall-back list entries
+ * launched for, one-launch tail, order repair before the first unit pass, rings the second unit pass is launched for, the
+ * holes form (count pass first)}.  tests/test_route_choice.py drives it. */
+#define LFX_ROUTE_REPORT_WORDS 14
+#define LFX_ROUTE_STATE_WORDS 5
+#define LFX_ROUTE_CHOICE_WORDS 7
 int lfx_route_choice(const uint32_t report[LFX_ROUTE_REPORT_WORDS], uint32_t report_rings, uint32_t state[LFX_ROUTE_STATE_WORDS],
                      int organised_possible, uint32_t batch, uint32_t max_rings, uint32_t choice[LFX_ROUTE_CHOICE_WORDS]);
 

@@ -58,7 +58,7 @@ class GatherStep(C.Structure):
 
 
 OUT_FEATURES, OUT_LABELS, OUT_CURVATURE, OUT_SORTED_INDEX, OUT_ALL = 1, 2, 4, 8, 15
-STREAM_UNKNOWN, STREAM_TURNED_RINGS, STREAM_NO_GRID = 0, 1, 2
+STREAM_UNKNOWN, STREAM_TURNED_RINGS, STREAM_NO_GRID, STREAM_GRID_WITH_HOLES = 0, 1, 2, 3
 
 
 class ScanResult(C.Structure):

@@ -180,13 +180,21 @@ RouteChoice choose_route(RouteState & st, const RoutePins & pin, bool organised_
       if (!cut_ran && 4u * order_fell > of && 2u * order_fell > fell) {st.use_xform = true;}
       if (cut_ran && 50u * turned < of * max_rings) {st.use_xform = false;}
     }
+    if (was_fused && of) {
+      // most of what fell back did so for a (0, 0, 0) record alone (zero filter on): a grid with holes -- count its valid
+      // returns first and take it in place; back to the plain form once (almost) no ring group holds such a record
+      const uint32_t zero_fell = rep[lfx::kCntZeroFell], holes_ran = rep[lfx::kCntHolesRan], zero_groups = rep[lfx::kCntZeroGroups];
+      if (!holes_ran && 4u * zero_fell > of && 2u * zero_fell > fell) {st.use_holes = true;}
+      if (holes_ran && 50u * zero_groups < of) {st.use_holes = false;}
+    }
     if (pin.xform >= 0) {st.use_xform = pin.xform != 0;}
+    if (pin.holes >= 0) {st.use_holes = pin.holes != 0;}
     if (pin.fused >= 0) {
       fused = pin.fused != 0;
     } else {
       if (was_fused && of) {
         // (a report from before the transforms were switched on says nothing about the route with them)
-        const bool mostly_not = 4u * fell > of && !(st.use_xform && !cut_ran);
+        const bool mostly_not = 4u * fell > of && !(st.use_xform && !cut_ran) && !(st.use_holes && !rep[lfx::kCntHolesRan]);
         if (mostly_not && !st.bucket_all) {st.retry_in = 16;}
         st.bucket_all = mostly_not;
       }
@@ -206,6 +214,7 @@ RouteChoice choose_route(RouteState & st, const RoutePins & pin, bool organised_
   }
   ch.fused = fused;
   ch.xform = fused && st.use_xform;
+  ch.holes = fused && st.use_holes && !ch.xform;       // (the holes form takes rings as they stand)
   // more than a twentieth of the rings of an earlier batch needed their order repaired: expect the same now
   ch.pre_order = st.pre_order;
   if (pin.pre_order >= 0) {
@@ -303,6 +312,12 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   const RouteChoice choice = choose_route(c->route, c->route_pins, c->fused_possible && canon && chunks != 0, batch, c->max_rings);
   const bool fused = choice.fused, short_tail = choice.short_tail;
+  const bool holes = choice.holes && c->drop_zero != 0u;
+  if (holes && !c->cum16.p) {
+    // (the table of the holes form: a context only pays for it once its stream turns out to be such a grid)
+    const size_t entries = (size_t)c->max_batch * c->max_rings * lfx::cum_stride(c->cap) + 1024u;
+    if (c->cum16.alloc(entries) != hipSuccess) {c->cum16.p = nullptr; return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the table of the holes form");}
+  }
   const uint32_t fb_grid = choice.fb_grid;             // list entries the bucketing kernels are launched for
   if (chunks == 0) {
     // every scan of the batch is empty: no kernel runs; the result tables say so
@@ -331,11 +346,17 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
         pts, c->scan_begin.p, c->max_rings, c->cap, c->xform.p, counters);
     }
     const uint32_t groups = (c->max_rings + 3u) / 4u;
+    if (holes) {
+      // the count pass of the holes form: valid returns per ring and piece of 16 columns, every ring's length
+      Timed t(c, 10, st);
+      hipLaunchKernelGGL(lfx::grid_count_kernel, dim3(groups, batch), dim3(256), 0, st,
+        pts, c->scan_begin.p, c->scan_geom.p, c->max_rings, lfx::cum_stride(c->cap), c->cum16.p, c->ring_count.p, unit_tab, counters);
+    }
     {
       Timed t(c, 7, st);
       const UnitOrgArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, unit_tab,
-        c->xform.p, c->scan_geom.p};
-      launch_unit_org(c->unit_variant, (int)c->unit_chunks, xf, dim3(groups, (uint32_t)c->dev.B, batch), c->unit_lds_pad, st, a);
+        holes ? reinterpret_cast<const uint32_t *>(c->cum16.p) : c->xform.p, c->scan_geom.p};
+      launch_unit_org(c->unit_variant, (int)c->unit_chunks, xf, holes, dim3(groups, (uint32_t)c->dev.B, batch), c->unit_lds_pad, st, a);
     }
   }
   const lfx::RingExtractArgs ex{c->dev, c->cap, c->stage_flags, c->max_rings, pts, c->layout, c->scan_begin.p, c->ring_count.p, c->sxy.p, c->sz.p,
@@ -682,11 +703,11 @@ int lfx_route_choice(const uint32_t report[LFX_ROUTE_REPORT_WORDS], uint32_t rep
   RouteState st;
   std::memcpy(st.report, report, sizeof(st.report));
   st.report_rings = report_rings;
-  st.use_xform = state[0] != 0; st.bucket_all = state[1] != 0; st.retry_in = state[2]; st.pre_order = state[3] != 0;
+  st.use_xform = state[0] != 0; st.bucket_all = state[1] != 0; st.retry_in = state[2]; st.pre_order = state[3] != 0; st.use_holes = state[4] != 0;
   const RouteChoice ch = choose_route(st, RoutePins(), organised_possible != 0, batch, max_rings);
-  state[0] = st.use_xform; state[1] = st.bucket_all; state[2] = st.retry_in; state[3] = st.pre_order;
+  state[0] = st.use_xform; state[1] = st.bucket_all; state[2] = st.retry_in; state[3] = st.pre_order; state[4] = st.use_holes;
   choice[0] = ch.fused; choice[1] = ch.xform; choice[2] = ch.fb_grid; choice[3] = ch.short_tail; choice[4] = ch.pre_order;
-  choice[5] = ch.redo_cap;
+  choice[5] = ch.redo_cap; choice[6] = ch.holes;
   return LFX_OK;
 }
 
@@ -796,8 +817,9 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   // what the caller knows about its stream: the state the route selection would otherwise reach after a batch or two
   if (config->stream_hint == LFX_STREAM_TURNED_RINGS) {c->route.use_xform = true;}
   if (config->stream_hint == LFX_STREAM_NO_GRID) {c->route.bucket_all = true; c->route.retry_in = 16;}
-  if (config->stream_hint > LFX_STREAM_NO_GRID) {
-    g_create_error = "stream_hint must be LFX_STREAM_UNKNOWN, LFX_STREAM_TURNED_RINGS or LFX_STREAM_NO_GRID";
+  if (config->stream_hint == LFX_STREAM_GRID_WITH_HOLES) {c->route.use_holes = true;}
+  if (config->stream_hint > LFX_STREAM_GRID_WITH_HOLES) {
+    g_create_error = "stream_hint must be LFX_STREAM_UNKNOWN, LFX_STREAM_TURNED_RINGS, LFX_STREAM_NO_GRID or LFX_STREAM_GRID_WITH_HOLES";
     delete c;
     return LFX_ERR_INVALID_ARGUMENT;
   }
@@ -836,6 +858,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (const char * dbg = LFX_DEBUG_ENV("TOTALS_KERNEL")) {c->totals_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = LFX_DEBUG_ENV("SHORT_TAIL")) {c->route_pins.short_tail = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = LFX_DEBUG_ENV("XFORM")) {c->route_pins.xform = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = LFX_DEBUG_ENV("HOLES")) {c->route_pins.holes = std::atoi(dbg) != 0 ? 1 : 0;}
   c->slow_grid = 1024;
   if (const char * dbg = LFX_DEBUG_ENV("REDO_CAP")) {c->route_pins.redo_cap = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = LFX_DEBUG_ENV("PRE_ORDER")) {c->route_pins.pre_order = std::atoi(dbg) != 0 ? 1 : 0;}
@@ -911,6 +934,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
       t.fb_count = c->counters.p + par * lfx::kParityCounters + lfx::kCntFallback;
       t.fb_list = c->fb_list.p;
       t.scan_flags = c->scan_flags.p + (size_t)par * nb;
+      t.sidx = c->sidx.p;
       t.ring_nedge = c->ring_nedge.p + par * tables; t.ring_nsurf = c->ring_nsurf.p + par * tables;
       t.rec32 = c->rec32.p; t.prm = c->dev;
       e = hipMemcpy(c->unit_tab.p + par, &t, sizeof(t), hipMemcpyHostToDevice);
@@ -958,7 +982,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->scan_geom.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
-  c->ring_sbase.release(); c->ring_flags.release(); c->counters.release(); c->scan_flags.release(); c->tail_ticket.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->counters.release(); c->scan_flags.release(); c->tail_ticket.release(); c->cum16.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
@@ -1042,7 +1066,7 @@ int lfx_scan_routes(lfx_ctx * c, void * stream, uint8_t * routes)
   LFX_HIP(c, hipStreamSynchronize(st));
   for (uint32_t s = 0; s < c->last_batch; s++) {
     const uint32_t e = c->h_status[s * 4 + lfx::kInfoError];
-    routes[s] = lfx::scan_is_organised(e) ? (c->last_used_xform ? 2 : 1) : 0;
+    routes[s] = lfx::scan_is_organised(e) ? ((e & lfx::kScanHoles) ? 3 : (c->last_used_xform ? 2 : 1)) : 0;
   }
   return LFX_OK;
 }

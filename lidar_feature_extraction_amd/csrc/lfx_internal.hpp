@@ -48,17 +48,17 @@ struct UnitArgs
   uint32_t redo_cap;
 };
 #define LFX_DECLARE_UNIT_LAUNCHERS(V) \
-  void launch_unit_org_v##V(int chunks, bool xf, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a); \
+  void launch_unit_org_v##V(int chunks, bool xf, bool holes, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a); \
   void launch_unit_v##V(bool second, int chunks, bool loop, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitArgs & a);
 LFX_DECLARE_UNIT_LAUNCHERS(0) LFX_DECLARE_UNIT_LAUNCHERS(1) LFX_DECLARE_UNIT_LAUNCHERS(2) LFX_DECLARE_UNIT_LAUNCHERS(3)
 #undef LFX_DECLARE_UNIT_LAUNCHERS
-inline void launch_unit_org(int variant, int chunks, bool xf, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a)
+inline void launch_unit_org(int variant, int chunks, bool xf, bool holes, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a)
 {
   switch (variant) {
-    case 0: launch_unit_org_v0(chunks, xf, grid, lds_pad, st, a); break;
-    case 1: launch_unit_org_v1(chunks, xf, grid, lds_pad, st, a); break;
-    case 2: launch_unit_org_v2(chunks, xf, grid, lds_pad, st, a); break;
-    default: launch_unit_org_v3(chunks, xf, grid, lds_pad, st, a); break;
+    case 0: launch_unit_org_v0(chunks, xf, holes, grid, lds_pad, st, a); break;
+    case 1: launch_unit_org_v1(chunks, xf, holes, grid, lds_pad, st, a); break;
+    case 2: launch_unit_org_v2(chunks, xf, holes, grid, lds_pad, st, a); break;
+    default: launch_unit_org_v3(chunks, xf, holes, grid, lds_pad, st, a); break;
   }
 }
 inline void launch_unit(int variant, bool second, int chunks, bool loop, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitArgs & a)
@@ -129,18 +129,19 @@ struct RouteState
   uint32_t report[lfx::kCounters] = {};  // the counters block of the last batch whose report has landed (lfx_kernels_common.hpp)
   uint32_t report_rings = 0;             // rings of that batch (0 = no report yet)
   bool use_xform = false;                // rings arrive rotated / reversed: ring_cut_kernel ahead of the organised-scan kernel
+  bool use_holes = false;                // the grid holds (0, 0, 0) records the zero filter drops: grid_count_kernel + the holes form
   bool bucket_all = false;               // the stream is not organised: bucketing route for every scan
   uint32_t retry_in = 0;                 // ... and the organised-scan kernel is tried again in so many batches
   bool pre_order = false;                // order repair BEFORE the first unit pass (a stream that keeps arriving out of order)
 };
 struct RoutePins                         // LFX_DEBUG_FUSED / _XFORM / _SHORT_TAIL / _PRE_ORDER (0 / 1; -1 = not pinned), _REDO_CAP (0 = not)
 {
-  int fused = -1, xform = -1, short_tail = -1, pre_order = -1;
+  int fused = -1, xform = -1, short_tail = -1, pre_order = -1, holes = -1;
   uint32_t redo_cap = 0;
 };
 struct RouteChoice
 {
-  bool fused = false, xform = false, short_tail = false, pre_order = false;
+  bool fused = false, xform = false, short_tail = false, pre_order = false, holes = false;
   uint32_t fb_grid = 0, redo_cap = 0;
 };
 
@@ -186,6 +187,7 @@ struct lfx_ctx
     ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list, xform,
     sidx, rec_idx, edge_idx,
     surf_idx, d_sidx, counters, scan_flags, tail_ticket;
+  lfx_host::DevBuf<uint16_t> cum16;      // grid_count_kernel's table (the holes form), allocated with the first batch that needs it
   // The batch's accumulators (counters, scan_flags, ring_nedge / ring_nsurf) exist twice: batch k uses set `parity`, its
   // compaction zeroes the other one over the scans the batch before last left dirty there (par_dirty).  aux_dirty: scans whose
   // bucketing-route tables (look-back flags, ring flags, ring transforms) a batch since the last reset may have touched.

@@ -99,14 +99,22 @@ enum { kInfoRings = 0, kInfoError = 1, kInfoEdge = 2, kInfoSurface = 3 };
 // bits of scan_info[s][kInfoError]: errors, and the route the scan took.  kScanFused: the organised-scan kernel took
 // the scan (ring r's position k IS input point k * rings + r: nothing was staged, sxy / sz / sidx hold nothing for
 // it); kScanFellBack: that kernel (or the host) handed the scan to the bucketing route, whose staged arrays are valid.
-enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u, kScanOrderFell = 0x400u };
+// kScanHoles (beside kScanFused): the scan is a grid whose invalid returns are (0, 0, 0) records, taken in place by the holes
+// form of the organised-scan kernel: position k of ring r is the ring's k-th VALID column, its original index is in sidx
+// (nothing else was staged: x, y, z come from the record).  kScanZeroFell / kScanCountFell: bookkeeping of the kernels.
+enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u, kScanOrderFell = 0x400u,
+                  kScanHoles = 0x800u, kScanZeroFell = 0x1000u, kScanCountFell = 0x2000u };
 __host__ __device__ inline bool scan_is_organised(uint32_t err) {return (err & (kScanFused | kScanFellBack)) == kScanFused;}
+// ... and its positions are its columns (no index array): the plain organised form
+__host__ __device__ inline bool scan_is_grid(uint32_t err) {return (err & (kScanFused | kScanFellBack | kScanHoles)) == kScanFused;}
 // counters[kCounters] (one block per batch parity, see kParityCounters): rings deferred by the first unit pass, repaired after it, sent to the workgroup-per-ring
 // kernel, repaired before it; scans on the fall-back list; whether the organised-scan kernel ran; scans in the batch
 // ... scans the organised-scan kernel gave up on because a ring was not in angle order (the rest of the pattern held);
 // rings ring_cut_kernel found rotated / reversed; whether it ran
+// ... scans the plain organised-scan kernel gave up for a (0, 0, 0) record alone (zero filter on); whether the holes form
+// ran; (holes form) ring groups that held such a record
 enum { kCntDefer = 0, kCntRedo = 1, kCntSlow = 2, kCntPreFixed = 3, kCntFallback = 4, kCntFusedRan = 5, kCntBatch = 6,
-       kCntOrderFell = 7, kCntTurned = 8, kCntCutRan = 9, kCounters = 12 };
+       kCntOrderFell = 7, kCntTurned = 8, kCntCutRan = 9, kCntZeroFell = 10, kCntHolesRan = 11, kCntZeroGroups = 12, kCounters = 14 };
 // What a batch accumulates into with atomics -- the counters, the per-scan flag words, the organised route's ring totals --
 // exists TWICE: batch k uses set k mod 2, and its last kernel (feature_compact_kernel) leaves the other set zeroed for batch
 // k + 1.  No reset launch stands in front of a batch then: on the organised route a step is the unit kernel, the fall-back
@@ -167,6 +175,12 @@ constexpr int kUnitMaxBlocks = 64;        // per-unit count tables are sized for
 constexpr int kGeomStride = kUnitMaxBlocks + 2;
 enum { kDeferOrder = 1u, kDeferOther = 2u, kDeferMask = 3u, kRingSorted = 4u /* put in order by ring_order_kernel */ };
 
+// The holes form (grid_count_kernel + ring_unit_org_kernel<.., HOLES>): valid returns are counted per ring and PIECE of 16
+// columns; cum16[scan][ring][p] = valid returns of the ring in pieces 0 .. p - 1 (entry ceil(C / 16) = the ring's length).
+constexpr int kPieceCols = 16;
+__host__ __device__ inline uint32_t cum_stride(uint32_t ring_cap) {return ring_cap / kPieceCols + 4u;}      // entries per row
+constexpr int holes_loads(int chunks) {return chunks + 2;}       // pieces of 16 columns x 4 rings a wave loads: 64 (CH + 2) columns per unit
+
 constexpr int kUnitMaxChunks = 12;        // the long form: blocks of up to 768 positions (rings of up to ~4 500 points in 6 blocks)
 
 // AHasSmallerPolarAngleThanB for float fields (ring.hpp:54-99): the squares, the product of the
@@ -212,6 +226,7 @@ struct UnitTables
   uint32_t * ring_flags;
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
   uint32_t * scan_flags;                            // [batch]: the batch's error / route bits while it runs (feature_compact_kernel moves them into scan_info)
+  uint32_t * sidx;                                  // holes form of the organised-scan kernel: original index per ring position
   uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
   float4 * rec32;                                   // the unit kernels' record slots, [batch][max_rings][n_blocks] x rec_slot_places() x kRecBytes
   Params prm;                                       // the thresholds, for the kernels that do not have them as literals (read where a stage needs them)
@@ -226,6 +241,19 @@ __host__ __device__ constexpr uint32_t rec_slot_places(int padding_compiled_for,
 {
   return padding_compiled_for > 0 && padding_compiled_for <= 2 && chunks >= 5 ? 128u : 64u;
 }
+// A scan the organised-scan kernels cannot take (ring pattern, point count, angle order, a skip condition, a unit that
+// does not fit a wave) is flagged once and appended to the fall-back list: the bucketing route then redoes it whole.
+// why: kScanOrderFell / kScanZeroFell are counted (once per scan) for the host's choice of route -- a stream whose rings are
+// rotated / reversed gets ring_cut_kernel, a grid with (0, 0, 0) records the holes form.
+__device__ inline void scan_falls_back(const UnitTables * __restrict__ tab, uint32_t s, uint32_t why = 0u)
+{
+  const uint32_t bits = kScanFellBack | why;
+  const uint32_t old = atomicOr(tab->scan_flags + s, bits);
+  if ((old & kScanFellBack) == 0u) {tab->fb_list[atomicAdd(tab->fb_count, 1u)] = s;}
+  if ((why & kScanOrderFell) != 0u && (old & kScanOrderFell) == 0u) {atomicAdd(tab->fb_count + (kCntOrderFell - kCntFallback), 1u);}
+  if ((why & kScanZeroFell) != 0u && (old & kScanZeroFell) == 0u) {atomicAdd(tab->fb_count + (kCntZeroFell - kCntFallback), 1u);}
+}
+
 constexpr uint32_t kRecBytes = 20u;                       // per place: a 16-byte point and a 4-byte index
 constexpr uint32_t kUnitRecordsInSlot = 0x80000000u;      // in unit_span: written by the unit kernels, not by the workgroup-per-ring kernel
 

@@ -1098,6 +1098,96 @@ __device__ inline uint8_t process_ring(
   return kOk;
 }
 
+// The count pass of the HOLES form of the organised route (a driver that keeps the grid and writes invalid returns as
+// (0, 0, 0) records; the zero filter drops them, convert.py:162-163,192): position k of ring r is then the ring's k-th
+// VALID column, and a unit of ring_unit_org_kernel<.., HOLES> has to know where in the grid its positions lie -- and how long
+// the ring is, for its block boundaries -- before it can load anything.  One workgroup per (group of four adjacent rings,
+// scan) walks the group's columns once, lane = (column of a 16-column piece, ring of the group) as the unit kernel loads
+// them, and leaves per ring the exclusive prefix of its valid returns over the pieces (cum16, 2 B per ring and piece: 15 KB
+// per 64 x 1800 scan) and the ring's length (ring_count).  It reads every record's ring id, so the unit kernel need not: a
+// scan that is not the grid it claims to be goes on the fall-back list here.
+constexpr int kCountUnroll = 4;
+__global__ __launch_bounds__(256) void grid_count_kernel(
+  const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ geom, uint32_t R,
+  uint32_t stride /* cum_stride(ring capacity) */, uint16_t * __restrict__ cum16, uint32_t * __restrict__ ring_count,
+  const UnitTables * __restrict__ tab, uint32_t * __restrict__ counters)
+{
+  __shared__ uint16_t cnt[4][LFX_MAX_RING_POINTS / kPieceCols + 64];
+  __shared__ uint32_t flag[2];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = blockIdx.y;
+  uint32_t g = blockIdx.x;
+  {
+    // (the ring group is turned by the scan index exactly as ring_unit_org_kernel turns it: every XCD sees every group)
+    const uint32_t groups = gridDim.x;
+    const bool pairs = (groups & 15u) == 0u;
+    if (pairs) {g = (g & ~15u) | ((g & 7u) << 1) | ((g >> 3) & 1u);}
+    const uint32_t turn = (pairs ? 2u * s : s) & ((1u << (31 - __builtin_clz(groups))) - 1u);
+    g += turn;
+    g = g >= groups ? g - groups : g;
+  }
+  const uint32_t C = geom[s * kGeomStride];
+  if (s == 0u && blockIdx.x == 0u && tid == 0u) {counters[kCntHolesRan] = 1u;}
+  if (C == 0u) {                                      // not R rings x C columns (the host looked): the bucketing route's
+    if (blockIdx.x == 0u && tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)kScanCountFell); scan_falls_back(tab, s);}
+    return;
+  }
+  if (tid < 2u) {flag[tid] = 0u;}
+  const uint32_t n_pieces = (C + kPieceCols - 1u) / kPieceCols;
+  const uint32_t sub = lane & 3u, cq = lane >> 2, r0 = 4u * g, rr = r0 + sub, rload = rr < R ? rr : R - 1u;
+  const uint8_t * const base = pts + (size_t)scan_begin[s] * 32u + (size_t)rload * 32u;
+  const uint64_t ring_lanes = 0x1111111111111111ull << sub;
+  uint64_t wrong = 0, zeros = 0;
+  for (uint32_t t0 = wave; t0 < n_pieces; t0 += 4u * kCountUnroll) {
+    float4 rec[kCountUnroll];
+    uint32_t rw[kCountUnroll];
+#pragma unroll
+    for (int u = 0; u < kCountUnroll; u++) {
+      const uint32_t col = (t0 + 4u * u) * kPieceCols + cq;
+      const uint8_t * p = base + (size_t)(col < C ? col : C - 1u) * R * 32u;
+      rec[u] = *reinterpret_cast<const float4 *>(p);
+      rw[u] = *reinterpret_cast<const uint32_t *>(p + 20);
+    }
+#pragma unroll
+    for (int u = 0; u < kCountUnroll; u++) {
+      const uint32_t t = t0 + 4u * u;
+      const uint32_t col = t * kPieceCols + cq;
+      const bool in = col < C && rr < R;
+      const bool zero = rec[u].x == 0.f && rec[u].y == 0.f && rec[u].z == 0.f;
+      const uint64_t valid = __ballot(in && !zero);
+      wrong |= __ballot(in && (rw[u] & 0xFFFFu) != rr);
+      zeros |= __ballot(in && zero);
+      if (t < n_pieces && cq == 0u) {cnt[sub][t] = (uint16_t)__popcll(valid & ring_lanes);}
+    }
+  }
+  if (wrong != 0ull && lane == 0u) {flag[0] = 1u;}
+  if (zeros != 0ull && lane == 0u) {flag[1] = 1u;}
+  __syncthreads();
+  if (flag[0] != 0u) {
+    if (tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)kScanCountFell); scan_falls_back(tab, s);}
+    return;
+  }
+  if (flag[1] != 0u && tid == 0u) {atomicAdd(counters + kCntZeroGroups, 1u);}
+  // the scan is the unit kernel's, read in place as a grid with holes -- unless a unit or another ring group says otherwise
+  // (kScanFellBack beside these bits: the bucketing route's after all)
+  if (blockIdx.x == 0u && tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)(kScanFused | kScanHoles));}
+  // wave w: the exclusive prefix of ring r0 + w over the pieces
+  const uint32_t ring = r0 + wave;
+  if (ring >= R) {return;}
+  uint16_t * const row = cum16 + ((size_t)s * R + ring) * stride;
+  uint32_t carry = 0;
+  for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64u) {
+    const uint32_t p = p0 + lane;
+    const uint32_t v = p < n_pieces ? cnt[wave][p] : 0u;
+    const uint32_t incl = wave_inclusive_sum(v) + carry;
+    if (p < n_pieces) {row[p] = (uint16_t)(incl - v);}
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  if (lane == 0u) {
+    row[n_pieces] = (uint16_t)carry;
+    ring_count[s * kRings + ring] = carry;
+  }
+}
+
 // The ring transforms of an organised stream whose rings do not arrive in angle order: a driver that starts its scans
 // at another azimuth delivers every ring as a ROTATION of its sorted order, a clockwise sensor as its REVERSE (or
 // both).  One wave per ring: direction by majority over 64 sampled adjacent pairs, then the column of the ring's
@@ -1849,6 +1939,13 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
       return;
     }
     if (slot == 0u && lane == 0) {scan_info[s * 4 + kInfoError] = err;}
+    if (slot == max_rings - 1u && (err & (kScanHoles | kScanFellBack)) == kScanHoles) {
+      // a grid with holes read in place: its rings are those that kept a point (the other routes write the number themselves)
+      uint32_t occupied = 0;
+      for (uint32_t r = lane; r < max_rings; r += 64) {occupied += ring_count[s * kRings + r] != 0u ? 1u : 0u;}
+      occupied = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(occupied), 63);
+      if (lane == 0) {scan_info[s * 4 + kInfoRings] = occupied;}
+    }
     // a unit the unit kernels labelled keeps its records in its slot (points, then indices, in rank order: edges then surfaces;
     // beyond the slot's places at their ranks in the old arrays; the top bit of its span says so); a ring the workgroup-per-ring kernel
     // took in rec_pts / rec_idx, edges from the front of its positions and surfaces from their back
@@ -1980,7 +2077,7 @@ __global__ __launch_bounds__(256) void densify_kernel(
   const uint32_t at = scan_begin[s] - p0, n_points = scan_begin[s + 1] - scan_begin[s];
   d_label += at; d_curv += at; d_sidx += at;
   const uint32_t ring = blockIdx.x, tid = threadIdx.x;
-  const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]);     // position i of the ring is point i * rings + ring
+  const bool org = scan_is_grid(scan_info[s * 4 + kInfoError]);          // position i of the ring is point i * rings + ring (holes form: sidx says)
   __shared__ uint32_t part[256];
   part[tid] = (tid < ring && tid < max_rings) ? ring_count[s * kRings + tid] : 0u;
   __syncthreads();

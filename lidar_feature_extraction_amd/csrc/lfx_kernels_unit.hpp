@@ -371,17 +371,6 @@ static __device__ unsigned long long g_unit_stamps[kStampUnits * kStampSlots];  
 #define LFX_STAMP(n) do {} while (0)
 #endif
 
-// A scan the organised-scan kernel cannot take (ring pattern, point count, angle order, a skip condition, a unit that
-// does not fit a wave) is flagged once and appended to the fall-back list: the bucketing route then redoes it whole.
-__device__ inline void scan_falls_back(const UnitTables * __restrict__ tab, uint32_t s, bool order_only = false)
-{
-  const uint32_t bits = kScanFellBack | (order_only ? (uint32_t)kScanOrderFell : 0u);
-  const uint32_t old = atomicOr(tab->scan_flags + s, bits);
-  if ((old & kScanFellBack) == 0u) {tab->fb_list[atomicAdd(tab->fb_count, 1u)] = s;}
-  // (counted for the host's choice of route: a stream whose rings are rotated / reversed gets ring_cut_kernel)
-  if (order_only && (old & kScanOrderFell) == 0u) {atomicAdd(tab->fb_count + (kCntOrderFell - kCntFallback), 1u);}
-}
-
 // ORG: the organised-scan form.  A driver's scan arrives column-major -- all rings of one firing, then the next
 // azimuth -- so that ring r's position k IS input point k * R + r (R = the sensor's ring count) and the rings are
 // angle-sorted as they stand.  Then nothing needs bucketing: the workgroup's four waves take the same block of four
@@ -399,6 +388,7 @@ struct OrgScan
   uint32_t R, r0, wave, drop_zero;
   const uint32_t * __restrict__ xform;    // [batch][256] ring transforms (XF instantiations only)
   const uint32_t * __restrict__ geom;     // [batch][kGeomStride]
+  const uint16_t * __restrict__ cum16;    // HOLES instantiations only: grid_count_kernel's prefix table, rows of cum_stride(cap) entries
 };
 
 // (The FULL form of the body -- every chunk processed whatever the span, no chunk skipped, so that a stage is straight-line code --
@@ -429,7 +419,7 @@ __device__ inline UnitGeom unit_geometry(int N, int P, int B, int j, int b0, int
 // in registers.  Returns 0, or the reason the unit cannot be taken here (kDeferOrder / kDeferOther); feature records go
 // to positions [rec_lo, ...) (edges, ascending) and (..., rec_hi) (surfaces, descending) of the ring's record arrays,
 // their numbers to n_edge / n_surface.
-template<int PT, int CH, bool DEF, bool ORG, bool XF>
+template<int PT, int CH, bool DEF, bool ORG, bool XF, bool SIDX = false>
 __device__ __forceinline__ uint32_t unit_core(
   const Params & prm, UnitLds<CH> & U, const UnitGeom & G, uint32_t dbg_flags, uint32_t s, uint32_t slot, int j,
   const float (&x)[CH], const float (&y)[CH], const float (&z)[CH], const uint32_t (&src)[CH],
@@ -986,6 +976,7 @@ __device__ __forceinline__ uint32_t unit_core(
   g_f64_t * const curv_u = (g_f64_t *)curv_s + ((ptrdiff_t)off + g0);
   g_f32x4_t * const rec_u = (g_f32x4_t *)tab->rec_pts + (off + rec_lo);
   g_u32_t * const idx_u = (g_u32_t *)tab->rec_idx + (off + rec_lo);
+  g_u32_t * const sidx_u = SIDX ? (g_u32_t *)tab->sidx + ((ptrdiff_t)off + g0) : nullptr;      // (the holes form: where each position came from)
   (void)rec_hi;
   // The unit's feature records do not go out chunk by chunk into two arrays at the unit's place among the ring's
   // positions -- a handful of partial writes 4.8 KB away from the next unit's, which cost the kernel 150-180 us of its 1 020
@@ -1005,6 +996,7 @@ __device__ __forceinline__ uint32_t unit_core(
       if (own) {
         label_u[(uint32_t)q] = (uint8_t)l;
         if (curv_s != nullptr) {curv_u[(uint32_t)q] = cv;}       // (wave-uniform: a context created without LFX_OUT_CURVATURE has no such array)
+        if constexpr (SIDX) {sidx_u[(uint32_t)q] = src[k];}
       }
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
       lab[k] = l;
@@ -1109,7 +1101,7 @@ __device__ __forceinline__ void unit_body(
 #define LFX_DEFER(reason) \
   do { \
     if (ORG) { \
-      if (lane == 0) {scan_falls_back(tab, s, (reason) == kDeferOrder);} \
+      if (lane == 0) {scan_falls_back(tab, s, (reason) == kDeferOrder ? (uint32_t)kScanOrderFell : 0u);} \
     } else if (lane == 0 && (atomicOr(tab->ring_flags + s * kRings + slot, (reason)) & kDeferMask) == 0u) { \
       defer_list[atomicAdd(defer_count, 1u)] = s * kRings + slot; \
     } \
@@ -1181,6 +1173,7 @@ __device__ __forceinline__ void unit_body(
     }
     __builtin_amdgcn_sched_barrier(0);                // (the scheduler otherwise pulls the first chunk's ring test up between the loads)
     uint64_t wrong = 0;
+    uint32_t zero_seen = 0;                           // (a (0, 0, 0) record among the unit's: the scan is one for the holes form)
     f32_alias_t * zex = reinterpret_cast<f32_alias_t *>(slabs[sub].r);
 #pragma unroll
     for (int m = 0; m < CH; m++) {
@@ -1189,7 +1182,11 @@ __device__ __forceinline__ void unit_body(
       // the record must carry the ring id its place implies; with the zero-point filter on, a (0, 0, 0) record
       // would not be part of the scan (convert.py:162-163,192): not this kernel's case either
       uint64_t bad = bal((rw[m] & 0xFFFFu) != rr);
-      if (og.drop_zero) {bad |= bal(rec[m].x == 0.f) & bal(rec[m].y == 0.f) & bal(rec[m].z == 0.f);}
+      if (og.drop_zero) {
+        const uint64_t zb = bal(rec[m].x == 0.f) & bal(rec[m].y == 0.f) & bal(rec[m].z == 0.f);
+        bad |= zb;
+        zero_seen |= (zb & in) != 0ull ? 1u : 0u;
+      }
       wrong |= bad & in;
       const bool inl = lanes(in);
       slabs[sub].pxy[q] = make_float2(inl ? rec[m].x : 0.f, inl ? rec[m].y : 0.f);
@@ -1197,7 +1194,13 @@ __device__ __forceinline__ void unit_body(
     }
     wrong &= bal(rr < og.R);
     __syncthreads();                                  // the only workgroup barrier: the slabs are handed over
-    if (wrong != 0ull) {LFX_DEFER(kDeferOther);}
+    if (wrong != 0ull) {
+      if (zero_seen != 0u) {
+        if (lane == 0) {scan_falls_back(tab, s, (uint32_t)kScanZeroFell);}
+        return;
+      }
+      LFX_DEFER(kDeferOther);
+    }
     if (slot >= og.R) {return;}                       // ring count not a multiple of four: no such ring
 #pragma unroll
     for (int k = 0; k < CH; k++) {
@@ -1262,6 +1265,197 @@ __device__ __forceinline__ void unit_body(
 #undef LFX_DEFER
 }
 
+// HOLES: the organised-scan form for a grid whose invalid returns are (0, 0, 0) records that the zero filter drops
+// (lfx_config.drop_zero_points; convert.py:162-163,192).  Position k of ring r is then the ring's k-th VALID column: the
+// ring's length, hence its block boundaries, and where in the grid a unit's positions lie all depend on the holes before
+// them -- grid_count_kernel has left, per ring and piece of 16 columns, the number of valid returns before the piece (cum16).
+// A workgroup is still block j of four adjacent rings, and its waves still load whole 128-byte lines, lane = (column of a
+// piece, ring of the group): the first piece that holds a position one of the four units needs up to the last such piece
+// (64 (CH + 2) columns at most: more holes than that and the scan is the bucketing route's).  Every wave works that range
+// out for itself -- the four rows of the prefix table in registers, entry = lane, one round trip; geometry per lane for
+// the ring of its records; start and end piece of each ring by ballot -- so that the hand-over through the slabs remains the
+// workgroup's only barrier.  A valid record goes to slab position (prefix of its piece) + (its rank among the ring's valid
+// records of the piece) - (the unit's first position); z and the record's COLUMN travel with it (the column is the
+// position's original index: sidx, for the consumers).  From the hand-over on a unit is any other unit (unit_core).
+template<int PT, int CH, bool DEF>
+__device__ __forceinline__ void unit_body_holes(
+  const Params & prm, UnitLds<CH> * __restrict__ slabs, uint32_t ring_cap, uint32_t max_rings, uint32_t dbg_flags, uint32_t s,
+  uint32_t slot, int j, const UnitTables * __restrict__ tab, const OrgScan & og)
+{
+  constexpr int kLoads = holes_loads(CH);              // pieces a wave loads (4 waves: 4 kLoads pieces = 64 kLoads columns)
+  constexpr int kRowLoads = CH <= 6 ? 3 : 5;           // a ring's row of cum16, 64 entries per load (rings of up to 3 056 / 5 104 columns)
+  constexpr int kQv = (kLoads + 3) / 4;                // registers that hold the prefixes of the workgroup's pieces, 16 per register and ring
+  const int lane = threadIdx.x & 63;
+  const uint32_t w = og.wave;
+  UnitLds<CH> & U = slabs[w];
+  const int P = PT > 0 ? PT : prm.P, B = prm.B;
+  const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
+  const uint32_t rr = og.r0 + sub, rload = rr < og.R ? rr : og.R - 1u;
+  // ---- head: one round trip for everything the geometry needs
+  const uint32_t scan_first = og.scan_begin[s];
+  const uint32_t C = og.geom[s * kGeomStride];
+  const uint32_t flags = tab->scan_flags[s];
+  const uint32_t stride = cum_stride(ring_cap);
+  const int N_l = (int)og.ring_count_out[s * kRings + rload];          // the length of the ring of this lane's records
+  uint32_t cum[4][kRowLoads];                                          // cum[r][u]: entry 64 u + lane of ring r0 + r's row
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t ring = og.r0 + (uint32_t)r < og.R ? og.r0 + (uint32_t)r : og.R - 1u;
+    const uint16_t * row = og.cum16 + ((size_t)s * og.R + ring) * stride;
+#pragma unroll
+    for (int u = 0; u < kRowLoads; u++) {cum[r][u] = row[64 * u + lane];}      // (beyond the row: the next row or the array's pad, masked below)
+  }
+  asm volatile ("" :: "s"(scan_first), "s"(C), "s"(flags));
+  // (both tests are the same for the four waves: the count kernel set the bit before this kernel started)
+  if (C == 0u || (flags & kScanCountFell) != 0u) {return;}
+  const int n_pieces = (int)((C + kPieceCols - 1u) / kPieceCols);
+  LFX_STAMP(0);
+  // ---- geometry, per lane for the ring of its records: lanes with bit 2 clear evaluate boundary j, the others j + 1
+  //      (index_range.cpp:60-66: one evaluation of the f64 formula), exchanged with the lane four places on
+  int b0_l, b1_l;
+  {
+    const int hi = (lane >> 2) & 1;
+    const int mine = block_boundary(N_l, P, B, j + hi);
+    const int other = __shfl_xor(mine, 4);
+    b0_l = hi ? other : mine;
+    b1_l = hi ? mine : other;
+  }
+  // (skip conditions, over-long rings and units that do not fit a wave are the bucketing route's: the scan falls back)
+  bool dead_l = rr >= og.R || N_l == 0;                               // (a ring without a valid return is no ring of the scan)
+  bool defer_l = false;
+  if (!dead_l && (N_l < 2 * P + 1 || N_l - 2 * P < B || (uint32_t)N_l > ring_cap)) {dead_l = true; defer_l = j == 0;}
+  const int o0_l = j == 0 ? 0 : b0_l, o1_l = j == B - 1 ? N_l : b1_l;
+  const int g0_l = o0_l - (P + 1), span_l = o1_l + (P + 1) - g0_l;
+  if (!dead_l && (b1_l - b0_l < 2 || span_l > 64 * CH)) {dead_l = true; defer_l = true;}
+  const int first_l = g0_l < 0 ? 0 : g0_l;                             // first / last ring position the unit needs
+  const int last_l = (o1_l + P + 1 < N_l ? o1_l + P + 1 : N_l) - 1;
+  // this wave's own ring, as scalars (lane w holds ring r0 + w's values)
+  const int N = __builtin_amdgcn_readlane(N_l, (int)w);
+  const bool dead = __builtin_amdgcn_readlane((int)dead_l, (int)w) != 0;
+  const bool defer = __builtin_amdgcn_readlane((int)defer_l, (int)w) != 0;
+  if (defer && lane == 0) {scan_falls_back(tab, s);}
+  // ---- the pieces the four units need: piece of position x = #{p in [1, n_pieces] : cum[p] <= x}
+  int pstart = 0x7FFFFFFF, pend = -1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (__builtin_amdgcn_readlane((int)dead_l, r) != 0) {continue;}
+    const int first = __builtin_amdgcn_readlane(first_l, r), last = __builtin_amdgcn_readlane(last_l, r);
+    int ps = 0, pe = 0;
+#pragma unroll
+    for (int u = 0; u < kRowLoads; u++) {
+      const int e = 64 * u + lane;
+      const bool ok = e >= 1 && e <= n_pieces;
+      ps += __popcll(bal(ok && (int)cum[r][u] <= first));
+      pe += __popcll(bal(ok && (int)cum[r][u] <= last));
+    }
+    pstart = ps < pstart ? ps : pstart;
+    pend = pe > pend ? pe : pend;
+  }
+  const int n_need = pend - pstart + 1;
+  if (n_need <= 0) {return;}                                           // none of the four rings has a unit here (all four waves alike)
+  if (n_need > 4 * kLoads) {                                           // too many holes for this form: the bucketing route's scan
+    if (w == 0u && lane == 0) {scan_falls_back(tab, s);}
+    return;
+  }
+  // ---- loads: the prefixes of the workgroup's pieces for this lane's ring (piece 16 v + cq in register v: the table again,
+  //      from cache this time), then the records -- wave w takes pieces w, w + 4, ...
+  uint32_t qv[kQv];
+  {
+    const uint16_t * row = og.cum16 + ((size_t)s * og.R + rload) * stride;
+#pragma unroll
+    for (int v = 0; v < kQv; v++) {
+      const int e = pstart + 16 * v + (int)cq;
+      qv[v] = row[e < n_pieces ? e : n_pieces];
+    }
+  }
+  float4 rec[kLoads];
+  const uint8_t * const base = og.pts + (size_t)scan_first * 32u + (size_t)rload * 32u;
+#pragma unroll
+  for (int m = 0; m < kLoads; m++) {
+    const int t = 4 * m + (int)w;
+    const uint32_t col = (uint32_t)(pstart + t) * kPieceCols + cq;
+    rec[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < n_need && col < C) {rec[m] = *reinterpret_cast<const float4 *>(base + (size_t)col * og.R * 32u);}
+  }
+  {
+    uint32_t * zb = &U.bits[0][0];
+    constexpr int kBitDwords = kUnitBitArrays * UnitLds<CH>::kBitWords;
+#pragma unroll
+    for (int w0 = 0; w0 < kBitDwords; w0 += 64) {
+      if (w0 + 64 <= kBitDwords || lane + w0 < kBitDwords) {zb[lane + w0] = 0u;}
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- the valid records to their positions in their ring's slab
+  {
+    f32_alias_t * zex = reinterpret_cast<f32_alias_t *>(slabs[sub].r);
+    u32_alias_t * cex = reinterpret_cast<u32_alias_t *>(slabs[sub].r) + 64 * CH;      // (the columns: the upper half of the range slab)
+    const uint64_t ring_lanes = 0x1111111111111111ull << sub;
+#pragma unroll
+    for (int m = 0; m < kLoads; m++) {
+      const int t = 4 * m + (int)w;
+      const uint32_t col = (uint32_t)(pstart + t) * kPieceCols + cq;
+      const bool valid = t < n_need && col < C && !dead_l && !(rec[m].x == 0.f && rec[m].y == 0.f && rec[m].z == 0.f);
+      const uint64_t vm = bal(valid) & ring_lanes;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+      // the prefix of piece t of this lane's ring: held by lane 4 (t mod 16) + sub in register t / 16
+      const uint32_t before = (uint32_t)__shfl((int)qv[(t >> 4) < kQv ? (t >> 4) : kQv - 1], 4 * (t & 15) + (int)sub);
+      const int q = (int)(before + rank) - g0_l;
+      if (valid && (uint32_t)q < (uint32_t)(64 * CH)) {
+        slabs[sub].pxy[q] = make_float2(rec[m].x, rec[m].y);
+        zex[q] = rec[m].z;
+        cex[q] = col;
+      }
+    }
+  }
+  __syncthreads();                                    // the only workgroup barrier: the slabs are handed over
+  if (dead) {return;}
+  const int b0 = __builtin_amdgcn_readlane(b0_l, (int)w), b1 = __builtin_amdgcn_readlane(b1_l, (int)w);
+  const UnitGeom G = unit_geometry(N, P, B, j, b0, b1);
+  const int o0 = G.o0, o1 = G.o1, qlo = G.qlo, qhi = G.qhi;
+  const size_t off = ring_base(s, slot, max_rings, ring_cap);
+  LFX_STAMP(1);
+  float x[CH], y[CH], z[CH];
+  uint32_t src[CH];
+#pragma unroll
+  for (int k = 0; k < CH; k++) {
+    const int q = 64 * k + lane;
+    const bool in = lanes(in_span(q, qlo, qhi));
+    const float2 v = U.pxy[q];
+    x[k] = in ? v.x : 0.f; y[k] = in ? v.y : 0.f;
+    z[k] = reinterpret_cast<const f32_alias_t *>(U.r)[q];
+    src[k] = reinterpret_cast<const u32_alias_t *>(U.r)[64 * CH + q] * og.R + slot;
+  }
+  LFX_WAVE_SYNC();
+  // (positions outside the ring were never written: the slab's x, y there must read as zero for the window stages)
+#pragma unroll
+  for (int k = 0; k < CH; k++) {
+    const int q = 64 * k + lane;
+    if (!lanes(in_span(q, qlo, qhi))) {U.pxy[q] = make_float2(0.f, 0.f);}
+  }
+  LFX_WAVE_SYNC();
+  uint32_t pe = 0, ps = 0;
+  {
+    const uint32_t why = unit_core<PT, CH, DEF, false, false, true>(prm, U, G, dbg_flags, s, slot, j, x, y, z, src, tab, false, og, off, max_rings,
+      (uint32_t)o0, (uint32_t)o1, pe, ps, lane);
+    if (why != 0u) {
+      if (lane == 0) {scan_falls_back(tab, s, why == kDeferOrder ? (uint32_t)kScanOrderFell : 0u);}
+      return;
+    }
+  }
+  if (lane == 0) {
+    const size_t ui = ((size_t)s * kRings + slot) * kUnitMaxBlocks + j;
+    tab->unit_ne[ui] = pe;
+    tab->unit_ns[ui] = ps;
+    tab->unit_span[ui] = kUnitRecordsInSlot | ((uint32_t)o1 << 16) | (uint32_t)o0;
+    (void)__hip_atomic_fetch_add(tab->ring_nedge + s * kRings + slot, pe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(tab->ring_nsurf + s * kRings + slot, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the ring's length is in ring_count already, the scan's route bits in its flag word: grid_count_kernel; the number of
+    // its rings that hold a point is counted by feature_compact_kernel)
+    if (j == 0) {tab->ring_status[s * kRings + slot] = kOk;}
+  }
+}
+
 // SECOND = false: first pass over the scans on the fall-back list (every scan of the batch when the organised-scan
 // kernel is not in use), grid = (units of a scan / 4, list entries or fewer); rings it cannot take go on
 // `defer_list` with the reason.  SECOND = true: second pass over the rings ring_order_kernel
@@ -1294,7 +1488,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) void r
   UnitLds<CH> * U = &lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
-  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr};
+  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr, nullptr};
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
@@ -1333,12 +1527,13 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) void r
 #else
 #define LFX_ORG_ATTR
 #endif
-template<int V, int CH, bool XF>
-__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF)) LFX_ORG_ATTR void ring_unit_org_kernel(
+template<int V, int CH, bool XF, bool HOLES = false>
+__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF || HOLES)) LFX_ORG_ATTR void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform, const uint32_t * __restrict__ geom)
+  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform /* HOLES: grid_count_kernel's cum16 */, const uint32_t * __restrict__ geom)
 {
+  static_assert(!(XF && HOLES), "the holes form takes rings as they stand");
   __shared__ UnitLds<CH> lds[kUnitWaves];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // grid = (groups of four rings, blocks, scans): dispatched in the order group, block, scan, no division to find them.
@@ -1365,8 +1560,12 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF)) LF
     g = g >= groups ? g - groups : g;
   }
 #endif
-  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, geom};
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, geom, reinterpret_cast<const uint16_t *>(xform)};
   const uint32_t slot = 4u * g + wave;
+  if constexpr (HOLES) {
+    unit_body_holes<UnitVariant<V>::kPT, CH, UnitVariant<V>::kDEF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, tab, og);
+    return;
+  }
   unit_body<UnitVariant<V>::kPT, CH, UnitVariant<V>::kDEF, true, XF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, nullptr, nullptr, nullptr, nullptr, tab, nullptr,
     nullptr, false, og);
 }

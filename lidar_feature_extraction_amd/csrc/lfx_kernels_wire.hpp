@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void colored_pack_kernel(
   const uint32_t s = blockIdx.y, ring = blockIdx.x, tid = threadIdx.x;
   if (ring_status[s * kRings + ring] != kOk) {return;}
   const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]);     // nothing was staged: every field from the record
+  const bool grid = scan_is_grid(scan_info[s * 4 + kInfoError]);         // ... and the index from the position (the holes form keeps sidx)
   __shared__ uint32_t before;
   if (tid == 0) {before = 0;}
   __syncthreads();
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void colored_pack_kernel(
   const uint32_t table[8] = {0xFFFFFFFFu, 0xFFFF0000u, 0xFFFF3F00u, 0xFFFF0000u, 0xFFFF3F00u, 0xFF7F7F7Fu, 0xFFFF00FFu, 0xFF00FF00u};
   for (uint32_t i = tid; i < n; i += blockDim.x) {
     if (at + i >= capacity) {break;}
-    const uint32_t orig = org ? ring_column(xform[s * kRings + ring], i, n) * max_rings + ring : sidx[off + i];
+    const uint32_t orig = grid ? ring_column(xform[s * kRings + ring], i, n) * max_rings + ring : sidx[off + i];
     const uint8_t * rec = pts + ((size_t)scan_begin[s] + orig) * L.step;
     const float2 xy = org ? make_float2(load_f32(rec + L.ox, L.be), load_f32(rec + L.oy, L.be)) : sxy[off + i];
     // z from the input record (the staged z of a ring the workgroup-per-ring kernel sorted itself is not re-ordered)

@@ -17,7 +17,8 @@ static_assert(lfx::UnitVariant<LFX_VARIANT>::kPT == kUnitVariantPadding[LFX_VARI
 #define LFX_CAT(a, b) LFX_CAT2(a, b)
 
 // chunks: 3, 4, 5, 6 or lfx::kUnitMaxChunks (the span variant the context picked for its longest ring)
-void LFX_CAT(launch_unit_org_v, LFX_VARIANT)(int chunks, bool xf, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a)
+// holes: the form for grids whose invalid returns are (0, 0, 0) records (a.xform = grid_count_kernel's table then)
+void LFX_CAT(launch_unit_org_v, LFX_VARIANT)(int chunks, bool xf, bool holes, dim3 grid, uint32_t lds_pad, hipStream_t st, const UnitOrgArgs & a)
 {
   constexpr int V = LFX_VARIANT;
   void (*kern)(lfx::Params, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t *, const uint32_t *, uint32_t *,
@@ -28,6 +29,11 @@ void LFX_CAT(launch_unit_org_v, LFX_VARIANT)(int chunks, bool xf, dim3 grid, uin
    &lfx::ring_unit_org_kernel<V, lfx::kUnitMaxChunks, XFV>)
   kern = xf ? LFX_PICK_ORG(true) : LFX_PICK_ORG(false);
 #undef LFX_PICK_ORG
+  if (holes) {
+    kern = chunks == 5 ? &lfx::ring_unit_org_kernel<V, 5, false, true> : chunks == 4 ? &lfx::ring_unit_org_kernel<V, 4, false, true> :
+      chunks == 3 ? &lfx::ring_unit_org_kernel<V, 3, false, true> : chunks == 6 ? &lfx::ring_unit_org_kernel<V, 6, false, true> :
+      &lfx::ring_unit_org_kernel<V, lfx::kUnitMaxChunks, false, true>;
+  }
   hipLaunchKernelGGL(kern, grid, dim3(64 * lfx::kUnitWaves), lds_pad, st,
     a.prm, a.cap, a.flags, a.max_rings, a.drop_zero, a.pts, a.scan_begin, a.ring_count, a.tab, a.xform, a.geom);
 }

@@ -8,7 +8,7 @@ import pytest
 
 from lidar_feature_extraction_amd import binding as LB
 
-DEFER, REDO, SLOW, PREFIXED, FALLBACK, FUSED_RAN, BATCH, ORDER_FELL, TURNED, CUT_RAN = range(10)
+DEFER, REDO, SLOW, PREFIXED, FALLBACK, FUSED_RAN, BATCH, ORDER_FELL, TURNED, CUT_RAN, ZERO_FELL, HOLES_RAN, ZERO_GROUPS = range(13)
 
 
 @pytest.fixture(scope="module")
@@ -21,13 +21,18 @@ def lib():
 
 
 def choose(lib, report=None, rings=0, state=(0, 0, 0, 0), possible=1, batch=64, max_rings=64):
-    rep = (C.c_uint32 * 12)()
+    rep = (C.c_uint32 * 14)()                                  # LFX_ROUTE_REPORT_WORDS
     for k, v in (report or {}).items():
         rep[k] = v
-    st = (C.c_uint32 * 4)(*state)
-    ch = (C.c_uint32 * 6)()
+    # LFX_ROUTE_STATE_WORDS = 5: (use_xform, bucket_all, retry_in, pre_order, use_holes); rows written before the holes form
+    # existed give four and get four back
+    st = (C.c_uint32 * 5)(*(tuple(state) + (0,) * (5 - len(state))))
+    ch = (C.c_uint32 * 7)()                                    # LFX_ROUTE_CHOICE_WORDS
     assert lib.lfx_route_choice(rep, rings, st, possible, batch, max_rings, ch) == 0
-    return dict(fused=ch[0], xform=ch[1], fb_grid=ch[2], short_tail=ch[3], pre_order=ch[4], redo_cap=ch[5]), tuple(st)
+    out = dict(fused=ch[0], xform=ch[1], fb_grid=ch[2], short_tail=ch[3], pre_order=ch[4], redo_cap=ch[5], holes=ch[6])
+    if len(state) == 4:
+        assert st[4] == 0, "nothing in these rows asks for the holes form"
+    return out, tuple(st)[:len(state)]
 
 
 CLEAN = {FUSED_RAN: 1, BATCH: 64, FALLBACK: 0}
@@ -57,6 +62,19 @@ ROWS = [
     ("(almost) no ring needs a transform any more: back to plain loads",
      dict(report={FUSED_RAN: 1, BATCH: 64, FALLBACK: 0, CUT_RAN: 1, TURNED: 10}, rings=4096, state=(1, 0, 0, 0)),
      dict(fused=1, xform=0, short_tail=1), (0, 0, 0, 0)),
+    ("most scans fell back for a (0, 0, 0) record alone (zero filter on): the holes form from now on, organised route kept",
+     dict(report={FUSED_RAN: 1, BATCH: 64, FALLBACK: 60, ZERO_FELL: 58}, rings=4096, state=(0, 0, 0, 0, 0)), dict(fused=1, xform=0, holes=1, fb_grid=64),
+     (0, 0, 0, 0, 1)),
+    ("with the count pass the stream is clean: the holes form stays while ring groups keep holding such records (one-launch tail)",
+     dict(report={FUSED_RAN: 1, BATCH: 64, FALLBACK: 0, HOLES_RAN: 1, ZERO_GROUPS: 1024}, rings=4096, state=(0, 0, 0, 0, 1)),
+     dict(fused=1, holes=1, short_tail=1), (0, 0, 0, 0, 1)),
+    ("(almost) no ring group holds a zero record any more: back to the plain form",
+     dict(report={FUSED_RAN: 1, BATCH: 64, FALLBACK: 0, HOLES_RAN: 1, ZERO_GROUPS: 1}, rings=4096, state=(0, 0, 0, 0, 1)),
+     dict(fused=1, holes=0, short_tail=1), (0, 0, 0, 0, 0)),
+    ("a stream hint (grid with holes) before any report: the count pass from the first batch on",
+     dict(state=(0, 0, 0, 0, 1)), dict(fused=1, holes=1, fb_grid=8), (0, 0, 0, 0, 1)),
+    ("rings turned AND holes: the transforms win (the holes form takes rings as they stand)",
+     dict(state=(1, 0, 0, 0, 1)), dict(fused=1, xform=1, holes=0), (1, 0, 0, 0, 1)),
     ("a stream hint (turned rings) before any report: transforms from the first batch on",
      dict(state=(1, 0, 0, 0)), dict(fused=1, xform=1, fb_grid=8), (1, 0, 0, 0)),
     ("a stream hint (no grid): bucketing from the first batch on, retried later",
