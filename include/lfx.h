@@ -29,7 +29,8 @@ extern "C" {
 #define LFX_VERSION 1
 #define LFX_MAX_PADDING 63          /* convolution_padding: up to 15 the window kernels (the fast routes); 16 .. 63 every ring takes the
                                     * workgroup-per-ring kernel, whose labelling then walks the positions in reach (slow, same results) */
-#define LFX_MAX_RING_ID 255         /* ring ids must be < 256 (every spinning lidar fielded today) */
+#define LFX_MAX_RING_ID 65535       /* a ring id is the uint16 of PointXYZIR (point_type.hpp:62-86) */
+#define LFX_MAX_RINGS 256           /* distinct ring ids a context takes (every spinning lidar fielded today has fewer) */
 #define LFX_MAX_RING_POINTS 4608    /* points of one ring must fit one workgroup's LDS (25 B each); 6 blocks of the unit kernels' long form */
 
 /* The nine node parameters: extraction/include/lidar_feature_extraction/hyper_parameter.hpp:32-65
@@ -97,6 +98,12 @@ typedef struct lfx_config {
   uint32_t stream_hint;           /* LFX_STREAM_*: what the caller knows about the order its driver publishes in.  The
                                    * library finds the route for a stream from what the first batches report (nothing to
                                    * configure); a hint only spares the FIRST batch of a stream the slower route         */
+  const uint16_t *ring_ids;       /* the sensor's ring ids where they are not 0 .. max_rings-1 (the reference buckets by
+                                   * whatever uint16 a point carries, ring.hpp:114-125): n_ring_ids distinct ids, at most
+                                   * LFX_MAX_RINGS of them; results list rings by id ascending.  NULL: ids 0 .. max_rings-1 --
+                                   * and the host entry points (lfx_extract*) look the ids of a scan up themselves when a
+                                   * point carries another one (lfx_set_ring_ids does the same for the device path)       */
+  uint32_t n_ring_ids;
 } lfx_config;
 
 #define LFX_STREAM_UNKNOWN 0u      /* start on the organised route, adapt                                               */
@@ -139,7 +146,8 @@ enum lfx_error {
   LFX_ERR_NO_DEVICE = -2,         /* no HIP device / kernel image: the product has NO CPU fallback */
   LFX_ERR_HIP = -3,
   LFX_ERR_CAPACITY = -4,          /* more points / scans than the context was created for     */
-  LFX_ERR_RING_ID = -5,           /* a point carries ring > LFX_MAX_RING_ID                    */
+  LFX_ERR_RING_ID = -5,           /* a point carries a ring id the context does not know (lfx_config.ring_ids,
+                                   * lfx_set_ring_ids), or a scan more than LFX_MAX_RINGS distinct ones */
   LFX_ERR_OUT_OF_MEMORY = -6,
   LFX_ERR_NO_RING_FIELD = -7,     /* the cloud has no "ring" field: RingIsAvailable (ring.cpp:36-44) is false and the
                                    * node shuts down (feature_extraction.cpp:103-108)            */
@@ -254,6 +262,11 @@ int lfx_device_results(const lfx_ctx *ctx, lfx_device_view *view);
  * reads the last batch's scan_info and returns LFX_ERR_RING_ID / LFX_ERR_HIP if any scan carries an error bit
  * (the clouds of such a scan are not to be used), else LFX_OK.  first_bad (may be NULL): index of the first such scan. */
 int lfx_batch_status(lfx_ctx *ctx, void *stream, uint32_t *first_bad);
+/* The sensor's ring ids for a context created without lfx_config.ring_ids (n distinct ids, n <= the context's max_rings;
+ * any order: results list rings by id ascending).  ids = NULL: back to 0 .. max_rings-1.  Takes effect with the next
+ * batch; ids other than 0 .. n-1 go through the bucketing route (the organised-scan kernel reads ring r at column
+ * offset r).  Waits for the context's stream. */
+int lfx_set_ring_ids(lfx_ctx *ctx, const uint16_t *ids, uint32_t n);
 /* Which route each scan of the last batch took (diagnostics; waits for `stream`): routes[s] = 1 read in place by the
  * organised-scan kernel, 2 the same through per-ring transforms (rings rotated / reversed in the stream), 3 read in place
  * as a grid with (0, 0, 0) records that the zero filter dropped (sorted_index holds its points' indices), 0 bucketed. */

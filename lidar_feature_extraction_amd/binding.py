@@ -48,7 +48,8 @@ INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64 = range(1, 9)
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("max_points_per_scan", C.c_uint32), ("max_batch", C.c_uint32),
                 ("max_points_per_ring", C.c_uint32), ("max_rings", C.c_uint32), ("drop_zero_points", C.c_uint32),
-                ("layout", Layout), ("outputs", C.c_uint32), ("stream_hint", C.c_uint32)]
+                ("layout", Layout), ("outputs", C.c_uint32), ("stream_hint", C.c_uint32),
+                ("ring_ids", C.POINTER(C.c_uint16)), ("n_ring_ids", C.c_uint32)]
 
 
 class GatherStep(C.Structure):

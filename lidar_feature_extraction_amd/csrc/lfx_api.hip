@@ -4,6 +4,7 @@
 // There is no CPU implementation of the path here: without a gfx950 device every entry point fails.
 #include "lfx_internal.hpp"
 
+#include <algorithm>
 #include <cstddef>
 #include "lfx_kernels_extract.hpp"
 
@@ -236,6 +237,40 @@ RouteChoice choose_route(RouteState & st, const RoutePins & pin, bool organised_
   return ch;
 }
 
+// The sensor's ring ids (lfx_config.ring_ids, lfx_set_ring_ids, or looked up in a scan by the host entry points): slots by
+// id ascending -- the order results list rings in.  Ids 0 .. n-1 are the default (no table; the organised route stays
+// possible); anything else goes through ring_slot in the bucketing kernel.
+int install_ring_ids(lfx_ctx * c, const uint16_t * ids, uint32_t n, bool given)
+{
+  std::vector<uint16_t> v(ids, ids + n);
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  if (v.size() > c->max_rings) {
+    return fail(c, LFX_ERR_RING_ID, "the scan carries " + std::to_string(v.size()) + " distinct ring ids, the context takes " + std::to_string(c->max_rings) +
+                  " (max_rings; at most LFX_MAX_RINGS)");
+  }
+  bool identity = true;
+  for (size_t k = 0; k < v.size(); k++) {identity = identity && v[k] == k;}
+  LFX_HIP(c, hipSetDevice(c->device));
+  if (c->stream) {LFX_HIP(c, hipStreamSynchronize(c->stream));}
+  c->ids_given = given;
+  if (identity) {
+    c->slot_id.clear();
+    c->fused_possible = c->organised_by_config;
+    return LFX_OK;
+  }
+  if (!c->ring_slot.p && c->ring_slot.alloc(65536) != hipSuccess) {
+    c->ring_slot.p = nullptr;
+    return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the ring id table");
+  }
+  std::vector<uint16_t> table(65536, (uint16_t)0xFFFFu);
+  for (size_t k = 0; k < v.size(); k++) {table[v[k]] = (uint16_t)k;}
+  LFX_HIP(c, hipMemcpy(c->ring_slot.p, table.data(), table.size() * 2, hipMemcpyHostToDevice));
+  c->slot_id = v;
+  c->fused_possible = false;               // (the organised-scan kernel reads ring r at column offset r)
+  return LFX_OK;
+}
+
 // Launch the kernels for `batch` scans whose records lie back to back at d_points.
 int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uint32_t batch, hipStream_t st)
 {
@@ -312,12 +347,7 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
   }
   const RouteChoice choice = choose_route(c->route, c->route_pins, c->fused_possible && canon && chunks != 0, batch, c->max_rings);
   const bool fused = choice.fused, short_tail = choice.short_tail;
-  const bool holes = choice.holes && c->drop_zero != 0u;
-  if (holes && !c->cum16.p) {
-    // (the table of the holes form: a context only pays for it once its stream turns out to be such a grid)
-    const size_t entries = (size_t)c->max_batch * c->max_rings * lfx::cum_stride(c->cap) + 1024u;
-    if (c->cum16.alloc(entries) != hipSuccess) {c->cum16.p = nullptr; return fail(c, LFX_ERR_OUT_OF_MEMORY, "cannot allocate the table of the holes form");}
-  }
+  const bool holes = choice.holes && c->drop_zero != 0u && c->cum16.p != nullptr;
   const uint32_t fb_grid = choice.fb_grid;             // list entries the bucketing kernels are launched for
   if (chunks == 0) {
     // every scan of the batch is empty: no kernel runs; the result tables say so
@@ -350,12 +380,13 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
       // the count pass of the holes form: valid returns per ring and piece of 16 columns, every ring's length
       Timed t(c, 10, st);
       hipLaunchKernelGGL(lfx::grid_count_kernel, dim3(groups, batch), dim3(256), 0, st,
-        pts, c->scan_begin.p, c->scan_geom.p, c->max_rings, lfx::cum_stride(c->cap), c->cum16.p, c->ring_count.p, unit_tab, counters);
+        pts, c->scan_begin.p, c->scan_geom.p, c->max_rings, lfx::cum_stride(c->cap), c->cum16.p, c->ring_count.p, unit_tab, counters,
+        c->hole_desc.p, c->cap, 64u * c->unit_chunks, 4u * (uint32_t)lfx::holes_loads((int)c->unit_chunks));
     }
     {
       Timed t(c, 7, st);
       const UnitOrgArgs a{c->dev, c->cap, c->unit_flags, c->max_rings, c->drop_zero, pts, c->scan_begin.p, c->ring_count.p, unit_tab,
-        holes ? reinterpret_cast<const uint32_t *>(c->cum16.p) : c->xform.p, c->scan_geom.p};
+        c->xform.p, c->scan_geom.p};
       launch_unit_org(c->unit_variant, (int)c->unit_chunks, xf, holes, dim3(groups, (uint32_t)c->dev.B, batch), c->unit_lds_pad, st, a);
     }
   }
@@ -385,7 +416,8 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     }
     hipLaunchKernelGGL(kern, dim3(chunks, fb_grid), dim3(lfx::kChunkThreads), 0, st,
       pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p, scan_flags,
-      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p);
+      c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero, fb_count, c->fb_list.p,
+      c->slot_id.empty() ? nullptr : c->ring_slot.p);
   }
   // the near-empty launches of the bucketing route are kept small while the organised-scan kernel takes the stream
   const uint32_t list_grid = fused ? (c->slow_grid < 4u * fb_grid ? c->slow_grid : 4u * fb_grid) : c->slow_grid;
@@ -536,7 +568,7 @@ int fetch_finish(lfx_ctx * c, const FetchPlan & plan, HostScan * hosts, lfx_scan
     const uint32_t * rcount = hdr + 4;
     const uint8_t * rstat = reinterpret_cast<const uint8_t *>(hdr + 4 + lfx::kRings);
     if (hdr[lfx::kInfoError] & lfx::kErrRingId) {
-      return fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context was not created for (max_rings / LFX_MAX_RING_ID)");
+      return fail(c, LFX_ERR_RING_ID, "a point carries a ring id the context does not know (max_rings, lfx_config.ring_ids, lfx_set_ring_ids)");
     }
     if (hdr[lfx::kInfoError] & lfx::kErrTimeout) {
       return fail(c, LFX_ERR_HIP, "ring bucketing timed out waiting for an earlier chunk (the workgroups of a scan were not dispatched in index order)");
@@ -546,7 +578,7 @@ int fetch_finish(lfx_ctx * c, const FetchPlan & plan, HostScan * hosts, lfx_scan
     uint32_t dense = 0, nr = 0;
     for (uint32_t r = 0; r < c->max_rings; r++) {
       if (rcount[r] == 0) {continue;}
-      h.ring_id.push_back((uint16_t)r);
+      h.ring_id.push_back(c->slot_id.empty() ? (uint16_t)r : c->slot_id[r]);
       h.ring_count.push_back(rcount[r]);
       h.ring_offset.push_back(dense);
       h.ring_status.push_back(rstat[r]);
@@ -854,6 +886,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   // the organised-scan kernel needs to know the sensor's ring count (max_rings given) and reads PointXYZIR records
   c->fused_possible = c->fast_path && config->max_rings != 0 && c->max_points < (1u << 27) && c->layout.step == 32 && c->layout.ox == 0 &&
     c->layout.oy == 4 && c->layout.oz == 8 && c->layout.oring == 20 && c->layout.rtype == LFX_FIELD_UINT16 && c->layout.be == 0;
+  c->organised_by_config = c->fused_possible;
   if (const char * dbg = LFX_DEBUG_ENV("FUSED")) {c->route_pins.fused = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = LFX_DEBUG_ENV("TOTALS_KERNEL")) {c->totals_env = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = LFX_DEBUG_ENV("SHORT_TAIL")) {c->route_pins.short_tail = std::atoi(dbg) != 0 ? 1 : 0;}
@@ -898,6 +931,11 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   ok(c->d_label.alloc(c->max_points)); ok(c->d_curv.alloc(c->max_points)); ok(c->d_sidx.alloc(c->max_points));
   ok(c->edge_pts.alloc(tc)); ok(c->surf_pts.alloc(tc)); ok(c->edge_idx.alloc(tc)); ok(c->surf_idx.alloc(tc));
   ok(c->unit_tab.alloc(2));
+  if (c->drop_zero && c->fused_possible) {
+    // the tables of the holes form of the organised route (grid_count_kernel): prefix rows and unit descriptors
+    ok(c->cum16.alloc(nb * c->max_rings * lfx::cum_stride(c->cap) + 1024u));
+    ok(c->hole_desc.alloc(nb * c->max_rings * (size_t)c->dev.B));
+  }
   if (c->fast_path) {
     // the unit kernels' record slots: 20 bytes per place (a point and its index), 64 or 128 places per unit, units back to back
     const size_t slots = nb * c->max_rings * (size_t)c->dev.B;
@@ -934,7 +972,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
       t.fb_count = c->counters.p + par * lfx::kParityCounters + lfx::kCntFallback;
       t.fb_list = c->fb_list.p;
       t.scan_flags = c->scan_flags.p + (size_t)par * nb;
-      t.sidx = c->sidx.p;
+      t.sidx = c->sidx.p; t.cum16 = c->cum16.p; t.hole_desc = c->hole_desc.p;
       t.ring_nedge = c->ring_nedge.p + par * tables; t.ring_nsurf = c->ring_nsurf.p + par * tables;
       t.rec32 = c->rec32.p; t.prm = c->dev;
       e = hipMemcpy(c->unit_tab.p + par, &t, sizeof(t), hipMemcpyHostToDevice);
@@ -968,6 +1006,15 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
     lfx_destroy(c);
     return e == hipErrorOutOfMemory ? LFX_ERR_OUT_OF_MEMORY : LFX_ERR_HIP;
   }
+  c->organised_by_config = c->fused_possible;
+  if (config->ring_ids != nullptr && config->n_ring_ids != 0u) {
+    const int rc = install_ring_ids(c, config->ring_ids, config->n_ring_ids, true);
+    if (rc != LFX_OK) {
+      g_create_error = c->err;
+      lfx_destroy(c);
+      return rc;
+    }
+  }
   *out = c;
   return LFX_OK;
 }
@@ -982,7 +1029,7 @@ void lfx_destroy(lfx_ctx * c)
   c->scan_begin.release(); c->scan_info.release(); c->scan_geom.release(); c->chunk_base.release();
   c->ring_count.release(); c->chunk_flags.release(); c->d_label.release(); c->d_curv.release(); c->d_sidx.release();
   c->ring_status.release(); c->ring_nedge.release(); c->ring_nsurf.release(); c->ring_ebase.release();
-  c->ring_sbase.release(); c->ring_flags.release(); c->counters.release(); c->scan_flags.release(); c->tail_ticket.release(); c->cum16.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
+  c->ring_sbase.release(); c->ring_flags.release(); c->counters.release(); c->scan_flags.release(); c->tail_ticket.release(); c->cum16.release(); c->hole_desc.release(); c->ring_slot.release(); c->slow_list.release(); c->defer_list.release(); c->redo_list.release(); c->fb_list.release(); c->xform.release(); c->unit_ne.release(); c->unit_ns.release(); c->unit_span.release();
   c->sxy.release(); c->sz.release(); c->sidx.release(); c->rec_pts.release(); c->rec_idx.release(); c->label_s.release();
   c->unit_tab.release();
   if (c->h_counters) {(void)hipHostFree(c->h_counters); c->h_counters = nullptr;}
@@ -1051,6 +1098,19 @@ int lfx_batch_status(lfx_ctx * c, void * stream, uint32_t * first_bad)
     }
   }
   return LFX_OK;
+}
+
+int lfx_set_ring_ids(lfx_ctx * c, const uint16_t * ids, uint32_t n)
+{
+  if (!c || (ids == nullptr && n != 0u) || n > LFX_MAX_RINGS) {return LFX_ERR_INVALID_ARGUMENT;}
+  if (c->slots[0].busy || c->slots[1].busy) {return fail(c, LFX_ERR_INVALID_ARGUMENT, "a submitted scan is still in flight (lfx_extract_wait)");}
+  if (ids == nullptr) {
+    c->slot_id.clear();
+    c->ids_given = false;
+    c->fused_possible = c->organised_by_config;
+    return LFX_OK;
+  }
+  return install_ring_ids(c, ids, n, true);
 }
 
 int lfx_scan_routes(lfx_ctx * c, void * stream, uint8_t * routes)
@@ -1139,9 +1199,44 @@ int extract_batch_impl(
     if (urc != LFX_OK) {return urc;}
     at += bytes;
   }
-  const int rc = run_batch(c, c->staging.p, n32.data(), batch, c->stream);
+  int rc = run_batch(c, c->staging.p, n32.data(), batch, c->stream);
   if (rc != LFX_OK) {return rc;}
-  return fetch(c, 0, batch, c->stream, mask, out);
+  rc = fetch(c, 0, batch, c->stream, mask, out);
+  if (rc == LFX_ERR_RING_ID && !c->ids_given) {
+    // A point carries an id that is not 0 .. max_rings-1 and the caller has named none: the reference buckets by whatever
+    // uint16 a point carries (ring.hpp:114-125), so the ids of these scans are looked up here, on the host's copy of the
+    // records -- a pass over one field; nothing of the path itself runs on the host -- and the batch runs again with them.
+    std::vector<uint8_t> seen(65536, 0);
+    bool wide = false;
+    for (uint32_t s = 0; s < batch; s++) {
+      const uint8_t * p = static_cast<const uint8_t *>(points[s]);
+      for (size_t k = 0; k < n_points[s]; k++) {
+        const uint8_t * f = p + k * c->layout.step + c->layout.oring;
+        uint32_t id;
+        switch (c->layout.rtype) {
+          case LFX_FIELD_INT8: id = (uint32_t)(int32_t)*reinterpret_cast<const int8_t *>(f); break;
+          case LFX_FIELD_UINT8: id = *f; break;
+          case LFX_FIELD_INT32: case LFX_FIELD_UINT32: {uint32_t v; std::memcpy(&v, f, 4); id = c->layout.be ? __builtin_bswap32(v) : v; break;}
+          default: {
+            uint16_t v; std::memcpy(&v, f, 2); v = c->layout.be ? __builtin_bswap16(v) : v;
+            id = c->layout.rtype == LFX_FIELD_INT16 ? (uint32_t)(int32_t)(int16_t)v : v;
+          }
+        }
+        if (id > 65535u) {wide = true;} else {seen[id] = 1;}
+      }
+    }
+    if (wide) {return fail(c, LFX_ERR_RING_ID, "a point carries a ring id above 65535 (the reference's ring field is a uint16, point_type.hpp:62-86)");}
+    std::vector<uint16_t> ids;
+    for (uint32_t id = 0; id < 65536u; id++) {if (seen[id]) {ids.push_back((uint16_t)id);}}
+    // (ids the context already knows stay: a sensor's rings need not all show up in every scan)
+    for (uint16_t id : c->slot_id) {if (!seen[id]) {ids.push_back(id);}}
+    rc = install_ring_ids(c, ids.data(), (uint32_t)ids.size(), false);
+    if (rc != LFX_OK) {return rc;}
+    rc = run_batch(c, c->staging.p, n32.data(), batch, c->stream);
+    if (rc != LFX_OK) {return rc;}
+    rc = fetch(c, 0, batch, c->stream, mask, out);
+  }
+  return rc;
 }
 }  // namespace
 

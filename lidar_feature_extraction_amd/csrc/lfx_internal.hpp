@@ -187,7 +187,14 @@ struct lfx_ctx
     ring_nsurf, ring_ebase, ring_sbase, ring_flags, unit_ne, unit_ns, unit_span, slow_list, defer_list, redo_list, fb_list, xform,
     sidx, rec_idx, edge_idx,
     surf_idx, d_sidx, counters, scan_flags, tail_ticket;
-  lfx_host::DevBuf<uint16_t> cum16;      // grid_count_kernel's table (the holes form), allocated with the first batch that needs it
+  // Ring ids that are not 0 .. max_rings-1 (lfx_config.ring_ids, lfx_set_ring_ids, or found by the host entry points in a
+  // scan that carried another id): slot_id[k] = the id of slot k (ascending), ring_slot the device table id -> slot the
+  // bucketing kernel reads; empty = the id is the slot.  ids_given: the caller said so (no looking up by the library).
+  lfx_host::DevBuf<uint16_t> ring_slot;
+  std::vector<uint16_t> slot_id;
+  bool ids_given = false, organised_by_config = false;
+  lfx_host::DevBuf<uint16_t> cum16;      // grid_count_kernel's prefix table (the holes form; contexts with the zero filter on)
+  lfx_host::DevBuf<uint4> hole_desc;     // ... and its unit descriptors
   // The batch's accumulators (counters, scan_flags, ring_nedge / ring_nsurf) exist twice: batch k uses set `parity`, its
   // compaction zeroes the other one over the scans the batch before last left dirty there (par_dirty).  aux_dirty: scans whose
   // bucketing-route tables (look-back flags, ring flags, ring transforms) a batch since the last reset may have touched.

@@ -177,6 +177,10 @@ enum { kDeferOrder = 1u, kDeferOther = 2u, kDeferMask = 3u, kRingSorted = 4u /* 
 
 // The holes form (grid_count_kernel + ring_unit_org_kernel<.., HOLES>): valid returns are counted per ring and PIECE of 16
 // columns; cum16[scan][ring][p] = valid returns of the ring in pieces 0 .. p - 1 (entry ceil(C / 16) = the ring's length).
+// Per (ring, block) unit grid_count_kernel also leaves a DESCRIPTOR -- the ring's length, the block's two boundaries
+// (index_range.cpp:60-66), the first and the last piece that hold a position the unit needs -- so that a unit's head is four
+// scalar loads (its workgroup's four rings) and no search: {N | b0 << 16, b1 | flags << 16, first piece | last piece << 16, 0}.
+constexpr uint32_t kHoleUnitDead = 1u;                // flags: the ring has no unit here (no valid return at all)
 constexpr int kPieceCols = 16;
 __host__ __device__ inline uint32_t cum_stride(uint32_t ring_cap) {return ring_cap / kPieceCols + 4u;}      // entries per row
 constexpr int holes_loads(int chunks) {return chunks + 2;}       // pieces of 16 columns x 4 rings a wave loads: 64 (CH + 2) columns per unit
@@ -227,6 +231,8 @@ struct UnitTables
   uint32_t * scan_info, * fb_count, * fb_list;      // organised-scan kernel: a scan it cannot take goes on the fall-back list
   uint32_t * scan_flags;                            // [batch]: the batch's error / route bits while it runs (feature_compact_kernel moves them into scan_info)
   uint32_t * sidx;                                  // holes form of the organised-scan kernel: original index per ring position
+  const uint16_t * cum16;                           // ... grid_count_kernel's prefix table, rows of cum_stride(cap) entries, [batch][max_rings]
+  const uint4 * hole_desc;                          // ... and its unit descriptors, [batch][max_rings][n_blocks]
   uint32_t * ring_nedge, * ring_nsurf;              // organised-scan kernel: every unit adds its counts to its ring's (feature_compact_kernel)
   float4 * rec32;                                   // the unit kernels' record slots, [batch][max_rings][n_blocks] x rec_slot_places() x kRecBytes
   Params prm;                                       // the thresholds, for the kernels that do not have them as literals (read where a stage needs them)

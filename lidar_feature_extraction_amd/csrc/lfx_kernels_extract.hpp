@@ -48,7 +48,8 @@ __device__ __forceinline__ void scatter_chunk(
   uint32_t s, const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
   uint32_t * __restrict__ scan_info, uint32_t * __restrict__ scan_flags, float2 * __restrict__ sxy, float * __restrict__ sz,
-  uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero)
+  uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero,
+  const uint16_t * __restrict__ ring_slot /* [65536] ring id -> slot (0xFFFF: not one of the sensor's), or nullptr: the id is the slot */)
 {
   const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
   const uint32_t b = scan_begin[s], n = scan_begin[s + 1] - b;
@@ -100,6 +101,9 @@ __device__ __forceinline__ void scatter_chunk(
         z[i] = load_f32(p + L.oz, L.be);
         ring = load_ring(p + L.oring, L.rtype, L.be);
       }
+      // (the reference buckets by whatever id a point carries, ring.hpp:114-125: ids that are not 0 .. rings-1 go through the
+      // context's table to the slot of their rank among the sensor's ids)
+      if (ring_slot != nullptr) {ring = ring < 65536u ? ring_slot[ring] : 0xFFFFu;}
       key[i] = ring < max_rings ? ring : kRings;
       if (ring >= max_rings) {bad_ring = true;}
       // the upstream converter's filter (point_type_converter/convert.py:162-163,192): all-zero points
@@ -275,24 +279,24 @@ __device__ __forceinline__ void scatter_chunk(
 // workgroup has one entry at most and no loop -- the loop costs the kernel 40 registers, a handful of spills and, measured
 // on a ragged stream, a third of its speed.
 template<bool CANON, bool ONE = false>
-__global__ __launch_bounds__(kChunkThreads, ONE ? 1 : 4) void ring_scatter_kernel(
+__global__ __launch_bounds__(kChunkThreads, ONE ? 1 : 3) void ring_scatter_kernel(
   const uint8_t * __restrict__ pts, Layout L, const uint32_t * __restrict__ scan_begin,
   uint32_t * __restrict__ chunk_base, uint32_t * __restrict__ chunk_flags, uint32_t * __restrict__ ring_count,
   uint32_t * __restrict__ scan_info, uint32_t * __restrict__ scan_flags, float2 * __restrict__ sxy, float * __restrict__ sz,
   uint32_t * __restrict__ sidx, uint32_t max_chunks, uint32_t max_rings, uint32_t cap, uint32_t drop_zero,
-  const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list)
+  const uint32_t * __restrict__ fb_count, const uint32_t * __restrict__ fb_list, const uint16_t * __restrict__ ring_slot)
 {
   const uint32_t n_list = *fb_count;
   if (ONE) {
     if (blockIdx.y < n_list) {
       scatter_chunk<CANON>(fb_list[blockIdx.y], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, scan_flags, sxy, sz,
-        sidx, max_chunks, max_rings, cap, drop_zero);
+        sidx, max_chunks, max_rings, cap, drop_zero, ring_slot);
     }
     return;
   }
   for (uint32_t it = blockIdx.y; it < n_list; it += gridDim.y) {
     scatter_chunk<CANON>(fb_list[it], pts, L, scan_begin, chunk_base, chunk_flags, ring_count, scan_info, scan_flags, sxy, sz,
-      sidx, max_chunks, max_rings, cap, drop_zero);
+      sidx, max_chunks, max_rings, cap, drop_zero, ring_slot);
     __syncthreads();                        // the LDS blocks are reused by the next entry
   }
 }
@@ -1110,8 +1114,10 @@ constexpr int kCountUnroll = 4;
 __global__ __launch_bounds__(256) void grid_count_kernel(
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ geom, uint32_t R,
   uint32_t stride /* cum_stride(ring capacity) */, uint16_t * __restrict__ cum16, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab, uint32_t * __restrict__ counters)
+  const UnitTables * __restrict__ tab, uint32_t * __restrict__ counters, uint4 * __restrict__ desc /* [batch][R][B] */,
+  uint32_t ring_cap, uint32_t max_span /* positions a unit wave holds: 64 x chunks */, uint32_t max_pieces /* pieces a workgroup loads */)
 {
+  __shared__ uint32_t piece_lo[kUnitMaxBlocks], piece_hi[kUnitMaxBlocks];
   __shared__ uint16_t cnt[4][LFX_MAX_RING_POINTS / kPieceCols + 64];
   __shared__ uint32_t flag[2];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = blockIdx.y;
@@ -1132,6 +1138,7 @@ __global__ __launch_bounds__(256) void grid_count_kernel(
     return;
   }
   if (tid < 2u) {flag[tid] = 0u;}
+  if (tid < (uint32_t)kUnitMaxBlocks) {piece_lo[tid] = 0xFFFFFFFFu; piece_hi[tid] = 0u;}
   const uint32_t n_pieces = (C + kPieceCols - 1u) / kPieceCols;
   const uint32_t sub = lane & 3u, cq = lane >> 2, r0 = 4u * g, rr = r0 + sub, rload = rr < R ? rr : R - 1u;
   const uint8_t * const base = pts + (size_t)scan_begin[s] * 32u + (size_t)rload * 32u;
@@ -1167,25 +1174,78 @@ __global__ __launch_bounds__(256) void grid_count_kernel(
     return;
   }
   if (flag[1] != 0u && tid == 0u) {atomicAdd(counters + kCntZeroGroups, 1u);}
-  // the scan is the unit kernel's, read in place as a grid with holes -- unless a unit or another ring group says otherwise
+  __syncthreads();                                    // (flag[0] is raised again below)
+  // wave w: the exclusive prefix of ring r0 + w over the pieces (kept in LDS for the searches below)
+  const uint32_t ring = r0 + wave;
+  uint32_t N = 0;
+  if (ring < R) {
+    uint16_t * const row = cum16 + ((size_t)s * R + ring) * stride;
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64u) {
+      const uint32_t p = p0 + lane;
+      const uint32_t v = p < n_pieces ? cnt[wave][p] : 0u;
+      const uint32_t incl = wave_inclusive_sum(v) + carry;
+      if (p < n_pieces) {row[p] = (uint16_t)(incl - v); cnt[wave][p] = (uint16_t)(incl - v);}
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    N = carry;
+    if (lane == 0u) {
+      row[n_pieces] = (uint16_t)N;
+      cnt[wave][n_pieces] = (uint16_t)N;
+      ring_count[s * kRings + ring] = N;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // lane j: the descriptor of unit (ring, block j) -- what unit_body works out for a unit of a bucketed ring, and the pieces
+  // that hold its first and its last position
+  const int P = tab->prm.P, B = tab->prm.B;
+  bool defer = false;
+  if (ring < R && (int)lane < B) {
+    const int j = (int)lane, Ni = (int)N;
+    uint32_t flags = N == 0u ? kHoleUnitDead : 0u;       // (a ring without a valid return is no ring of the scan)
+    int b0 = 0, b1 = 0, ps = 0, pe = 0;
+    if (flags == 0u && (Ni < 2 * P + 1 || Ni - 2 * P < B || N > ring_cap)) {flags = kHoleUnitDead; defer = true;}      // skip conditions, over-long rings: the bucketing route's
+    if (flags == 0u) {
+      b0 = block_boundary(Ni, P, B, j);
+      b1 = block_boundary(Ni, P, B, j + 1);
+      const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? Ni : b1;
+      const int g0 = o0 - (P + 1), span = o1 + (P + 1) - g0;
+      if (b1 - b0 < 2 || span > (int)max_span) {
+        flags = kHoleUnitDead; defer = true;
+      } else {
+        const int first = g0 < 0 ? 0 : g0, last = (o1 + P + 1 < Ni ? o1 + P + 1 : Ni) - 1;
+        // the piece of position x: the last p with prefix[p] <= x (prefix[0] = 0, prefix[n_pieces] = N > x)
+        auto piece_of = [&](int x) {
+            int lo = 0, hi = (int)n_pieces;
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if ((int)cnt[wave][mid] <= x) {lo = mid;} else {hi = mid;}
+            }
+            return lo;
+          };
+        ps = piece_of(first);
+        pe = piece_of(last);
+        atomicMin(&piece_lo[j], (uint32_t)ps);
+        atomicMax(&piece_hi[j], (uint32_t)pe);
+      }
+    }
+    desc[((size_t)s * R + ring) * (uint32_t)B + (uint32_t)j] =
+      make_uint4(N | ((uint32_t)b0 << 16), (uint32_t)b1 | (flags << 16), (uint32_t)ps | ((uint32_t)pe << 16), 0u);
+  }
+  if (__ballot(defer) != 0ull && lane == 0u) {flag[0] = 1u;}
+  __syncthreads();
+  // (more columns between the first and the last position of a block's four units than a workgroup loads: too many holes)
+  if (tid < (uint32_t)B && piece_lo[tid] != 0xFFFFFFFFu && piece_hi[tid] - piece_lo[tid] + 1u > max_pieces) {flag[0] = 1u;}
+  __syncthreads();
+  if (flag[0] != 0u) {
+    if (tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)kScanCountFell); scan_falls_back(tab, s);}
+    return;
+  }
+  // the scan is the unit kernel's, read in place as a grid with holes -- unless another ring group says otherwise
   // (kScanFellBack beside these bits: the bucketing route's after all)
   if (blockIdx.x == 0u && tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)(kScanFused | kScanHoles));}
-  // wave w: the exclusive prefix of ring r0 + w over the pieces
-  const uint32_t ring = r0 + wave;
-  if (ring >= R) {return;}
-  uint16_t * const row = cum16 + ((size_t)s * R + ring) * stride;
-  uint32_t carry = 0;
-  for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64u) {
-    const uint32_t p = p0 + lane;
-    const uint32_t v = p < n_pieces ? cnt[wave][p] : 0u;
-    const uint32_t incl = wave_inclusive_sum(v) + carry;
-    if (p < n_pieces) {row[p] = (uint16_t)(incl - v);}
-    carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  }
-  if (lane == 0u) {
-    row[n_pieces] = (uint16_t)carry;
-    ring_count[s * kRings + ring] = carry;
-  }
 }
 
 // The ring transforms of an organised stream whose rings do not arrive in angle order: a driver that starts its scans
@@ -1775,7 +1835,7 @@ __global__ __launch_bounds__(kChunkThreads, 1) void fallback_tail_kernel(
     const uint32_t n_chunks = (n + kChunkPoints - 1) / kChunkPoints;
     if (blockIdx.x < n_chunks) {
       scatter_chunk<CANON>(s, sc.pts, sc.L, sc.scan_begin, sc.chunk_base, sc.chunk_flags, sc.ring_count, sc.scan_info, sc.scan_flags,
-        sc.sxy, sc.sz, sc.sidx, sc.max_chunks, sc.max_rings, sc.cap, sc.drop_zero);
+        sc.sxy, sc.sz, sc.sidx, sc.max_chunks, sc.max_rings, sc.cap, sc.drop_zero, nullptr);
       // everything this chunk staged is out before its ticket is drawn; the last to draw sees every chunk's
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();

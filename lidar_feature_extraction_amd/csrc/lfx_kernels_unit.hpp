@@ -388,7 +388,6 @@ struct OrgScan
   uint32_t R, r0, wave, drop_zero;
   const uint32_t * __restrict__ xform;    // [batch][256] ring transforms (XF instantiations only)
   const uint32_t * __restrict__ geom;     // [batch][kGeomStride]
-  const uint16_t * __restrict__ cum16;    // HOLES instantiations only: grid_count_kernel's prefix table, rows of cum_stride(cap) entries
 };
 
 // (The FULL form of the body -- every chunk processed whatever the span, no chunk skipped, so that a stage is straight-line code --
@@ -1283,7 +1282,6 @@ __device__ __forceinline__ void unit_body_holes(
   uint32_t slot, int j, const UnitTables * __restrict__ tab, const OrgScan & og)
 {
   constexpr int kLoads = holes_loads(CH);              // pieces a wave loads (4 waves: 4 kLoads pieces = 64 kLoads columns)
-  constexpr int kRowLoads = CH <= 6 ? 3 : 5;           // a ring's row of cum16, 64 entries per load (rings of up to 3 056 / 5 104 columns)
   constexpr int kQv = (kLoads + 3) / 4;                // registers that hold the prefixes of the workgroup's pieces, 16 per register and ring
   const int lane = threadIdx.x & 63;
   const uint32_t w = og.wave;
@@ -1291,77 +1289,55 @@ __device__ __forceinline__ void unit_body_holes(
   const int P = PT > 0 ? PT : prm.P, B = prm.B;
   const uint32_t sub = (uint32_t)lane & 3u, cq = (uint32_t)lane >> 2;
   const uint32_t rr = og.r0 + sub, rload = rr < og.R ? rr : og.R - 1u;
-  // ---- head: one round trip for everything the geometry needs
+  // ---- head: scalar loads only (one round trip through the scalar cache: the vector memory path is where the other waves'
+  //      records queue -- with the four rows of the prefix table fetched and searched here a unit's head took 10 600 cycles of
+  //      its 38 000, round 6) -- the scan's first point, its columns, its flags, and the four units' descriptors
   const uint32_t scan_first = og.scan_begin[s];
   const uint32_t C = og.geom[s * kGeomStride];
   const uint32_t flags = tab->scan_flags[s];
-  const uint32_t stride = cum_stride(ring_cap);
-  const int N_l = (int)og.ring_count_out[s * kRings + rload];          // the length of the ring of this lane's records
-  uint32_t cum[4][kRowLoads];                                          // cum[r][u]: entry 64 u + lane of ring r0 + r's row
+  const uint16_t * __restrict__ cum16 = tab->cum16;
+  const uint4 * __restrict__ dsc = tab->hole_desc + ((size_t)s * og.R) * (uint32_t)B + (uint32_t)j;
+  uint4 d[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const uint32_t ring = og.r0 + (uint32_t)r < og.R ? og.r0 + (uint32_t)r : og.R - 1u;
-    const uint16_t * row = og.cum16 + ((size_t)s * og.R + ring) * stride;
-#pragma unroll
-    for (int u = 0; u < kRowLoads; u++) {cum[r][u] = row[64 * u + lane];}      // (beyond the row: the next row or the array's pad, masked below)
+    d[r] = dsc[(size_t)ring * (uint32_t)B];
   }
-  asm volatile ("" :: "s"(scan_first), "s"(C), "s"(flags));
+  asm volatile ("" :: "s"(scan_first), "s"(C), "s"(flags), "s"(d[0].x), "s"(d[1].x), "s"(d[2].x), "s"(d[3].x));
   // (both tests are the same for the four waves: the count kernel set the bit before this kernel started)
   if (C == 0u || (flags & kScanCountFell) != 0u) {return;}
+  const uint32_t stride = cum_stride(ring_cap);
   const int n_pieces = (int)((C + kPieceCols - 1u) / kPieceCols);
   LFX_STAMP(0);
-  // ---- geometry, per lane for the ring of its records: lanes with bit 2 clear evaluate boundary j, the others j + 1
-  //      (index_range.cpp:60-66: one evaluation of the f64 formula), exchanged with the lane four places on
-  int b0_l, b1_l;
-  {
-    const int hi = (lane >> 2) & 1;
-    const int mine = block_boundary(N_l, P, B, j + hi);
-    const int other = __shfl_xor(mine, 4);
-    b0_l = hi ? other : mine;
-    b1_l = hi ? mine : other;
+  // ---- the pieces the four units need, and per lane the geometry of the unit its records belong to
+  int pstart = 0x7FFFFFFF, pend = -1;
+  int N_l = 0, b0_l = 0, b1_l = 0;
+  bool dead_l = true;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const bool dead_r = og.r0 + (uint32_t)r >= og.R || ((d[r].y >> 16) & kHoleUnitDead) != 0u;
+    if (!dead_r) {
+      const int ps = (int)(d[r].z & 0xFFFFu), pe = (int)(d[r].z >> 16);
+      pstart = ps < pstart ? ps : pstart;
+      pend = pe > pend ? pe : pend;
+    }
+    if (sub == (uint32_t)r) {
+      N_l = (int)(d[r].x & 0xFFFFu); b0_l = (int)(d[r].x >> 16); b1_l = (int)(d[r].y & 0xFFFFu);
+      dead_l = dead_r;
+    }
   }
-  // (skip conditions, over-long rings and units that do not fit a wave are the bucketing route's: the scan falls back)
-  bool dead_l = rr >= og.R || N_l == 0;                               // (a ring without a valid return is no ring of the scan)
-  bool defer_l = false;
-  if (!dead_l && (N_l < 2 * P + 1 || N_l - 2 * P < B || (uint32_t)N_l > ring_cap)) {dead_l = true; defer_l = j == 0;}
   const int o0_l = j == 0 ? 0 : b0_l, o1_l = j == B - 1 ? N_l : b1_l;
-  const int g0_l = o0_l - (P + 1), span_l = o1_l + (P + 1) - g0_l;
-  if (!dead_l && (b1_l - b0_l < 2 || span_l > 64 * CH)) {dead_l = true; defer_l = true;}
-  const int first_l = g0_l < 0 ? 0 : g0_l;                             // first / last ring position the unit needs
-  const int last_l = (o1_l + P + 1 < N_l ? o1_l + P + 1 : N_l) - 1;
+  const int g0_l = o0_l - (P + 1);
+  (void)o1_l;
   // this wave's own ring, as scalars (lane w holds ring r0 + w's values)
   const int N = __builtin_amdgcn_readlane(N_l, (int)w);
   const bool dead = __builtin_amdgcn_readlane((int)dead_l, (int)w) != 0;
-  const bool defer = __builtin_amdgcn_readlane((int)defer_l, (int)w) != 0;
-  if (defer && lane == 0) {scan_falls_back(tab, s);}
-  // ---- the pieces the four units need: piece of position x = #{p in [1, n_pieces] : cum[p] <= x}
-  int pstart = 0x7FFFFFFF, pend = -1;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    if (__builtin_amdgcn_readlane((int)dead_l, r) != 0) {continue;}
-    const int first = __builtin_amdgcn_readlane(first_l, r), last = __builtin_amdgcn_readlane(last_l, r);
-    int ps = 0, pe = 0;
-#pragma unroll
-    for (int u = 0; u < kRowLoads; u++) {
-      const int e = 64 * u + lane;
-      const bool ok = e >= 1 && e <= n_pieces;
-      ps += __popcll(bal(ok && (int)cum[r][u] <= first));
-      pe += __popcll(bal(ok && (int)cum[r][u] <= last));
-    }
-    pstart = ps < pstart ? ps : pstart;
-    pend = pe > pend ? pe : pend;
-  }
   const int n_need = pend - pstart + 1;
-  if (n_need <= 0) {return;}                                           // none of the four rings has a unit here (all four waves alike)
-  if (n_need > 4 * kLoads) {                                           // too many holes for this form: the bucketing route's scan
-    if (w == 0u && lane == 0) {scan_falls_back(tab, s);}
-    return;
-  }
-  // ---- loads: the prefixes of the workgroup's pieces for this lane's ring (piece 16 v + cq in register v: the table again,
-  //      from cache this time), then the records -- wave w takes pieces w, w + 4, ...
+  if (n_need <= 0 || n_need > 4 * kLoads) {return;}                    // none of the four rings has a unit here (more pieces than a workgroup loads: the count kernel has sent such a scan to the bucketing route)
+  LFX_STAMP(13);
   uint32_t qv[kQv];
   {
-    const uint16_t * row = og.cum16 + ((size_t)s * og.R + rload) * stride;
+    const uint16_t * row = cum16 + ((size_t)s * og.R + rload) * stride;
 #pragma unroll
     for (int v = 0; v < kQv; v++) {
       const int e = pstart + 16 * v + (int)cq;
@@ -1408,6 +1384,7 @@ __device__ __forceinline__ void unit_body_holes(
       }
     }
   }
+  LFX_STAMP(14);
   __syncthreads();                                    // the only workgroup barrier: the slabs are handed over
   if (dead) {return;}
   const int b0 = __builtin_amdgcn_readlane(b0_l, (int)w), b1 = __builtin_amdgcn_readlane(b1_l, (int)w);
@@ -1471,8 +1448,17 @@ template<int V> struct UnitVariant
   static constexpr bool kDEF = V == 0;
 };
 
+// (registers: the budget of the kernels that apply ring transforms -- at variant 0's 72 the 5-chunk forms spilled two vector
+// registers to scratch; the LOOP forms, which keep a list walk's state live around the body, one workgroup per CU fewer again:
+// they spilled 18-62.  Round 6: no kernel a stream can reach touches scratch, tools/kernel_resources.py.)
+constexpr int unit_list_waves_per_simd(int ch, int variant, bool loop)
+{
+  // (variant 2 stages 128 records per unit from 5 chunks on: a workgroup per CU fewer there too)
+  const int w = unit_waves_per_simd(ch, variant, true) - (variant == 2 && ch >= 5 ? 1 : 0);
+  return loop ? (w > 4 ? w - 3 : (w > 1 ? w - 1 : 1)) : w;
+}
 template<int V, bool SECOND, int CH, bool LOOP = false>
-__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) void ring_unit_kernel(
+__global__ __launch_bounds__(64 * kUnitWaves, unit_list_waves_per_simd(CH, V, LOOP)) void ring_unit_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, const uint32_t * __restrict__ ring_count,
   const float2 * __restrict__ sxy, const float * __restrict__ sz,
   const uint32_t * __restrict__ sidx, const UnitTables * __restrict__ tab,
@@ -1488,7 +1474,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) void r
   UnitLds<CH> * U = &lds[wave];
   const uint32_t B = (uint32_t)prm.B;
   uint32_t u = blockIdx.x * kUnitWaves + wave;
-  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr, nullptr};
+  const OrgScan none{nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, nullptr};
   if (SECOND) {
     // one unit per wave here too: the grid covers every unit of the batch and the waves beyond the
     // repaired rings leave at once (a grid-stride loop around unit_body costs registers)
@@ -1528,10 +1514,10 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V)) void r
 #define LFX_ORG_ATTR
 #endif
 template<int V, int CH, bool XF, bool HOLES = false>
-__global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF || HOLES)) LFX_ORG_ATTR void ring_unit_org_kernel(
+__global__ __launch_bounds__(64 * kUnitWaves, HOLES ? unit_list_waves_per_simd(CH, V, false) : unit_waves_per_simd(CH, V, XF)) LFX_ORG_ATTR void ring_unit_org_kernel(
   Params prm, uint32_t ring_cap, uint32_t dbg_flags, uint32_t max_rings, uint32_t drop_zero,
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, uint32_t * __restrict__ ring_count,
-  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform /* HOLES: grid_count_kernel's cum16 */, const uint32_t * __restrict__ geom)
+  const UnitTables * __restrict__ tab, const uint32_t * __restrict__ xform, const uint32_t * __restrict__ geom)
 {
   static_assert(!(XF && HOLES), "the holes form takes rings as they stand");
   __shared__ UnitLds<CH> lds[kUnitWaves];
@@ -1560,7 +1546,7 @@ __global__ __launch_bounds__(64 * kUnitWaves, unit_waves_per_simd(CH, V, XF || H
     g = g >= groups ? g - groups : g;
   }
 #endif
-  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, geom, reinterpret_cast<const uint16_t *>(xform)};
+  const OrgScan og{pts, scan_begin, ring_count, max_rings, 4u * g, wave, drop_zero, xform, geom};
   const uint32_t slot = 4u * g + wave;
   if constexpr (HOLES) {
     unit_body_holes<UnitVariant<V>::kPT, CH, UnitVariant<V>::kDEF>(prm, lds, ring_cap, max_rings, dbg_flags, s, slot, j, tab, og);

@@ -93,7 +93,8 @@ class FeatureExtraction:
     """One context = one GPU = one calling thread (feature_extraction.cpp:65-87,185)."""
 
     def __init__(self, params=None, device=0, max_points_per_scan=262144, max_batch=1,
-                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None, outputs=0, stream_hint=0, test_hooks=None):
+                 max_points_per_ring=0, max_rings=0, drop_zero_points=False, layout=None, outputs=0, stream_hint=0, test_hooks=None,
+                 ring_ids=None):
         # test_hooks: the context comes from the test-hooks build of the library (B.HOOKS_LIB_PATH), the only one whose
         # lfx_create reads the LFX_DEBUG_* switches (tests and tools/ only).  None: that build exactly when such a switch is
         # set in the environment -- the shipped library would not see it
@@ -113,8 +114,11 @@ class FeatureExtraction:
         self._step = lay.point_step or 32
         # outputs: B.OUT_* mask of what ExtractFeatures / extract_batch bring back (0 = everything); the two clouds always do
         # stream_hint: B.STREAM_* (what the caller knows about the order its driver publishes in; spares the first batch a slower route)
+        # ring_ids: the sensor's ring ids where they are not 0 .. max_rings-1 (lfx_config.ring_ids); None: the host entry points
+        # look them up in a scan that carries another id
+        ids = None if ring_ids is None else (C.c_uint16 * len(ring_ids))(*[int(r) for r in ring_ids])
         cfg = B.Config(C.sizeof(B.Config), max_points_per_scan, max_batch, max_points_per_ring, max_rings, int(bool(drop_zero_points)), lay,
-                       int(outputs), int(stream_hint))
+                       int(outputs), int(stream_hint), ids, 0 if ids is None else len(ring_ids))
         self._pinned = []
         cp = self.params.to_c()
         rc = self._L.lfx_create(C.byref(self._ctx), device, C.byref(cp), C.byref(cfg))
@@ -276,8 +280,17 @@ class FeatureExtraction:
             C.c_void_p(int(stream))))
         return self._align_results(res)[0]
 
+    def set_ring_ids(self, ring_ids):
+        """lfx_set_ring_ids: the sensor's ring ids for the device path (None: back to 0 .. max_rings-1)."""
+        if ring_ids is None:
+            B.check(self._ctx, self._L.lfx_set_ring_ids(self._ctx, None, 0), self._L)
+            return
+        ids = (C.c_uint16 * len(ring_ids))(*[int(r) for r in ring_ids])
+        B.check(self._ctx, self._L.lfx_set_ring_ids(self._ctx, ids, len(ring_ids)), self._L)
+
     def scan_routes(self, n_scans, stream=0):
-        """lfx_scan_routes: per scan of the last batch 1 = read in place, 2 = in place through ring transforms, 0 = bucketed."""
+        """lfx_scan_routes: per scan of the last batch 1 = read in place, 2 = in place through ring transforms, 3 = in place as a
+        grid with (0, 0, 0) records the zero filter dropped, 0 = bucketed."""
         out = np.zeros(n_scans, np.uint8)
         B.check(self._ctx, self._L.lfx_scan_routes(self._ctx, C.c_void_p(int(stream)), C.c_void_p(out.ctypes.data)), self._L)
         return out

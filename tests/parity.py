@@ -30,3 +30,23 @@ def status_codes_equal_where_single_cause(got, want):
     for g, w in zip(got.ring_status.tolist(), want["ring_status"].tolist()):
         if w in (1, 2, 3):
             assert g == w
+
+
+def assert_filtered_equal(got, want, keep, zero, ctx=""):
+    """The zero filter (lfx_config.drop_zero_points; convert.py:162-163,192): `got` is the HIP path on a cloud whose (0, 0, 0)
+    records (mask `zero`) it dropped itself, `want` the oracle on the cloud WITHOUT them (`keep` = their indices in the full
+    cloud).  Same bar as assert_scan_equal, indices mapped through `keep`."""
+    assert want["angle_ties"] == 0 or ctx.endswith("[ties]"), ctx + ": input has angle ties; compare in canonical mode only"
+    assert got.ring_id.tolist() == want["ring_id"].tolist(), ctx + ": ring ids"
+    assert got.ring_count.tolist() == want["ring_count"].tolist(), ctx + ": ring counts"
+    assert np.array_equal(got.sorted_index, keep[want["sorted_index"]].astype(np.uint32)), ctx + ": ring projection (angle-sorted indices)"
+    assert np.array_equal(got.ring_status != 0, want["ring_status"] != 0), ctx + ": skipped rings differ"
+    bad = np.nonzero(got.labels[keep] != want["labels"])[0]
+    assert bad.size == 0, ctx + ": %d labels differ, first at kept point %d: got %d want %d" % (
+        bad.size, bad[0], got.labels[keep][bad[0]], want["labels"][bad[0]])
+    assert not got.labels[zero].any(), ctx + ": a dropped record carries a label"
+    assert got.curvature[keep].tobytes() == want["curvature"].tobytes(), ctx + ": curvature bits"
+    assert np.array_equal(got.edge_index, keep[want["edge_index"]].astype(np.uint32)), ctx + ": edge index set"
+    assert np.array_equal(got.surface_index, keep[want["surface_index"]].astype(np.uint32)), ctx + ": surface index set"
+    assert got.edge_points.tobytes() == want["edge_points"].tobytes(), ctx + ": edge cloud"
+    assert got.surface_points.tobytes() == want["surface_points"].tobytes(), ctx + ": surface cloud"

@@ -7,9 +7,11 @@ import numpy as np
 
 from lidar_feature_extraction_amd import FeatureExtraction, HyperParameters, make_scan
 from oracle import binding as OB
-from tests.parity import assert_scan_equal
+from lidar_feature_extraction_amd import binding as LB
+from tests.parity import assert_scan_equal, assert_filtered_equal
 
-ORDERS = ["sorted", "rotated", "reversed", "revrot", "shuffled", "ragged", "ragrot"]
+# ("zeros": a grid whose invalid returns are (0, 0, 0) records, zero filter on -- the holes form of the organised route)
+ORDERS = ["sorted", "rotated", "reversed", "revrot", "shuffled", "ragged", "ragrot", "zeros", "zeros"]
 
 
 def draw(rng):
@@ -38,6 +40,9 @@ def draw(rng):
         kw["shuffle"] = True
     if order in ("ragged", "ragrot"):
         kw["drop_fraction"] = float(rng.uniform(0.01, 0.4))
+    if order == "zeros":
+        # (share of the returns zeroed, a stretch of columns without a return, whether the context is told)
+        kw["_zeros"] = (float(rng.choice([0.0, 0.01, 0.05, 0.05, 0.15, 0.3])), int(rng.integers(0, 3)) == 0, int(rng.integers(0, 2)) == 0)
     seed = int(rng.integers(1, 1 << 30))
     sigma = float(rng.choice([0.01, 0.002, 0.03]))
     exact_cap = bool(rng.integers(0, 2))
@@ -47,7 +52,10 @@ def draw(rng):
 def run_case(case, rng):
     import os
     rings, cols, hp, order, kw, seed, sigma, exact_cap = draw(rng)
+    zeros = kw.pop("_zeros", None)
     clouds = [make_scan(rings, cols, seed=seed + i, sigma=sigma, **kw) for i in range(2)]
+    if zeros is not None:
+        return run_zeros_case(case, rng, rings, cols, hp, clouds, zeros, seed, exact_cap)
     # a third of the contexts that know the sensor look for rotated / reversed rings from the first batch on
     pin = bool(rng.integers(0, 3) == 0)
     if pin:
@@ -74,6 +82,41 @@ def run_case(case, rng):
     finally:
         f.close()
     return order
+
+
+def run_zeros_case(case, rng, rings, cols, hp, clouds, zeros, seed, exact_cap):
+    """A grid with (0, 0, 0) records against the oracle on the filtered cloud (assert_filtered_equal)."""
+    fraction, gap, hinted = zeros
+    masks = []
+    for i, c in enumerate(clouds):
+        z = rng.uniform(0.0, 1.0, len(c)) < fraction
+        if gap:
+            lo = int(rng.integers(0, cols))
+            width = int(rng.integers(1, max(2, cols // 3)))
+            z |= (np.arange(len(c)) // rings >= lo) & (np.arange(len(c)) // rings < lo + width) & (rng.uniform(0.0, 1.0, len(c)) < 0.9)
+        for f in ("x", "y", "z"):
+            c[f][z] = 0.0
+        masks.append(z)
+    f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=2, max_points_per_ring=cols if exact_cap else 0,
+                          max_rings=rings, drop_zero_points=True, stream_hint=LB.STREAM_GRID_WITH_HOLES if hinted else 0)
+    op = OB.Params(hp.padding, hp.neighbor_degree_threshold, hp.distance_diff_threshold, hp.parallel_beam_min_range_ratio,
+                   hp.edge_threshold, hp.surface_threshold, hp.min_range, hp.max_range, hp.n_blocks)
+    keeps = [np.nonzero(~z)[0] for z in masks]
+    want = []
+    for c, keep in zip(clouds, keeps):
+        w = OB.extract(np.ascontiguousarray(c[keep]), op, canonical_ties=False)
+        if w["angle_ties"] or w["curvature_ties"]:
+            w = OB.extract(np.ascontiguousarray(c[keep]), op, canonical_ties=True)
+        want.append(w)
+    try:
+        for rep in range(3):                       # (the route follows the report: plain form, holes form, the bucketing route)
+            got = f.extract_batch(clouds)
+            for i in range(len(clouds)):
+                assert_filtered_equal(got[i], want[i], keeps[i], masks[i], "case %d: %dx%d P%d B%d zeros %.2f%s%s rep%d scan%d seed%d[ties]" % (
+                    case, rings, cols, hp.padding, hp.n_blocks, fraction, " gap" if gap else "", " hinted" if hinted else "", rep, i, seed))
+    finally:
+        f.close()
+    return "zeros"
 
 
 def run_cases(n_cases, seed=7, report_every=0):

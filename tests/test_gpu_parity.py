@@ -705,6 +705,49 @@ def test_zero_point_filter_matches_the_upstream_converter():
     f2.close()
 
 
+def test_ring_ids_are_whatever_uint16_the_points_carry():
+    """The reference buckets by the id a point carries (an unordered_map<int, ...> over a uint16 field, ring.hpp:114-125,
+    point_type.hpp:62-86): ids need not be 0 .. rings-1.  The host entry point looks the ids of such a scan up itself; the
+    device path is told (lfx_config.ring_ids / lfx_set_ring_ids).  LFX_ERR_RING_ID is left for more distinct ids than a
+    context takes."""
+    import torch
+    base = make_scan(3, 900, seed=77)
+    c = base.copy()
+    c["ring"] = np.array([0, 300, 65535], np.uint16)[base["ring"]]
+    want = OB.extract(c, canonical_ties=False)
+    assert want["ring_id"].tolist()[:3] == [0, 300, 65535]
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=2, max_points_per_ring=900, max_rings=3)
+    got = f.ExtractFeatures(c)                       # (the first call finds an id it does not know, looks them up, runs again)
+    assert_scan_equal(got, want, "looked up")
+    assert_scan_equal(f.ExtractFeatures(c), want, "second call")
+    assert_scan_equal(f.ExtractFeatures(base), OB.extract(base, canonical_ties=False), "a scan with ids 0 .. 2 next: looked up again")
+    f.close()
+    # told at creation: the device path, ids in any order
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=2, max_points_per_ring=900, max_rings=3, ring_ids=[65535, 0, 300])
+    d = torch.from_numpy(c.view(np.uint8)).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    f.extract_batch_device(d.data_ptr(), np.array([len(c)], np.uint32), st)
+    assert_scan_equal(f.download(0, st), want, "device path, ids given")
+    f.set_ring_ids(None)                             # ... and taken back: ids 0 .. 2 again, the organised route with them
+    d0 = torch.from_numpy(base.view(np.uint8)).to("cuda:0")
+    for _ in range(2):
+        f.extract_batch_device(d0.data_ptr(), np.array([len(base)], np.uint32), st)
+    assert f.scan_routes(1, st).tolist() == [1]
+    assert_scan_equal(f.download(0, st), OB.extract(base, canonical_ties=False), "ids taken back")
+    f.close()
+    # more distinct ids than the context takes: the error that is left
+    many = make_scan(8, 400, seed=78)
+    many["ring"] = (many["ring"].astype(np.uint32) * 1000 + 7).astype(np.uint16)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(many), max_batch=1, max_points_per_ring=400, max_rings=4)
+    with pytest.raises(LB.LfxError) as e:
+        f.ExtractFeatures(many)
+    assert e.value.code == -5 and "distinct ring ids" in str(e.value)
+    f.close()
+    f = FeatureExtraction(device=0, max_points_per_scan=len(many), max_batch=1, max_points_per_ring=400, max_rings=8)
+    assert_scan_equal(f.ExtractFeatures(many), OB.extract(many, canonical_ties=False), "eight ids of a thousand apart")
+    f.close()
+
+
 def _zeroed(c, fraction, seed, columns=None, rings=None):
     """A copy of grid scan c with a share of its returns written as (0, 0, 0) records (or whole columns / rings of them)."""
     c = c.copy()

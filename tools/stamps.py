@@ -18,11 +18,19 @@ NAMES = ["entry->checks", "boundaries", "A load", "B range", "C order+links+jump
          "E curvature", "F order masks + D occlusion+reach", "F edge pass", "F surface pass + labels word", "G labels+curvature+records"]
 batch, rings, cols = 256, 64, 1800
 clouds = [make_scan(rings, cols, seed=1234 + i) for i in range(8)]
+# --holes FRACTION: that share of the returns written as (0, 0, 0) records, zero filter on: the HOLES form of the kernel
+holes = float(sys.argv[sys.argv.index("--holes") + 1]) if "--holes" in sys.argv else 0.0
+if holes > 0.0:
+    for j, c in enumerate(clouds):
+        gone = np.random.Generator(np.random.PCG64(99 + j)).uniform(0.0, 1.0, len(c)) < holes
+        for f in ("x", "y", "z"):
+            c[f][gone] = 0.0
 tiled = [clouds[i % 8] for i in range(batch)]
 d = torch.from_numpy(concat(tiled).view(np.uint8)).cuda()
 n = np.array([len(c) for c in tiled], np.uint32)
 fx = FeatureExtraction(HyperParameters(), device=0, max_points_per_scan=len(clouds[0]), max_batch=batch,
-                       max_points_per_ring=cols, max_rings=rings)
+                       max_points_per_ring=cols, max_rings=rings, drop_zero_points=holes > 0.0,
+                       stream_hint=B.STREAM_GRID_WITH_HOLES if holes > 0.0 else 0)
 for _ in range(5):
     fx.extract_batch_device(d.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
@@ -52,6 +60,12 @@ if "--skew" in sys.argv:
     for u in range(len(t)):
         byx.setdefault((u // 6 // 4) % 8, []).append(t1[u] - first)
     print("mean end per ring group mod 8 (the XCDs, before the groups are turned): " + " ".join("%d:%.1f" % (k, np.mean(v) / 100.0) for k, v in sorted(byx.items())))
+if holes > 0.0:
+    # the holes form's stage A: 0 = head loads asked for, 13 = geometry and piece range known (the prefix rows have arrived),
+    # 14 = records loaded and scattered into the slabs, 1 = hand-over barrier passed
+    for a, b, what in ((0, 13, "head: prefix rows + geometry + piece range"), (13, 14, "record loads + scatter"), (14, 1, "hand-over barrier")):
+        dt = t[:, b] - t[:, a]
+        print("%-44s median %6d  p90 %6d" % (what, np.median(dt), np.percentile(dt, 90)))
 life = t[:, 10] - t[:, 0]
 print("lifetime (stamp 0 -> 10): median %d  p10 %d  p90 %d shader cycles" % (np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
 stages = {}
