@@ -95,7 +95,7 @@ EXPORTS = [
     "lfx_localize_batch", "lfx_localize_host",
     "lfx_layout_from_fields", "lfx_pack_xyz", "lfx_pack_xyz12", "lfx_pack_colored", "lfx_pack_features", "lfx_download_scan", "lfx_stage_ring", "lfx_stage_convolution1d",
     "lfx_stage_ring_projection", "lfx_label_to_color", "lfx_color_points_by_label", "lfx_set_profiling", "lfx_set_profiling_interval", "lfx_kernel_times", "lfx_kernel_name",
-    "lfx_route_choice", "lfx_set_log_callback", "lfx_box_calibration", "lfx_gather_counts_slot", "lfx_gather_payload2",
+    "lfx_route_choice", "lfx_set_log_callback", "lfx_box_calibration", "lfx_gather_counts_slot", "lfx_gather_payload2", "lfx_set_ring_ids",
 ]
 """Every symbol include/lfx.h declares (tests/test_abi.py checks the library exports each)."""
 

@@ -1228,8 +1228,12 @@ int extract_batch_impl(
     if (wide) {return fail(c, LFX_ERR_RING_ID, "a point carries a ring id above 65535 (the reference's ring field is a uint16, point_type.hpp:62-86)");}
     std::vector<uint16_t> ids;
     for (uint32_t id = 0; id < 65536u; id++) {if (seen[id]) {ids.push_back((uint16_t)id);}}
-    // (ids the context already knows stay: a sensor's rings need not all show up in every scan)
-    for (uint16_t id : c->slot_id) {if (!seen[id]) {ids.push_back(id);}}
+    // (ids the context already knows stay while there is room: a sensor's rings need not all show up in every scan)
+    {
+      std::vector<uint16_t> both = ids;
+      for (uint16_t id : c->slot_id) {if (!seen[id]) {both.push_back(id);}}
+      if (both.size() <= c->max_rings) {ids = both;}
+    }
     rc = install_ring_ids(c, ids.data(), (uint32_t)ids.size(), false);
     if (rc != LFX_OK) {return rc;}
     rc = run_batch(c, c->staging.p, n32.data(), batch, c->stream);

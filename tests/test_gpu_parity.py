@@ -482,12 +482,30 @@ def test_curvature_ties_canonical(fx):
     assert_scan_equal(got, want, "curvties[ties]")
 
 
-def test_error_on_ring_id_out_of_range(fx):
+def test_a_stray_ring_id_is_a_ring_of_its_own():
+    """One point with an id no other point has: the reference gives it a ring of its own (ring.hpp:114-125), which
+    RemoveSparseRings then drops (ring.cpp:46-59).  (Until round 6: LFX_ERR_RING_ID for the whole call.)  On the device path,
+    where the library has no copy of the records to look ids up in, the error stands until the caller names the ids."""
+    import torch
     c = make_scan(4, 200, seed=1)
     c["ring"][17] = 300
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=8)
+    want = OB.extract(c, canonical_ties=False)
+    assert 300 in want["ring_id"].tolist()
+    assert_scan_equal(f.ExtractFeatures(c), want, "stray id")
+    f.close()
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=8)
+    d = torch.from_numpy(c.view(np.uint8)).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    f.extract_batch_device(d.data_ptr(), np.array([len(c)], np.uint32), st)
     with pytest.raises(LB.LfxError) as e:
-        fx.ExtractFeatures(c)
+        f.batch_status(st)
     assert e.value.code == -5
+    f.set_ring_ids([0, 1, 2, 3, 300])
+    f.extract_batch_device(d.data_ptr(), np.array([len(c)], np.uint32), st)
+    f.batch_status(st)
+    assert_scan_equal(f.download(0, st), want, "stray id, device path, ids named")
+    f.close()
 
 
 def test_capacity_errors():
