@@ -131,7 +131,9 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
                        hp.edge_threshold, hp.surface_threshold, hp.min_range, hp.max_range, hp.n_blocks)
     fx = FeatureExtraction(hp, device=dev.index, max_points_per_scan=max(len(c) for c in clouds), max_batch=batch,
                            max_points_per_ring=max(cols, 64), max_rings=rings, drop_zero_points=drop_zero_fraction > 0.0,
-                           outputs=0 if curvature else (LB.OUT_FEATURES | LB.OUT_LABELS | LB.OUT_SORTED_INDEX))
+                           outputs=0 if curvature else (LB.OUT_FEATURES | LB.OUT_LABELS | LB.OUT_SORTED_INDEX),
+                           # (what the caller knows about its stream: spares the first batch the plain form's refusal)
+                           stream_hint=LB.STREAM_GRID_WITH_HOLES if drop_zero_fraction > 0.0 else 0)
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(warmup):
         fx.extract_batch_device(d_points.data_ptr(), n_list, stream)
@@ -243,7 +245,8 @@ def main():
         n_streams = 2
     hp_main = HyperParameters.launch_yaml() if a.params == "launch_yaml" else HyperParameters()
     fxs = [FeatureExtraction(hp_main, device=local_rank, max_points_per_scan=n_pts, max_batch=a.batch,
-                             max_points_per_ring=cap, max_rings=a.rings, drop_zero_points=a.drop_zero) for _ in range(n_streams)]
+                             max_points_per_ring=cap, max_rings=a.rings, drop_zero_points=a.drop_zero,
+                             stream_hint=3 if (a.drop_zero and a.drop_fraction > 0) else 0) for _ in range(n_streams)]      # (3 = LFX_STREAM_GRID_WITH_HOLES)
     fx = fxs[0]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     if will_gather:
@@ -531,10 +534,14 @@ def main():
     algo_bytes = 25 * pts_batch + 16 * feat_batch
     achieved = algo_bytes / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9
     traffic, traffic_stale = None, False              # not measured in this run: read from the committed PMC profile of this workload
+    tj = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
+            # (one section per workload: "<rings>x<cols>x<batch>", "+zeros" for the grid with (0, 0, 0) records -- tools/merge_pmc.py)
+            key = "%dx%dx%d%s" % (a.rings, a.cols, a.batch, "+zeros" if a.drop_zero and a.drop_fraction > 0 else "")
+            tj = tj.get("sections", {}).get(key, tj if "sections" not in tj else {})
             if tj.get("batch") == a.batch and tj.get("rings") == a.rings and tj.get("cols") == a.cols:
                 # the counters were collected on kernels whose source the file names by hash; after an edit they say nothing
                 if tj.get("kernels_sha256") == kernels_sha256():

@@ -399,7 +399,11 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     const lfx::ScatterArgs sc{pts, c->layout, c->scan_begin.p, c->chunk_base.p, c->chunk_flags.p, c->ring_count.p, c->scan_info.p, scan_flags,
       c->sxy.p, c->sz.p, c->sidx.p, c->max_chunks, c->max_rings, c->cap, c->drop_zero};
     const uint32_t turns = (batch + lfx::kTailMaxTurns - 1u) / lfx::kTailMaxTurns;
-    const dim3 grid(chunks, fb_grid > turns ? fb_grid : turns);
+    // (two rows of workgroups, not the eight the list routes guess: this route is only taken while nothing has been falling
+    // back, the rows walk a list that turns out longer, and 1 024 workgroups of 80 KB of LDS that read one word and leave
+    // were 6 us of a 98 us step at 128 x 2048 x 32)
+    const uint32_t rows = fb_grid < 2u ? fb_grid : 2u;
+    const dim3 grid(chunks, rows > turns ? rows : turns);
     if (canon) {
       hipLaunchKernelGGL(lfx::fallback_tail_kernel<true>, grid, dim3(lfx::kChunkThreads), c->ring_lds, st, sc, ex, fb_count, c->fb_list.p, c->tail_ticket.p);
     } else {

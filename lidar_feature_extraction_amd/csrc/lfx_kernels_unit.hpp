@@ -1455,7 +1455,7 @@ constexpr int unit_list_waves_per_simd(int ch, int variant, bool loop)
 {
   // (variant 2 stages 128 records per unit from 5 chunks on: a workgroup per CU fewer there too)
   const int w = unit_waves_per_simd(ch, variant, true) - (variant == 2 && ch >= 5 ? 1 : 0);
-  return loop ? (w > 4 ? w - 3 : (w > 1 ? w - 1 : 1)) : w;
+  return loop ? (w > 4 ? (w - 3 < 4 ? w - 3 : 4) : (w > 1 ? w - 1 : 1)) : w;
 }
 template<int V, bool SECOND, int CH, bool LOOP = false>
 __global__ __launch_bounds__(64 * kUnitWaves, unit_list_waves_per_simd(CH, V, LOOP)) void ring_unit_kernel(
