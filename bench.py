@@ -677,7 +677,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
             import localize_bench
-            one = localize_bench.run(rings=a.rings, cols=a.cols, batch=1, map_scans=16, steps=9, device=local_rank, kd_scans=1)
+            one = localize_bench.run(rings=a.rings, cols=a.cols, batch=1, map_scans=16, steps=9, device=local_rank, kd_scans=1, cpu_scans=1)
             many = localize_bench.run(rings=a.rings, cols=a.cols, batch=32, map_scans=16, steps=3, device=local_rank)
         except Exception as e:             # noqa: BLE001  (a side measurement must not cost the line its headline)
             one = many = None
@@ -688,7 +688,12 @@ def main():
                         "surface_map_points": one["surface_map_points"],
                         # the consumer's own baseline and roof: a KD-tree on this host (search only: a lower bound of the reference's
                         # Update) and the bytes its neighbour search has to read over the time the whole Update takes
-                        "cpu_baseline": dict(one["kdtree_host"], unit="ms/scan", kind="port"),
+                        "cpu_baseline": dict(one["kdtree_host"], unit="ms/scan", kind="port",
+                                             # the oracle's own Update of the same scan (oracle/lfx_oracle_loc.cpp: Optimizer::Run with an
+                                             # exhaustive neighbour search where the reference walks a KD-tree), one core
+                                             oracle_update_ms_per_scan=one.get("cpu_oracle_ms_per_scan"),
+                                             oracle_update_note=one.get("cpu_oracle_note"),
+                                             max_pose_difference_to_oracle=one.get("max_pose_difference_to_oracle")),
                         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                      "achieved": round(one["search_bytes_per_scan"] / (1e-3 * one["localize_ms_per_scan"]) / 1e9, 2),
                                      "frac": round(one["search_bytes_per_scan"] / (1e-3 * one["localize_ms_per_scan"]) / 1e9 / HBM_PEAK_GBS, 5),
