@@ -1110,7 +1110,10 @@ __device__ inline uint8_t process_ring(
 // them, and leaves per ring the exclusive prefix of its valid returns over the pieces (cum16, 2 B per ring and piece: 15 KB
 // per 64 x 1800 scan) and the ring's length (ring_count).  It reads every record's ring id, so the unit kernel need not: a
 // scan that is not the grid it claims to be goes on the fall-back list here.
-constexpr int kCountUnroll = 4;
+#ifndef LFX_COUNT_UNROLL
+#define LFX_COUNT_UNROLL 4
+#endif
+constexpr int kCountUnroll = LFX_COUNT_UNROLL;       // (pieces in flight per wave; A/B: -DLFX_COUNT_UNROLL=n)
 __global__ __launch_bounds__(256) void grid_count_kernel(
   const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ geom, uint32_t R,
   uint32_t stride /* cum_stride(ring capacity) */, uint16_t * __restrict__ cum16, uint32_t * __restrict__ ring_count,

@@ -995,7 +995,9 @@ __device__ __forceinline__ uint32_t unit_core(
       if (own) {
         label_u[(uint32_t)q] = (uint8_t)l;
         if (curv_s != nullptr) {curv_u[(uint32_t)q] = cv;}       // (wave-uniform: a context created without LFX_OUT_CURVATURE has no such array)
+#ifndef LFX_WHATIF_NO_SIDX       // (diagnostic: what the holes form's index array costs; downloads of such scans are wrong without it)
         if constexpr (SIDX) {sidx_u[(uint32_t)q] = src[k];}
+#endif
       }
       const uint64_t fe = bal(l == kEdge), fs = bal(l == kSurface);
       lab[k] = l;

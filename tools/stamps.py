@@ -16,8 +16,12 @@ from lidar_feature_extraction_amd import binding as B
 # sync; the labels' way back to the chunk form belongs to the surface pass's slot)
 NAMES = ["entry->checks", "boundaries", "A load", "B range", "C order+links+jumps+range+beam", "(sync)",
          "E curvature", "F order masks + D occlusion+reach", "F edge pass", "F surface pass + labels word", "G labels+curvature+records"]
-batch, rings, cols = 256, 64, 1800
-clouds = [make_scan(rings, cols, seed=1234 + i) for i in range(8)]
+def _opt(name, default):
+    return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+
+
+batch, rings, cols = _opt("--batch", 256), _opt("--rings", 64), _opt("--cols", 1800)      # (the stamped scan is LFX_STAMP_SCAN = 128: batch > 128)
+clouds = [make_scan(rings, cols, seed=1234 + i, vfov_deg=22.5 if rings >= 128 else 15.0) for i in range(8)]
 # --holes FRACTION: that share of the returns written as (0, 0, 0) records, zero filter on: the HOLES form of the kernel
 holes = float(sys.argv[sys.argv.index("--holes") + 1]) if "--holes" in sys.argv else 0.0
 if holes > 0.0:
