@@ -248,6 +248,68 @@ def test_route_follows_the_stream_while_the_host_runs_ahead():
     f.close()
 
 
+def test_batches_of_changing_size_and_stream_on_one_context():
+    """No reset launch stands in front of an organised batch (round 6): the batch's accumulators exist twice and every batch's
+    compaction zeroes the other set over the scans the batch before last dirtied there; the bucketing route's tables are
+    reset when a batch takes that route or follows one that did.  Batch sizes and streams change from call to call here --
+    large after small, organised after shuffled after organised, a scan that falls back in an otherwise clean batch, an
+    empty scan, zero records with the filter on -- and every scan of every batch must equal the oracle."""
+    import torch
+    from lidar_feature_extraction_amd import concat
+    R, C = 16, 600
+    st = torch.cuda.current_stream().cuda_stream
+    f = FeatureExtraction(device=0, max_points_per_scan=R * C, max_batch=12, max_points_per_ring=C, max_rings=R, drop_zero_points=True)
+    plain = [make_scan(R, C, seed=3100 + i) for i in range(12)]
+    shuffled = [make_scan(R, C, seed=3200 + i, shuffle=True) for i in range(12)]
+    ragged = [make_scan(R, C, seed=3300 + i, drop_fraction=0.1) for i in range(12)]
+    rotated = [make_scan(R, C, seed=3400 + i, start_col=77) for i in range(12)]
+    zeroed = [_zeroed(make_scan(R, C, seed=3500 + i), 0.06, 70 + i) for i in range(12)]
+    empty = plain[0][:0]
+    want = {}
+
+    def oracle_of(c, zero=None):
+        key = (c.ctypes.data, len(c))
+        if key not in want:
+            keep = np.arange(len(c)) if zero is None else np.nonzero(~zero)[0]
+            want[key] = (OB.extract(np.ascontiguousarray(c[keep]), canonical_ties=False), keep, np.zeros(len(c), bool) if zero is None else zero)
+        return want[key]
+
+    def run(scans, zeros=None, what=""):
+        d = torch.from_numpy(concat(scans).view(np.uint8).copy()).cuda() if sum(len(c) for c in scans) else torch.zeros(32, dtype=torch.uint8).cuda()
+        f.extract_batch_device(d.data_ptr(), np.array([len(c) for c in scans], np.uint32), st)
+        for k, c in enumerate(scans):
+            g = f.download(k, st)
+            if len(c) == 0:
+                assert len(g.labels) == 0 and len(g.edge_index) == 0 and len(g.surface_index) == 0 and len(g.ring_id) == 0, what + ": empty scan %d" % k
+                continue
+            w, keep, z = oracle_of(c, None if zeros is None else zeros[k])
+            from tests.parity import assert_filtered_equal
+            assert_filtered_equal(g, w, keep, z, "%s scan %d" % (what, k))
+        torch.cuda.synchronize()
+
+    run(plain[:12], what="12 organised")
+    run(plain[:12], what="12 organised again (one-launch tail from here on)")
+    run(plain[:3], what="3 organised after 12")
+    run(plain[:12], what="12 organised after 3 (the other set was dirtied over 12 scans two batches ago)")
+    run([plain[0], rotated[1], plain[2], empty, plain[4]], what="a rotated scan and an empty one among organised ones (the tail redoes the rotated one)")
+    run(plain[:12], what="12 organised after a fall-back")
+    run(shuffled[:5], what="5 shuffled (the list routes: the reset kernel runs)")
+    run(shuffled[:5], what="5 shuffled again")
+    for k in range(4):
+        run(shuffled[:7], what="7 shuffled, batch %d (the stream moves to the bucketing route)" % k)
+    run(plain[:12], what="12 organised after bucketing batches")
+    for k in range(20):
+        run(plain[:2 + (5 * k) % 11], what="organised, changing sizes, batch %d" % k)
+    run([c for c, _ in zeroed[:6]], [z for _, z in zeroed[:6]], what="6 with zero records (plain form refuses them)")
+    for k in range(4):
+        run([c for c, _ in zeroed[:1 + 3 * k]], [z for _, z in zeroed[:1 + 3 * k]], what="zero records, batch %d (the holes form after the report)" % k)
+    run(ragged[:9], what="9 ragged after the holes form")
+    run(plain[:12], what="12 organised at the end")
+    run([empty, empty], what="two empty scans")
+    run(plain[:4], what="4 organised after an empty batch")
+    f.close()
+
+
 @pytest.mark.parametrize("tail", [None, "short"])
 def test_organised_scan_kernel_more_fall_backs_than_expected(tail):
     """The bucketing route is launched for as many scans as earlier batches sent to it (plus a few); scans beyond
