@@ -457,7 +457,10 @@ def main():
             dist.all_gather(every, mine)
         else:
             every = [mine]
-        return [dict(zip(keys, [int(v) for v in t.cpu().tolist()])) for t in every]
+        out_stats = [dict(zip(keys, [int(v) for v in t.cpu().tolist()])) for t in every]
+        for st in out_stats:
+            st["bytes_match"] = bool(st["bytes_match"])
+        return out_stats
 
     comm_stats, dst0 = None, None
     if use_gather:

@@ -89,6 +89,14 @@ public:
   FeatureExtraction(const FeatureExtraction &) = delete;
   FeatureExtraction & operator=(const FeatureExtraction &) = delete;
 
+  // The sensor's ring ids where they are not 0 .. rings-1 (the reference buckets by whatever uint16 a point carries,
+  // ring.hpp:114-125).  ExtractFeatures finds them by itself; a caller that knows them spares the first scan a second run.
+  void SetRingIds(const std::vector<std::uint16_t> & ids) const
+  {
+    const int rc = lfx_set_ring_ids(ctx_, ids.empty() ? nullptr : ids.data(), static_cast<std::uint32_t>(ids.size()));
+    if (rc != LFX_OK) {throw Error(rc, lfx_last_error(ctx_));}
+  }
+
   // A point buffer in pinned host memory, owned by this object: lfx_extract reads it by DMA (a buffer from anywhere
   // else is first copied through the context's staging buffer).  Let GetPointCloud fill it.
   PointXYZIR * PinnedPoints(std::size_t capacity)
