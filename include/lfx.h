@@ -184,9 +184,12 @@ typedef struct lfx_scan_result {
  * scan_info[s][1] carries error bits (1: a ring id >= max_rings, 4: bucketing timed out -- lfx_batch_status turns
  * them into a return code) and the route the scan took: (bits & LFX_SCAN_ROUTE_MASK) == LFX_SCAN_ORGANISED means the
  * scan arrived column-major with ring == index mod max_rings and was read in place: position k of ring r IS input
- * point k * max_rings + r and sorted_index holds nothing for that scan. */
+ * point k * max_rings + r and sorted_index holds nothing for that scan.  Any other value: sorted_index holds every ring
+ * position's original index -- a bucketed scan, or (bit LFX_SCAN_GRID_WITH_HOLES, without LFX_SCAN_ORGANISED) a grid with
+ * (0, 0, 0) records that the zero filter dropped, read in place (lfx_scan_routes: 3). */
 #define LFX_SCAN_ROUTE_MASK 0x300u
 #define LFX_SCAN_ORGANISED 0x100u
+#define LFX_SCAN_GRID_WITH_HOLES 0x800u
 typedef struct lfx_device_view {
   uint32_t batch;
   uint32_t max_rings;             /* ring ids the layout has room for                            */

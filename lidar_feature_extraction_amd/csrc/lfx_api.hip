@@ -1130,7 +1130,7 @@ int lfx_scan_routes(lfx_ctx * c, void * stream, uint8_t * routes)
   LFX_HIP(c, hipStreamSynchronize(st));
   for (uint32_t s = 0; s < c->last_batch; s++) {
     const uint32_t e = c->h_status[s * 4 + lfx::kInfoError];
-    routes[s] = lfx::scan_is_organised(e) ? ((e & lfx::kScanHoles) ? 3 : (c->last_used_xform ? 2 : 1)) : 0;
+    routes[s] = lfx::scan_took_holes(e) ? 3 : (lfx::scan_is_organised(e) ? (c->last_used_xform ? 2 : 1) : 0);
   }
   return LFX_OK;
 }

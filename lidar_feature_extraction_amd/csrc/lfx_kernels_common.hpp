@@ -105,6 +105,9 @@ enum { kInfoRings = 0, kInfoError = 1, kInfoEdge = 2, kInfoSurface = 3 };
 enum : uint32_t { kErrRingId = 1u, kErrTimeout = 4u, kScanFused = 0x100u, kScanFellBack = 0x200u, kScanOrderFell = 0x400u,
                   kScanHoles = 0x800u, kScanZeroFell = 0x1000u, kScanCountFell = 0x2000u };
 __host__ __device__ inline bool scan_is_organised(uint32_t err) {return (err & (kScanFused | kScanFellBack)) == kScanFused;}
+// The PUBLISHED word of a holes scan (scan_info, feature_compact_kernel) carries kScanHoles WITHOUT kScanFused: to a caller that
+// tests (bits & 0x300) == 0x100 (include/lfx.h, LFX_SCAN_ORGANISED) such a scan is one whose sorted_index is valid -- it is.
+__host__ __device__ inline bool scan_took_holes(uint32_t err) {return (err & (kScanHoles | kScanFellBack)) == kScanHoles;}
 // ... and its positions are its columns (no index array): the plain organised form
 __host__ __device__ inline bool scan_is_grid(uint32_t err) {return (err & (kScanFused | kScanFellBack | kScanHoles)) == kScanFused;}
 // counters[kCounters] (one block per batch parity, see kParityCounters): rings deferred by the first unit pass, repaired after it, sent to the workgroup-per-ring

@@ -1991,17 +1991,19 @@ __global__ __launch_bounds__(256) void feature_compact_kernel(
     // The scan's flag word becomes part of its results here (the batch's kernels OR into a word of their own set, which the
     // NEXT batch's compaction zeroes again; scan_info itself is only ever written).  An empty scan has been through no kernel
     // that writes its rows: no rings, no features -- and what the tables still hold of an earlier batch is not its.
+    // (a holes scan is published without kScanFused: lfx_kernels_common.hpp scan_took_holes)
+    const uint32_t err_pub = (err & kScanHoles) != 0u ? (err & ~(uint32_t)kScanFused) : err;
     if (n_scan == 0u) {
       if (lane == 0) {
         ring_count_w[s * kRings + slot] = 0u;
         if (slot == 0u) {
-          scan_info[s * 4 + kInfoRings] = 0u; scan_info[s * 4 + kInfoError] = err;
+          scan_info[s * 4 + kInfoRings] = 0u; scan_info[s * 4 + kInfoError] = err_pub;
           scan_info[s * 4 + kInfoEdge] = 0u; scan_info[s * 4 + kInfoSurface] = 0u;
         }
       }
       return;
     }
-    if (slot == 0u && lane == 0) {scan_info[s * 4 + kInfoError] = err;}
+    if (slot == 0u && lane == 0) {scan_info[s * 4 + kInfoError] = err_pub;}
     if (slot == max_rings - 1u && (err & (kScanHoles | kScanFellBack)) == kScanHoles) {
       // a grid with holes read in place: its rings are those that kept a point (the other routes write the number themselves)
       uint32_t occupied = 0;

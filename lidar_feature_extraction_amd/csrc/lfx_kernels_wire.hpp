@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void colored_pack_kernel(
 {
   const uint32_t s = blockIdx.y, ring = blockIdx.x, tid = threadIdx.x;
   if (ring_status[s * kRings + ring] != kOk) {return;}
-  const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]);     // nothing was staged: every field from the record
+  const bool org = scan_is_organised(scan_info[s * 4 + kInfoError]) || scan_took_holes(scan_info[s * 4 + kInfoError]);     // nothing was staged: every field from the record
   const bool grid = scan_is_grid(scan_info[s * 4 + kInfoError]);         // ... and the index from the position (the holes form keeps sidx)
   __shared__ uint32_t before;
   if (tid == 0) {before = 0;}

@@ -1099,6 +1099,62 @@ def test_wire_payloads_of_the_three_published_clouds(fx):
     assert 7 not in [int(r) for r, st in zip(w1["ring_id"], w1["ring_status"]) if st == 0]    # the sparse ring is left out
 
 
+def test_wire_payloads_and_route_word_of_a_grid_with_holes():
+    """The consumers of a scan read in place as a grid with zero records (route 3): colored_scan takes x, y, z from the
+    input records and the index from sorted_index; the published route word carries LFX_SCAN_GRID_WITH_HOLES without
+    LFX_SCAN_ORGANISED, so that a caller written against the two-route contract ((bits & 0x300) == 0x100: positions are
+    columns, no index array) treats it as a scan whose sorted_index is valid -- which it is."""
+    import torch
+    R, C = 16, 900
+    c, zero = _zeroed(make_scan(R, C, seed=97), 0.05, 9)
+    keep = np.nonzero(~zero)[0]
+    want = OB.extract(np.ascontiguousarray(c[keep]), canonical_ties=False)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_points_per_ring=C, max_rings=R, drop_zero_points=True,
+                          stream_hint=LB.STREAM_GRID_WITH_HOLES)
+    dev = torch.from_numpy(c.view(np.uint8).copy()).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    f.extract_batch_device(dev.data_ptr(), [len(c)], st)
+    assert f.scan_routes(1, st).tolist() == [3]
+    v = f.device_view()
+    info = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    hip = LB.C.CDLL("libamdhip64.so")
+    hip.hipMemcpy(LB.C.c_void_p(info.data_ptr()), LB.C.cast(v.scan_info, LB.C.c_void_p), 16, 3)
+    bits = int(info.cpu().numpy().view(np.uint32)[1])
+    assert (bits & 0x300) != 0x100 and (bits & 0x800) == 0x800, hex(bits)
+    sidx = torch.zeros(R * ((C + 63) // 64 * 64), dtype=torch.int32, device="cuda:0")
+    hip.hipMemcpy(LB.C.c_void_p(sidx.data_ptr()), LB.C.cast(v.sorted_index, LB.C.c_void_p), sidx.numel() * 4, 3)
+    cap = v.ring_capacity
+    sidx = sidx.cpu().numpy().view(np.uint32)
+    at = 0
+    for rid, cnt in zip(want["ring_id"], want["ring_count"]):
+        assert np.array_equal(sidx[rid * cap:rid * cap + cnt], keep[want["sorted_index"][at:at + cnt]].astype(np.uint32)), "sorted_index of ring %d" % rid
+        at += cnt
+    n = len(c)
+    col = torch.zeros((n, 8), dtype=torch.float32, device="cuda:0")
+    coffs = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    f.pack_colored(col.data_ptr(), coffs.data_ptr(), n, st)
+    e = torch.zeros((n, 4), dtype=torch.float32, device="cuda:0")
+    s2 = torch.zeros((n, 4), dtype=torch.float32, device="cuda:0")
+    offs = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    f.pack_xyz(e.data_ptr(), s2.data_ptr(), offs.data_ptr(), n, st)
+    torch.cuda.synchronize()
+    col, coffs, e, s2, offs = col.cpu().numpy(), coffs.cpu().numpy(), e.cpu().numpy(), s2.cpu().numpy(), offs.cpu().numpy()
+    order = []
+    at = 0
+    for rid, cnt, stt in zip(want["ring_id"], want["ring_count"], want["ring_status"]):
+        if stt == 0:
+            order.extend(keep[want["sorted_index"][at:at + cnt]])
+        at += cnt
+    order = np.asarray(order, dtype=np.int64)
+    got = col[coffs[0]:coffs[1]]
+    assert len(got) == len(order)
+    assert np.array_equal(got[:, 0], c["x"][order]) and np.array_equal(got[:, 1], c["y"][order]) and np.array_equal(got[:, 2], c["z"][order])
+    ei, si = keep[want["edge_index"]], keep[want["surface_index"]]
+    assert offs[1] - offs[0] == len(ei) and offs[3] - offs[2] == len(si)
+    assert np.array_equal(e[offs[0]:offs[1], 0], c["x"][ei]) and np.array_equal(s2[offs[2]:offs[3], 2], c["z"][si])
+    f.close()
+
+
 def test_ring_id_beyond_max_rings_is_an_error():
     c = make_scan(8, 300, seed=3)
     f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=4)
