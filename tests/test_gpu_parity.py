@@ -556,6 +556,20 @@ def test_a_stray_ring_id_is_a_ring_of_its_own():
     assert 300 in want["ring_id"].tolist()
     assert_scan_equal(f.ExtractFeatures(c), want, "stray id")
     f.close()
+    # ... and ids looked up in one odd scan do not keep a stream of ids 0 .. rings-1 off the organised route: when a later scan
+    # carries an id the table does not hold and both sets together exceed the context's rings, the new scan's ids stand alone
+    odd = make_scan(8, 300, seed=5)
+    odd["ring"][odd["ring"] == 7] = 300
+    plain8 = make_scan(8, 300, seed=6)
+    f = FeatureExtraction(device=0, max_points_per_scan=len(odd), max_batch=1, max_points_per_ring=300, max_rings=8)
+    assert_scan_equal(f.ExtractFeatures(odd), OB.extract(odd, canonical_ties=False), "ring 7 numbered 300")
+    routes = []
+    for k in range(4):
+        g = f.ExtractFeatures(plain8)
+        routes.append(int(f.scan_routes(1, 0)[0]))
+    assert routes[-1] == 1, routes
+    assert_scan_equal(g, OB.extract(plain8, canonical_ties=False), "ids 0 .. 7 again")
+    f.close()
     f = FeatureExtraction(device=0, max_points_per_scan=len(c), max_batch=1, max_rings=8)
     d = torch.from_numpy(c.view(np.uint8)).to("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
