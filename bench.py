@@ -175,6 +175,15 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
     fx.close()
     del d_points
     torch.cuda.empty_cache()
+    # the dominant kernel's real HBM bytes, where the committed PMC profile has a section for this workload measured on these sources
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        sec = tj.get("sections", {}).get("%dx%dx%d%s" % (rings, cols, batch, "+zeros" if drop_zero_fraction > 0.0 else ""))
+        if sec and sec.get("kernels_sha256") == kernels_sha256() and curvature and params == "code defaults":
+            traffic = sec.get("hbm_bytes_per_launch", {}).get(dominant)
+    except Exception:
+        traffic = None
     name = WORKLOADS.get((rings, cols), "%dx%d" % (rings, cols))
     if drop_zero_fraction > 0.0:
         name += ", %.0f %% of the returns written as (0, 0, 0) and filtered (convert.py:162-163)" % (100 * drop_zero_fraction)
@@ -186,6 +195,7 @@ def side_config(dev, rings, cols, batch, steps, warmup, drop_zero_fraction=0.0, 
             "ms_per_step": round(1e3 * dt / steps, 4), "dominant_kernel": dominant,
             "frac": round(algo / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
             "whole_path_frac": round(algo / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "traffic_gbs": (round(traffic / (max(per_launch_us[dominant], 1e-9) * 1e-6) / 1e9, 1) if traffic else None),
             "kernel_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items() if v > 0}, "parity_spot_check": parity}
 
 
