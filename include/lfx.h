@@ -177,11 +177,12 @@ typedef struct lfx_scan_result {
 } lfx_scan_result;
 
 /* Device-resident results of the last lfx_extract_batch_device call (device pointers owned by
- * the context).  Per-point outputs are RING-MAJOR with a fixed capacity per ring id: ring r of
+ * the context).  Per-point outputs are RING-MAJOR with a fixed capacity per ring slot (the ring id; with lfx_config.ring_ids /
+ * lfx_set_ring_ids the id's rank among the sensor's ids): ring r of
  * scan s owns positions [(s * max_rings + r) * ring_capacity, + ring_count[s][r]) of labels_sorted,
  * curvature_sorted and sorted_index, angle ascending.  The feature clouds are dense: scan s owns the
  * first n_edge / n_surface records from scan_begin[s] (scan_info[s][2], [3]).
- * scan_info[s][1] carries error bits (1: a ring id >= max_rings, 4: bucketing timed out -- lfx_batch_status turns
+ * scan_info[s][1] carries error bits (1: a ring id the context does not know, 4: bucketing timed out -- lfx_batch_status turns
  * them into a return code) and the route the scan took: (bits & LFX_SCAN_ROUTE_MASK) == LFX_SCAN_ORGANISED means the
  * scan arrived column-major with ring == index mod max_rings and was read in place: position k of ring r IS input
  * point k * max_rings + r and sorted_index holds nothing for that scan.  Any other value: sorted_index holds every ring
@@ -199,8 +200,8 @@ typedef struct lfx_device_view {
   const double *curvature_sorted; /* device; NULL in a context created without LFX_OUT_CURVATURE */
   const uint32_t *sorted_index;   /* device: original index (within its scan) of ring position k */
   const uint32_t *scan_info;      /* device [batch][4]: occupied rings, error bits, n_edge, n_surface */
-  const uint32_t *ring_count;     /* device [batch][256] by ring id                              */
-  const uint8_t *ring_status;     /* device [batch][256] by ring id (valid where ring_count > 0) */
+  const uint32_t *ring_count;     /* device [batch][256] by ring slot                            */
+  const uint8_t *ring_status;     /* device [batch][256] by ring slot (valid where ring_count > 0) */
   const float *edge_points;       /* device [total][4]                                           */
   const uint32_t *edge_index;
   const float *surface_points;
