@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--watchdog-seconds", type=float, default=120.0,
                     help="N > 1 (or --force-gather): a step or a fence that makes no progress for this long ends the process with exit code 4 and says where")
     ap.add_argument("--test-stall-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests only: this rank stops making progress in its third step (the watchdog's test)
+    ap.add_argument("--test-stall-step", type=int, default=2, help=argparse.SUPPRESS)       # ... or in this step (0-based, warm-up included)
     ap.add_argument("--gather-lanes", type=int, default=0,
                     help="gathers in flight (a communicator and a side stream each; step k on lane k mod L): 0 = 2 with a rotating "
                          "destination (the steps' exchanges overlap on their different links), 1 with a fixed one")
@@ -288,7 +289,7 @@ def main():
         # If the communicator cannot be made on some rank (the RCCL library does not open, the id does not arrive), every
         # rank drops the gather together and the line says so ("sharding"): a measurement of the sharded extraction without
         # its exchange is worth more than none.
-        gather, gather0, gather_error = None, None, None
+        gather, gather0, gather_error, id0 = None, None, None, None
         # (one id more than the lanes: the communicator of the second, fixed-destination region -- see "gather_dst0" below)
         second_region = a.gather_dst == "rotate" and not a.no_second_region
         n_ids = n_lanes + (1 if second_region else 0)
@@ -316,9 +317,8 @@ def main():
                 gather = CloudGather(fx, rank, world, [all_ids[128 * k:128 * (k + 1)] for k in range(n_lanes)],
                                      dst="rotate" if a.gather_dst == "rotate" else int(a.gather_dst), device=dev,
                                      capacity_points=feat_cap * world, batch=a.batch, pairs=use_pairs, profile=True)
-                if second_region:
-                    gather0 = CloudGather(fx, rank, world, [all_ids[128 * n_lanes:128 * (n_lanes + 1)]], dst=0, device=dev,
-                                          capacity_points=feat_cap * world, batch=a.batch, pairs=False, profile=True)
+                # (the second region's communicator is made when its turn comes, behind the headline's numbers: see below)
+                id0 = all_ids[128 * n_lanes:128 * (n_lanes + 1)] if second_region else None
             except Exception as e:         # noqa: BLE001
                 gather_error = "rank %d: %s" % (rank, e)
         if world > 1:
@@ -328,10 +328,9 @@ def main():
                 gather_error = "another rank could not create its communicator"
         if gather_error is not None:
             print("bench.py: gather disabled: %s" % gather_error, file=sys.stderr)
-            for g in (gather, gather0):
-                if g is not None:
-                    g.close()
-            gather = gather0 = None
+            if gather is not None:
+                gather.close()
+            gather = None
             use_gather = False
 
     # Watchdog (N > 1): the first real multi-rank run of a flow is the one the driver times, and a hang there would cost
@@ -354,6 +353,18 @@ def main():
                     return
                 if progress["where"] == "host-side measurements":        # (no rank waits for another there: nothing to watch)
                     continue
+                if progress.get("phase") == "second region" and idle > min(a.watchdog_seconds, 60.0):
+                    # the headline's numbers are complete and stashed: a second region that hangs costs only itself
+                    print("bench.py: rank %d: the second (fixed-destination) region made no progress for %.0f s in '%s': abandoned"
+                          % (rank, idle, progress["where"]), file=sys.stderr)
+                    if progress.get("stash") is not None:
+                        line = dict(progress["stash"], gather_dst0={"error": "no progress for %.0f s in '%s': abandoned (the numbers above are complete)" % (idle, progress["where"])})
+                        print(json.dumps(line))
+                        sys.stdout.flush()
+                    sys.stderr.flush()
+                    os._exit(0)
+                if idle > a.watchdog_seconds and progress.get("printed"):
+                    os._exit(0)
                 if idle > a.watchdog_seconds:
                     g = cur["gather"]
                     lane = ("pair of steps %d, %d" % ((progress["step"] - 1) & ~1, ((progress["step"] - 1) & ~1) + 1)) if (use_gather and g is not None and g.pairs) \
@@ -366,7 +377,7 @@ def main():
 
     def step():
         mark("step")
-        if a.test_stall_rank == rank and step_no[0] == 2:
+        if a.test_stall_rank == rank and step_no[0] == a.test_stall_step:
             time.sleep(1e6)
         k = step_no[0] % n_streams
         step_no[0] += 1
@@ -476,33 +487,6 @@ def main():
     if use_gather:
         mark("comm stats")
         comm_stats = all_ranks(gather.comm_report())
-        if gather0 is not None:
-            cur["gather"] = gather0
-            steps2 = max(4, a.steps // 2)
-            for _ in range(2):
-                step()
-            fence()
-            gather0.gather_ms()                  # (drop the warm-up's spans)
-            t0 = time.perf_counter()
-            for _ in range(steps2):
-                step()
-            fence()
-            dt2 = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([dt2], dtype=torch.float64, device=ddev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt2 = float(t.item())
-            g_ms, g_n = gather0.gather_ms()
-            g2 = g_ms / max(g_n, 1)
-            if world > 1:
-                t = torch.tensor([g2], dtype=torch.float64, device=ddev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                g2 = float(t.item())
-            dst0 = {"value": round(a.batch * steps2 * world / dt2, 2), "unit": "scans/s", "steps": steps2, "ms_per_step": round(1e3 * dt2 / steps2, 4),
-                    "gather_ms_per_step": round(g2, 4), "comm_stats": all_ranks(gather0.comm_report()),
-                    "note": "the same steps with every step's clouds gathered to rank 0 (the destination BASELINE.json's metric names), one "
-                            "exchange in flight on a communicator of its own, timed between the same fences right after the headline's region"}
-            cur["gather"] = gather
     mark("host-side measurements")
 
     # what THIS box gives right now (outside the timed region, ~50 ms): a plain float4 copy of 1 GiB and the shader clock
@@ -769,10 +753,52 @@ def main():
             out["comm_stats_note"] = ("lfx_comm_stats of every rank after the headline's region (warm-up included): ncclSend / ncclRecv calls, the bytes "
                                       "they carried, counts all-gathers; expected_* = 12 B x the feature points + one offsets table per cloud pair, from "
                                       "the totals the exchanges themselves returned")
+    # ---- the second region: every step's clouds gathered to rank 0 (the destination BASELINE.json's metric names), on a
+    #      communicator of its own, made only now -- the headline's numbers are complete and stashed, so that whatever this
+    #      region does (an exception on one rank, a hang: the watchdog then prints the stashed line and ends the process with
+    #      exit code 0) costs only itself
+    if use_gather and id0 is not None and fxs:
+        progress["stash"] = out if rank == 0 else None
+        progress["phase"] = "second region"
+        mark("second region: communicator")
+        try:
+            gather0 = CloudGather(fx, rank, world, [id0], dst=0, device=dev, capacity_points=feat_cap * world, batch=a.batch, pairs=False, profile=True)
+            cur["gather"] = gather0
+            steps2 = max(4, a.steps // 2)
+            for _ in range(2):
+                step()
+            fence()
+            gather0.gather_ms()                  # (drop the warm-up's spans)
+            t0 = time.perf_counter()
+            for _ in range(steps2):
+                step()
+            fence()
+            dt2 = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt2], dtype=torch.float64, device=ddev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            g_ms, g_n = gather0.gather_ms()
+            g2 = g_ms / max(g_n, 1)
+            if world > 1:
+                t = torch.tensor([g2], dtype=torch.float64, device=ddev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                g2 = float(t.item())
+            dst0 = {"value": round(a.batch * steps2 * world / dt2, 2), "unit": "scans/s", "steps": steps2, "ms_per_step": round(1e3 * dt2 / steps2, 4),
+                    "gather_ms_per_step": round(g2, 4), "comm_stats": all_ranks(gather0.comm_report()),
+                    "note": "the same steps with every step's clouds gathered to rank 0 (the destination BASELINE.json's metric names), one "
+                            "exchange in flight on a communicator of its own, timed between the same fences after the headline's region"}
+        except Exception as e:             # noqa: BLE001
+            dst0 = {"error": "%s: %s" % (type(e).__name__, e)}
+        cur["gather"] = gather
+        progress["phase"] = None
+        progress["stash"] = None
+    if rank == 0:
         if dst0 is not None:
             out["gather_dst0"] = dst0
         print(json.dumps(out))
         sys.stdout.flush()
+    progress["printed"] = True             # (from here on a rank that waits in vain ends quietly: the line is out)
     mark("closing")
     if use_gather:
         gather.close()

@@ -110,3 +110,27 @@ def test_a_rank_that_stops_is_reported_not_waited_for():
         assert p.returncode == 4, "rank %d exit %s:\n%s" % (r, p.returncode, err[-2000:])
         assert "bench.py watchdog: rank %d of 2 has made no progress" % r in err, err[-2000:]
         assert not [l for l in outs[r][0].decode().splitlines() if l.startswith("{")], "no line from a run that hung"
+
+
+def test_a_second_region_that_hangs_costs_only_itself():
+    """The fixed-destination region runs AFTER the headline's numbers are complete (and stashed): rank 1 stops in its second
+    step there; after a minute without progress every rank ends with exit code 0 and rank 0 has printed the headline's line,
+    `gather_dst0` saying what happened."""
+    world = 2
+    base = dict(os.environ, WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                LFX_RCCL_LIB=_shim(), LFX_LIB_PATH=os.path.join(ROOT, "lidar_feature_extraction_amd", "_lib", "liblfx_testhooks.so"))
+    # steps before the second region: 1 warm-up + 2 x 3 timed = 7 (no warm-up by the clock); the region's own second step is step 8
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--batch", "8", "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--no-cpu-baseline", "--dist-backend", "gloo", "--warm-seconds", "0", "--watchdog-seconds", "20",
+           "--test-stall-rank", "1", "--test-stall-step", "8"]
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    _sweep()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d exit %s:\n%s" % (r, p.returncode, outs[r][1].decode(errors="replace")[-3000:])
+    lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["parity_spot_check"] is True and d["comm_stats"][1]["bytes_match"]
+    assert "abandoned" in d["gather_dst0"]["error"], d["gather_dst0"]
