@@ -379,9 +379,19 @@ int run_batch(lfx_ctx * c, const void * d_points, const uint32_t * n_points, uin
     if (holes) {
       // the count pass of the holes form: valid returns per ring and piece of 16 columns, every ring's length
       Timed t(c, 10, st);
+      // (a workgroup per scan, reading its records as they lie, where the batch fills the device with those; else a
+      // workgroup per ring group and scan)
+      const uint32_t row_words = c->cap / lfx::kPieceCols + 1u;
+      const size_t count_lds = ((size_t)c->max_rings * row_words + 2u * groups * (size_t)c->dev.B) * 4u;
+      if (batch >= c->scan_count_from && count_lds <= 144u * 1024u) {
+        hipLaunchKernelGGL(lfx::scan_count_kernel, dim3(batch), dim3(lfx::kScanCountThreads), count_lds, st,
+          pts, c->scan_begin.p, c->scan_geom.p, c->max_rings, lfx::cum_stride(c->cap), c->cum16.p, c->ring_count.p, unit_tab, counters,
+          c->hole_desc.p, c->cap, 64u * c->unit_chunks, 4u * (uint32_t)lfx::holes_loads((int)c->unit_chunks), row_words);
+      } else {
       hipLaunchKernelGGL(lfx::grid_count_kernel, dim3(groups, batch), dim3(256), 0, st,
         pts, c->scan_begin.p, c->scan_geom.p, c->max_rings, lfx::cum_stride(c->cap), c->cum16.p, c->ring_count.p, unit_tab, counters,
         c->hole_desc.p, c->cap, 64u * c->unit_chunks, 4u * (uint32_t)lfx::holes_loads((int)c->unit_chunks));
+      }
     }
     {
       Timed t(c, 7, st);
@@ -896,6 +906,7 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (const char * dbg = LFX_DEBUG_ENV("SHORT_TAIL")) {c->route_pins.short_tail = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = LFX_DEBUG_ENV("XFORM")) {c->route_pins.xform = std::atoi(dbg) != 0 ? 1 : 0;}
   if (const char * dbg = LFX_DEBUG_ENV("HOLES")) {c->route_pins.holes = std::atoi(dbg) != 0 ? 1 : 0;}
+  if (const char * dbg = LFX_DEBUG_ENV("SCAN_COUNT_FROM")) {c->scan_count_from = (uint32_t)std::atoi(dbg);}      // batch from which the count pass is one workgroup per scan
   c->slow_grid = 1024;
   if (const char * dbg = LFX_DEBUG_ENV("REDO_CAP")) {c->route_pins.redo_cap = (uint32_t)std::atoi(dbg);}
   if (const char * dbg = LFX_DEBUG_ENV("PRE_ORDER")) {c->route_pins.pre_order = std::atoi(dbg) != 0 ? 1 : 0;}
@@ -988,6 +999,9 @@ int lfx_create(lfx_ctx ** out, int device_id, const lfx_params * params, const l
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::ring_extract_kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfx::ring_lds_bytes(LFX_MAX_RING_POINTS));
+  }
+  if (e == hipSuccess) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::scan_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
   }
   if (e == hipSuccess) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(lfx::fallback_tail_kernel<true>),

@@ -199,6 +199,7 @@ struct lfx_ctx
   // compaction zeroes the other one over the scans the batch before last left dirty there (par_dirty).  aux_dirty: scans whose
   // bucketing-route tables (look-back flags, ring flags, ring transforms) a batch since the last reset may have touched.
   uint32_t parity = 0, par_dirty[2] = {0u, 0u}, aux_dirty = 0;
+  uint32_t scan_count_from = 256;        // batches of so many scans take scan_count_kernel for the holes form's count pass (LFX_DEBUG_SCAN_COUNT_FROM)
   lfx_host::DevBuf<uint8_t> ring_status, label_s, staging, d_label;
   lfx_host::DevBuf<double> d_curv;
   lfx_host::DevBuf<float2> sxy;

@@ -1251,6 +1251,143 @@ __global__ __launch_bounds__(256) void grid_count_kernel(
   if (blockIdx.x == 0u && tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)(kScanFused | kScanHoles));}
 }
 
+// The same count pass for LARGE batches, one workgroup per SCAN: the scan's records are read as they lie -- a wave's 64 lanes
+// take 64 consecutive records, 2 KB in one piece, instead of sixteen 128-byte lines 2 KB apart -- and every valid record adds one
+// to its (ring, piece) word in LDS; prefixes, ring lengths and unit descriptors as grid_count_kernel writes them.  Worth it
+// where there are scans enough to fill the device with one workgroup each (the host: batch >= 256); grid_count_kernel's
+// workgroup per (ring group, scan) stays for small batches.  LDS: (rings + 1) x (pieces + 1) words, given by the host.
+constexpr int kScanCountThreads = 1024;
+__global__ __launch_bounds__(kScanCountThreads) void scan_count_kernel(
+  const uint8_t * __restrict__ pts, const uint32_t * __restrict__ scan_begin, const uint32_t * __restrict__ geom, uint32_t R,
+  uint32_t stride /* cum_stride(ring capacity) */, uint16_t * __restrict__ cum16, uint32_t * __restrict__ ring_count,
+  const UnitTables * __restrict__ tab, uint32_t * __restrict__ counters, uint4 * __restrict__ desc /* [batch][R][B] */,
+  uint32_t ring_cap, uint32_t max_span, uint32_t max_pieces, uint32_t row_words /* words per ring's row in LDS: pieces of the longest scan + 1 */)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];      // [R][row_words]; behind it piece_lo / piece_hi [groups][B]
+  __shared__ uint32_t flag[2];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), s = blockIdx.x;
+  const uint32_t C = geom[s * kGeomStride];
+  if (s == 0u && tid == 0u) {counters[kCntHolesRan] = 1u;}
+  if (C == 0u) {                                      // not R rings x C columns (the host looked): the bucketing route's
+    if (tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)kScanCountFell); scan_falls_back(tab, s);}
+    return;
+  }
+  const int P = tab->prm.P, B = tab->prm.B;
+  const uint32_t groups = (R + 3u) / 4u;
+  uint32_t * const piece_lo = cnt + (size_t)R * row_words, * const piece_hi = piece_lo + groups * (uint32_t)B;
+  for (uint32_t k = tid; k < R * row_words; k += kScanCountThreads) {cnt[k] = 0u;}
+  for (uint32_t k = tid; k < groups * (uint32_t)B; k += kScanCountThreads) {piece_lo[k] = 0xFFFFFFFFu; piece_hi[k] = 0u;}
+  if (tid < 2u) {flag[tid] = 0u;}
+  __syncthreads();
+  const uint32_t n_pieces = (C + kPieceCols - 1u) / kPieceCols, n = C * R;
+  const uint8_t * const base = pts + (size_t)scan_begin[s] * 32u;
+  // record e = column e / R, ring e mod R; a thread's records are 1 024 apart: both numbers move by constants
+  const uint32_t dcol = (uint32_t)kScanCountThreads / R, dring = (uint32_t)kScanCountThreads % R;
+  uint32_t col = tid / R, ring = tid % R;
+  bool wrong = false, zeros = false;
+  for (uint32_t e0 = tid; e0 < n; e0 += kCountUnroll * kScanCountThreads) {
+    float4 rec[kCountUnroll];
+    uint32_t rw[kCountUnroll];
+#pragma unroll
+    for (int u = 0; u < kCountUnroll; u++) {
+      const uint32_t e = e0 + (uint32_t)u * kScanCountThreads;
+      const uint8_t * p = base + (size_t)(e < n ? e : n - 1u) * 32u;
+      rec[u] = *reinterpret_cast<const float4 *>(p);
+      rw[u] = *reinterpret_cast<const uint32_t *>(p + 20);
+    }
+#pragma unroll
+    for (int u = 0; u < kCountUnroll; u++) {
+      const uint32_t e = e0 + (uint32_t)u * kScanCountThreads;
+      if (e < n) {
+        const bool zero = rec[u].x == 0.f && rec[u].y == 0.f && rec[u].z == 0.f;
+        wrong = wrong || (rw[u] & 0xFFFFu) != ring;
+        zeros = zeros || zero;
+        if (!zero) {atomicAdd(&cnt[ring * row_words + (col >> 4)], 1u);}
+      }
+      col += dcol; ring += dring;
+      if (ring >= R) {ring -= R; col += 1u;}
+    }
+  }
+  if (__ballot(wrong) != 0ull && lane == 0u) {flag[0] = 1u;}
+  if (__ballot(zeros) != 0ull && lane == 0u) {flag[1] = 1u;}
+  __syncthreads();
+  if (flag[0] != 0u) {
+    if (tid == 0u) {atomicOr(tab->scan_flags + s, (uint32_t)kScanCountFell); scan_falls_back(tab, s);}
+    return;
+  }
+  if (flag[1] != 0u && tid == 0u) {atomicAdd(counters + kCntZeroGroups, groups);}      // (counted in ring groups, as grid_count_kernel counts)
+  // wave w: the exclusive prefixes of rings w, w + 16, ... over the pieces (kept in LDS for the searches below)
+  for (uint32_t r = wave; r < R; r += kScanCountThreads / 64) {
+    uint16_t * const row = cum16 + ((size_t)s * R + r) * stride;
+    uint32_t * const lrow = cnt + (size_t)r * row_words;
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64u) {
+      const uint32_t p = p0 + lane;
+      const uint32_t v = p < n_pieces ? lrow[p] : 0u;
+      const uint32_t incl = wave_inclusive_sum(v) + carry;
+      if (p < n_pieces) {row[p] = (uint16_t)(incl - v); lrow[p] = incl - v;}
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0u) {
+      row[n_pieces] = (uint16_t)carry;
+      lrow[n_pieces] = carry;
+      ring_count[s * kRings + r] = carry;
+    }
+  }
+  __syncthreads();
+  // thread (ring, block j): the unit's descriptor, as grid_count_kernel
+  bool defer = false;
+  for (uint32_t k = tid; k < R * (uint32_t)B; k += kScanCountThreads) {
+    const uint32_t r = k / (uint32_t)B;
+    const int j = (int)(k - r * (uint32_t)B);
+    const uint32_t * const lrow = cnt + (size_t)r * row_words;
+    const uint32_t N = lrow[n_pieces];
+    const int Ni = (int)N;
+    uint32_t flags = N == 0u ? kHoleUnitDead : 0u;       // (a ring without a valid return is no ring of the scan)
+    int b0 = 0, b1 = 0, ps = 0, pe = 0;
+    if (flags == 0u && (Ni < 2 * P + 1 || Ni - 2 * P < B || N > ring_cap)) {flags = kHoleUnitDead; defer = true;}
+    if (flags == 0u) {
+      b0 = block_boundary(Ni, P, B, j);
+      b1 = block_boundary(Ni, P, B, j + 1);
+      const int o0 = j == 0 ? 0 : b0, o1 = j == B - 1 ? Ni : b1;
+      const int g0 = o0 - (P + 1), span = o1 + (P + 1) - g0;
+      if (b1 - b0 < 2 || span > (int)max_span) {
+        flags = kHoleUnitDead; defer = true;
+      } else {
+        const int first = g0 < 0 ? 0 : g0, last = (o1 + P + 1 < Ni ? o1 + P + 1 : Ni) - 1;
+        auto piece_of = [&](int x) {
+            int lo = 0, hi = (int)n_pieces;
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if ((int)lrow[mid] <= x) {lo = mid;} else {hi = mid;}
+            }
+            return lo;
+          };
+        ps = piece_of(first);
+        pe = piece_of(last);
+        atomicMin(&piece_lo[(r >> 2) * (uint32_t)B + (uint32_t)j], (uint32_t)ps);
+        atomicMax(&piece_hi[(r >> 2) * (uint32_t)B + (uint32_t)j], (uint32_t)pe);
+      }
+    }
+    desc[((size_t)s * R + r) * (uint32_t)B + (uint32_t)j] =
+      make_uint4(N | ((uint32_t)b0 << 16), (uint32_t)b1 | (flags << 16), (uint32_t)ps | ((uint32_t)pe << 16), 0u);
+  }
+  if (__ballot(defer) != 0ull && lane == 0u) {flag[0] = 1u;}
+  __syncthreads();
+  for (uint32_t k = tid; k < groups * (uint32_t)B; k += kScanCountThreads) {
+    if (piece_lo[k] != 0xFFFFFFFFu && piece_hi[k] - piece_lo[k] + 1u > max_pieces) {flag[0] = 1u;}
+  }
+  __syncthreads();
+  if (tid == 0u) {
+    if (flag[0] != 0u) {
+      atomicOr(tab->scan_flags + s, (uint32_t)kScanCountFell);
+      scan_falls_back(tab, s);
+    } else {
+      atomicOr(tab->scan_flags + s, (uint32_t)(kScanFused | kScanHoles));
+    }
+  }
+}
+
 // The ring transforms of an organised stream whose rings do not arrive in angle order: a driver that starts its scans
 // at another azimuth delivers every ring as a ROTATION of its sorted order, a clockwise sensor as its REVERSE (or
 // both).  One wave per ring: direction by majority over 64 sampled adjacent pairs, then the column of the ring's

@@ -97,8 +97,15 @@ def run_zeros_case(case, rng, rings, cols, hp, clouds, zeros, seed, exact_cap):
         for f in ("x", "y", "z"):
             c[f][z] = 0.0
         masks.append(z)
-    f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=2, max_points_per_ring=cols if exact_cap else 0,
-                          max_rings=rings, drop_zero_points=True, stream_hint=LB.STREAM_GRID_WITH_HOLES if hinted else 0)
+    import os
+    by_scan = bool(rng.integers(0, 2))             # the count pass of large batches (one workgroup per scan), pinned on for these two scans
+    if by_scan:
+        os.environ["LFX_DEBUG_SCAN_COUNT_FROM"] = "1"
+    try:
+        f = FeatureExtraction(hp, device=0, max_points_per_scan=rings * cols, max_batch=2, max_points_per_ring=cols if exact_cap else 0,
+                              max_rings=rings, drop_zero_points=True, stream_hint=LB.STREAM_GRID_WITH_HOLES if hinted else 0)
+    finally:
+        os.environ.pop("LFX_DEBUG_SCAN_COUNT_FROM", None)
     op = OB.Params(hp.padding, hp.neighbor_degree_threshold, hp.distance_diff_threshold, hp.parallel_beam_min_range_ratio,
                    hp.edge_threshold, hp.surface_threshold, hp.min_range, hp.max_range, hp.n_blocks)
     keeps = [np.nonzero(~z)[0] for z in masks]
