@@ -572,7 +572,7 @@ def main():
         # (the path's own kernels only: the file also holds the calibration copy, the runtime's fills and the download kernels
         # of the parity check, none of which is part of a step)
         tj_all = sum(v for k, v in tj.get("hbm_bytes_per_launch", {}).items()
-                     if isinstance(v, (int, float)) and k.startswith(("ring_", "feature_", "batch_", "fallback_", "grid_")))
+                     if isinstance(v, (int, float)) and k.startswith(("ring_", "feature_", "batch_", "fallback_", "grid_", "scan_count")))
         roofline["ceiling"] = {"whole_path_frac_at_box_copy_rate": round(algo_bytes / (tj_all / (box["copy_gbs"] * 1e9)) / 1e9 / HBM_PEAK_GBS, 5),
                                "hbm_bytes_per_step": int(tj_all)}
 

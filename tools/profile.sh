@@ -53,13 +53,13 @@ json.dump({"batch": opt("--batch", 1024), "rings": opt("--rings", 64), "cols": o
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB per dispatch, mean over dispatches); "
                    "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md: it counts 128-B requests at 64 B)",
            "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": hbm,
-           "hbm_bytes_per_launch_total": sum(v for k, v in hbm.items() if k.startswith(("ring_", "feature_", "batch_", "fallback_", "grid_")))},
+           "hbm_bytes_per_launch_total": sum(v for k, v in hbm.items() if k.startswith(("ring_", "feature_", "batch_", "fallback_", "grid_", "scan_count")))},
           open(out + "/pmc_traffic.json", "w"), indent=1)
 sq = mean_per_kernel(out + "/pmc_sq1")
 for extra in ("/pmc_sq2", "/pmc_sq3", "/pmc_sq4"):
     for k, v in mean_per_kernel(out + extra).items():
         sq.setdefault(k, {}).update(v)
-keep = {k: v for k, v in sq.items() if k.startswith(("ring_unit", "ring_stream", "ring_scatter", "feature_compact", "grid_count"))}
+keep = {k: v for k, v in sq.items() if k.startswith(("ring_unit", "ring_stream", "ring_scatter", "feature_compact", "grid_count", "scan_count"))}
 for k, v in keep.items():
     w = v.get("SQ_WAVES", 0) or 1
     v["per_wave"] = {c: round(v[c] / w, 1) for c in v if c.startswith(("SQ_INSTS", "SQ_WAVE_CYCLES", "SQ_ACTIVE", "SQ_WAIT"))}
