@@ -118,3 +118,26 @@ def test_a_stream_that_turns_bad_and_recovers(lib):
     assert routes[4:19] == [0] * 15 and routes[19] == 1      # retried after 16 batches, still bad
     assert routes[20:35] == [0] * 15 and routes[35] == 1     # the second retry finds the stream clean ...
     assert routes[36:] == [1, 1, 1, 1]                       # ... and the organised route stays
+
+
+def test_a_stream_that_grows_holes_and_loses_them(lib):
+    """The state carried through a sequence (zero filter on): a clean grid -> zero records in every scan for 20 batches -> clean
+    again.  The plain form refuses such scans (they fall back one by one), the report says why, the holes form takes over with
+    the next batch and stays while ring groups keep holding zero records; then back to the plain form -- never the bucketing
+    route for every scan."""
+    state = (0, 0, 0, 0, 0)
+    report, rings = None, 0
+    seen = []
+    for k in range(40):
+        ch, state = choose(lib, report=report, rings=rings, state=state)
+        seen.append((ch["fused"], ch["holes"]))
+        holes_now = 3 <= k < 23
+        if ch["holes"]:
+            report = {FUSED_RAN: 1, BATCH: 64, FALLBACK: 0, HOLES_RAN: 1, ZERO_GROUPS: 1024 if holes_now else 0}
+        else:
+            report = {FUSED_RAN: 1, BATCH: 64, FALLBACK: 64 if holes_now else 0, ZERO_FELL: 64 if holes_now else 0}
+        rings = 4096
+    assert all(f == 1 for f, _ in seen), "the organised route throughout: %s" % seen
+    assert [h for _, h in seen[:4]] == [0, 0, 0, 0]            # the batch after the first report of zero records is the first with the count pass
+    assert all(h == 1 for _, h in seen[4:24]), seen[4:24]
+    assert all(h == 0 for _, h in seen[25:]), seen[24:]         # one batch of holes form on clean scans reports "no zero records": back
